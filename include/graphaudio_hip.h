@@ -1,0 +1,167 @@
+/*
+ * graphaudio_hip.h -- C ABI of libgraphaudio_hip.so, the MI355X-native offline render path
+ * for GraphAudio's per-block DSP hot path.
+ *
+ * This is the drop-in boundary.  Every entry point is a flat C mirror
+ * of one public member of the reference's AudioContextBase / AudioNode / AudioParam surface;
+ * the reference member each one replaces is cited as (file:line), relative to the reference
+ * repository root.  A managed host (C# [LibraryImport], see INTEGRATION.md and
+ * bindings/csharp/) or the Python ctypes host in graphaudio_amd/ replays graph construction
+ * through these calls and then asks for whole renders: O(1) native calls per Render().
+ *
+ * Conventions (same as the reference's own P/Invoke layers, GraphAudio.IO/Libsndfile.cs:36-68,
+ * GraphAudio.Realtime/Miniaudio.cs:303-349): cdecl, opaque handle, int result codes with
+ * 0 = success and negatives = errors, error-string getter, every pointer argument borrowed
+ * for the duration of the call only.  One context is driven by one thread at a time
+ * (AudioContextBase.cs:59-62); different contexts may be used concurrently.
+ *
+ * The same header is compiled by the CPU oracle (oracle/ga_oracle.cpp) with
+ * -DGA_FN(n)=gao_##n so the test-only oracle exposes the identical surface under a gao_ prefix.
+ */
+#ifndef GRAPHAUDIO_HIP_H
+#define GRAPHAUDIO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef GA_FN
+#define GA_FN(name) ga_##name
+#endif
+
+#if defined(__GNUC__)
+#define GA_EXPORT __attribute__((visibility("default")))
+#else
+#define GA_EXPORT
+#endif
+
+/* ---- result codes: what the managed wrapper turns back into the reference's exceptions ---- */
+#define GA_OK 0
+#define GA_ERR_INVALID_ARGUMENT (-1)  /* ArgumentException           (OfflineAudioContext.cs:32-51) */
+#define GA_ERR_OUT_OF_RANGE (-2)      /* ArgumentOutOfRangeException (AudioBuffer.cs:18, AudioNodeInput.cs:43) */
+#define GA_ERR_INVALID_OPERATION (-3) /* InvalidOperationException   (ConvolverNode.cs:45-49, AudioBufferSourceNode.cs:83-90) */
+#define GA_ERR_DISPOSED (-4)          /* ObjectDisposedException     (AudioContextBase.cs:54,268) */
+#define GA_ERR_CYCLE (-5)             /* InvalidOperationException "Audio graph cycle detected" (Nodes/AudioNode.cs:157-160) */
+#define GA_ERR_UNSUPPORTED (-6)       /* graph uses a feature outside the accelerated path: host must fall back to the CPU context */
+#define GA_ERR_DEVICE (-7)            /* HIP runtime error */
+#define GA_ERR_OUT_OF_MEMORY (-8)
+#define GA_ERR_NO_DEVICE (-9)         /* no gfx950 device / HIP code object missing: the product never falls back to a CPU path */
+
+/* ---- enums (numeric values follow declaration order in the reference) ---- */
+enum { /* node types creatable through ga_node_create; the destination is always node id 0 */
+  GA_NODE_DESTINATION = 0,   /* Nodes/AudioDestinationNode.cs:9 */
+  GA_NODE_BUFFER_SOURCE = 1, /* Nodes/AudioBufferSourceNode.cs:13 ; params: 0 = playbackRate (k-rate) */
+  GA_NODE_GAIN = 2,          /* Nodes/GainNode.cs:9            ; params: 0 = gain (a-rate) */
+  GA_NODE_BIQUAD = 3,        /* Nodes/BiQuadFilterNode.cs:10   ; params: 0 = frequency (a), 1 = Q (a), 2 = gain dB (k) */
+  GA_NODE_CONVOLVER = 4      /* Nodes/ConvolverNode.cs:10      ; no params */
+};
+enum { GA_FILTER_LOWPASS = 0, GA_FILTER_HIGHPASS, GA_FILTER_BANDPASS, GA_FILTER_NOTCH, GA_FILTER_ALLPASS,
+       GA_FILTER_PEAKING, GA_FILTER_LOWSHELF, GA_FILTER_HIGHSHELF }; /* BiQuadFilterNode.cs:288-298 */
+enum { GA_COUNT_MODE_MAX = 0, GA_COUNT_MODE_CLAMPED_MAX = 1, GA_COUNT_MODE_EXPLICIT = 2 }; /* AudioNodeInput.cs:258-272 */
+enum { GA_INTERP_SPEAKERS = 0, GA_INTERP_DISCRETE = 1 };                                    /* AudioNodeInput.cs:246-256 */
+
+typedef struct ga_context ga_context;
+
+/* Counters filled by ga_get_stats (reference has only BufferPool.GetStatistics, BufferPool.cs:133-149). */
+typedef struct ga_stats {
+  int64_t blocks_rendered;      /* AudioContextBase.CurrentBlock (AudioContextBase.cs:223) */
+  int64_t chunks;               /* device render chunks executed */
+  int64_t segments;             /* control-state segments executed */
+  int64_t kernel_launches;
+  double  device_ms_total;      /* sum of per-chunk device time, HIP events on the context's stream */
+  /* dominant-kernel timing (the spectral multiply-accumulate of PartitionedConvolver.cs:154-223) */
+  int64_t mac_launches;
+  double  mac_ms_total;
+  double  mac_flops_total;      /* algorithmic flops: 8 * P * 129 per channel-instance per block */
+  double  mac_bytes_total;      /* algorithmic bytes per SURVEY.md section 8(d) streaming formulation */
+  double  fft_ms_total;         /* forward rfft256 + inverse/overlap-add kernels */
+  double  other_ms_total;       /* source / biquad / gain / mix / param-curve kernels */
+  int64_t device_bytes_in_use;
+  int32_t n_nodes;
+  int32_t n_conv_rows;          /* convolver channel-instances resident on the device */
+} ga_stats;
+
+/* ---- library ---- */
+GA_EXPORT const char* GA_FN(strerror)(int code);              /* cf. sf_strerror, GraphAudio.IO/Libsndfile.cs:48-56 */
+GA_EXPORT const char* GA_FN(version)(void);
+GA_EXPORT int GA_FN(device_count)(void);                       /* number of visible gfx950 devices; 0 if none */
+
+/* ---- context: OfflineAudioContext(int sampleRate = 48000)  (OfflineAudioContext.cs:18, AudioContextBase.cs:35-47) ---- */
+GA_EXPORT int GA_FN(context_create)(int sample_rate, int device_ordinal, ga_context** out);
+GA_EXPORT int GA_FN(context_destroy)(ga_context* ctx);         /* AudioContextBase.Dispose, AudioContextBase.cs:243-260 */
+GA_EXPORT const char* GA_FN(last_error)(ga_context* ctx);      /* message of the last failing call on this context */
+GA_EXPORT double GA_FN(current_time)(ga_context* ctx);         /* AudioContextBase.CurrentTime, AudioContextBase.cs:28 */
+GA_EXPORT int64_t GA_FN(current_block)(ga_context* ctx);       /* AudioContextBase.CurrentBlock, AudioContextBase.cs:223 */
+GA_EXPORT int GA_FN(set_option)(ga_context* ctx, const char* key, double value); /* tuning knobs, see DESIGN.md */
+GA_EXPORT int GA_FN(get_stats)(ga_context* ctx, ga_stats* out);
+
+/* ---- PlayableAudioBuffer.FromChannelArrays (PlayableAudioBuffer.cs:122-145): immutable sample storage ---- */
+GA_EXPORT int GA_FN(buffer_create)(ga_context* ctx, const float* const* planar, int channels, int64_t frames,
+                                   int sample_rate, int* out_buffer_id);
+GA_EXPORT int GA_FN(buffer_release)(ga_context* ctx, int buffer_id);
+
+/* ---- nodes: constructors of GainNode / BiQuadFilterNode / ConvolverNode / AudioBufferSourceNode ---- */
+GA_EXPORT int GA_FN(node_create)(ga_context* ctx, int node_type, int* out_node_id);
+GA_EXPORT int GA_FN(node_dispose)(ga_context* ctx, int node);  /* AudioNode.Dispose, Nodes/AudioNode.cs:207-238 */
+/* AudioNode.Connect(destination, outputIndex, inputIndex), Nodes/AudioNode.cs:68-73,109-123 */
+GA_EXPORT int GA_FN(node_connect)(ga_context* ctx, int src, int dst, int output_index, int input_index);
+/* AudioNode.Disconnect(destination?, outputIndex, inputIndex), Nodes/AudioNode.cs:78-81,129-150 ; dst < 0 = all */
+GA_EXPORT int GA_FN(node_disconnect)(ga_context* ctx, int src, int dst, int output_index, int input_index);
+/* AudioNode.Connect(AudioParam, outputIndex) / Disconnect(AudioParam, ...), Nodes/AudioNode.cs:86-103 */
+GA_EXPORT int GA_FN(node_connect_param)(ga_context* ctx, int src, int dst_node, int dst_param, int output_index);
+GA_EXPORT int GA_FN(node_disconnect_param)(ga_context* ctx, int src, int dst_node, int dst_param, int output_index);
+/* 1 once a scheduled source has raised Ended (AudioBufferSourceNode.cs:378-389); the host raises the event */
+GA_EXPORT int GA_FN(node_has_ended)(ga_context* ctx, int node);
+
+/* AudioNodeInput.SetChannelCount / SetChannelCountMode / SetChannelInterpretation (AudioNodeInput.cs:41-58) */
+GA_EXPORT int GA_FN(input_set_channel_count)(ga_context* ctx, int node, int input_index, int count);
+GA_EXPORT int GA_FN(input_set_channel_count_mode)(ga_context* ctx, int node, int input_index, int mode);
+GA_EXPORT int GA_FN(input_set_channel_interpretation)(ga_context* ctx, int node, int input_index, int interpretation);
+/* AudioDestinationNode.SetChannelCount (Nodes/AudioDestinationNode.cs:23-32) */
+GA_EXPORT int GA_FN(destination_set_channel_count)(ga_context* ctx, int channels);
+/* channel count of the destination's last output buffer, or 2 before the first block: what Render(int) sizes by
+ * (OfflineAudioContext.cs:108-124) */
+GA_EXPORT int GA_FN(destination_output_channels)(ga_context* ctx);
+
+/* ---- AudioParam (AudioParam.cs:34-49, 252-331) ---- */
+GA_EXPORT int GA_FN(param_set_value)(ga_context* ctx, int node, int param, float value);
+GA_EXPORT int GA_FN(param_get_value)(ga_context* ctx, int node, int param, float* out);
+GA_EXPORT int GA_FN(param_set_value_at_time)(ga_context* ctx, int node, int param, float value, double start_time);
+GA_EXPORT int GA_FN(param_linear_ramp_to_value_at_time)(ga_context* ctx, int node, int param, float value, double end_time);
+GA_EXPORT int GA_FN(param_exponential_ramp_to_value_at_time)(ga_context* ctx, int node, int param, float value, double end_time);
+GA_EXPORT int GA_FN(param_set_target_at_time)(ga_context* ctx, int node, int param, float target, double start_time,
+                                              double time_constant);
+GA_EXPORT int GA_FN(param_cancel_scheduled_values)(ga_context* ctx, int node, int param, double cancel_time);
+
+/* ---- AudioBufferSourceNode (Nodes/AudioBufferSourceNode.cs:39-129) ---- */
+GA_EXPORT int GA_FN(source_set_buffer)(ga_context* ctx, int node, int buffer_id); /* buffer_id < 0 = null */
+GA_EXPORT int GA_FN(source_set_loop)(ga_context* ctx, int node, int loop, double loop_start, double loop_end);
+GA_EXPORT int GA_FN(source_start)(ga_context* ctx, int node, double when, double offset, double duration);
+GA_EXPORT int GA_FN(source_stop)(ga_context* ctx, int node, double when);
+
+/* ---- BiQuadFilterNode.Type (Nodes/BiQuadFilterNode.cs:21-37) ---- */
+GA_EXPORT int GA_FN(biquad_set_type)(ga_context* ctx, int node, int filter_type);
+
+/* ---- ConvolverNode.Normalize / EnableTrueStereo / Buffer (Nodes/ConvolverNode.cs:25-95) ---- */
+GA_EXPORT int GA_FN(convolver_set_normalize)(ga_context* ctx, int node, int normalize);
+GA_EXPORT int GA_FN(convolver_set_enable_true_stereo)(ga_context* ctx, int node, int enable);
+GA_EXPORT int GA_FN(convolver_set_buffer)(ga_context* ctx, int node, int buffer_id); /* buffer_id < 0 = null */
+
+/* ---- OfflineAudioContext.Render(float[][] output, int frameCount, int startIndex = 0) (OfflineAudioContext.cs:30-102)
+ * out_planar[ch] points at a host array of at least start_index + frame_count floats.  DSP state, the block clock
+ * and the leftover-frame cache persist across calls exactly as in the reference. */
+GA_EXPORT int GA_FN(render)(ga_context* ctx, float* const* out_planar, int out_channels, int64_t frame_count,
+                            int64_t start_index);
+/* Same, but out_planar[ch] are DEVICE pointers on the context's GPU (used so the destination bus of a sharded render
+ * can be summed across GPUs with RCCL without a host round trip).  The oracle build returns GA_ERR_UNSUPPORTED. */
+GA_EXPORT int GA_FN(render_device)(ga_context* ctx, float* const* out_planar_dev, int out_channels, int64_t frame_count,
+                                   int64_t start_index);
+/* Run the render on this HIP stream (a hipStream_t passed as void*) instead of the context's own stream. */
+GA_EXPORT int GA_FN(context_set_stream)(ga_context* ctx, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRAPHAUDIO_HIP_H */
