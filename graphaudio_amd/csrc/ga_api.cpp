@@ -1,0 +1,623 @@
+// ga_api.cpp -- the C ABI of include/graphaudio_hip.h over the engine (ga_engine.hpp).
+// Every entry point validates its arguments like the reference member it replaces, never throws across the
+// boundary, and returns 0 or a negative GA_ERR_* code (message via ga_last_error).
+#include <algorithm>
+#include <cstring>
+
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+
+#include "ga_engine.hpp"
+
+using namespace ga;
+
+// GA_BACKTRACE=1 in the environment: print a native backtrace on SIGSEGV (debug aid, off by default)
+static void ga_segv_handler(int sig) {
+  void* frames[64];
+  int n = backtrace(frames, 64);
+  const char msg[] = "\n[graphaudio_hip] fatal signal, native backtrace:\n";
+  (void)!write(2, msg, sizeof(msg) - 1);
+  backtrace_symbols_fd(frames, n, 2);
+  signal(sig, SIG_DFL);
+  raise(sig);
+}
+__attribute__((constructor)) static void ga_install_handler() {
+  const char* e = getenv("GA_BACKTRACE");
+  if (e && e[0] == '1') signal(SIGSEGV, ga_segv_handler);
+}
+
+struct ga_context {
+  Context c;
+  explicit ga_context(int sr) : c(sr) {}
+};
+
+namespace {
+template <class F>
+int guard(ga_context* h, F&& f) {
+  if (!h) return GA_ERR_INVALID_ARGUMENT;
+  try {
+    f(h->c);
+    return GA_OK;
+  } catch (const Err& e) {
+    h->c.lastError = e.msg;
+    return e.code;
+  } catch (const std::bad_alloc&) {
+    h->c.lastError = "out of host memory";
+    return GA_ERR_OUT_OF_MEMORY;
+  } catch (const std::exception& e) {
+    h->c.lastError = e.what();
+    return GA_ERR_INVALID_OPERATION;
+  } catch (...) {
+    h->c.lastError = "unknown error";
+    return GA_ERR_INVALID_OPERATION;
+  }
+}
+NodeS* typed(Context& c, int id, int type) {
+  NodeS* n = c.node(id);
+  if (n->type != type) fail(GA_ERR_INVALID_ARGUMENT, "node has the wrong type for this call");
+  return n;
+}
+float clampf(float v, float mn, float mx) {  // Math.Clamp(float, float, float)
+  if (v < mn) return mn;
+  if (v > mx) return mx;
+  return v;
+}
+void addEvent(ParamS& p, const ParamEvent& e) {  // AudioParam.AddEvent, AudioParam.cs:333-352
+  size_t lo = 0, hi = p.events.size();
+  while (lo < hi) {
+    size_t mid = (lo + hi) >> 1;
+    if (e.time < p.events[mid].time) hi = mid; else lo = mid + 1;
+  }
+  p.events.insert(p.events.begin() + lo, e);
+}
+ParamS makeParam(float def, float mn, float mx, bool arate) {
+  ParamS p;
+  p.def = def;
+  p.minv = mn;
+  p.maxv = mx;
+  p.arate = arate;
+  p.value = def;
+  return p;
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------
+// OfflineAudioContext.Render (OfflineAudioContext.cs:30-102) on top of runChunk
+// ------------------------------------------------------------------------------------------------------
+void Context::render(float* const* out, int channels, int64_t frameCount, int64_t startIndex, bool deviceOut) {
+  if (channels == 0 || !out) fail(GA_ERR_INVALID_ARGUMENT, "Output buffer must have at least one channel.");
+  if (frameCount <= 0) fail(GA_ERR_OUT_OF_RANGE, "Frame count must be positive.");
+  if (startIndex < 0) fail(GA_ERR_OUT_OF_RANGE, "Start index must be non-negative.");
+  if (channels < 0 || channels > 32) fail(GA_ERR_OUT_OF_RANGE, "channelIndex");
+  for (int ch = 0; ch < channels; ch++)
+    if (!out[ch]) fail(GA_ERR_INVALID_ARGUMENT, "Channel buffer is null.");
+  if (disposed) fail(GA_ERR_DISPOSED, "context disposed");
+  GA_HIP(hipSetDevice(device));
+  const hipMemcpyKind kind = deviceOut ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  int64_t written = 0;
+  if (cachedFrames > 0) {  // leftover frames of the previous call's last block (:55-75)
+    if (channels > cachedCh) fail(GA_ERR_OUT_OF_RANGE, "channelIndex");
+    int toCopy = (int)std::min<int64_t>(cachedFrames, frameCount);
+    for (int ch = 0; ch < channels; ch++)
+      GA_HIP(hipMemcpyAsync(out[ch] + startIndex, cacheDev + (size_t)ch * kBlock + (kBlock - cachedFrames), sizeof(float) * toCopy,
+                            kind, stream));
+    GA_HIP(hipStreamSynchronize(stream));
+    written = toCopy;
+    cachedFrames -= toCopy;
+  }
+  while (written < frameCount) {
+    int64_t need = frameCount - written;
+    int64_t nblk = (need + kBlock - 1) / kBlock;
+    // chunk size: bounded by the option and by device memory (slabs + convolver planes scale with the block count)
+    int64_t limit = maxChunkBlocks;
+    {
+      size_t freeB = 0, totalB = 0;
+      if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
+        double perBlock = 0;
+        int convRowsMax = 0;
+        for (auto& g : groups) convRowsMax = std::max(convRowsMax, (int)((g->rows.size() + 127) / 128 * 128));
+        perBlock += (double)convRowsMax * kBins * 4.0 * 4.0;
+        perBlock += ((double)nodes.size() * 2.0 + 64.0) * kBlock * 4.0;
+        double budget = ((double)freeB + (double)slabBlocks.size() * (double)((size_t)1 << 30) * 0.0) * memBudgetFraction;
+        // memory already held by slabs / planes is reused, so add it back to the budget
+        budget += (double)(planes[0].bytes + planes[1].bytes + planes[2].bytes + planes[3].bytes);
+        budget += (double)slabAll.size() * (double)slabFrames * 4.0;
+        int64_t byMem = (int64_t)(budget / std::max(perBlock, 1.0));
+        limit = std::max<int64_t>(1, std::min<int64_t>(limit, byMem));
+      }
+    }
+    nblk = std::min(nblk, limit);
+    runChunk(nblk, nullptr);
+    const int64_t done = chunkBlocksDone;
+    if (done <= 0) fail(GA_ERR_INVALID_OPERATION, "render made no progress");
+    // buffer.GetChannelSpan(ch) throws for ch >= destination channel count (:82-85)
+    if (channels > chunkMinDestCh) fail(GA_ERR_OUT_OF_RANGE, "channelIndex");
+    const int64_t chunkFrames = done * kBlock;
+    const int64_t toCopy = std::min(chunkFrames, need);
+    for (int ch = 0; ch < channels; ch++)
+      GA_HIP(hipMemcpyAsync(out[ch] + startIndex + written, busSlabs[ch], sizeof(float) * toCopy, kind, stream));
+    const int64_t excess = chunkFrames - toCopy;  // < 128: only the last block can be partial (:89-100)
+    if (excess > 0) {
+      cachedCh = chunkMinDestCh;
+      for (int ch = 0; ch < cachedCh; ch++)
+        GA_HIP(hipMemcpyAsync(cacheDev + (size_t)ch * kBlock, busSlabs[ch] + chunkFrames - kBlock, sizeof(float) * kBlock,
+                              hipMemcpyDeviceToDevice, stream));
+      cachedFrames = (int)excess;
+    }
+    GA_HIP(hipStreamSynchronize(stream));
+    written += toCopy;
+  }
+  stats.device_bytes_in_use = devBytes;
+}
+
+extern "C" {
+
+const char* ga_strerror(int code) {
+  switch (code) {
+    case GA_OK: return "ok";
+    case GA_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case GA_ERR_OUT_OF_RANGE: return "argument out of range";
+    case GA_ERR_INVALID_OPERATION: return "invalid operation";
+    case GA_ERR_DISPOSED: return "object disposed";
+    case GA_ERR_CYCLE: return "audio graph cycle detected";
+    case GA_ERR_UNSUPPORTED: return "unsupported on the device path";
+    case GA_ERR_DEVICE: return "HIP device error";
+    case GA_ERR_OUT_OF_MEMORY: return "out of memory";
+    case GA_ERR_NO_DEVICE: return "no HIP device";
+    default: return "unknown error code";
+  }
+}
+const char* ga_version(void) { return "graphaudio-hip 0.1 (gfx950)"; }
+int ga_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int ga_context_create(int sample_rate, int device_ordinal, ga_context** out) {
+  if (!out) return GA_ERR_INVALID_ARGUMENT;
+  if (sample_rate <= 0) return GA_ERR_OUT_OF_RANGE;  // AudioContextBase.cs:37-38
+  ga_context* h = nullptr;
+  try {
+    h = new ga_context(sample_rate);
+    h->c.init_device(device_ordinal);
+    auto d = std::make_unique<NodeS>();  // AudioDestinationNode: 1 input with channelCount 2, no outputs (:17-21)
+    d->id = 0;
+    d->type = GA_NODE_DESTINATION;
+    d->inputs.resize(1);
+    d->inputs[0].channelCount = 2;
+    h->c.nodes.push_back(std::move(d));
+    *out = h;
+    return GA_OK;
+  } catch (const Err& e) {
+    delete h;
+    return e.code;
+  } catch (...) {
+    delete h;
+    return GA_ERR_DEVICE;
+  }
+}
+int ga_context_destroy(ga_context* ctx) {
+  delete ctx;
+  return GA_OK;
+}
+const char* ga_last_error(ga_context* ctx) { return ctx ? ctx->c.lastError.c_str() : ""; }
+double ga_current_time(ga_context* ctx) { return ctx ? ctx->c.currentTime : 0.0; }
+int64_t ga_current_block(ga_context* ctx) { return ctx ? ctx->c.currentBlock : 0; }
+int ga_set_option(ga_context* ctx, const char* key, double value) {
+  return guard(ctx, [&](Context& c) {
+    std::string k = key ? key : "";
+    if (k == "max_chunk_blocks") c.maxChunkBlocks = std::max<int64_t>(1, std::min<int64_t>(32768, (int64_t)value));
+    else if (k == "profile") c.profile = value != 0;
+    else if (k == "mem_budget_fraction") c.memBudgetFraction = std::min(0.95, std::max(0.05, value));
+    else fail(GA_ERR_INVALID_ARGUMENT, "unknown option " + k);
+  });
+}
+int ga_get_stats(ga_context* ctx, ga_stats* out) {
+  return guard(ctx, [&](Context& c) {
+    if (!out) fail(GA_ERR_INVALID_ARGUMENT, "null pointer");
+    c.stats.device_bytes_in_use = c.devBytes;
+    c.stats.n_nodes = (int)c.nodes.size();
+    int rows = 0;
+    for (auto& g : c.groups) rows += (int)g->rows.size();
+    c.stats.n_conv_rows = rows;
+    *out = c.stats;
+  });
+}
+int ga_context_set_stream(ga_context* ctx, void* hip_stream) {
+  return guard(ctx, [&](Context& c) {
+    GA_HIP(hipStreamSynchronize(c.stream));
+    if (c.ownStream && c.stream) (void)hipStreamDestroy(c.stream);
+    c.stream = (hipStream_t)hip_stream;
+    c.ownStream = false;
+  });
+}
+
+int ga_buffer_create(ga_context* ctx, const float* const* planar, int channels, int64_t frames, int sample_rate, int* out_id) {
+  return guard(ctx, [&](Context& c) {
+    if (!planar || !out_id) fail(GA_ERR_INVALID_ARGUMENT, "null pointer");
+    if (channels < 1 || channels > 32) fail(GA_ERR_OUT_OF_RANGE, "Channel count must be between 1 and 32");
+    if (frames < 0) fail(GA_ERR_OUT_OF_RANGE, "Length must be non-negative");
+    if (sample_rate <= 0) fail(GA_ERR_OUT_OF_RANGE, "Sample rate must be positive");
+    auto b = std::make_unique<PlayBuf>();
+    b->channels = channels;
+    b->length = frames;
+    b->sampleRate = sample_rate;
+    b->stride = (frames + 8 + 63) / 64 * 64;  // a few floats of slack: the resampler window looks back 4 samples
+    b->host.resize(channels);
+    GA_HIP(hipSetDevice(c.device));
+    size_t bytes = (size_t)b->stride * channels * sizeof(float);
+    b->dev = (float*)c.dalloc(bytes);
+    GA_HIP(hipMemsetAsync(b->dev, 0, bytes, c.stream));
+    for (int i = 0; i < channels; i++) {
+      if (!planar[i]) fail(GA_ERR_INVALID_ARGUMENT, "null channel pointer");
+      b->host[i].assign(planar[i], planar[i] + frames);
+      if (frames)
+        GA_HIP(hipMemcpyAsync(b->dev + (size_t)i * b->stride, planar[i], sizeof(float) * frames, hipMemcpyHostToDevice, c.stream));
+    }
+    GA_HIP(hipStreamSynchronize(c.stream));
+    c.buffers.push_back(std::move(b));
+    *out_id = (int)c.buffers.size() - 1;
+  });
+}
+int ga_buffer_release(ga_context* ctx, int buffer_id) {
+  return guard(ctx, [&](Context& c) { (void)c.buffer(buffer_id); });  // storage lives until the context is destroyed
+}
+
+int ga_node_create(ga_context* ctx, int node_type, int* out_id) {
+  return guard(ctx, [&](Context& c) {
+    if (!out_id) fail(GA_ERR_INVALID_ARGUMENT, "null pointer");
+    auto n = std::make_unique<NodeS>();
+    n->id = (int)c.nodes.size();
+    n->type = node_type;
+    const float FMAX = std::numeric_limits<float>::max();
+    switch (node_type) {
+      case GA_NODE_BUFFER_SOURCE:
+        n->outputs.resize(1);
+        n->params.push_back(makeParam(1.f, 0.001f, 1000.f, false));  // AudioBufferSourceNode.cs:76
+        break;
+      case GA_NODE_GAIN:
+        n->inputs.resize(1);
+        n->outputs.resize(1);
+        n->params.push_back(makeParam(1.f, -FMAX, FMAX, true));  // GainNode.cs:21-26
+        break;
+      case GA_NODE_BIQUAD:
+        n->inputs.resize(1);
+        n->outputs.resize(1);
+        n->params.push_back(makeParam(1000.f, 1.f, c.sampleRate / 2.f, true));  // BiQuadFilterNode.cs:63-82
+        n->params.push_back(makeParam(1.f, 0.001f, 1000.f, true));
+        n->params.push_back(makeParam(0.f, -60.f, 60.f, false));
+        c.updateBiquadCoefficients(*n, 1000.f, 1.0f, 0.f);  // constructor call (:84)
+        n->coefDirty = true;
+        break;
+      case GA_NODE_CONVOLVER:
+        n->inputs.resize(1);
+        n->outputs.resize(1);
+        break;
+      default: fail(GA_ERR_INVALID_ARGUMENT, "unknown node type");
+    }
+    *out_id = n->id;
+    c.nodes.push_back(std::move(n));
+  });
+}
+int ga_node_dispose(ga_context* ctx, int node) {
+  return guard(ctx, [&](Context& c) {
+    NodeS* n = c.node(node);
+    if (n->disposed) return;
+    Context* cp = &c;
+    c.executeOrPost([cp, node]() { cp->doDispose(node); });
+  });
+}
+int ga_node_connect(ga_context* ctx, int src, int dst, int output_index, int input_index) {
+  return guard(ctx, [&](Context& c) {
+    c.node(src);
+    c.node(dst);
+    Context* cp = &c;
+    c.executeOrPost([cp, src, dst, output_index, input_index]() {  // DoConnect, Nodes/AudioNode.cs:111-120
+      NodeS* s = cp->nodes[src].get();
+      NodeS* d = cp->nodes[dst].get();
+      if (output_index < 0 || output_index >= (int)s->outputs.size()) fail(GA_ERR_OUT_OF_RANGE, "outputIndex");
+      if (input_index < 0 || input_index >= (int)d->inputs.size()) fail(GA_ERR_OUT_OF_RANGE, "inputIndex");
+      cp->connectTo(src, output_index, InRef{dst, input_index});
+    });
+  });
+}
+int ga_node_disconnect(ga_context* ctx, int src, int dst, int output_index, int input_index) {
+  return guard(ctx, [&](Context& c) {
+    c.node(src);
+    if (dst >= 0) c.node(dst);
+    Context* cp = &c;
+    c.executeOrPost([cp, src, dst, output_index, input_index]() {  // DoDisconnect, Nodes/AudioNode.cs:131-147
+      NodeS* s = cp->nodes[src].get();
+      if (output_index < 0 || output_index >= (int)s->outputs.size()) fail(GA_ERR_OUT_OF_RANGE, "outputIndex");
+      if (dst < 0) {
+        cp->outputDisconnectAll(src, output_index);
+      } else {
+        NodeS* d = cp->nodes[dst].get();
+        if (input_index < 0 || input_index >= (int)d->inputs.size()) fail(GA_ERR_OUT_OF_RANGE, "inputIndex");
+        cp->disconnectFrom(src, output_index, InRef{dst, input_index});
+      }
+    });
+  });
+}
+int ga_node_connect_param(ga_context* ctx, int src, int dst_node, int dst_param, int output_index) {
+  return guard(ctx, [&](Context& c) {
+    NodeS* s = c.node(src);
+    c.param(dst_node, dst_param);
+    if (output_index < 0 || output_index >= (int)s->outputs.size()) fail(GA_ERR_OUT_OF_RANGE, "outputIndex");
+    Context* cp = &c;
+    c.executeOrPost([cp, src, dst_node, dst_param, output_index]() { cp->connectTo(src, output_index, InRef{dst_node, -1 - dst_param}); });
+  });
+}
+int ga_node_disconnect_param(ga_context* ctx, int src, int dst_node, int dst_param, int output_index) {
+  return guard(ctx, [&](Context& c) {
+    NodeS* s = c.node(src);
+    c.param(dst_node, dst_param);
+    if (output_index < 0 || output_index >= (int)s->outputs.size()) fail(GA_ERR_OUT_OF_RANGE, "outputIndex");
+    Context* cp = &c;
+    c.executeOrPost([cp, src, dst_node, dst_param, output_index]() { cp->disconnectFrom(src, output_index, InRef{dst_node, -1 - dst_param}); });
+  });
+}
+int ga_node_has_ended(ga_context* ctx, int node) {
+  int r = 0;
+  int rc = guard(ctx, [&](Context& c) {
+    NodeS* n = c.node(node);
+    r = (n->type == GA_NODE_BUFFER_SOURCE && n->endedRaised) ? 1 : 0;
+  });
+  return rc < 0 ? rc : r;
+}
+
+int ga_input_set_channel_count(ga_context* ctx, int node, int input_index, int count) {
+  return guard(ctx, [&](Context& c) {
+    NodeS* n = c.node(node);
+    if (input_index < 0 || input_index >= (int)n->inputs.size()) fail(GA_ERR_OUT_OF_RANGE, "inputIndex");
+    if (count < 1 || count > 32) fail(GA_ERR_OUT_OF_RANGE, "Channel count must be between 1 and 32");  // AudioNodeInput.cs:43-44
+    n->inputs[input_index].channelCount = count;
+    n->inputs[input_index].dirty = true;
+  });
+}
+int ga_input_set_channel_count_mode(ga_context* ctx, int node, int input_index, int mode) {
+  return guard(ctx, [&](Context& c) {
+    NodeS* n = c.node(node);
+    if (input_index < 0 || input_index >= (int)n->inputs.size()) fail(GA_ERR_OUT_OF_RANGE, "inputIndex");
+    if (mode < 0 || mode > 2) fail(GA_ERR_INVALID_ARGUMENT, "mode");
+    n->inputs[input_index].mode = mode;
+  });
+}
+int ga_input_set_channel_interpretation(ga_context* ctx, int node, int input_index, int interp) {
+  return guard(ctx, [&](Context& c) {
+    NodeS* n = c.node(node);
+    if (input_index < 0 || input_index >= (int)n->inputs.size()) fail(GA_ERR_OUT_OF_RANGE, "inputIndex");
+    n->inputs[input_index].interp = interp;  // stored; MixBuffer ignores it (AudioNodeInput.cs:182-244)
+  });
+}
+int ga_destination_set_channel_count(ga_context* ctx, int channels) {
+  return guard(ctx, [&](Context& c) {
+    if (channels < 1 || channels > 32) fail(GA_ERR_OUT_OF_RANGE, "channels");  // AudioDestinationNode.cs:25-26
+    Context* cp = &c;
+    c.executeOrPost([cp, channels]() {
+      cp->nodes[0]->inputs[0].channelCount = channels;
+      cp->nodes[0]->inputs[0].dirty = true;
+    });
+  });
+}
+int ga_destination_output_channels(ga_context* ctx) {
+  if (!ctx) return GA_ERR_INVALID_ARGUMENT;
+  return ctx->c.destOutCh > 0 ? ctx->c.destOutCh : 2;  // OfflineAudioContext.cs:113-114
+}
+
+int ga_param_set_value(ga_context* ctx, int node, int param, float value) {
+  return guard(ctx, [&](Context& c) {  // Value setter: clamp + cancel all events (AudioParam.cs:37-48)
+    ParamS* p = c.param(node, param);
+    p->value = clampf(value, p->minv, p->maxv);
+    p->events.clear();
+  });
+}
+int ga_param_get_value(ga_context* ctx, int node, int param, float* out) {
+  return guard(ctx, [&](Context& c) {
+    if (!out) fail(GA_ERR_INVALID_ARGUMENT, "null pointer");
+    *out = c.param(node, param)->value;
+  });
+}
+int ga_param_set_value_at_time(ga_context* ctx, int node, int param, float value, double t) {
+  return guard(ctx, [&](Context& c) {  // AudioParam.cs:252-261
+    ParamS* p = c.param(node, param);
+    ParamEvent e{};
+    e.type = 0;
+    e.value = clampf(value, p->minv, p->maxv);
+    e.time = t;
+    addEvent(*p, e);
+  });
+}
+int ga_param_linear_ramp_to_value_at_time(ga_context* ctx, int node, int param, float value, double t) {
+  return guard(ctx, [&](Context& c) {  // AudioParam.cs:266-275
+    ParamS* p = c.param(node, param);
+    ParamEvent e{};
+    e.type = 1;
+    e.value = clampf(value, p->minv, p->maxv);
+    e.time = t;
+    addEvent(*p, e);
+  });
+}
+int ga_param_exponential_ramp_to_value_at_time(ga_context* ctx, int node, int param, float value, double t) {
+  return guard(ctx, [&](Context& c) {  // AudioParam.cs:280-292
+    ParamS* p = c.param(node, param);
+    float v = clampf(value, p->minv, p->maxv);
+    if (v <= 0.f) fail(GA_ERR_INVALID_ARGUMENT, "Exponential ramp target must be > 0");
+    ParamEvent e{};
+    e.type = 2;
+    e.value = v;
+    e.time = t;
+    addEvent(*p, e);
+  });
+}
+int ga_param_set_target_at_time(ga_context* ctx, int node, int param, float target, double t, double tc) {
+  return guard(ctx, [&](Context& c) {  // AudioParam.cs:297-307
+    ParamS* p = c.param(node, param);
+    ParamEvent e{};
+    e.type = 3;
+    e.target = clampf(target, p->minv, p->maxv);
+    e.time = t;
+    e.time_constant = tc;
+    addEvent(*p, e);
+  });
+}
+int ga_param_cancel_scheduled_values(ga_context* ctx, int node, int param, double cancel_time) {
+  return guard(ctx, [&](Context& c) {  // AudioParam.cs:312-331
+    ParamS* p = c.param(node, param);
+    size_t survivors = 0;
+    for (size_t i = 0; i < p->events.size(); i++) {
+      if (p->events[i].time < cancel_time) survivors++; else break;
+    }
+    p->events.resize(survivors);
+  });
+}
+
+int ga_source_set_buffer(ga_context* ctx, int node, int buffer_id) {
+  return guard(ctx, [&](Context& c) {
+    NodeS* n = typed(c, node, GA_NODE_BUFFER_SOURCE);
+    if (buffer_id >= 0) c.buffer(buffer_id);
+    n->bufId = buffer_id < 0 ? -1 : buffer_id;
+  });
+}
+int ga_source_set_loop(ga_context* ctx, int node, int loop, double loop_start, double loop_end) {
+  return guard(ctx, [&](Context& c) {
+    NodeS* n = typed(c, node, GA_NODE_BUFFER_SOURCE);
+    n->loop = loop != 0;
+    n->loopStart = std::max(0.0, loop_start);
+    n->loopEnd = std::max(0.0, loop_end);
+  });
+}
+int ga_source_start(ga_context* ctx, int node, double when, double offset, double duration) {
+  return guard(ctx, [&](Context& c) {
+    typed(c, node, GA_NODE_BUFFER_SOURCE);
+    Context* cp = &c;
+    c.executeOrPost([cp, node, when, offset, duration]() {  // AudioBufferSourceNode.cs:81-111
+      NodeS& s = *cp->nodes[node];
+      if (s.hasStarted) fail(GA_ERR_INVALID_OPERATION, "AudioBufferSourceNode can only be started once.");
+      if (s.bufId < 0) fail(GA_ERR_INVALID_OPERATION, "Cannot start without a buffer set");
+      s.hasStarted = true;
+      s.startTime = std::max(0.0, when);
+      s.offset = std::max(0.0, offset);
+      s.duration = duration;
+      s.playbackPosition = (int64_t)(s.offset * cp->buffers[s.bufId]->sampleRate);
+      s.rsBlocks = 0;
+      if (!(std::isinf(duration) && duration > 0) && duration >= 0) {
+        s.stopTime = s.startTime + duration;
+        s.hasStopped = true;
+      }
+    });
+  });
+}
+int ga_source_stop(ga_context* ctx, int node, double when) {
+  return guard(ctx, [&](Context& c) {
+    typed(c, node, GA_NODE_BUFFER_SOURCE);
+    Context* cp = &c;
+    c.executeOrPost([cp, node, when]() {  // AudioBufferSourceNode.cs:118-126
+      NodeS& s = *cp->nodes[node];
+      if (s.hasStopped) return;
+      double at = std::max(0.0, when);
+      s.stopTime = std::isnan(s.stopTime) ? at : std::min(s.stopTime, at);
+      s.hasStopped = true;
+    });
+  });
+}
+int ga_biquad_set_type(ga_context* ctx, int node, int filter_type) {
+  return guard(ctx, [&](Context& c) {
+    typed(c, node, GA_NODE_BIQUAD);
+    if (filter_type < 0 || filter_type > GA_FILTER_HIGHSHELF) fail(GA_ERR_INVALID_ARGUMENT, "filter type");
+    Context* cp = &c;
+    c.executeOrPost([cp, node, filter_type]() {  // BiQuadFilterNode.cs:24-36
+      NodeS& b = *cp->nodes[node];
+      if (b.filterType != filter_type) {
+        b.filterType = filter_type;
+        b.coefDirty = true;
+      }
+    });
+  });
+}
+int ga_convolver_set_normalize(ga_context* ctx, int node, int normalize) {
+  return guard(ctx, [&](Context& c) { typed(c, node, GA_NODE_CONVOLVER)->normalize = normalize != 0; });
+}
+int ga_convolver_set_enable_true_stereo(ga_context* ctx, int node, int enable) {
+  return guard(ctx, [&](Context& c) { typed(c, node, GA_NODE_CONVOLVER)->enableTrueStereo = enable != 0; });
+}
+int ga_convolver_set_buffer(ga_context* ctx, int node, int buffer_id) {
+  return guard(ctx, [&](Context& c) {  // ConvolverNode.Buffer setter, ConvolverNode.cs:25-79
+    NodeS* n = typed(c, node, GA_NODE_CONVOLVER);
+    Context* cp = &c;
+    if (buffer_id < 0) {
+      c.post([cp, node]() {
+        NodeS& nd = *cp->nodes[node];
+        nd.irBuf = -1;
+        nd.ir.reset();
+        for (auto& r : nd.convRows)
+          if (r.group) r.group->rows[r.idx] = {-1, 0};
+        nd.convRows.clear();
+        nd.effectiveOutCh = 0;
+        nd.isTrueStereo = false;
+        nd.inputs[0].mode = GA_COUNT_MODE_MAX;
+      });
+      return;
+    }
+    PlayBuf* b = c.buffer(buffer_id);
+    if (b->sampleRate != c.sampleRate)
+      fail(GA_ERR_INVALID_OPERATION, "Impulse response buffer sample rate must match the audio context sample rate.");
+    // spectra are built eagerly with the CURRENT Normalize flag (:51-56); the swap is posted (:58-77)
+    std::shared_ptr<IrSpectra> sp = c.irSpectra(buffer_id, n->normalize);
+    c.post([cp, node, buffer_id, sp]() {
+      NodeS& nd = *cp->nodes[node];
+      // new PartitionedConvolver instances: fresh (zero) delay line and overlap
+      for (auto& r : nd.convRows)
+        if (r.group) r.group->rows[r.idx] = {-1, 0};
+      nd.convRows.clear();
+      nd.irBuf = buffer_id;
+      nd.ir = sp;
+      int channels = sp->nch;
+      nd.isTrueStereo = (channels == 4 && nd.enableTrueStereo);
+      nd.effectiveOutCh = nd.isTrueStereo ? 2 : channels;
+      nd.inputs[0].channelCount = nd.isTrueStereo ? 2 : channels;
+      nd.inputs[0].dirty = true;
+      nd.inputs[0].mode = GA_COUNT_MODE_EXPLICIT;
+      for (int ch = 0; ch < channels; ch++) {
+        auto key = std::make_pair(sp.get(), ch);
+        ConvGroup* g;
+        auto it = cp->groupOf.find(key);
+        if (it == cp->groupOf.end()) {
+          auto ng = std::make_unique<ConvGroup>();
+          ng->ir = sp;
+          ng->irCh = ch;
+          ng->P = sp->P;
+          g = ng.get();
+          cp->groups.push_back(std::move(ng));
+          cp->groupOf[key] = g;
+        } else {
+          g = it->second;
+        }
+        // rows are append-only while a group holds live state: a freed row would need its delay line cleared
+        int idx = (int)g->rows.size();
+        g->rows.push_back({node, ch});
+        if (idx < g->rp && g->histR) {  // the column may hold stale scratch data: a new convolver starts from zero state
+          const int hist = g->P - 1;
+          if (hist > 0) {
+            GA_HIP(hipMemset2DAsync(g->histR + idx, (size_t)g->rp * 4, 0, 4, (size_t)kBins * hist, cp->stream));
+            GA_HIP(hipMemset2DAsync(g->histI + idx, (size_t)g->rp * 4, 0, 4, (size_t)kBins * hist, cp->stream));
+          }
+          GA_HIP(hipMemsetAsync(g->overlap[0] + (size_t)idx * kBlock, 0, kBlock * 4, cp->stream));
+          GA_HIP(hipMemsetAsync(g->overlap[1] + (size_t)idx * kBlock, 0, kBlock * 4, cp->stream));
+        }
+        nd.convRows.push_back(ConvRowRef{g, idx});
+      }
+    });
+  });
+}
+
+int ga_render(ga_context* ctx, float* const* out_planar, int out_channels, int64_t frame_count, int64_t start_index) {
+  return guard(ctx, [&](Context& c) { c.render(out_planar, out_channels, frame_count, start_index, false); });
+}
+int ga_render_device(ga_context* ctx, float* const* out_planar_dev, int out_channels, int64_t frame_count, int64_t start_index) {
+  return guard(ctx, [&](Context& c) { c.render(out_planar_dev, out_channels, frame_count, start_index, true); });
+}
+
+}  // extern "C"

@@ -1,0 +1,1211 @@
+// ga_chunk.cpp -- control-plane simulation and the per-chunk device executor (see ga_engine.hpp).
+#include <algorithm>
+#include <array>
+#include <cstring>
+#include <unordered_map>
+
+#include "ga_engine.hpp"
+
+namespace ga {
+
+static inline uint64_t hmix(uint64_t h, uint64_t v) {
+  h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+  return h;
+}
+static inline int64_t roundup(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+// ======================================================================================================
+// job tables: built on the host while planning, uploaded once, then every recorded launch runs in order
+// ======================================================================================================
+enum LaunchKind { LK_OTHER = 0, LK_FFT = 1, LK_MAC = 2 };
+struct Plan {
+  std::vector<uint8_t> host;
+  struct L {
+    std::function<void(uint8_t*)> fn;
+    int kind;
+  };
+  std::vector<L> launches;
+  size_t put(const void* p, size_t bytes) {
+    size_t off = (host.size() + 15) & ~(size_t)15;
+    host.resize(off + bytes);
+    if (bytes) std::memcpy(&host[off], p, bytes);
+    return off;
+  }
+  template <class T>
+  size_t putv(const std::vector<T>& v) {
+    return put(v.data(), v.size() * sizeof(T));
+  }
+  void add(int kind, std::function<void(uint8_t*)> fn) { launches.push_back(L{std::move(fn), kind}); }
+};
+
+// ======================================================================================================
+// slabs: chunk-frame indexed float arrays handed to node outputs / mixed inputs for the duration of a chunk
+// ======================================================================================================
+static float* getSlab(Context& c) {
+  if (c.slabFree.empty()) {
+    size_t slabBytes = (size_t)c.slabFrames * sizeof(float);
+    size_t count = std::max<size_t>(8, std::min<size_t>(1024, ((size_t)1 << 30) / slabBytes));
+    char* blk = (char*)c.dalloc(slabBytes * count);
+    c.slabBlocks.push_back(blk);
+    for (size_t i = 0; i < count; i++) {
+      float* p = (float*)(blk + i * slabBytes);
+      c.slabAll.push_back(p);
+      c.slabFree.push_back(p);
+    }
+  }
+  float* p = c.slabFree.back();
+  c.slabFree.pop_back();
+  return p;
+}
+static void resetSlabs(Context& c, int64_t frames) {
+  int64_t need = roundup(frames, 256);
+  if (need > c.slabFrames) {
+    GA_HIP(hipStreamSynchronize(c.stream));
+    size_t oldBytes = (size_t)c.slabFrames * sizeof(float);
+    size_t perBlock = oldBytes ? std::max<size_t>(8, std::min<size_t>(1024, ((size_t)1 << 30) / oldBytes)) : 0;
+    for (void* p : c.slabBlocks) c.dfree(p, oldBytes * perBlock);
+    c.slabBlocks.clear();
+    c.slabAll.clear();
+    c.slabFrames = need;
+  }
+  c.slabFree = c.slabAll;
+}
+
+// ======================================================================================================
+// source scheduling (AudioBufferSourceNode.Process control flow, AudioBufferSourceNode.cs:131-389) as a per-chunk
+// timeline of phases.  bt[i] = block start times, bt[i+1] = t1 of block i (AudioContextBase.cs:78-79).
+// ======================================================================================================
+struct SrcGeom {
+  int64_t loopStartFrame, loopEndFrame, durationEndFrame;
+  double effectiveRate;
+};
+static SrcGeom sourceGeom(Context& c, NodeS& s, PlayBuf& b) {
+  SrcGeom g;
+  float playbackRate = s.params[0].value;  // k-rate, no automation on the device path yet
+  double sampleRateRatio = b.sampleRate / (double)c.sampleRate;
+  g.effectiveRate = sampleRateRatio * playbackRate;
+  g.loopStartFrame = (int64_t)(s.loopStart * b.sampleRate);
+  g.loopEndFrame = s.loopEnd > 0 ? (int64_t)(s.loopEnd * b.sampleRate) : b.length;
+  g.loopEndFrame = std::min(g.loopEndFrame, b.length);
+  g.loopStartFrame = std::min(g.loopStartFrame, g.loopEndFrame);
+  g.durationEndFrame = s.duration < std::numeric_limits<double>::infinity()
+                           ? (int64_t)(s.offset * b.sampleRate) + (int64_t)(s.duration * b.sampleRate)
+                           : b.length;
+  g.durationEndFrame = std::min(g.durationEndFrame, b.length);
+  return g;
+}
+
+static Resampler& resamplerFor(Context& c, double rate) {
+  uint64_t key;
+  std::memcpy(&key, &rate, 8);
+  auto it = c.resamplers.find(key);
+  if (it == c.resamplers.end()) {
+    auto r = std::make_unique<Resampler>();
+    r->rate = rate;
+    it = c.resamplers.emplace(key, std::move(r)).first;
+  }
+  return *it->second;
+}
+
+// bounded replay of ONE block of CubicResampler.Process (CubicResampler.cs:26-63) from a trajectory state
+static void resampleBlockBounded(const ResampleBlock& st, double rate, int64_t avail, int& produced, int64_t& consumedAfter) {
+  int64_t in = st.consumed;
+  double Pos = st.pos;
+  int ready = st.ready;
+  while (ready < 4 && in < avail) {
+    in++;
+    ready++;
+  }
+  produced = 0;
+  if (ready == 4) {
+    while (produced < kBlock) {
+      int consume = (int)Pos;
+      if (in + consume > avail) break;
+      in += consume;
+      Pos -= consume;
+      produced++;
+      Pos += rate;
+    }
+  }
+  consumedAfter = in;
+}
+
+struct SrcPlanOut {
+  int64_t playedBlocks = 0;  // PLAY + END blocks inside the chunk (advance of the node's state)
+  bool reachedEnd = false;   // an END block with stopTime NaN was reached (stopTime := t1)
+  int64_t endBlock = -1;
+  bool gone = false;         // Ended raised + Dispose queued inside the chunk
+  int64_t goneAt = -1;       // first block at which the node is disconnected
+  int64_t partialBlock = -1; // resampler: block with fewer than 128 outputs
+  int partialProduced = 0;
+};
+
+static SrcPlanOut planSource(Context& c, NodeS& s, int64_t n, const std::vector<double>& bt) {
+  SrcPlanOut po;
+  s.spans.clear();
+  PlayBuf* b = s.bufId >= 0 ? c.buffers[s.bufId].get() : nullptr;
+  if (!s.hasStarted || !b || s.disposed) {
+    s.spans.push_back(SrcSpan{0, SRC_IDLE, 0, 0});
+    return po;
+  }
+  // first block with t1 > startTime
+  int64_t bs = std::upper_bound(bt.begin() + 1, bt.begin() + 1 + n, s.startTime) - (bt.begin() + 1);
+  if (bs >= n || (!std::isnan(s.stopTime) && !(bt[bs] < s.stopTime))) {
+    s.spans.push_back(SrcSpan{0, SRC_IDLE, 0, 0});
+    return po;
+  }
+  if (bs > 0) s.spans.push_back(SrcSpan{0, SRC_IDLE, 0, 0});
+  SrcGeom g = sourceGeom(c, s, *b);
+  const int64_t INF = std::numeric_limits<int64_t>::max() / 4;
+  // kTime: relative index of the block after which Ended is raised because t1 >= stopTime
+  int64_t kTime = INF;
+  if (!std::isnan(s.stopTime)) {
+    int64_t kb = std::lower_bound(bt.begin() + 1 + bs, bt.begin() + 1 + n, s.stopTime) - (bt.begin() + 1 + bs);
+    kTime = kb;  // may be >= n - bs: not inside this chunk
+  }
+  // kData: relative index of the first END (cleared) block
+  int64_t kData = INF;
+  const bool rate1 = g.effectiveRate == 1.0;
+  int64_t pos = s.playbackPosition;
+  if (s.loop) {
+    if (!rate1) fail(GA_ERR_UNSUPPORTED, "looping playback with resampling is not on the device path yet");
+    int64_t loopLen = g.loopEndFrame - g.loopStartFrame;
+    if (loopLen <= 0) kData = 0;  // available <= 0 on the first iteration: hasMoreData stays false
+  } else if (rate1) {
+    int64_t rem = g.durationEndFrame - pos;
+    kData = rem <= 0 ? 0 : (rem + kBlock - 1) / kBlock - 1;
+  } else {
+    Resampler& rs = resamplerFor(c, g.effectiveRate);
+    if (s.rsBlocks == 0) s.rsStartPos = pos;
+    int64_t avail = g.durationEndFrame - s.rsStartPos;
+    int64_t need = s.rsBlocks + (n - bs) + 2;
+    rs.extend(need + 1);
+    // first trajectory block whose unbounded consumption would exceed the available input
+    int64_t jx = s.rsBlocks;
+    {
+      int64_t lo = s.rsBlocks, hi = need - 1;  // consumed at the END of block j = blocks[j+1].consumed
+      while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (rs.blocks[mid + 1].consumed > avail) hi = mid; else lo = mid + 1;
+      }
+      jx = (rs.blocks[lo + 1].consumed > avail) ? lo : INF;
+    }
+    if (avail <= 0) {
+      kData = 0;
+    } else if (jx != INF) {
+      int produced;
+      int64_t consumedAfter;
+      resampleBlockBounded(rs.blocks[jx], g.effectiveRate, avail, produced, consumedAfter);
+      if (produced == 0 || consumedAfter >= avail) {
+        kData = jx - s.rsBlocks;
+      } else {
+        kData = jx - s.rsBlocks + 1;
+        po.partialBlock = bs + (jx - s.rsBlocks);
+        po.partialProduced = produced;
+      }
+    }
+  }
+  // blocks [0, min(kData, kTime+1)) PLAY ; [kData, kTime] END ; gone after min(kTime, kData if stopTime was NaN)
+  int64_t kGone;  // relative index of the last processed block (Ended raised after it)
+  if (std::isnan(s.stopTime)) kGone = kData; else kGone = std::max(kTime, (int64_t)-1);
+  if (!std::isnan(s.stopTime) && kTime == INF) kGone = INF;
+  int64_t playEnd = std::min(kData, kGone == INF ? INF : kGone + 1);  // exclusive
+  int64_t rel = 0;
+  if (playEnd > 0) {
+    s.spans.push_back(SrcSpan{bs, SRC_PLAY, pos, s.rsBlocks});
+    rel = playEnd;
+  }
+  if (kData < (kGone == INF ? INF : kGone + 1) && bs + kData < n) {
+    s.spans.push_back(SrcSpan{bs + kData, SRC_END, pos + kData * kBlock, s.rsBlocks + kData});
+    if (std::isnan(s.stopTime)) {
+      po.reachedEnd = true;
+      po.endBlock = bs + kData;
+    }
+  }
+  (void)rel;
+  if (kGone != INF && bs + kGone + 1 <= n) {
+    po.gone = true;
+    po.goneAt = bs + kGone + 1;
+    if (po.goneAt < n) s.spans.push_back(SrcSpan{po.goneAt, SRC_GONE, 0, 0});
+  }
+  int64_t lastProcessed = std::min<int64_t>(n, kGone == INF ? n : bs + kGone + 1);
+  po.playedBlocks = lastProcessed - bs;
+  // drop spans starting at or beyond the chunk end
+  while (!s.spans.empty() && s.spans.back().b0 >= n) s.spans.pop_back();
+  if (po.partialBlock >= n) po.partialBlock = -1;
+  return po;
+}
+
+static const SrcSpan& spanAt(const NodeS& s, int64_t b) {
+  size_t i = s.spans.size() - 1;
+  while (i > 0 && s.spans[i].b0 > b) i--;
+  return s.spans[i];
+}
+
+// ======================================================================================================
+// control-plane simulation
+// ======================================================================================================
+struct Sim {
+  Context& c;
+  int64_t n;
+  int64_t blockNumber = 0;
+  Segment* cur = nullptr;
+  int64_t brel = 0;
+
+  int computeOutputChannelCount(InputS& in) {  // AudioNodeInput.cs:140-168
+    switch (in.mode) {
+      case GA_COUNT_MODE_EXPLICIT: return in.channelCount;
+      case GA_COUNT_MODE_CLAMPED_MAX: {
+        int mx = 0;
+        for (const Conn& cn : in.connected) {
+          int ch = c.nodes[cn.node]->outputs[cn.out].bufCh;
+          if (ch) mx = std::max(mx, ch);
+        }
+        return std::min(mx == 0 ? in.channelCount : mx, in.channelCount);
+      }
+      default: {
+        int mx = in.channelCount;
+        for (const Conn& cn : in.connected) {
+          int ch = c.nodes[cn.node]->outputs[cn.out].bufCh;
+          if (ch) mx = std::max(mx, ch);
+        }
+        return mx;
+      }
+    }
+  }
+
+  void pull(NodeS& n_, int i, InSeg& is) {  // AudioNodeInput.Pull, AudioNodeInput.cs:100-138
+    InputS& in = n_.inputs[i];
+    if (in.connected.empty()) {
+      in.bufCh = in.channelCount;
+      in.dirty = false;
+      in.silent = true;
+      is.bufCh = in.bufCh;
+      is.silent = true;
+      return;
+    }
+    int outCh = computeOutputChannelCount(in);
+    in.dirty = false;
+    in.bufCh = outCh;
+    bool mixed = false;
+    for (size_t k = 0; k < in.connected.size(); k++) {
+      Conn cn = in.connected[k];
+      evalNode(cn.node);
+      OutputS& o = c.nodes[cn.node]->outputs[cn.out];
+      if (o.bufCh != 0 && !o.silent) {
+        is.terms.push_back(TermS{cn.node, cn.out, o.bufCh});
+        mixed = true;
+      }
+    }
+    in.silent = !mixed;
+    is.bufCh = in.bufCh;
+    is.silent = in.silent;
+  }
+
+  void evalNode(int id) {  // AudioNode.ProcessInternal, Nodes/AudioNode.cs:152-183
+    NodeS& n_ = *c.nodes[id];
+    if (n_.lastProcessedBlock == blockNumber) return;
+    if (n_.isProcessing) fail(GA_ERR_CYCLE, "Audio graph cycle detected at node " + std::to_string(id));
+    n_.isProcessing = true;
+    n_.lastProcessedBlock = blockNumber;
+    NodeSeg ns;
+    ns.id = id;
+    ns.ins.resize(n_.inputs.size());
+    for (int i = 0; i < (int)n_.inputs.size(); i++) pull(n_, i, ns.ins[i]);
+    process(n_, ns);
+    n_.isProcessing = false;
+    cur->nodes.push_back(std::move(ns));
+  }
+
+  void process(NodeS& n_, NodeSeg& ns) {
+    switch (n_.type) {
+      case GA_NODE_DESTINATION:  // AudioDestinationNode.cs:42-64
+        ns.outCh = ns.ins[0].bufCh;
+        ns.outSilent = ns.ins[0].silent;
+        c.destOutCh = ns.outCh;
+        break;
+      case GA_NODE_GAIN:  // GainNode.cs:29-61
+        n_.outputs[0].bufCh = ns.ins[0].bufCh;
+        n_.outputs[0].silent = ns.ins[0].silent;
+        break;
+      case GA_NODE_BIQUAD: {  // BiQuadFilterNode.cs:87-147
+        n_.outputs[0].bufCh = ns.ins[0].bufCh;
+        n_.outputs[0].silent = ns.ins[0].silent;
+        if (!ns.ins[0].silent) {
+          float nyq = c.sampleRate / 2.f;
+          float f = n_.params[0].value;
+          f = f < 1.f ? 1.f : (f > nyq ? nyq : f);
+          float q = std::max(0.001f, n_.params[1].value);
+          float gainDb = n_.params[2].value;
+          // usedFreq/usedQ start every block at 1000 / 1.0 (_lastFrequency/_lastQ are never updated, :13-14,111-112)
+          if (n_.coefDirty || std::fabs(f - 1000.f) > 0.001f || std::fabs(q - 1.0f) > 0.0001f) {
+            c.updateBiquadCoefficients(n_, f, q, gainDb);
+            n_.coefDirty = false;
+          }
+          ns.bqActive = true;
+          ns.b0 = n_.b0; ns.b1 = n_.b1; ns.b2 = n_.b2; ns.a1 = n_.a1; ns.a2 = n_.a2;
+        }
+        break;
+      }
+      case GA_NODE_CONVOLVER:  // ConvolverNode.cs:102-155
+        if (!n_.ir) {
+          n_.outputs[0].bufCh = ns.ins[0].bufCh;
+          n_.outputs[0].silent = true;
+        } else {
+          n_.outputs[0].bufCh = n_.effectiveOutCh;
+          n_.outputs[0].silent = false;  // MarkAsNonSilent even for silent input (:153)
+        }
+        break;
+      case GA_NODE_BUFFER_SOURCE: {
+        const SrcSpan& sp = spanAt(n_, brel);
+        PlayBuf* b = n_.bufId >= 0 ? c.buffers[n_.bufId].get() : nullptr;
+        ns.srcPhase = sp.phase;
+        ns.srcBuf = n_.bufId;
+        if (sp.phase == SRC_PLAY && b) {
+          n_.outputs[0].bufCh = b->channels;
+          n_.outputs[0].silent = false;
+          ns.srcPos = sp.pos + (brel - sp.b0) * kBlock;
+          ns.srcBlk = sp.blkIdx + (brel - sp.b0);
+        } else if (sp.phase == SRC_END && b) {  // whole block cleared (:360-368)
+          n_.outputs[0].bufCh = b->channels;
+          n_.outputs[0].silent = true;
+        } else {  // ProduceSilence: 1-channel silent buffer (:391-402)
+          n_.outputs[0].bufCh = 1;
+          n_.outputs[0].silent = true;
+        }
+        break;
+      }
+      default: fail(GA_ERR_UNSUPPORTED, "node type not supported on the device path");
+    }
+    if (!n_.outputs.empty()) {
+      ns.outCh = n_.outputs[0].bufCh;
+      ns.outSilent = n_.outputs[0].silent;
+    }
+  }
+
+  uint64_t hashSeg(const Segment& s) {
+    uint64_t h = 1469598103934665603ull;
+    for (const NodeSeg& ns : s.nodes) {
+      h = hmix(h, (uint64_t)ns.id);
+      h = hmix(h, ((uint64_t)ns.outCh << 8) | (ns.outSilent ? 1 : 0) | ((uint64_t)ns.srcPhase << 4) | (ns.bqActive ? 2 : 0));
+      for (const InSeg& is : ns.ins) {
+        h = hmix(h, ((uint64_t)is.bufCh << 1) | (is.silent ? 1 : 0));
+        for (const TermS& t : is.terms) h = hmix(h, ((uint64_t)t.node << 16) | ((uint64_t)t.out << 8) | (uint64_t)t.ch);
+      }
+    }
+    return h;
+  }
+};
+
+// ======================================================================================================
+// executor
+// ======================================================================================================
+struct Exec {
+  Context& c;
+  int64_t n, frames;
+  Plan plan;
+  std::vector<Segment>& segs;
+  std::unordered_map<uint64_t, float*> nodeSlab, inSlab;
+  std::vector<std::vector<std::vector<const float*>>> outViews;  // [segment][node][channel]
+  // per (level) batch tables
+  std::vector<const float*> terms;
+  std::vector<MixJob> mixJobs;
+  std::vector<DownmixJob> dmJobs;
+  std::vector<GainJob> gainJobs;
+  std::vector<BiquadJob> bqJobs;
+  std::vector<LoopJob> loopJobs;
+  std::vector<ResampleJob> rsJobs;
+  std::vector<ResampleBlock> traj;  // per-chunk trajectory table (all rates + custom tail blocks)
+  bool mixAligned = true;
+  // conv inputs: node -> slot -> per segment view
+  std::unordered_map<int, std::vector<std::vector<const float*>>> convIn;
+
+  Exec(Context& c_, int64_t n_, std::vector<Segment>& s) : c(c_), n(n_), frames(n_ * kBlock), segs(s) {}
+
+  float* slabFor(std::unordered_map<uint64_t, float*>& m, uint64_t key) {
+    auto it = m.find(key);
+    if (it != m.end()) return it->second;
+    float* p = getSlab(c);
+    m[key] = p;
+    return p;
+  }
+  float* nodeOut(int node, int ch) { return slabFor(nodeSlab, ((uint64_t)node << 8) | (uint64_t)ch); }
+  float* inMixed(int node, int input, int ch) { return slabFor(inSlab, ((uint64_t)node << 16) | ((uint64_t)input << 8) | (uint64_t)ch); }
+
+  void noteAlign(const float* p, int64_t f0) {
+    if (((uintptr_t)(p + f0)) & 15) mixAligned = false;
+  }
+
+  // AudioNodeInput.Pull + MixBuffer (AudioNodeInput.cs:100-138,182-244) for one input over one segment
+  std::vector<const float*> resolveInput(int si, const NodeSeg& ns, int i, bool force, float* const* forcedSlabs) {
+    const Segment& sg = segs[si];
+    const InSeg& is = ns.ins[i];
+    const int dstCh = is.bufCh;
+    const int64_t f0 = sg.b0 * kBlock, nf = (sg.b1 - sg.b0) * kBlock;
+    std::vector<std::vector<const float*>> lists(dstCh);
+    for (const TermS& t : is.terms) {
+      const auto& uv = outViews[si][t.node];
+      const int srcCh = t.ch;
+      if (srcCh == dstCh) {
+        for (int ch = 0; ch < dstCh; ch++)
+          if (uv[ch]) lists[ch].push_back(uv[ch]);
+      } else if (srcCh == 1 && dstCh > 1) {
+        if (uv[0])
+          for (int ch = 0; ch < dstCh; ch++) lists[ch].push_back(uv[0]);
+      } else if (srcCh > 1 && dstCh == 1) {
+        // (sum over channels) * 1/sqrt(N), AudioNodeInput.cs:214-228
+        DownmixJob dj;
+        dj.out = getSlab(c);
+        dj.term0 = (int)terms.size();
+        dj.nch = srcCh;
+        dj.scale = 1.0f / std::sqrt((float)srcCh);
+        dj.f0 = f0;
+        dj.n = nf;
+        for (int ch = 0; ch < srcCh; ch++) terms.push_back(uv[ch] ? uv[ch] : c.zeros);
+        dmJobs.push_back(dj);
+        lists[0].push_back(dj.out);
+      } else {
+        int m = std::min(srcCh, dstCh);
+        for (int ch = 0; ch < m; ch++)
+          if (uv[ch]) lists[ch].push_back(uv[ch]);
+      }
+    }
+    std::vector<const float*> views(dstCh, nullptr);
+    for (int ch = 0; ch < dstCh; ch++) {
+      auto& l = lists[ch];
+      if (!force) {
+        if (l.empty()) continue;
+        if (l.size() == 1) {
+          views[ch] = l[0];
+          continue;
+        }
+      }
+      float* out = forcedSlabs ? forcedSlabs[ch] : inMixed(ns.id, i, ch);
+      if (!out) continue;
+      MixJob mj;
+      mj.out = out;
+      mj.term0 = (int)terms.size();
+      mj.nterms = (int)l.size();
+      mj.f0 = f0;
+      mj.n = nf;
+      for (const float* p : l) {
+        terms.push_back(p);
+        noteAlign(p, f0);
+      }
+      noteAlign(out, f0);
+      mixJobs.push_back(mj);
+      views[ch] = out;
+    }
+    return views;
+  }
+
+  void flushLevel() {
+    // order: down-mix -> mix -> sources -> gain -> biquad (everything in one level is independent)
+    size_t termsOff = plan.putv(terms);
+    if (!dmJobs.empty()) {
+      size_t off = plan.putv(dmJobs);
+      int nj = (int)dmJobs.size();
+      int64_t mx = 0;
+      for (auto& j : dmJobs) mx = std::max(mx, j.n);
+      hipStream_t st = c.stream;
+      plan.add(LK_OTHER, [=](uint8_t* base) {
+        launch_downmix(st, (const DownmixJob*)(base + off), nj, (const float* const*)(base + termsOff), mx);
+      });
+    }
+    if (!mixJobs.empty()) {
+      size_t off = plan.putv(mixJobs);
+      int nj = (int)mixJobs.size();
+      int64_t mx = 0;
+      for (auto& j : mixJobs) mx = std::max(mx, j.n);
+      bool v4 = mixAligned;
+      hipStream_t st = c.stream;
+      plan.add(LK_OTHER, [=](uint8_t* base) {
+        launch_mix(st, (const MixJob*)(base + off), nj, (const float* const*)(base + termsOff), mx, v4);
+      });
+    }
+    if (!loopJobs.empty()) {
+      size_t off = plan.putv(loopJobs);
+      int nj = (int)loopJobs.size();
+      int64_t mx = 0;
+      for (auto& j : loopJobs) mx = std::max(mx, j.n);
+      hipStream_t st = c.stream;
+      plan.add(LK_OTHER, [=](uint8_t* base) { launch_loop_source(st, (const LoopJob*)(base + off), nj, mx); });
+    }
+    if (!rsJobs.empty()) {
+      size_t off = plan.putv(rsJobs);
+      int nj = (int)rsJobs.size();
+      int64_t mx = 0;
+      for (auto& j : rsJobs) mx = std::max(mx, j.nblocks);
+      hipStream_t st = c.stream;
+      rsLaunches.push_back(RsLaunch{off, nj, mx});
+      plan.add(LK_OTHER, [this, st, idx = rsLaunches.size() - 1](uint8_t* base) {
+        const RsLaunch& r = rsLaunches[idx];
+        launch_resample(st, (const ResampleJob*)(base + r.off), r.nj, (const ResampleBlock*)(base + trajOffFinal), r.mx);
+      });
+    }
+    if (!gainJobs.empty()) {
+      size_t off = plan.putv(gainJobs);
+      int nj = (int)gainJobs.size();
+      int64_t mx = 0;
+      for (auto& j : gainJobs) mx = std::max(mx, j.n);
+      hipStream_t st = c.stream;
+      plan.add(LK_OTHER, [=](uint8_t* base) { launch_gain(st, (const GainJob*)(base + off), nj, mx); });
+    }
+    if (!bqJobs.empty()) {
+      size_t off = plan.putv(bqJobs);
+      int nj = (int)bqJobs.size();
+      hipStream_t st = c.stream;
+      plan.add(LK_OTHER, [=](uint8_t* base) { launch_biquad(st, (const BiquadJob*)(base + off), nj); });
+    }
+    terms.clear();
+    mixJobs.clear();
+    dmJobs.clear();
+    gainJobs.clear();
+    bqJobs.clear();
+    loopJobs.clear();
+    rsJobs.clear();
+    mixAligned = true;
+  }
+  struct RsLaunch {
+    size_t off;
+    int nj;
+    int64_t mx;
+  };
+  std::vector<RsLaunch> rsLaunches;
+  size_t trajOffFinal = 0;
+};
+
+// ======================================================================================================
+// convolver rows <-> groups
+// ======================================================================================================
+static ConvGroup* groupFor(Context& c, const std::shared_ptr<IrSpectra>& ir, int ch) {
+  auto key = std::make_pair(ir.get(), ch);
+  auto it = c.groupOf.find(key);
+  if (it != c.groupOf.end()) return it->second;
+  auto g = std::make_unique<ConvGroup>();
+  g->ir = ir;
+  g->irCh = ch;
+  g->P = ir->P;
+  ConvGroup* gp = g.get();
+  c.groups.push_back(std::move(g));
+  c.groupOf[key] = gp;
+  return gp;
+}
+
+// make sure the group's state arrays cover all rows; new rows start from zero state
+static void ensureGroupState(Context& c, ConvGroup& g) {
+  int need = (int)roundup(std::max<size_t>(g.rows.size(), 1), 128);
+  if (need <= g.rp) return;
+  const int hist = g.P - 1;
+  size_t hBytes = (size_t)kBins * std::max(hist, 1) * need * sizeof(float);
+  size_t oBytes = (size_t)need * kBlock * sizeof(float);
+  float* nr = (float*)c.dalloc(hBytes);
+  float* ni = (float*)c.dalloc(hBytes);
+  float* o0 = (float*)c.dalloc(oBytes);
+  float* o1 = (float*)c.dalloc(oBytes);
+  GA_HIP(hipMemsetAsync(nr, 0, hBytes, c.stream));
+  GA_HIP(hipMemsetAsync(ni, 0, hBytes, c.stream));
+  GA_HIP(hipMemsetAsync(o0, 0, oBytes, c.stream));
+  GA_HIP(hipMemsetAsync(o1, 0, oBytes, c.stream));
+  if (g.rp > 0) {
+    if (hist > 0 && !g.histZero) {
+      GA_HIP(hipMemcpy2DAsync(nr, (size_t)need * 4, g.histR, (size_t)g.rp * 4, (size_t)g.rp * 4, (size_t)kBins * hist,
+                              hipMemcpyDeviceToDevice, c.stream));
+      GA_HIP(hipMemcpy2DAsync(ni, (size_t)need * 4, g.histI, (size_t)g.rp * 4, (size_t)g.rp * 4, (size_t)kBins * hist,
+                              hipMemcpyDeviceToDevice, c.stream));
+    }
+    GA_HIP(hipMemcpyAsync(o0, g.overlap[g.ovCur], (size_t)g.rp * kBlock * 4, hipMemcpyDeviceToDevice, c.stream));
+    GA_HIP(hipStreamSynchronize(c.stream));
+    size_t oldH = (size_t)kBins * std::max(hist, 1) * g.rp * sizeof(float);
+    c.dfree(g.histR, oldH);
+    c.dfree(g.histI, oldH);
+    c.dfree(g.overlap[0], (size_t)g.rp * kBlock * 4);
+    c.dfree(g.overlap[1], (size_t)g.rp * kBlock * 4);
+  }
+  g.histR = nr;
+  g.histI = ni;
+  g.overlap[0] = o0;
+  g.overlap[1] = o1;
+  g.ovCur = 0;
+  g.rp = need;
+}
+
+// ======================================================================================================
+// runChunk
+// ======================================================================================================
+void Context::runChunk(int64_t n, float* const* /*unused*/) {
+  GA_HIP(hipSetDevice(device));
+  if (disposed) fail(GA_ERR_DISPOSED, "context disposed");
+  drain();  // AudioContextBase.cs:57
+  latched = true;
+
+  // ---- reachability, level, convolver depth on the graph as it stands after the queued commands ----
+  for (auto& np : nodes) {
+    np->reachable = false;
+    np->isProcessing = false;
+    np->level = 0;
+    np->depth = 0;
+  }
+  std::vector<int> topo;
+  {
+    std::vector<int> color(nodes.size(), 0);
+    std::function<void(int)> dfs = [&](int id) {
+      if (color[id] == 2) return;
+      if (color[id] == 1) fail(GA_ERR_CYCLE, "Audio graph cycle detected at node " + std::to_string(id));
+      color[id] = 1;
+      NodeS& nd = *nodes[id];
+      nd.reachable = true;
+      for (auto& p : nd.params)
+        if (!p.modulation.empty())
+          fail(GA_ERR_UNSUPPORTED, "audio-rate AudioParam modulation is not on the device path yet");
+      int lvl = 0, dep = 0;
+      for (auto& in : nd.inputs)
+        for (const Conn& cn : in.connected) {
+          dfs(cn.node);
+          NodeS& up = *nodes[cn.node];
+          lvl = std::max(lvl, up.level + 1);
+          dep = std::max(dep, up.depth + ((up.type == GA_NODE_CONVOLVER && up.ir) ? 1 : 0));
+        }
+      nd.level = lvl;
+      nd.depth = dep;
+      color[id] = 2;
+      topo.push_back(id);
+    };
+    dfs(0);
+  }
+  int maxDepth = 0, maxLevel = 0;
+  for (int id : topo) {
+    maxDepth = std::max(maxDepth, nodes[id]->depth);
+    maxLevel = std::max(maxLevel, nodes[id]->level);
+    NodeS& nd = *nodes[id];
+    if (nd.type == GA_NODE_BUFFER_SOURCE && !nd.params[0].events.empty())
+      fail(GA_ERR_UNSUPPORTED, "playbackRate automation is not on the device path yet");
+    if (nd.type == GA_NODE_BIQUAD)
+      for (auto& p : nd.params)
+        if (!p.events.empty()) fail(GA_ERR_UNSUPPORTED, "BiQuadFilterNode parameter automation is not on the device path yet");
+  }
+
+  // ---- block clock (accumulated, AudioContextBase.cs:78-79) ----
+  std::vector<double> bt(n + 1);
+  bt[0] = currentTime;
+  const double increment = (double)kBlock / sampleRate;
+  for (int64_t i = 0; i < n; i++) bt[i + 1] = bt[i] + increment;
+
+  // ---- plan sources ----
+  std::vector<int> srcIds;
+  std::vector<SrcPlanOut> srcPlans;
+  std::vector<int64_t> breaks;
+  for (int id : topo) {
+    NodeS& nd = *nodes[id];
+    if (nd.type != GA_NODE_BUFFER_SOURCE) continue;
+    srcIds.push_back(id);
+    srcPlans.push_back(planSource(*this, nd, n, bt));
+    for (const SrcSpan& sp : nd.spans)
+      if (sp.b0 > 0 && sp.b0 < n) breaks.push_back(sp.b0);
+    if (srcPlans.back().partialBlock >= 0) {
+      breaks.push_back(srcPlans.back().partialBlock);
+      if (srcPlans.back().partialBlock + 1 < n) breaks.push_back(srcPlans.back().partialBlock + 1);
+    }
+  }
+  std::sort(breaks.begin(), breaks.end());
+  breaks.erase(std::unique(breaks.begin(), breaks.end()), breaks.end());
+  std::unordered_map<int64_t, std::vector<int>> goneAt;
+  for (size_t i = 0; i < srcIds.size(); i++)
+    if (srcPlans[i].gone && srcPlans[i].goneAt < n) goneAt[srcPlans[i].goneAt].push_back(srcIds[i]);
+
+  // ---- simulate ----
+  std::vector<Segment> segs;
+  Sim sim{*this, n};
+  int minDestCh = 32;
+  {
+    int64_t b = 0;
+    uint64_t prevHash = lastHash;
+    const size_t kMaxSegs = 96;
+    while (b < n) {
+      if (segs.size() >= kMaxSegs) {  // too fragmented: stop the chunk here, the caller continues with a new one
+        n = b;
+        break;
+      }
+      auto g = goneAt.find(b);
+      if (g != goneAt.end())
+        for (int id : g->second) doDispose(id);  // queued Dispose() runs in the next block's DrainCommands
+      Segment sg;
+      sg.b0 = b;
+      sim.cur = &sg;
+      sim.brel = b;
+      sim.blockNumber = currentBlock + b + 1;
+      inRender = true;
+      try {
+        sim.evalNode(0);
+      } catch (...) {
+        inRender = false;
+        throw;
+      }
+      inRender = false;
+      sg.hash = sim.hashSeg(sg);
+      int64_t nb;
+      if (sg.hash != prevHash) {
+        nb = b + 1;
+      } else {
+        auto it = std::upper_bound(breaks.begin(), breaks.end(), b);
+        nb = it == breaks.end() ? n : *it;
+      }
+      sg.b1 = std::min(nb, n);
+      prevHash = sg.hash;
+      minDestCh = std::min(minDestCh, sg.nodes.back().outCh);
+      b = sg.b1;
+      segs.push_back(std::move(sg));
+    }
+    lastHash = prevHash;
+    if (n < (int64_t)bt.size() - 1) bt.resize(n + 1);
+  }
+  chunkMinDestCh = minDestCh;
+  const int64_t frames = n * kBlock;
+
+  // ---- device resources for this chunk ----
+  resetSlabs(*this, frames);
+  if (zerosLen < frames) {
+    if (zeros) {
+      GA_HIP(hipStreamSynchronize(stream));
+      dfree(zeros, (size_t)zerosLen * 4);
+    }
+    zerosLen = roundup(frames, 4096);
+    zeros = (float*)dalloc((size_t)zerosLen * 4);
+    GA_HIP(hipMemsetAsync(zeros, 0, (size_t)zerosLen * 4, stream));
+  }
+  if (busCapFrames < frames) {
+    GA_HIP(hipStreamSynchronize(stream));
+    for (float* p : busSlabs) dfree(p, (size_t)busCapFrames * 4);
+    busSlabs.clear();
+    busCapFrames = roundup(frames, 4096);
+  }
+  while ((int)busSlabs.size() < 32 && (int)busSlabs.size() < std::max(destOutCh, 2)) busSlabs.push_back((float*)dalloc((size_t)busCapFrames * 4));
+  {
+    int mx = 0;
+    for (auto& sg : segs) mx = std::max(mx, sg.nodes.back().outCh);
+    while ((int)busSlabs.size() < mx) busSlabs.push_back((float*)dalloc((size_t)busCapFrames * 4));
+  }
+
+  Exec ex(*this, n, segs);
+  ex.outViews.resize(segs.size());
+  ex.plan.host.resize(16);  // reserved header
+
+  // ---- AudioParam curves (AudioParam.cs:93-166) for automated gain params: one launch for the whole chunk ----
+  {
+    std::vector<ParamJob> pjobs;
+    std::vector<ParamEvent> events;
+    for (int id : topo) {
+      NodeS& nd = *nodes[id];
+      for (auto& p : nd.params) p.curve = nullptr;
+      if (nd.type != GA_NODE_GAIN) continue;
+      ParamS& p = nd.params[0];
+      if (p.events.empty()) continue;
+      p.curve = getSlab(*this);
+      ParamJob pj;
+      pj.out = p.curve;
+      pj.ev0 = (int)events.size();
+      pj.nev = (int)p.events.size();
+      pj.value = p.value;
+      pj.arate = p.arate ? 1 : 0;
+      pj.b0 = 0;
+      pj.nblocks = n;
+      events.insert(events.end(), p.events.begin(), p.events.end());
+      pjobs.push_back(pj);
+    }
+    if (!pjobs.empty()) {
+      size_t jo = ex.plan.putv(pjobs), eo = ex.plan.putv(events), bo = ex.plan.putv(bt);
+      int nj = (int)pjobs.size();
+      double dt = 1.0 / sampleRate;
+      hipStream_t st = stream;
+      int64_t nn = n;
+      ex.plan.add(LK_OTHER, [=](uint8_t* base) {
+        launch_param_curve(st, (const ParamJob*)(base + jo), nj, (const ParamEvent*)(base + eo), (const double*)(base + bo), dt, nn);
+      });
+    }
+  }
+
+  // resampler trajectories used in this chunk go into one device table
+  for (auto& kv : resamplers) kv.second->devOffset = -1;
+
+  // ---- convolver scratch planes are shared by all groups: size them for the largest group BEFORE any recorded
+  //      launch captures their address ----
+  {
+    size_t xMax = 0, yMax = 0;
+    for (int id : topo) {
+      NodeS& nd = *nodes[id];
+      if (nd.type != GA_NODE_CONVOLVER || !nd.ir) continue;
+      for (auto& rr : nd.convRows) {
+        ConvGroup& g = *rr.group;
+        ensureGroupState(*this, g);
+        const int ty_ = (int)roundup(n, 64), tx_ = ty_ + g.P + 128;
+        xMax = std::max(xMax, (size_t)kBins * tx_ * g.rp * sizeof(float));
+        yMax = std::max(yMax, (size_t)kBins * ty_ * g.rp * sizeof(float));
+      }
+    }
+    if (xMax) {
+      ensure(planes[0], xMax);
+      ensure(planes[1], xMax);
+      ensure(planes[2], yMax);
+      ensure(planes[3], yMax);
+    }
+  }
+
+  // ---- stages: convolver depth d ; inside a stage every segment is executed level by level ----
+  for (int d = 0; d <= maxDepth; d++) {
+    for (size_t si = 0; si < segs.size(); si++) {
+      Segment& sg = segs[si];
+      if (ex.outViews[si].empty()) ex.outViews[si].resize(nodes.size());
+      const int64_t f0 = sg.b0 * kBlock, nf = (sg.b1 - sg.b0) * kBlock, nb = sg.b1 - sg.b0;
+      // nodes of this stage ordered by level
+      std::vector<const NodeSeg*> todo;
+      for (const NodeSeg& ns : sg.nodes)
+        if (nodes[ns.id]->depth == d) todo.push_back(&ns);
+      std::stable_sort(todo.begin(), todo.end(), [&](const NodeSeg* a, const NodeSeg* b2) { return nodes[a->id]->level < nodes[b2->id]->level; });
+      int curLevel = -1;
+      for (const NodeSeg* nsp : todo) {
+        const NodeSeg& ns = *nsp;
+        NodeS& nd = *nodes[ns.id];
+        if (nd.level != curLevel) {
+          ex.flushLevel();
+          curLevel = nd.level;
+        }
+        auto& ov = ex.outViews[si][ns.id];
+        ov.assign(std::max(ns.outCh, 1), nullptr);
+        switch (nd.type) {
+          case GA_NODE_BUFFER_SOURCE: {
+            if (ns.srcPhase != SRC_PLAY) break;  // silent: ZERO views
+            PlayBuf& pb = *buffers[ns.srcBuf];
+            SrcGeom g = sourceGeom(*this, nd, pb);
+            if (g.effectiveRate == 1.0 && !nd.loop) {
+              // zero-copy: the node's output for these blocks IS the buffer (AudioBufferSourceNode.cs:186-222)
+              for (int ch = 0; ch < pb.channels; ch++) ov[ch] = pb.dev + (size_t)ch * pb.stride + ns.srcPos - f0;
+            } else if (g.effectiveRate == 1.0) {
+              for (int ch = 0; ch < pb.channels; ch++) {
+                LoopJob lj;
+                lj.buf = pb.dev + (size_t)ch * pb.stride;
+                lj.out = ex.nodeOut(ns.id, ch);
+                lj.pos0 = ns.srcPos;  // map() below handles positions beyond loopEnd
+                lj.loop_start = g.loopStartFrame;
+                lj.loop_end = g.loopEndFrame;
+                lj.f0 = f0;
+                lj.n = nf;
+                ex.loopJobs.push_back(lj);
+                ov[ch] = lj.out;
+              }
+            } else {
+              Resampler& rs = resamplerFor(*this, g.effectiveRate);
+              if (rs.devOffset < 0) {
+                rs.devOffset = (int)ex.traj.size();
+                ex.traj.insert(ex.traj.end(), rs.blocks.begin(), rs.blocks.end());
+              }
+              int64_t avail = g.durationEndFrame - nd.rsStartPos;
+              // a partial block (input ran out) is its own one-block segment with a custom trajectory entry
+              int traj0 = rs.devOffset + (int)ns.srcBlk;
+              for (size_t k = 0; k < srcIds.size(); k++)
+                if (srcIds[k] == ns.id && srcPlans[k].partialBlock == sg.b0) {
+                  ResampleBlock rb = rs.blocks[ns.srcBlk];
+                  rb.produced = srcPlans[k].partialProduced;
+                  traj0 = (int)ex.traj.size();
+                  ex.traj.push_back(rb);
+                }
+              for (int ch = 0; ch < pb.channels; ch++) {
+                ResampleJob rj;
+                rj.buf = pb.dev + (size_t)ch * pb.stride;
+                rj.out = ex.nodeOut(ns.id, ch);
+                rj.start_pos = nd.rsStartPos;
+                rj.avail = avail;
+                rj.traj0 = traj0;
+                rj.rate = g.effectiveRate;
+                rj.b0 = sg.b0;
+                rj.nblocks = nb;
+                ex.rsJobs.push_back(rj);
+                ov[ch] = rj.out;
+              }
+            }
+            break;
+          }
+          case GA_NODE_GAIN: {
+            auto iv = ex.resolveInput((int)si, ns, 0, false, nullptr);
+            if (ns.ins[0].silent) break;  // cleared output (GainNode.cs:41-46)
+            for (int ch = 0; ch < ns.outCh; ch++) {
+              if (!iv[ch]) continue;
+              GainJob gj;
+              gj.in = iv[ch];
+              gj.out = ex.nodeOut(ns.id, ch);
+              gj.curve = nd.params[0].curve;
+              gj.gain = nd.params[0].value;
+              gj.f0 = f0;
+              gj.n = nf;
+              ex.gainJobs.push_back(gj);
+              ov[ch] = gj.out;
+            }
+            break;
+          }
+          case GA_NODE_BIQUAD: {
+            auto iv = ex.resolveInput((int)si, ns, 0, false, nullptr);
+            if (!ns.bqActive) break;  // silent input: cleared output, state frozen (BiQuadFilterNode.cs:103-108)
+            if (!nd.bqState) {
+              const size_t per = 32 * 2 * sizeof(float);
+              const size_t blk = (size_t)1 << 20;
+              if (bqBlocks.empty() || bqUsed + per > blk) {
+                void* p = dalloc(blk);
+                GA_HIP(hipMemsetAsync(p, 0, blk, stream));
+                bqBlocks.push_back(p);
+                bqUsed = 0;
+              }
+              nd.bqState = (float*)((char*)bqBlocks.back() + bqUsed);
+              bqUsed += per;
+            }
+            for (int ch = 0; ch < ns.outCh; ch++) {
+              BiquadJob bj;
+              bj.in = iv[ch] ? iv[ch] : zeros;
+              bj.out = ex.nodeOut(ns.id, ch);
+              bj.state = nd.bqState + 2 * ch;
+              bj.b0 = ns.b0; bj.b1 = ns.b1; bj.b2 = ns.b2; bj.a1 = ns.a1; bj.a2 = ns.a2;
+              bj.f0 = f0;
+              bj.n = nf;
+              ex.bqJobs.push_back(bj);
+              ov[ch] = bj.out;
+            }
+            break;
+          }
+          case GA_NODE_CONVOLVER: {
+            auto iv = ex.resolveInput((int)si, ns, 0, false, nullptr);
+            if (!nd.ir) break;  // no IR: cleared output (ConvolverNode.cs:107-119)
+            auto& ci = ex.convIn[ns.id];
+            if (ci.empty()) ci.assign(segs.size(), std::vector<const float*>());
+            ci[si] = iv;
+            for (int ch = 0; ch < ns.outCh; ch++) ov[ch] = ex.nodeOut(ns.id, ch);
+            break;
+          }
+          case GA_NODE_DESTINATION: {
+            // the destination aliases its input buffer (AudioDestinationNode.cs:44-50): mix straight into the bus
+            std::vector<float*> forced(std::max(ns.ins[0].bufCh, 1), nullptr);
+            for (int ch = 0; ch < ns.ins[0].bufCh && ch < (int)busSlabs.size(); ch++) forced[ch] = busSlabs[ch];
+            ex.resolveInput((int)si, ns, 0, true, forced.data());
+            break;
+          }
+          default: break;
+        }
+      }
+      ex.flushLevel();
+    }
+
+    // ---- convolvers whose inputs are complete (depth d): once per chunk over all blocks ----
+    std::map<ConvGroup*, std::vector<std::pair<int, int>>> active;  // group -> (node, slot)
+    for (int id : topo) {
+      NodeS& nd = *nodes[id];
+      if (nd.type != GA_NODE_CONVOLVER || !nd.ir || nd.depth != d) continue;
+      if (ex.convIn.find(id) == ex.convIn.end()) continue;
+      for (int slot = 0; slot < (int)nd.convRows.size(); slot++) active[nd.convRows[slot].group].push_back({id, slot});
+    }
+    std::unordered_map<int, std::array<float*, 4>> tsTemps;  // true-stereo temp outputs per node
+    for (auto& kv : active) {
+      ConvGroup& g = *kv.first;
+      const int P = g.P, hist = P - 1;
+      const int nrows = (int)g.rows.size();
+      std::vector<ConvRowIO> rio(nrows, ConvRowIO{nullptr, nullptr});
+      for (auto& ns_ : kv.second) {
+        NodeS& nd = *nodes[ns_.first];
+        const int slot = ns_.second;
+        const int idx = nd.convRows[slot].idx;
+        // which input channel feeds this row: discrete -> slot ; true stereo -> L,L,R,R for h0,h1,h2,h3 (ConvolverNode.cs:127-151)
+        const int inCh = nd.isTrueStereo ? (slot >> 1) : slot;
+        auto& ci = ex.convIn[ns_.first];
+        const float* stable = nullptr;
+        bool same = true, first = true;
+        for (size_t si = 0; si < segs.size(); si++) {
+          const float* v = (ci[si].empty() || inCh >= (int)ci[si].size()) ? nullptr : ci[si][inCh];
+          if (first) { stable = v; first = false; } else if (v != stable) same = false;
+        }
+        const float* in = stable;
+        if (!same) {  // materialise: per segment copy / zero fill into a row slab
+          float* slab = getSlab(*this);
+          for (size_t si = 0; si < segs.size(); si++) {
+            const float* v = (ci[si].empty() || inCh >= (int)ci[si].size()) ? nullptr : ci[si][inCh];
+            MixJob mj;
+            mj.out = slab;
+            mj.term0 = (int)ex.terms.size();
+            mj.nterms = v ? 1 : 0;
+            mj.f0 = segs[si].b0 * kBlock;
+            mj.n = (segs[si].b1 - segs[si].b0) * kBlock;
+            if (v) {
+              ex.terms.push_back(v);
+              ex.noteAlign(v, mj.f0);
+            }
+            ex.mixJobs.push_back(mj);
+          }
+          in = slab;
+        }
+        float* out;
+        if (nd.isTrueStereo) {
+          out = getSlab(*this);  // temp1 / temp2, summed below (ConvolverNode.cs:137-143)
+        } else {
+          out = ex.nodeOut(ns_.first, slot);
+        }
+        rio[idx] = ConvRowIO{in, out};
+        if (nd.isTrueStereo) {
+          auto& tt = tsTemps[ns_.first];
+          if (slot == 0) tt = {nullptr, nullptr, nullptr, nullptr};
+          tt[slot] = out;
+        }
+      }
+      ex.flushLevel();
+      const int rp = g.rp;
+      const int ty = (int)roundup(n, 64);
+      const int tx = ty + P + 128;
+      ConvPlanes pl{(float*)planes[0].p, (float*)planes[1].p, (float*)planes[2].p, (float*)planes[3].p, tx, ty, rp};
+      size_t rioOff = ex.plan.putv(rio);
+      hipStream_t st = stream;
+      Twiddles tw{w128, w256};
+      const int nn = (int)n;
+      float* hR = g.histR;
+      float* hI = g.histI;
+      const bool hz = g.histZero;
+      const float* hr = g.ir->hr + (size_t)g.irCh * kBins * P;
+      const float* hi = g.ir->hi + (size_t)g.irCh * kBins * P;
+      float* ovIn = g.overlap[g.ovCur];
+      float* ovOut = g.overlap[g.ovCur ^ 1];
+      g.ovCur ^= 1;
+      g.histZero = false;
+      ex.plan.add(LK_FFT, [=](uint8_t* base) {
+        // frequency-domain delay line of the previous chunk(s) in front of this chunk's spectra
+        if (hist > 0) {
+          launch_plane_copy(st, pl.xr, tx, 0, hz ? nullptr : hR, hist, 0, hist, rp);
+          launch_plane_copy(st, pl.xi, tx, 0, hz ? nullptr : hI, hist, 0, hist, rp);
+        }
+        // rows beyond this chunk that the banded MAC may touch for its (discarded) padded outputs
+        int tail = std::min(tx - (hist + nn), 256);
+        launch_plane_copy(st, pl.xr, tx, hist + nn, nullptr, 0, 0, tail, rp);
+        launch_plane_copy(st, pl.xi, tx, hist + nn, nullptr, 0, 0, tail, rp);
+        launch_rfft_fwd(st, (const ConvRowIO*)(base + rioOff), nrows, nn, hist, pl, tw);
+      });
+      ex.plan.add(LK_MAC, [=](uint8_t*) { launch_spectral_mac_shared(st, pl, hr, hi, P, nn, nrows); });
+      ex.plan.add(LK_FFT, [=](uint8_t* base) {
+        launch_irfft_ola(st, (const ConvRowIO*)(base + rioOff), nrows, nn, pl, ovIn, ovOut, tw);
+        if (hist > 0) {  // keep the last P-1 spectra for the next chunk (the FDL, PartitionedConvolver.cs:122-128)
+          launch_plane_copy(st, hR, hist, 0, pl.xr, tx, nn, hist, rp);
+          launch_plane_copy(st, hI, hist, 0, pl.xi, tx, nn, hist, rp);
+        }
+      });
+      stats.mac_flops_total += 8.0 * P * kBins * (double)kv.second.size() * (double)n;
+      // streaming-formulation bytes: per channel-instance per block FDL read + write + input, IR once per block per channel
+      stats.mac_bytes_total += ((double)P * kBins * 8.0 + kBins * 8.0 + 512.0) * (double)kv.second.size() * (double)n +
+                               (double)P * kBins * 8.0 * (double)n;
+      stats.mac_launches += 1;
+    }
+    // true stereo: outL = conv0(L) + conv2(R) ; outR = conv1(L) + conv3(R)  (ConvolverNode.cs:127-144)
+    for (auto& kv : tsTemps) {
+      hipStream_t st = stream;
+      int64_t fr = frames;
+      for (int o = 0; o < 2; o++) {
+        float* out = ex.nodeOut(kv.first, o);
+        float *a = kv.second[o], *b2 = kv.second[o + 2];
+        if (a && b2) ex.plan.add(LK_OTHER, [=](uint8_t*) { launch_pair_sum(st, out, a, b2, fr); });
+      }
+    }
+  }
+
+  // ---- upload tables, run ----
+  ex.trajOffFinal = ex.plan.putv(ex.traj);
+  size_t tbytes = ex.plan.host.size();
+  if (tablesHostBytes < tbytes) {
+    if (tablesHost) {
+      GA_HIP(hipStreamSynchronize(stream));
+      (void)hipHostFree(tablesHost);
+    }
+    tablesHostBytes = tbytes + tbytes / 4 + 4096;
+    GA_HIP(hipHostMalloc(&tablesHost, tablesHostBytes, hipHostMallocDefault));
+  }
+  ensure(tables, tablesHostBytes);
+  std::memcpy(tablesHost, ex.plan.host.data(), tbytes);
+  GA_HIP(hipMemcpyAsync(tables.p, tablesHost, tbytes, hipMemcpyHostToDevice, stream));
+  uint8_t* base = (uint8_t*)tables.p;
+
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
+  std::vector<int> evKind;
+  hipEvent_t evBegin = nullptr, evEnd = nullptr;
+  if (profile) {
+    GA_HIP(hipEventCreate(&evBegin));
+    GA_HIP(hipEventCreate(&evEnd));
+    GA_HIP(hipEventRecord(evBegin, stream));
+  }
+  for (auto& l : ex.plan.launches) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (profile) {
+      GA_HIP(hipEventCreate(&e0));
+      GA_HIP(hipEventCreate(&e1));
+      GA_HIP(hipEventRecord(e0, stream));
+    }
+    l.fn(base);
+    if (profile) {
+      GA_HIP(hipEventRecord(e1, stream));
+      evs.push_back({e0, e1});
+      evKind.push_back(l.kind);
+    }
+    stats.kernel_launches++;
+  }
+  if (profile) GA_HIP(hipEventRecord(evEnd, stream));
+  GA_HIP(hipGetLastError());
+  GA_HIP(hipStreamSynchronize(stream));
+  if (profile) {
+    float ms = 0;
+    GA_HIP(hipEventElapsedTime(&ms, evBegin, evEnd));
+    stats.device_ms_total += ms;
+    for (size_t i = 0; i < evs.size(); i++) {
+      GA_HIP(hipEventElapsedTime(&ms, evs[i].first, evs[i].second));
+      if (evKind[i] == LK_MAC) stats.mac_ms_total += ms;
+      else if (evKind[i] == LK_FFT) stats.fft_ms_total += ms;
+      else stats.other_ms_total += ms;
+      (void)hipEventDestroy(evs[i].first);
+      (void)hipEventDestroy(evs[i].second);
+    }
+    (void)hipEventDestroy(evBegin);
+    (void)hipEventDestroy(evEnd);
+  }
+
+  // ---- commit the control state to the end of the chunk ----
+  for (size_t i = 0; i < srcIds.size(); i++) {
+    NodeS& s = *nodes[srcIds[i]];
+    SrcPlanOut& po = srcPlans[i];
+    // recompute progress against the (possibly shortened) chunk
+    if (s.spans.empty()) continue;
+    int64_t firstPlay = -1;
+    for (const SrcSpan& sp : s.spans)
+      if ((sp.phase == SRC_PLAY || sp.phase == SRC_END) && firstPlay < 0) firstPlay = sp.b0;
+    if (firstPlay < 0 || firstPlay >= n) continue;
+    int64_t lastProcessed = n;
+    if (po.gone && po.goneAt <= n) lastProcessed = po.goneAt;
+    int64_t played = lastProcessed - firstPlay;
+    PlayBuf* pb = s.bufId >= 0 ? buffers[s.bufId].get() : nullptr;
+    bool rate1 = true;
+    if (pb) rate1 = sourceGeom(*this, s, *pb).effectiveRate == 1.0;
+    if (rate1) {
+      s.playbackPosition += played * kBlock;
+      if (s.loop && pb) {
+        SrcGeom g = sourceGeom(*this, s, *pb);
+        int64_t len = g.loopEndFrame - g.loopStartFrame;
+        if (s.playbackPosition >= g.loopEndFrame && len > 0)
+          s.playbackPosition = g.loopStartFrame + ((s.playbackPosition - g.loopEndFrame) % len);
+      }
+    } else {
+      s.rsBlocks += played;
+    }
+    if (po.reachedEnd && po.endBlock < n) {
+      s.stopTime = bt[po.endBlock + 1];
+      s.hasStopped = true;
+    }
+    if (po.gone && po.goneAt <= n) {
+      s.endedRaised = true;
+      if (po.goneAt == n) pending.push_back([this, id = srcIds[i]]() { doDispose(id); });  // runs in the next block's drain
+    }
+  }
+  currentBlock += n;
+  currentTime = bt[n];
+  stats.blocks_rendered = currentBlock;
+  stats.chunks++;
+  stats.segments += (int64_t)segs.size();
+  chunkBlocksDone = n;
+}
+
+}  // namespace ga

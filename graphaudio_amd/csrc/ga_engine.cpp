@@ -1,0 +1,389 @@
+// ga_engine.cpp -- graph state, command queue, device resources.  See ga_engine.hpp for the design overview and
+// ga_chunk.cpp for the control-plane simulation + chunk executor.
+#include "ga_engine.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+namespace ga {
+
+// ------------------------------------------------------------------------------------------------------
+// device resources
+// ------------------------------------------------------------------------------------------------------
+void* Context::dalloc(size_t bytes) {
+  void* p = nullptr;
+  if (bytes == 0) bytes = 256;
+  GA_HIP(hipMalloc(&p, bytes));
+  devBytes += (int64_t)bytes;
+  return p;
+}
+void Context::dfree(void* p, size_t bytes) {
+  if (!p) return;
+  (void)hipFree(p);
+  devBytes -= (int64_t)(bytes == 0 ? 256 : bytes);
+}
+void Context::ensure(DevArena& a, size_t bytes) {
+  if (a.bytes >= bytes) return;
+  if (a.p) {
+    GA_HIP(hipStreamSynchronize(stream));
+    dfree(a.p, a.bytes);
+    a.p = nullptr;
+    a.bytes = 0;
+  }
+  size_t nb = bytes + bytes / 8;
+  a.p = dalloc(nb);
+  a.bytes = nb;
+  GA_HIP(hipMemsetAsync(a.p, 0, nb, stream));
+}
+
+void Context::init_device(int dev) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    fail(GA_ERR_NO_DEVICE, "no HIP device visible: libgraphaudio_hip has no CPU fallback");
+  if (dev < 0 || dev >= count) fail(GA_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+  device = dev;
+  GA_HIP(hipSetDevice(dev));
+  GA_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  ownStream = true;
+  // twiddle tables in double precision, computed like the oracle does (libm cos/sin)
+  const double pi = 3.14159265358979323846264338327950288;
+  std::vector<double2> t128(64), t256(129);
+  for (int j = 0; j < 64; j++) t128[j] = make_double2(std::cos(2.0 * pi * j / 128.0), -std::sin(2.0 * pi * j / 128.0));
+  for (int k = 0; k <= 128; k++) t256[k] = make_double2(std::cos(2.0 * pi * k / 256.0), -std::sin(2.0 * pi * k / 256.0));
+  w128 = (double2*)dalloc(sizeof(double2) * 64);
+  w256 = (double2*)dalloc(sizeof(double2) * 129);
+  GA_HIP(hipMemcpy(w128, t128.data(), sizeof(double2) * 64, hipMemcpyHostToDevice));
+  GA_HIP(hipMemcpy(w256, t256.data(), sizeof(double2) * 129, hipMemcpyHostToDevice));
+  cacheDev = (float*)dalloc(sizeof(float) * 32 * kBlock);
+}
+
+Context::~Context() {
+  if (stream) (void)hipStreamSynchronize(stream);
+  for (auto& b : buffers)
+    if (b && b->dev) (void)hipFree(b->dev);
+  for (auto& kv : irCache) {
+    if (kv.second) {
+      if (kv.second->hr) (void)hipFree(kv.second->hr);
+      if (kv.second->hi) (void)hipFree(kv.second->hi);
+    }
+  }
+  for (auto& g : groups) {
+    if (g->histR) (void)hipFree(g->histR);
+    if (g->histI) (void)hipFree(g->histI);
+    if (g->overlap[0]) (void)hipFree(g->overlap[0]);
+    if (g->overlap[1]) (void)hipFree(g->overlap[1]);
+  }
+  for (auto& a : planes)
+    if (a.p) (void)hipFree(a.p);
+  if (tables.p) (void)hipFree(tables.p);
+  if (tablesHost) (void)hipHostFree(tablesHost);
+  for (void* p : slabBlocks) (void)hipFree(p);
+  for (void* p : bqBlocks) (void)hipFree(p);
+  for (float* p : busSlabs) (void)hipFree(p);
+  if (zeros) (void)hipFree(zeros);
+  if (w128) (void)hipFree(w128);
+  if (w256) (void)hipFree(w256);
+  if (cacheDev) (void)hipFree(cacheDev);
+  if (stream && ownStream) (void)hipStreamDestroy(stream);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// command queue (AudioContextBase.cs:266-305)
+// ------------------------------------------------------------------------------------------------------
+void Context::executeOrPost(std::function<void()> cmd) {
+  if (disposed) fail(GA_ERR_DISPOSED, "context disposed");
+  if (latched && !inRender) cmd(); else pending.push_back(std::move(cmd));
+}
+void Context::post(std::function<void()> cmd) {
+  if (disposed) fail(GA_ERR_DISPOSED, "context disposed");
+  pending.push_back(std::move(cmd));
+}
+void Context::drain() {  // exceptions thrown by queued commands are swallowed (:276-282)
+  while (!pending.empty()) {
+    auto cmd = std::move(pending.front());
+    pending.pop_front();
+    try {
+      cmd();
+    } catch (const Err&) {
+    }
+  }
+}
+
+NodeS* Context::node(int id) {
+  if (id < 0 || id >= (int)nodes.size()) fail(GA_ERR_INVALID_ARGUMENT, "bad node id");
+  return nodes[id].get();
+}
+ParamS* Context::param(int nid, int p) {
+  NodeS* n = node(nid);
+  if (p < 0 || p >= (int)n->params.size()) fail(GA_ERR_INVALID_ARGUMENT, "bad param index");
+  return &n->params[p];
+}
+PlayBuf* Context::buffer(int id) {
+  if (id < 0) return nullptr;
+  if (id >= (int)buffers.size() || !buffers[id]) fail(GA_ERR_INVALID_ARGUMENT, "bad buffer id");
+  return buffers[id].get();
+}
+InputS* Context::inputOf(const InRef& r) {
+  NodeS* n = nodes[r.node].get();
+  if (r.input >= 0) return &n->inputs[r.input];
+  return nullptr;  // param modulation inputs keep their list in ParamS::modulation
+}
+
+// ---- connections: AudioNodeOutput.ConnectTo / DisconnectFrom / DisconnectAll (AudioNodeOutput.cs:42-70) and
+//      AudioNodeInput.AddConnection / RemoveConnection / DisconnectAll (AudioNodeInput.cs:60-83) ----
+void Context::connectTo(int src, int out, InRef in) {
+  if (in.node == src) fail(GA_ERR_INVALID_OPERATION, "Cannot connect a node to itself");
+  OutputS& o = nodes[src]->outputs[out];
+  if (std::find(o.connectedInputs.begin(), o.connectedInputs.end(), in) != o.connectedInputs.end()) return;
+  o.connectedInputs.push_back(in);
+  if (in.input >= 0) {
+    InputS& i = nodes[in.node]->inputs[in.input];
+    Conn c{src, out};
+    if (std::find(i.connected.begin(), i.connected.end(), c) == i.connected.end()) {
+      i.connected.push_back(c);
+      i.dirty = true;
+    }
+  } else {
+    auto& m = nodes[in.node]->params[-1 - in.input].modulation;
+    std::pair<int, int> c{src, out};
+    if (std::find(m.begin(), m.end(), c) == m.end()) m.push_back(c);
+  }
+}
+static void removeFromInput(Context& c, int src, int out, InRef in) {
+  if (in.input >= 0) {
+    InputS& i = c.nodes[in.node]->inputs[in.input];
+    Conn cc{src, out};
+    auto it = std::find(i.connected.begin(), i.connected.end(), cc);
+    if (it != i.connected.end()) i.connected.erase(it);
+    i.dirty = true;
+  } else {
+    auto& m = c.nodes[in.node]->params[-1 - in.input].modulation;
+    std::pair<int, int> cc{src, out};
+    auto it = std::find(m.begin(), m.end(), cc);
+    if (it != m.end()) m.erase(it);
+  }
+}
+void Context::disconnectFrom(int src, int out, InRef in) {
+  OutputS& o = nodes[src]->outputs[out];
+  auto it = std::find(o.connectedInputs.begin(), o.connectedInputs.end(), in);
+  if (it != o.connectedInputs.end()) {
+    o.connectedInputs.erase(it);
+    removeFromInput(*this, src, out, in);
+  }
+}
+void Context::outputDisconnectAll(int src, int out) {
+  OutputS& o = nodes[src]->outputs[out];
+  std::vector<InRef> ins = o.connectedInputs;
+  o.connectedInputs.clear();
+  for (const InRef& in : ins) removeFromInput(*this, src, out, in);
+}
+void Context::inputDisconnectAll(InRef in) {
+  std::vector<Conn> outs;
+  if (in.input >= 0) {
+    outs = nodes[in.node]->inputs[in.input].connected;
+  } else {
+    for (auto& m : nodes[in.node]->params[-1 - in.input].modulation) outs.push_back(Conn{m.first, m.second});
+  }
+  for (const Conn& c : outs) disconnectFrom(c.node, c.out, in);
+  if (in.input >= 0) nodes[in.node]->inputs[in.input].dirty = true;
+}
+// DoDispose, Nodes/AudioNode.cs:212-235
+void Context::doDispose(int id) {
+  NodeS& n = *nodes[id];
+  if (n.disposed) return;
+  n.disposed = true;
+  for (int o = 0; o < (int)n.outputs.size(); o++) outputDisconnectAll(id, o);
+  for (int i = 0; i < (int)n.inputs.size(); i++) {
+    inputDisconnectAll(InRef{id, i});
+    n.inputs[i].bufCh = 0;  // AudioNodeInput.Dispose returns the buffer (:88-95)
+  }
+  for (int p = 0; p < (int)n.params.size(); p++) inputDisconnectAll(InRef{id, -1 - p});
+  // OnDispose
+  if (n.type == GA_NODE_BUFFER_SOURCE) n.bufId = -1;  // AudioBufferSourceNode.cs:412
+  if (n.type == GA_NODE_CONVOLVER) {                   // ConvolverNode.cs:166-175
+    n.ir.reset();
+    n.irBuf = -1;
+    for (auto& r : n.convRows)
+      if (r.group) r.group->rows[r.idx] = {-1, 0};
+    n.convRows.clear();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// BiQuadFilterNode.UpdateCoefficients (BiQuadFilterNode.cs:149-258), float32, host libm
+// ------------------------------------------------------------------------------------------------------
+void Context::updateBiquadCoefficients(NodeS& n, float frequency, float q, float gain) {
+  const float PI = 3.14159274f;
+  float w0 = 2.f * PI * frequency / sampleRate;
+  float cosW0 = std::cos(w0);
+  float sinW0 = std::sin(w0);
+  float alpha = sinW0 / (2.f * q);
+  float a0, A1, A2, B0, B1, B2;
+  switch (n.filterType) {
+    case GA_FILTER_LOWPASS:
+      B0 = (1.f - cosW0) / 2.f; B1 = 1.f - cosW0; B2 = (1.f - cosW0) / 2.f;
+      a0 = 1.f + alpha; A1 = -2.f * cosW0; A2 = 1.f - alpha;
+      break;
+    case GA_FILTER_HIGHPASS:
+      B0 = (1.f + cosW0) / 2.f; B1 = -(1.f + cosW0); B2 = (1.f + cosW0) / 2.f;
+      a0 = 1.f + alpha; A1 = -2.f * cosW0; A2 = 1.f - alpha;
+      break;
+    case GA_FILTER_BANDPASS:
+      B0 = alpha; B1 = 0.f; B2 = -alpha;
+      a0 = 1.f + alpha; A1 = -2.f * cosW0; A2 = 1.f - alpha;
+      break;
+    case GA_FILTER_NOTCH:
+      B0 = 1.f; B1 = -2.f * cosW0; B2 = 1.f;
+      a0 = 1.f + alpha; A1 = -2.f * cosW0; A2 = 1.f - alpha;
+      break;
+    case GA_FILTER_ALLPASS:
+      B0 = 1.f - alpha; B1 = -2.f * cosW0; B2 = 1.f + alpha;
+      a0 = 1.f + alpha; A1 = -2.f * cosW0; A2 = 1.f - alpha;
+      break;
+    case GA_FILTER_PEAKING: {
+      float A = std::pow(10.f, gain / 40.f);
+      B0 = 1.f + alpha * A; B1 = -2.f * cosW0; B2 = 1.f - alpha * A;
+      a0 = 1.f + alpha / A; A1 = -2.f * cosW0; A2 = 1.f - alpha / A;
+      break;
+    }
+    case GA_FILTER_LOWSHELF: {
+      float A = std::pow(10.f, gain / 40.f);
+      float sqrtA = std::sqrt(A);
+      float beta = sqrtA / q;
+      B0 = A * ((A + 1.f) - (A - 1.f) * cosW0 + beta * sinW0);
+      B1 = 2.f * A * ((A - 1.f) - (A + 1.f) * cosW0);
+      B2 = A * ((A + 1.f) - (A - 1.f) * cosW0 - beta * sinW0);
+      a0 = (A + 1.f) + (A - 1.f) * cosW0 + beta * sinW0;
+      A1 = -2.f * ((A - 1.f) + (A + 1.f) * cosW0);
+      A2 = (A + 1.f) + (A - 1.f) * cosW0 - beta * sinW0;
+      break;
+    }
+    case GA_FILTER_HIGHSHELF: {
+      float A = std::pow(10.f, gain / 40.f);
+      float sqrtA = std::sqrt(A);
+      float beta = sqrtA / q;
+      B0 = A * ((A + 1.f) + (A - 1.f) * cosW0 + beta * sinW0);
+      B1 = -2.f * A * ((A - 1.f) + (A + 1.f) * cosW0);
+      B2 = A * ((A + 1.f) + (A - 1.f) * cosW0 - beta * sinW0);
+      a0 = (A + 1.f) - (A - 1.f) * cosW0 + beta * sinW0;
+      A1 = 2.f * ((A - 1.f) - (A + 1.f) * cosW0);
+      A2 = (A + 1.f) - (A - 1.f) * cosW0 - beta * sinW0;
+      break;
+    }
+    default:
+      B0 = 1.f; B1 = 0.f; B2 = 0.f; a0 = 1.f; A1 = 0.f; A2 = 0.f;
+      break;
+  }
+  n.b0 = B0 / a0;
+  n.b1 = B1 / a0;
+  n.b2 = B2 / a0;
+  n.a1 = A1 / a0;
+  n.a2 = A2 / a0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// IR preparation (PartitionedConvolver..ctor / PrepareImpulseResponse / CalculateNormalizationScale,
+// PartitionedConvolver.cs:37-102): scale on the host in the reference's mixed precision, spectra with the same
+// rfft256 kernel the render path uses.
+// ------------------------------------------------------------------------------------------------------
+static float normalizationScale(const float* r, int64_t len) {
+  const float GainCalibration = -58;
+  const float MinPower = 0.000125f;
+  double sumSquared = 0;
+  for (int64_t i = 0; i < len; i++) {
+    float p = r[i] * r[i];
+    sumSquared += p;
+  }
+  float power = (float)std::sqrt(sumSquared / (double)len);
+  if (std::isnan(power) || std::isinf(power) || power < MinPower) power = MinPower;
+  float e = GainCalibration * 0.05f;
+  return (1.0f / power) * (float)std::pow(10.0, (double)e);
+}
+
+std::shared_ptr<IrSpectra> Context::irSpectra(int bufId, bool normalize) {
+  auto key = std::make_pair(bufId, normalize ? 1 : 0);
+  auto it = irCache.find(key);
+  if (it != irCache.end()) return it->second;
+  PlayBuf* b = buffer(bufId);
+  if (b->length <= 0) fail(GA_ERR_INVALID_ARGUMENT, "impulse response buffer is empty");
+  const int P = (int)((b->length + kBlock - 1) / kBlock);  // ceil(len / blockSize), :44
+  const int nch = b->channels;
+  auto sp = std::make_shared<IrSpectra>();
+  sp->P = P;
+  sp->nch = nch;
+  const int64_t padded = (int64_t)P * kBlock;
+  std::vector<float> scaled((size_t)nch * padded, 0.f);
+  for (int c = 0; c < nch; c++) {
+    float scale = normalize ? normalizationScale(b->host[c].data(), b->length) : 1.0f;
+    float* dst = &scaled[(size_t)c * padded];
+    const float* src = b->host[c].data();
+    for (int64_t i = 0; i < b->length; i++) dst[i] = src[i] * scale;  // float multiply (:80)
+  }
+  GA_HIP(hipSetDevice(device));
+  const int rp = 128;  // nch <= 32
+  float* dIn = (float*)dalloc(scaled.size() * sizeof(float));
+  size_t planeBytes = (size_t)kBins * P * rp * sizeof(float);
+  float* xr = (float*)dalloc(planeBytes);
+  float* xi = (float*)dalloc(planeBytes);
+  size_t hBytes = (size_t)nch * kBins * P * sizeof(float);
+  sp->hr = (float*)dalloc(hBytes);
+  sp->hi = (float*)dalloc(hBytes);
+  ConvRowIO* rowsDev = (ConvRowIO*)dalloc(sizeof(ConvRowIO) * nch);
+  std::vector<ConvRowIO> rows(nch);
+  for (int c = 0; c < nch; c++) rows[c] = ConvRowIO{dIn + (size_t)c * padded, nullptr};
+  GA_HIP(hipMemcpyAsync(dIn, scaled.data(), scaled.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+  GA_HIP(hipMemcpyAsync(rowsDev, rows.data(), sizeof(ConvRowIO) * nch, hipMemcpyHostToDevice, stream));
+  GA_HIP(hipMemsetAsync(xr, 0, planeBytes, stream));
+  GA_HIP(hipMemsetAsync(xi, 0, planeBytes, stream));
+  ConvPlanes pl{xr, xi, nullptr, nullptr, P, 0, rp};
+  // grid.y is limited to 65535 blocks per launch
+  for (int t0 = 0; t0 < P; t0 += 32768) {
+    int nb = std::min(32768, P - t0);
+    std::vector<ConvRowIO> r2(nch);
+    for (int c = 0; c < nch; c++) r2[c] = ConvRowIO{dIn + (size_t)c * padded + (size_t)t0 * kBlock, nullptr};
+    if (t0 > 0) {
+      GA_HIP(hipStreamSynchronize(stream));
+      GA_HIP(hipMemcpy(rowsDev, r2.data(), sizeof(ConvRowIO) * nch, hipMemcpyHostToDevice));
+    }
+    launch_rfft_fwd(stream, rowsDev, nch, nb, t0, pl, Twiddles{w128, w256});
+  }
+  launch_extract_ir(stream, sp->hr, sp->hi, xr, xi, P, rp, P, nch);
+  GA_HIP(hipStreamSynchronize(stream));
+  GA_HIP(hipGetLastError());
+  dfree(dIn, scaled.size() * sizeof(float));
+  dfree(xr, planeBytes);
+  dfree(xi, planeBytes);
+  dfree(rowsDev, sizeof(ConvRowIO) * nch);
+  irCache[key] = sp;
+  return sp;
+}
+
+// host replay of the CubicResampler position recurrence for unbounded input (CubicResampler.cs:31-60)
+void Resampler::extend(int64_t nblocks) {
+  while ((int64_t)blocks.size() < nblocks) {
+    ResampleBlock rb;
+    rb.consumed = consumedEnd;
+    rb.pos = posEnd;
+    rb.ready = readyEnd;
+    rb.produced = kBlock;
+    blocks.push_back(rb);
+    int64_t in = consumedEnd;
+    double Pos = posEnd;
+    int ready = readyEnd;
+    while (ready < 4) {
+      in++;
+      ready++;
+    }
+    for (int o = 0; o < kBlock; o++) {
+      int consume = (int)Pos;
+      in += consume;
+      Pos -= consume;
+      Pos += rate;
+    }
+    consumedEnd = in;
+    posEnd = Pos;
+    readyEnd = ready;
+  }
+}
+
+}  // namespace ga

@@ -1,0 +1,283 @@
+// ga_engine.hpp -- host side of libgraphaudio_hip.so: graph snapshot, control-plane simulation, chunk executor.
+//
+// How the reference's per-block pull model (AudioContextBase.ProcessBlock -> AudioNode.ProcessInternal ->
+// AudioNodeInput.Pull, AudioContextBase.cs:52-81, Nodes/AudioNode.cs:152-183, AudioNodeInput.cs:100-138) becomes a
+// device plan:
+//   1. CONTROL PLANE (host, no sample data).  Everything that decides *which* arithmetic happens -- channel counts,
+//      IsSilent flags, start/stop/ended scheduling, queued commands, the lagged ComputeOutputChannelCount -- depends
+//      only on the schedule, never on sample values.  simulate_chunk() replays the reference's depth-first traversal
+//      on that state alone and cuts the chunk into SEGMENTS of consecutive blocks with identical control state.
+//   2. DATA PLANE (device).  For every segment the nodes are executed level by level as batched kernels over all
+//      blocks of the segment at once; convolvers run once per chunk over all blocks (time-batched spectral MAC).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <deque>
+#include <functional>
+#include <limits>
+#include <map>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/graphaudio_hip.h"
+#include "ga_kernels.hpp"
+
+namespace ga {
+
+struct Err {
+  int code;
+  std::string msg;
+};
+[[noreturn]] inline void fail(int code, const std::string& m) { throw Err{code, m}; }
+#define GA_HIP(expr)                                                                                        \
+  do {                                                                                                      \
+    hipError_t e_ = (expr);                                                                                 \
+    if (e_ != hipSuccess)                                                                                   \
+      ::ga::fail(e_ == hipErrorOutOfMemory ? GA_ERR_OUT_OF_MEMORY : GA_ERR_DEVICE,                          \
+                 std::string(#expr) + ": " + hipGetErrorString(e_));                                        \
+  } while (0)
+
+// ---- AudioParam host state (AudioParam.cs:11-392) ----
+struct ParamS {
+  float def, minv, maxv;
+  bool arate;
+  float value;
+  std::vector<ParamEvent> events;
+  std::vector<std::pair<int, int>> modulation;  // connected outputs (node, output) -- unsupported on device yet
+  // per-chunk
+  float* curve = nullptr;  // chunk-frame indexed device curve when events are present
+};
+
+struct Conn {
+  int node;
+  int out;
+  bool operator==(const Conn& o) const { return node == o.node && out == o.out; }
+};
+struct InRef {
+  int node;
+  int input;  // >= 0 input index; < 0: param (-1 - param)
+  bool operator==(const InRef& o) const { return node == o.node && input == o.input; }
+};
+
+// AudioNodeInput (AudioNodeInput.cs:11-98)
+struct InputS {
+  int channelCount = 2;
+  int mode = GA_COUNT_MODE_MAX;
+  int interp = GA_INTERP_SPEAKERS;
+  std::vector<Conn> connected;
+  bool dirty = true;
+  int bufCh = 0;  // channel count of the input's AudioBuffer; 0 = none yet
+  bool silent = true;
+};
+struct OutputS {
+  std::vector<InRef> connectedInputs;
+  int bufCh = 0;  // AudioNodeOutput.Buffer channel count; 0 = null (owner not processed yet)
+  bool silent = true;
+};
+
+struct PlayBuf {
+  int channels = 0;
+  int64_t length = 0;
+  int64_t stride = 0;  // floats between channels on the device
+  int sampleRate = 0;
+  std::vector<std::vector<float>> host;
+  float* dev = nullptr;
+};
+
+struct IrSpectra {  // P zero-padded 256-point spectra per IR channel (PartitionedConvolver.cs:65-91)
+  int P = 0;
+  int nch = 0;
+  float* hr = nullptr;  // [nch][129][P]
+  float* hi = nullptr;
+};
+
+struct ConvGroup;   // rows sharing one IR channel's spectra
+struct ConvRowRef {
+  ConvGroup* group = nullptr;
+  int idx = -1;
+};
+
+// source phase timeline inside one chunk
+enum SrcPhase { SRC_IDLE = 0, SRC_PLAY = 1, SRC_END = 2, SRC_GONE = 3 };
+struct SrcSpan {
+  int64_t b0;      // chunk-relative first block
+  int phase;
+  int64_t pos;     // _playbackPosition at b0 (SRC_PLAY)
+  int64_t blkIdx;  // index of b0 in the resampler trajectory (resampled playback)
+};
+
+struct NodeS {
+  int id = 0, type = 0;
+  bool disposed = false;
+  std::vector<InputS> inputs;
+  std::vector<OutputS> outputs;
+  std::vector<ParamS> params;
+  int64_t lastProcessedBlock = -1;
+  bool isProcessing = false;
+  bool reachable = false;
+  int level = 0, depth = 0;
+
+  // AudioBufferSourceNode (AudioBufferSourceNode.cs:15-30)
+  int bufId = -1;
+  bool hasStarted = false, hasStopped = false, endedRaised = false;
+  double startTime = std::nan(""), stopTime = std::nan("");
+  double offset = 0, duration = std::numeric_limits<double>::infinity();
+  int64_t playbackPosition = 0;
+  bool loop = false;
+  double loopStart = 0, loopEnd = 0;
+  int64_t rsBlocks = 0;          // resampler: blocks played so far (index into the trajectory)
+  int64_t rsStartPos = 0;        // resampler: buffer index where consumption started
+  std::vector<SrcSpan> spans;    // per-chunk plan
+  // BiQuadFilterNode (BiQuadFilterNode.cs:12-19)
+  int filterType = GA_FILTER_LOWPASS;
+  float b0 = 0, b1 = 0, b2 = 0, a1 = 0, a2 = 0;
+  bool coefDirty = true;
+  float* bqState = nullptr;  // device [32][2]
+  // ConvolverNode (ConvolverNode.cs:12-16,87,95)
+  int irBuf = -1;
+  std::shared_ptr<IrSpectra> ir;
+  int effectiveOutCh = 0;
+  bool isTrueStereo = false, normalize = true, enableTrueStereo = true;
+  std::vector<ConvRowRef> convRows;
+};
+
+// one evaluated control state of a node within a segment
+struct TermS {
+  int node, out, ch;
+};
+struct InSeg {
+  int bufCh = 0;
+  bool silent = true;
+  std::vector<TermS> terms;  // non-silent contributors in connection order
+};
+struct NodeSeg {
+  int id = 0;
+  std::vector<InSeg> ins;
+  int outCh = 0;
+  bool outSilent = true;
+  int srcPhase = SRC_IDLE;
+  int64_t srcPos = 0;
+  int64_t srcBlk = 0;
+  int srcBuf = -1;  // buffer id at evaluation time (a later Dispose clears the node's reference)
+  bool bqActive = false;
+  float b0 = 0, b1 = 0, b2 = 0, a1 = 0, a2 = 0;
+};
+struct Segment {
+  int64_t b0 = 0, b1 = 0;  // chunk-relative block range
+  std::vector<NodeSeg> nodes;  // processing (post) order
+  uint64_t hash = 0;
+};
+
+struct ConvGroup {
+  std::shared_ptr<IrSpectra> ir;
+  int irCh = 0;
+  int P = 0;
+  std::vector<std::pair<int, int>> rows;  // (node id, row slot) ; node id < 0 = free row
+  int rp = 0;                             // allocated (padded) rows of the state arrays
+  float* histR = nullptr;                 // [129][P-1][rp]
+  float* histI = nullptr;
+  float* overlap[2] = {nullptr, nullptr}; // [rp][128], double buffered
+  int ovCur = 0;
+  bool histZero = true;
+};
+
+struct DevArena {  // grow-only device scratch
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+struct Resampler {  // host replay of CubicResampler's position recurrence (CubicResampler.cs:40-60) for one rate
+  double rate = 1.0;
+  std::vector<ResampleBlock> blocks;  // state at the start of each played block (unbounded input)
+  int64_t consumedEnd = 0;            // consumption after the last computed block
+  double posEnd = 0.0;
+  int readyEnd = 0;
+  int devOffset = -1;                 // offset in the per-chunk device trajectory table
+  void extend(int64_t nblocks);
+};
+
+struct Context {
+  int sampleRate;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool ownStream = true;
+  int64_t currentBlock = 0;
+  double currentTime = 0.0;
+  bool disposed = false;
+  bool latched = false;  // _renderThreadId != -1 (AudioContextBase.cs:59-62)
+  bool inRender = false;
+  std::deque<std::function<void()>> pending;
+  std::vector<std::unique_ptr<NodeS>> nodes;
+  std::vector<std::unique_ptr<PlayBuf>> buffers;
+  std::map<std::pair<int, int>, std::shared_ptr<IrSpectra>> irCache;  // (buffer id, normalize)
+  std::vector<std::unique_ptr<ConvGroup>> groups;
+  std::map<std::pair<IrSpectra*, int>, ConvGroup*> groupOf;
+  std::map<uint64_t, std::unique_ptr<Resampler>> resamplers;          // keyed by rate bits
+  std::string lastError;
+  ga_stats stats{};
+  // options
+  int64_t maxChunkBlocks = 4096;
+  double memBudgetFraction = 0.7;
+  bool profile = false;
+  // device resources
+  double2* w128 = nullptr;
+  double2* w256 = nullptr;
+  float* zeros = nullptr;  // zero page (chunk frames)
+  int64_t zerosLen = 0;
+  DevArena planes[4];      // xr, xi, yr, yi scratch shared by all groups
+  DevArena tables;         // per-chunk job tables
+  void* tablesHost = nullptr;
+  size_t tablesHostBytes = 0;
+  std::vector<float*> slabFree, slabAll;
+  int64_t slabFrames = 0;
+  std::vector<void*> slabBlocks;
+  std::vector<void*> bqBlocks;
+  size_t bqUsed = 0;
+  int64_t devBytes = 0;
+  // destination output of the last block (for Render(int) and the leftover cache)
+  int destOutCh = 0;
+  float* cacheDev = nullptr;  // [32][128]
+  int cachedFrames = 0, cachedCh = 0;
+
+  explicit Context(int sr) : sampleRate(sr) {}
+  ~Context();
+  void init_device(int device);
+  void* dalloc(size_t bytes);
+  void dfree(void* p, size_t bytes);
+  void ensure(DevArena& a, size_t bytes);
+
+  // command queue (AudioContextBase.cs:266-305)
+  void executeOrPost(std::function<void()> cmd);
+  void post(std::function<void()> cmd);
+  void drain();
+
+  NodeS* node(int id);
+  ParamS* param(int node, int p);
+  PlayBuf* buffer(int id);
+  InputS* inputOf(const InRef& r);
+
+  // graph edits (Nodes/AudioNode.cs:109-150,207-238; AudioNodeOutput.cs:42-70; AudioNodeInput.cs:60-83)
+  void connectTo(int src, int out, InRef in);
+  void disconnectFrom(int src, int out, InRef in);
+  void outputDisconnectAll(int src, int out);
+  void inputDisconnectAll(InRef in);
+  void doDispose(int id);
+
+  std::shared_ptr<IrSpectra> irSpectra(int bufId, bool normalize);
+  void updateBiquadCoefficients(NodeS& n, float frequency, float q, float gain);
+
+  void render(float* const* out, int channels, int64_t frames, int64_t start, bool deviceOut);
+  void runChunk(int64_t nblocks, float* const* bus);
+
+  int64_t busCapFrames = 0;
+  std::vector<float*> busSlabs;
+  uint64_t lastHash = 0;       // control-state hash of the last block of the previous chunk
+  int chunkMinDestCh = 0;      // smallest destination channel count over the blocks of the last chunk
+  int64_t chunkBlocksDone = 0; // blocks actually executed by the last runChunk
+};
+
+}  // namespace ga

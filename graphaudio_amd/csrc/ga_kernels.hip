@@ -1,0 +1,734 @@
+// ga_kernels.hip -- hand-written gfx950 (CDNA4, MI355X) kernels of the GraphAudio offline render path.
+//
+// Reference semantics each kernel reproduces are cited as (file:line) of the-byte-bender/GraphAudio.
+// Design notes (DESIGN.md has the full account):
+//  * wavefront = 64 lanes everywhere; one 256-point real FFT per wavefront, two complex points per lane,
+//    radix-2 butterflies exchanged with wave shuffles, double precision like the reference's FftFlat.
+//  * the spectral multiply-accumulate runs over ALL blocks of a render chunk at once: for one frequency bin it is
+//    a banded-Toeplitz GEMM  Y[rows x time] = X[rows x time'] * T(H)  executed on the f32 matrix cores
+//    (v_mfma_f32_16x16x4_f32, exact f32 fma chain), rows = convolver channel-instances sharing one IR channel.
+//  * serial-in-time recurrences (biquad, resampler) stage 64x64 tiles through LDS so HBM accesses stay coalesced.
+// Compiled with -ffp-contract=off: float32 elementwise arithmetic is unfused like the reference's; fused
+// multiply-adds appear only where written explicitly (fma(), MFMA).
+
+#include "ga_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+namespace ga {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// =====================================================================================================
+//  256-point real FFT on one wavefront (forward: RealFourierTransform.cs:62-88; inverse: :101-131)
+//  z[n] = x[2n] + i x[2n+1] (n < 128); lane l owns z[l] (slot 0) and z[l+64] (slot 1).
+// =====================================================================================================
+__device__ __forceinline__ double shx(double v, int mask) { return __shfl_xor(v, mask, 64); }
+__device__ __forceinline__ int rev6(int l) { return (int)(__brev((unsigned)l) >> 26); }
+
+struct LaneTw {   // per-lane twiddles, loaded once per kernel
+  double c[6], s[6];   // stage twiddles for half = 32,16,8,4,2,1 : W128^{(l & (half-1)) * 64/half}
+  double c1, s1;       // W128^l  (the in-lane stage)
+};
+
+__device__ __forceinline__ LaneTw load_lane_tw(const double2* __restrict w128, int lane) {
+  LaneTw t;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    int half = 32 >> i;
+    double2 w = w128[(lane & (half - 1)) * (64 / half)];
+    t.c[i] = w.x;
+    t.s[i] = w.y;
+  }
+  double2 w = w128[lane];
+  t.c1 = w.x;
+  t.s1 = w.y;
+  return t;
+}
+
+// decimation-in-frequency over the 64 lanes: natural order in, bit-reversed out
+template <int HALF, int IDX>
+__device__ __forceinline__ void dif_stage(double& ar, double& ai, const LaneTw& t, bool up) {
+  double pr = shx(ar, HALF), pi = shx(ai, HALF);
+  double sr = ar + pr, si = ai + pi;
+  double dr = pr - ar, di = pi - ai;
+  double ur = fma(dr, t.c[IDX], -(di * t.s[IDX]));
+  double ui = fma(dr, t.s[IDX], di * t.c[IDX]);
+  ar = up ? ur : sr;
+  ai = up ? ui : si;
+}
+// decimation-in-time over the 64 lanes with conjugated twiddles: bit-reversed in, natural out
+template <int HALF, int IDX>
+__device__ __forceinline__ void dit_stage(double& ar, double& ai, const LaneTw& t, bool up) {
+  double pr = shx(ar, HALF), pi = shx(ai, HALF);
+  double mr = up ? ar : pr, mi = up ? ai : pi;          // the upper element of the pair
+  double c = t.c[IDX], s = -t.s[IDX];                   // conj twiddle
+  double qr = fma(mr, c, -(mi * s));
+  double qi = fma(mr, s, mi * c);
+  ar = up ? (pr - qr) : (ar + qr);
+  ai = up ? (pi - qi) : (ai + qi);
+}
+
+constexpr int FFT_ROWS = 32;        // rows (channel-instances) per workgroup
+constexpr int STAGE_LD = FFT_ROWS + 1;
+
+// ---- forward ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rfft_fwd_kernel(const ConvRowIO* __restrict rows, int nrows, int nblocks, int hist,
+                                                       ConvPlanes pl, Twiddles tw) {
+  __shared__ float st_r[kBins * STAGE_LD];
+  __shared__ float st_i[kBins * STAGE_LD];
+  __shared__ double2 zs[4][128];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rowtile = blockIdx.x;
+  const int t = blockIdx.y;
+  const LaneTw ltw = load_lane_tw(tw.w128, lane);
+  const double2 wk0 = tw.w256[lane];        // for k = lane
+  const double2 wk1 = tw.w256[lane + 64];   // for k = lane + 64
+  const int zidx = rev6(lane) << 1;
+
+  for (int q = 0; q < FFT_ROWS / 4; q++) {
+    const int rl = wave * (FFT_ROWS / 4) + q;
+    const int row = rowtile * FFT_ROWS + rl;
+    const float* in = row < nrows ? rows[row].in : nullptr;
+    double s0r = 0.0, s0i = 0.0;
+    if (in) {
+      const float* p = in + (int64_t)t * kBlock + 2 * lane;
+      s0r = (double)p[0];     // float -> double, PartitionedConvolver.cs:106
+      s0i = (double)p[1];
+    }
+    // in-lane stage with the zero upper half (PartitionedConvolver.cs:107): (a + 0, (a - 0) * W128^l)
+    double s1r = fma(s0r, ltw.c1, -(s0i * ltw.s1));
+    double s1i = fma(s0r, ltw.s1, s0i * ltw.c1);
+    dif_stage<32, 0>(s0r, s0i, ltw, lane & 32); dif_stage<32, 0>(s1r, s1i, ltw, lane & 32);
+    dif_stage<16, 1>(s0r, s0i, ltw, lane & 16); dif_stage<16, 1>(s1r, s1i, ltw, lane & 16);
+    dif_stage<8, 2>(s0r, s0i, ltw, lane & 8);   dif_stage<8, 2>(s1r, s1i, ltw, lane & 8);
+    dif_stage<4, 3>(s0r, s0i, ltw, lane & 4);   dif_stage<4, 3>(s1r, s1i, ltw, lane & 4);
+    dif_stage<2, 4>(s0r, s0i, ltw, lane & 2);   dif_stage<2, 4>(s1r, s1i, ltw, lane & 2);
+    dif_stage<1, 5>(s0r, s0i, ltw, lane & 1);   dif_stage<1, 5>(s1r, s1i, ltw, lane & 1);
+    // slot j of lane l now holds Z[(rev6(l) << 1) | j]
+    zs[wave][zidx] = make_double2(s0r, s0i);
+    zs[wave][zidx + 1] = make_double2(s1r, s1i);
+    __syncthreads();
+    // real-FFT split: X[k] = E[k] + W256^k * (-i) * D[k]
+    {
+      const int k = lane;
+      double2 a = zs[wave][k];
+      double2 b = zs[wave][(128 - k) & 127];
+      double er = 0.5 * (a.x + b.x), ei = 0.5 * (a.y - b.y);
+      double dr = 0.5 * (a.x - b.x), di = 0.5 * (a.y + b.y);
+      double pr = fma(dr, wk0.x, -(di * wk0.y)), pi = fma(dr, wk0.y, di * wk0.x);
+      float xr = (float)(er + pi), xi = (float)(ei - pr);   // double -> float, PartitionedConvolver.cs:117-118
+      if (k == 0) xi = 0.f;
+      st_r[k * STAGE_LD + rl] = xr;
+      st_i[k * STAGE_LD + rl] = xi;
+      if (k == 0) {  // Nyquist: X[128] = Re Z[0] - Im Z[0], imaginary part zero (RealFourierTransform.cs:76-78)
+        st_r[128 * STAGE_LD + rl] = (float)(a.x - a.y);
+        st_i[128 * STAGE_LD + rl] = 0.f;
+      }
+    }
+    {
+      const int k = lane + 64;
+      double2 a = zs[wave][k];
+      double2 b = zs[wave][128 - k];
+      double er = 0.5 * (a.x + b.x), ei = 0.5 * (a.y - b.y);
+      double dr = 0.5 * (a.x - b.x), di = 0.5 * (a.y + b.y);
+      double pr = fma(dr, wk1.x, -(di * wk1.y)), pi = fma(dr, wk1.y, di * wk1.x);
+      st_r[k * STAGE_LD + rl] = (float)(er + pi);
+      st_i[k * STAGE_LD + rl] = (float)(ei - pr);
+    }
+    __syncthreads();
+  }
+  // coalesced store of the [bin][row] tile: 32 consecutive rows = one 128-byte line per bin
+  const size_t plane_t = (size_t)pl.tx * pl.rp;
+  const size_t base = (size_t)(hist + t) * pl.rp + (size_t)rowtile * FFT_ROWS;
+  for (int idx = tid; idx < kBins * FFT_ROWS; idx += 256) {
+    int k = idx / FFT_ROWS, r = idx % FFT_ROWS;
+    size_t o = (size_t)k * plane_t + base + r;
+    pl.xr[o] = st_r[k * STAGE_LD + r];
+    pl.xi[o] = st_i[k * STAGE_LD + r];
+  }
+}
+
+void launch_rfft_fwd(hipStream_t s, const ConvRowIO* rows_dev, int nrows, int nblocks, int hist, ConvPlanes pl, Twiddles tw) {
+  if (nrows <= 0 || nblocks <= 0) return;
+  dim3 grid((nrows + FFT_ROWS - 1) / FFT_ROWS, nblocks);
+  hipLaunchKernelGGL(rfft_fwd_kernel, grid, dim3(256), 0, s, rows_dev, nrows, nblocks, hist, pl, tw);
+}
+
+// ---- inverse + overlap-add ----------------------------------------------------------------------------
+constexpr int OLA_RUN = 16;   // consecutive blocks per workgroup (one extra inverse FFT recovers the incoming tail)
+
+__global__ __launch_bounds__(256) void irfft_ola_kernel(const ConvRowIO* __restrict rows, int nrows, int nblocks, ConvPlanes pl,
+                                                        const float* __restrict overlap_in, float* __restrict overlap_out, Twiddles tw) {
+  __shared__ float ys_r[kBins * STAGE_LD];
+  __shared__ float ys_i[kBins * STAGE_LD];
+  __shared__ float tail[FFT_ROWS][kBlock];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rowtile = blockIdx.x;
+  const int ta = blockIdx.y * OLA_RUN;
+  const int tb = min(ta + OLA_RUN, nblocks);
+  const LaneTw ltw = load_lane_tw(tw.w128, lane);
+  const int k0 = rev6(lane) << 1, k1 = k0 | 1;
+  const double2 wk0 = tw.w256[k0];
+  const double2 wk1 = tw.w256[k1];
+  const size_t plane_t = (size_t)pl.ty * pl.rp;
+
+  if (ta == 0) {  // incoming overlap of the chunk's first block = persistent _overlap (PartitionedConvolver.cs:28,148-149)
+    for (int idx = tid; idx < FFT_ROWS * kBlock; idx += 256) {
+      int r = idx / kBlock, i = idx % kBlock;
+      int row = rowtile * FFT_ROWS + r;
+      tail[r][i] = row < nrows ? overlap_in[(size_t)row * kBlock + i] : 0.f;
+    }
+  }
+  for (int t = (ta == 0 ? 0 : ta - 1); t < tb; t++) {
+    const bool pre = t < ta;   // only recompute block ta-1 to obtain its second half
+    __syncthreads();
+    const size_t base = (size_t)t * pl.rp + (size_t)rowtile * FFT_ROWS;
+    for (int idx = tid; idx < kBins * FFT_ROWS; idx += 256) {
+      int k = idx / FFT_ROWS, r = idx % FFT_ROWS;
+      size_t o = (size_t)k * plane_t + base + r;
+      ys_r[k * STAGE_LD + r] = pl.yr[o];
+      ys_i[k * STAGE_LD + r] = pl.yi[o];
+    }
+    __syncthreads();
+    for (int q = 0; q < FFT_ROWS / 4; q++) {
+      const int rl = wave * (FFT_ROWS / 4) + q;
+      const int row = rowtile * FFT_ROWS + rl;
+      if (row >= nrows) continue;   // wave-uniform
+      // Z[k] = (X[k] + conj X[128-k]) + i conj(W256^k) (X[k] - conj X[128-k])   (float -> double, :136)
+      double s0r, s0i, s1r, s1i;
+      {
+        double ar = ys_r[k0 * STAGE_LD + rl], ai = ys_i[k0 * STAGE_LD + rl];
+        double br = ys_r[(128 - k0) * STAGE_LD + rl], bi = -(double)ys_i[(128 - k0) * STAGE_LD + rl];
+        if (k0 == 0) { ai = 0.0; bi = 0.0; }   // rdft ignores Im of DC / Nyquist (RealFourierTransform.cs:120-123)
+        double er = ar + br, ei = ai + bi, dr = ar - br, di = ai - bi;
+        double pr = fma(dr, wk0.x, di * wk0.y), pi = fma(di, wk0.x, -(dr * wk0.y));   // d * conj(w)
+        s0r = er - pi;
+        s0i = ei + pr;
+      }
+      {
+        double ar = ys_r[k1 * STAGE_LD + rl], ai = ys_i[k1 * STAGE_LD + rl];
+        double br = ys_r[(128 - k1) * STAGE_LD + rl], bi = -(double)ys_i[(128 - k1) * STAGE_LD + rl];
+        double er = ar + br, ei = ai + bi, dr = ar - br, di = ai - bi;
+        double pr = fma(dr, wk1.x, di * wk1.y), pi = fma(di, wk1.x, -(dr * wk1.y));
+        s1r = er - pi;
+        s1i = ei + pr;
+      }
+      dit_stage<1, 5>(s0r, s0i, ltw, lane & 1);   dit_stage<1, 5>(s1r, s1i, ltw, lane & 1);
+      dit_stage<2, 4>(s0r, s0i, ltw, lane & 2);   dit_stage<2, 4>(s1r, s1i, ltw, lane & 2);
+      dit_stage<4, 3>(s0r, s0i, ltw, lane & 4);   dit_stage<4, 3>(s1r, s1i, ltw, lane & 4);
+      dit_stage<8, 2>(s0r, s0i, ltw, lane & 8);   dit_stage<8, 2>(s1r, s1i, ltw, lane & 8);
+      dit_stage<16, 1>(s0r, s0i, ltw, lane & 16); dit_stage<16, 1>(s1r, s1i, ltw, lane & 16);
+      dit_stage<32, 0>(s0r, s0i, ltw, lane & 32); dit_stage<32, 0>(s1r, s1i, ltw, lane & 32);
+      // in-lane stage: z[l] = s0 + s1 conj(W128^l), z[l+64] = s0 - s1 conj(W128^l); scale 2/n * 1/2 (:46,129)
+      double qr = fma(s1r, ltw.c1, s1i * ltw.s1), qi = fma(s1i, ltw.c1, -(s1r * ltw.s1));
+      const double scale = 1.0 / 256.0;
+      double h0 = (s0r + qr) * scale, h1 = (s0i + qi) * scale;   // time samples 2l, 2l+1
+      double g0 = (s0r - qr) * scale, g1 = (s0i - qi) * scale;   // time samples 128+2l, 128+2l+1
+      if (!pre) {
+        float* out = rows[row].out;
+        float o0 = (float)h0 + tail[rl][2 * lane];        // (float)y[i] + overlap[i]  (:148)
+        float o1 = (float)h1 + tail[rl][2 * lane + 1];
+        if (out) {
+          float2* op = reinterpret_cast<float2*>(out + (int64_t)t * kBlock + 2 * lane);
+          *op = make_float2(o0, o1);
+        }
+      }
+      tail[rl][2 * lane] = (float)g0;                      // overlap[i] = (float)y[i + 128]  (:149)
+      tail[rl][2 * lane + 1] = (float)g1;
+    }
+  }
+  if (tb == nblocks) {
+    __syncthreads();
+    for (int idx = tid; idx < FFT_ROWS * kBlock; idx += 256) {
+      int r = idx / kBlock, i = idx % kBlock;
+      int row = rowtile * FFT_ROWS + r;
+      if (row < nrows) overlap_out[(size_t)row * kBlock + i] = tail[r][i];
+    }
+  }
+}
+
+void launch_irfft_ola(hipStream_t s, const ConvRowIO* rows_dev, int nrows, int nblocks, ConvPlanes pl, const float* overlap_in,
+                      float* overlap_out, Twiddles tw) {
+  if (nrows <= 0 || nblocks <= 0) return;
+  dim3 grid((nrows + FFT_ROWS - 1) / FFT_ROWS, (nblocks + OLA_RUN - 1) / OLA_RUN);
+  hipLaunchKernelGGL(irfft_ola_kernel, grid, dim3(256), 0, s, rows_dev, nrows, nblocks, pl, overlap_in, overlap_out, tw);
+}
+
+// =====================================================================================================
+//  Shared-IR spectral multiply-accumulate on the f32 matrix cores.
+//  Reference: PartitionedConvolver.ProcessSpectralConvolution, PartitionedConvolver.cs:154-223
+//     acc[k] = sum_{p<P} FDL[(w+p)%P][k] * H[p][k]            (one block, one channel-instance)
+//  Here, for one bin k and all blocks t of the chunk and all rows r sharing H:
+//     Y[r][t] = sum_u X[r][t0 + u] * G[u - j],  j = t - t0,  G[m] = H[P-1-m] (0 <= m < P), a banded Toeplitz GEMM.
+//  Workgroup tile 128 rows x 64 blocks; wave tile 32 rows x 64 blocks = 2 x 4 MFMA 16x16 tiles, re+im accumulators.
+//  Taps are processed in segments of <= MAC_PSEG so the reversed taps fit LDS whatever P is.
+// =====================================================================================================
+constexpr int MAC_ROWS = 128;
+constexpr int MAC_TIME = 64;
+constexpr int MAC_KC = 16;                   // time steps (u) per LDS chunk
+constexpr int MAC_LD = MAC_ROWS + 16;        // padded row stride: lanes 16..31 land 16 banks away from lanes 0..15
+constexpr int MAC_PSEG = 1024;
+constexpr int MAC_GLEN = MAC_PSEG + 160;
+
+__global__ __launch_bounds__(256) void spectral_mac_shared_kernel(ConvPlanes pl, const float* __restrict hr, const float* __restrict hi,
+                                                                 int P, int ntt, int nrt, int total) {
+  __shared__ __attribute__((aligned(16))) float xs[2][2][MAC_KC * MAC_LD];   // [buffer][re/im][u][row]
+  __shared__ float gs[2][MAC_GLEN];                                           // reversed, zero padded taps (re, im)
+
+  // XCD-aware mapping: workgroups b and b+8 share an XCD (round-robin dispatch), give each XCD a contiguous range of
+  // (bin, row tile, time tile) so neighbouring time tiles -- which re-read 8/9 of the same X rows -- share one L2.
+  const int per = (total + 7) >> 3;
+  const int L = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (L >= total) return;
+  const int tt = L % ntt;
+  const int rt = (L / ntt) % nrt;
+  const int k = L / (ntt * nrt);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t0 = tt * MAC_TIME;
+  const int row0 = rt * MAC_ROWS;
+  const size_t xplane = (size_t)pl.tx * pl.rp;
+  const float* __restrict xr = pl.xr + (size_t)k * xplane + row0;
+  const float* __restrict xi = pl.xi + (size_t)k * xplane + row0;
+
+  f32x4 accr[2][4], acci[2][4];
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+      accr[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acci[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+  // global -> LDS staging assignment: thread -> (u = tid/32 and +8, rows 4*(tid%32) .. +3)
+  const int su = tid >> 5, sr4 = (tid & 31) * 4;
+  const int la = lane & 15, lk = lane >> 4;
+
+  for (int pa = 0; pa < P; pa += MAC_PSEG) {
+    const int Ps = min(MAC_PSEG, P - pa);
+    const int u0 = P - (pa + Ps);                  // plane-row offset of this tap segment
+    const int nch = (Ps + 63 + MAC_KC - 1) / MAC_KC + 0;
+    __syncthreads();                               // previous segment's LDS fully consumed
+    // G[m] for m in [-64, Ps+96): gs[m + 64]
+    for (int i = tid; i < MAC_GLEN; i += 256) {
+      int m = i - 64;
+      bool ok = (m >= 0) && (m < Ps);
+      int p = pa + Ps - 1 - m;
+      gs[0][i] = ok ? hr[(size_t)k * P + p] : 0.f;
+      gs[1][i] = ok ? hi[(size_t)k * P + p] : 0.f;
+    }
+    // prologue: chunk 0
+    float4 pr0, pr1, pi0, pi1;
+    {
+      size_t o0 = (size_t)(t0 + u0 + su) * pl.rp + sr4;
+      size_t o1 = (size_t)(t0 + u0 + su + 8) * pl.rp + sr4;
+      pr0 = *reinterpret_cast<const float4*>(xr + o0);
+      pr1 = *reinterpret_cast<const float4*>(xr + o1);
+      pi0 = *reinterpret_cast<const float4*>(xi + o0);
+      pi1 = *reinterpret_cast<const float4*>(xi + o1);
+    }
+    *reinterpret_cast<float4*>(&xs[0][0][su * MAC_LD + sr4]) = pr0;
+    *reinterpret_cast<float4*>(&xs[0][0][(su + 8) * MAC_LD + sr4]) = pr1;
+    *reinterpret_cast<float4*>(&xs[0][1][su * MAC_LD + sr4]) = pi0;
+    *reinterpret_cast<float4*>(&xs[0][1][(su + 8) * MAC_LD + sr4]) = pi1;
+    __syncthreads();
+
+    for (int c = 0; c < nch; c++) {
+      const int buf = c & 1;
+      const bool more = (c + 1) < nch;
+      if (more) {
+        size_t o0 = (size_t)(t0 + u0 + (c + 1) * MAC_KC + su) * pl.rp + sr4;
+        size_t o1 = o0 + (size_t)8 * pl.rp;
+        pr0 = *reinterpret_cast<const float4*>(xr + o0);
+        pr1 = *reinterpret_cast<const float4*>(xr + o1);
+        pi0 = *reinterpret_cast<const float4*>(xi + o0);
+        pi1 = *reinterpret_cast<const float4*>(xi + o1);
+      }
+      const float* __restrict xsr = xs[buf][0];
+      const float* __restrict xsi = xs[buf][1];
+#pragma unroll
+      for (int ks = 0; ks < MAC_KC / 4; ks++) {
+        const int uk = c * MAC_KC + ks * 4;     // first u of this K-step (wave uniform)
+        float ar[2], ai[2], nai[2];
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+          int off = (ks * 4 + lk) * MAC_LD + wave * 32 + m * 16 + la;
+          ar[m] = xsr[off];
+          ai[m] = xsi[off];
+          nai[m] = -ai[m];
+        }
+#pragma unroll
+        for (int n = 0; n < 4; n++) {
+          // band of N-tile n: u in [16n, 16n + 15 + Ps - 1]; skip K-steps entirely outside (B fragment all zero)
+          if (uk + 3 < 16 * n || uk > 16 * n + 14 + Ps) continue;
+          int gi = uk + lk - (16 * n + la) + 64;
+          float br = gs[0][gi], bi = gs[1][gi];
+#pragma unroll
+          for (int m = 0; m < 2; m++) {
+            // (a + ib)(c + id): re += ac - bd ; im += ad + bc   (PartitionedConvolver.cs:195-204, fused on the matrix core)
+            accr[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[m], br, accr[m][n], 0, 0, 0);
+            accr[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(nai[m], bi, accr[m][n], 0, 0, 0);
+            acci[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[m], bi, acci[m][n], 0, 0, 0);
+            acci[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[m], br, acci[m][n], 0, 0, 0);
+          }
+        }
+      }
+      if (more) {
+        const int nb = buf ^ 1;
+        *reinterpret_cast<float4*>(&xs[nb][0][su * MAC_LD + sr4]) = pr0;
+        *reinterpret_cast<float4*>(&xs[nb][0][(su + 8) * MAC_LD + sr4]) = pr1;
+        *reinterpret_cast<float4*>(&xs[nb][1][su * MAC_LD + sr4]) = pi0;
+        *reinterpret_cast<float4*>(&xs[nb][1][(su + 8) * MAC_LD + sr4]) = pi1;
+      }
+      __syncthreads();
+    }
+  }
+
+  // epilogue: C/D layout of v_mfma_f32_16x16x4_f32: column (time) = lane & 15, row = 4 * (lane >> 4) + reg
+  const size_t yplane = (size_t)pl.ty * pl.rp;
+  float* __restrict yr = pl.yr + (size_t)k * yplane + row0;
+  float* __restrict yi = pl.yi + (size_t)k * yplane + row0;
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+      int t = t0 + 16 * n + la;
+      size_t o = (size_t)t * pl.rp + wave * 32 + m * 16 + lk * 4;
+      *reinterpret_cast<f32x4*>(yr + o) = accr[m][n];
+      *reinterpret_cast<f32x4*>(yi + o) = acci[m][n];
+    }
+}
+
+void launch_spectral_mac_shared(hipStream_t s, ConvPlanes pl, const float* hr, const float* hi, int P, int nblocks, int nrows) {
+  if (nrows <= 0 || nblocks <= 0 || P <= 0) return;
+  int ntt = (nblocks + MAC_TIME - 1) / MAC_TIME;
+  int nrt = (nrows + MAC_ROWS - 1) / MAC_ROWS;
+  int total = kBins * ntt * nrt;
+  int grid = ((total + 7) / 8) * 8;
+  hipLaunchKernelGGL(spectral_mac_shared_kernel, dim3(grid), dim3(256), 0, s, pl, hr, hi, P, ntt, nrt, total);
+}
+
+// ---- plane utilities ----------------------------------------------------------------------------------
+__global__ void plane_copy_kernel(float* __restrict dst, int dst_t, int dst_t0, const float* __restrict src, int src_t, int src_t0,
+                                  int n, int rp) {
+  const int k = blockIdx.y;
+  const size_t per = (size_t)n * rp / 4;
+  float4* d = reinterpret_cast<float4*>(dst + ((size_t)k * dst_t + dst_t0) * rp);
+  const float4* s = src ? reinterpret_cast<const float4*>(src + ((size_t)k * src_t + src_t0) * rp) : nullptr;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (size_t)gridDim.x * blockDim.x)
+    d[i] = s ? s[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+void launch_plane_copy(hipStream_t s, float* dst, int dst_t, int dst_t0, const float* src, int src_t, int src_t0, int n, int rp) {
+  if (n <= 0) return;
+  size_t per = (size_t)n * rp / 4;
+  int gx = (int)((per + 255) / 256);
+  if (gx > 512) gx = 512;
+  hipLaunchKernelGGL(plane_copy_kernel, dim3(gx, kBins), dim3(256), 0, s, dst, dst_t, dst_t0, src, src_t, src_t0, n, rp);
+}
+
+__global__ void extract_ir_kernel(float* __restrict hr, float* __restrict hi, const float* __restrict xr, const float* __restrict xi,
+                                  int tx, int rp, int P, int nch) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over nch * kBins * P
+  int total = nch * kBins * P;
+  if (idx >= total) return;
+  int p = idx % P, k = (idx / P) % kBins, c = idx / (P * kBins);
+  size_t o = ((size_t)k * tx + p) * rp + c;
+  hr[idx] = xr[o];
+  hi[idx] = xi[o];
+}
+void launch_extract_ir(hipStream_t s, float* hr, float* hi, const float* xr, const float* xi, int tx, int rp, int P, int nch) {
+  int total = nch * kBins * P;
+  if (total <= 0) return;
+  hipLaunchKernelGGL(extract_ir_kernel, dim3((total + 255) / 256), dim3(256), 0, s, hr, hi, xr, xi, tx, rp, P, nch);
+}
+
+__global__ void pair_sum_kernel(float* __restrict out, const float* __restrict a, const float* __restrict b, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = a[i] + b[i];
+}
+void launch_pair_sum(hipStream_t s, float* out, const float* a, const float* b, int64_t n) {
+  if (n <= 0) return;
+  int g = (int)std::min<int64_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(pair_sum_kernel, dim3(g), dim3(256), 0, s, out, a, b, n);
+}
+
+// =====================================================================================================
+//  Mix (AudioNodeInput.Pull / MixBuffer, AudioNodeInput.cs:100-244): sequential float32 sum in connection order,
+//  starting from the cleared buffer (0 + t0 + t1 + ...), one thread per 1 or 4 frames.
+// =====================================================================================================
+template <int VEC>
+__global__ __launch_bounds__(256) void mix_kernel(const MixJob* __restrict jobs, const float* const* __restrict terms) {
+  const MixJob job = jobs[blockIdx.y];
+  const int64_t nv = (job.n + VEC - 1) / VEC;
+  const float* const* __restrict tp = terms + job.term0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t f = job.f0 + i * VEC;
+    if (VEC == 4) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      int j = 0;
+      for (; j + 4 <= job.nterms; j += 4) {   // four loads in flight, adds strictly in term order
+        float4 v0 = *reinterpret_cast<const float4*>(tp[j] + f);
+        float4 v1 = *reinterpret_cast<const float4*>(tp[j + 1] + f);
+        float4 v2 = *reinterpret_cast<const float4*>(tp[j + 2] + f);
+        float4 v3 = *reinterpret_cast<const float4*>(tp[j + 3] + f);
+        acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+        acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+        acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
+        acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+      }
+      for (; j < job.nterms; j++) {
+        float4 v = *reinterpret_cast<const float4*>(tp[j] + f);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+      *reinterpret_cast<float4*>(job.out + f) = acc;
+    } else {
+      float acc = 0.f;
+      for (int j = 0; j < job.nterms; j++) acc += tp[j][f];
+      job.out[f] = acc;
+    }
+  }
+}
+void launch_mix(hipStream_t s, const MixJob* jobs_dev, int njobs, const float* const* terms_dev, int64_t max_n, bool vec4) {
+  if (njobs <= 0 || max_n <= 0) return;
+  int64_t nv = vec4 ? (max_n + 3) / 4 : max_n;
+  int gx = (int)std::min<int64_t>((nv + 255) / 256, 2048);
+  if (vec4)
+    hipLaunchKernelGGL(mix_kernel<4>, dim3(gx, njobs), dim3(256), 0, s, jobs_dev, terms_dev);
+  else
+    hipLaunchKernelGGL(mix_kernel<1>, dim3(gx, njobs), dim3(256), 0, s, jobs_dev, terms_dev);
+}
+
+__global__ __launch_bounds__(256) void downmix_kernel(const DownmixJob* __restrict jobs, const float* const* __restrict terms) {
+  const DownmixJob job = jobs[blockIdx.y];
+  const float* const* __restrict tp = terms + job.term0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < job.n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t f = job.f0 + i;
+    float sum = 0.f;
+    for (int ch = 0; ch < job.nch; ch++) sum += tp[ch][f];   // AudioNodeInput.cs:221-226
+    job.out[f] = sum * job.scale;
+  }
+}
+void launch_downmix(hipStream_t s, const DownmixJob* jobs_dev, int njobs, const float* const* terms_dev, int64_t max_n) {
+  if (njobs <= 0 || max_n <= 0) return;
+  int gx = (int)std::min<int64_t>((max_n + 255) / 256, 2048);
+  hipLaunchKernelGGL(downmix_kernel, dim3(gx, njobs), dim3(256), 0, s, jobs_dev, terms_dev);
+}
+
+// ---- GainNode (GainNode.cs:48-58) ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gain_kernel(const GainJob* __restrict jobs) {
+  const GainJob job = jobs[blockIdx.y];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < job.n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t f = job.f0 + i;
+    float g = job.curve ? job.curve[f] : job.gain;
+    job.out[f] = job.in[f] * g;
+  }
+}
+void launch_gain(hipStream_t s, const GainJob* jobs_dev, int njobs, int64_t max_n) {
+  if (njobs <= 0 || max_n <= 0) return;
+  int gx = (int)std::min<int64_t>((max_n + 255) / 256, 1024);
+  hipLaunchKernelGGL(gain_kernel, dim3(gx, njobs), dim3(256), 0, s, jobs_dev);
+}
+
+// =====================================================================================================
+//  BiQuadFilterNode with constant coefficients (BiQuadFilterNode.cs:136-141): one lane per (node, channel),
+//  64 jobs per wavefront.  The wave stages a [64 jobs][64 frames] tile through LDS so every HBM access is a
+//  coalesced 256-byte row even though each lane walks its own slab serially.
+// =====================================================================================================
+constexpr int BQ_TILE = 64;
+__global__ __launch_bounds__(64) void biquad_kernel(const BiquadJob* __restrict jobs, int njobs) {
+  __shared__ float tile[64][BQ_TILE + 1];
+  const int lane = threadIdx.x;
+  const int j0 = blockIdx.x * 64;
+  const int myj = j0 + lane;
+  const bool have = myj < njobs;
+  BiquadJob me;
+  if (have) me = jobs[myj];
+  float w1 = 0.f, w2 = 0.f;
+  int64_t n = 0;
+  if (have) {
+    w1 = me.state[0];
+    w2 = me.state[1];
+    n = me.n;
+  }
+  int64_t nmax = n;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) nmax = max(nmax, (int64_t)__shfl_xor((long long)nmax, m, 64));
+  const int jcount = min(64, njobs - j0);
+  for (int64_t base = 0; base < nmax; base += BQ_TILE) {
+    // cooperative load: row r of the tile = frames [base, base+64) of job j0 + r
+    for (int r = 0; r < jcount; r++) {
+      const BiquadJob* jr = &jobs[j0 + r];
+      int64_t nr = jr->n;
+      int64_t fi = base + lane;
+      tile[r][lane] = fi < nr ? jr->in[jr->f0 + fi] : 0.f;
+    }
+    __syncthreads();
+    if (have) {
+      int cnt = (int)min<int64_t>(BQ_TILE, n - base);
+      for (int i = 0; i < cnt; i++) {
+        float x = tile[lane][i];
+        float w = x - me.a1 * w1 - me.a2 * w2;            // (:137)
+        float y = me.b0 * w + me.b1 * w1 + me.b2 * w2;    // (:138)
+        w2 = w1;
+        w1 = w;
+        tile[lane][i] = y;
+      }
+    }
+    __syncthreads();
+    for (int r = 0; r < jcount; r++) {
+      const BiquadJob* jr = &jobs[j0 + r];
+      int64_t nr = jr->n;
+      int64_t fi = base + lane;
+      if (fi < nr) jr->out[jr->f0 + fi] = tile[r][lane];
+    }
+    __syncthreads();
+  }
+  if (have) {
+    me.state[0] = w1;
+    me.state[1] = w2;
+  }
+}
+void launch_biquad(hipStream_t s, const BiquadJob* jobs_dev, int njobs) {
+  if (njobs <= 0) return;
+  hipLaunchKernelGGL(biquad_kernel, dim3((njobs + 63) / 64), dim3(64), 0, s, jobs_dev, njobs);
+}
+
+// =====================================================================================================
+//  AudioParam timeline (AudioParam.ComputeValueAtTime and helpers, AudioParam.cs:169-247), double precision,
+//  no contraction: sampleTime = blockTime + i * deltaTime (:116-120); k-rate samples at block start (:146).
+// =====================================================================================================
+__device__ float param_interp_linear(float v0, double t0, float v1, double t1, double t) {
+  double u = (t - t0) / (t1 - t0);
+  u = u < 0.0 ? 0.0 : (u > 1.0 ? 1.0 : u);
+  float d = v1 - v0;
+  return (float)((double)v0 + (double)d * u);
+}
+__device__ float param_interp_exp(float v0, double t0, float v1, double t1, double t) {
+  if (v0 <= 0 || v1 <= 0) return param_interp_linear(v0, t0, v1, t1, t);
+  double u = (t - t0) / (t1 - t0);
+  u = u < 0.0 ? 0.0 : (u > 1.0 ? 1.0 : u);
+  float ratio = v1 / v0;
+  return (float)((double)v0 * pow((double)ratio, u));
+}
+__device__ float param_set_target(const ParamEvent& e, float baseline, double time) {
+  double elapsed = time - e.time;
+  if (elapsed <= 0) return baseline;
+  double tc = e.time_constant > 0.001 ? e.time_constant : 0.001;
+  float d = baseline - e.target;
+  return (float)((double)e.target + (double)d * exp(-elapsed / tc));
+}
+__device__ float param_value_at(const ParamEvent* __restrict ev, int count, float value, double time) {
+  if (count == 0) return value;
+  float boundary = value;
+  for (int i = 0; i < count; i++) {
+    const ParamEvent& e = ev[i];
+    if (time < e.time) {
+      if (i == 0) return boundary;
+      const ParamEvent& prev = ev[i - 1];
+      if (e.type == 1) return param_interp_linear(prev.value, prev.time, e.value, e.time, time);
+      if (e.type == 2) return param_interp_exp(prev.value, prev.time, e.value, e.time, time);
+      if (prev.type == 3) return param_set_target(prev, boundary, time);
+      return prev.value;
+    }
+    if (e.type != 3) boundary = e.value;
+  }
+  const ParamEvent& last = ev[count - 1];
+  if (last.type == 3) return param_set_target(last, boundary, time);
+  return last.value;
+}
+__global__ __launch_bounds__(128) void param_curve_kernel(const ParamJob* __restrict jobs, const ParamEvent* __restrict events,
+                                                          const double* __restrict block_times, double delta_time) {
+  const ParamJob job = jobs[blockIdx.y];
+  const int i = threadIdx.x;
+  for (int64_t b = blockIdx.x; b < job.nblocks; b += gridDim.x) {
+    const int64_t blk = job.b0 + b;
+    const double bt = block_times[blk];
+    double st = job.arate ? bt + i * delta_time : bt;
+    job.out[blk * kBlock + i] = param_value_at(events + job.ev0, job.nev, job.value, st);
+  }
+}
+void launch_param_curve(hipStream_t s, const ParamJob* jobs_dev, int njobs, const ParamEvent* events_dev,
+                        const double* block_times_dev, double delta_time, int64_t max_blocks) {
+  if (njobs <= 0 || max_blocks <= 0) return;
+  int gx = (int)std::min<int64_t>(max_blocks, 4096);
+  hipLaunchKernelGGL(param_curve_kernel, dim3(gx, njobs), dim3(128), 0, s, jobs_dev, events_dev, block_times_dev, delta_time);
+}
+
+// ---- looping rate-1 source (AudioBufferSourceNode.cs:186-235) --------------------------------------------
+__global__ __launch_bounds__(256) void loop_source_kernel(const LoopJob* __restrict jobs) {
+  const LoopJob job = jobs[blockIdx.y];
+  const int64_t len = job.loop_end - job.loop_start;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < job.n; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t u = job.pos0 + i;
+    if (u >= job.loop_end) u = job.loop_start + (len > 0 ? (u - job.loop_end) % len : 0);
+    job.out[job.f0 + i] = job.buf[u];
+  }
+}
+void launch_loop_source(hipStream_t s, const LoopJob* jobs_dev, int njobs, int64_t max_n) {
+  if (njobs <= 0 || max_n <= 0) return;
+  int gx = (int)std::min<int64_t>((max_n + 255) / 256, 1024);
+  hipLaunchKernelGGL(loop_source_kernel, dim3(gx, njobs), dim3(256), 0, s, jobs_dev);
+}
+
+// =====================================================================================================
+//  CubicResampler (CubicResampler.cs:26-63).  The double-precision position recurrence is replayed on the host
+//  once per distinct rate (the "trajectory"); every (job, block) pair is then independent: one lane walks the 128
+//  outputs of its block with exactly the reference's per-sample arithmetic.  64 consecutive blocks of one job per
+//  wavefront; outputs go through LDS so the HBM stores are coalesced.
+// =====================================================================================================
+__global__ __launch_bounds__(64) void resample_kernel(const ResampleJob* __restrict jobs, const ResampleBlock* __restrict traj) {
+  __shared__ float tile[64][kBlock + 1];
+  const ResampleJob job = jobs[blockIdx.y];
+  const int lane = threadIdx.x;
+  const int64_t bl0 = (int64_t)blockIdx.x * 64;
+  if (bl0 >= job.nblocks) return;
+  const int64_t b = bl0 + lane;
+  const bool have = b < job.nblocks;
+  if (have) {
+    const ResampleBlock rb = traj[job.traj0 + b];
+    const float* __restrict in = job.buf + job.start_pos;
+    int64_t ip = rb.consumed;           // next input index (relative)
+    double Pos = rb.pos;
+    int ready = rb.ready;
+    float S0 = 0.f, S1 = 0.f, S2 = 0.f, S3 = 0.f;
+    // the window holds the last `ready` consumed samples (Shift, CubicResampler.cs:91-97)
+    if (ready >= 1) S3 = in[ip - 1];
+    if (ready >= 2) S2 = in[ip - 2];
+    if (ready >= 3) S1 = in[ip - 3];
+    if (ready >= 4) S0 = in[ip - 4];
+    while (ready < 4 && ip < job.avail) {   // priming (:31-35)
+      S0 = S1; S1 = S2; S2 = S3; S3 = in[ip++];
+      ready++;
+    }
+    int outp = 0;
+    if (ready == 4) {
+      for (; outp < rb.produced; outp++) {
+        int consume = (int)Pos;
+        for (int i = 0; i < consume; i++) { S0 = S1; S1 = S2; S2 = S3; S3 = in[ip++]; }
+        Pos -= consume;
+        float t = (float)Pos;
+        tile[lane][outp] = S1 + t * (0.5f * (S2 - S0) + t * ((S0 - 2.5f * S1 + 2.f * S2 - 0.5f * S3) + t * (0.5f * (S3 - S0) + 1.5f * (S1 - S2))));
+        Pos += job.rate;
+      }
+    }
+    for (; outp < kBlock; outp++) tile[lane][outp] = 0.f;   // outputSpan.Slice(outIdx).Clear()
+  }
+  __syncthreads();
+  const int nb = (int)min<int64_t>(64, job.nblocks - bl0);
+  float* __restrict out = job.out + (job.b0 + bl0) * kBlock;
+  for (int r = 0; r < nb; r++) {
+    out[(int64_t)r * kBlock + lane] = tile[r][lane];
+    out[(int64_t)r * kBlock + 64 + lane] = tile[r][64 + lane];
+  }
+}
+void launch_resample(hipStream_t s, const ResampleJob* jobs_dev, int njobs, const ResampleBlock* traj_dev, int64_t max_blocks) {
+  if (njobs <= 0 || max_blocks <= 0) return;
+  int gx = (int)((max_blocks + 63) / 64);
+  hipLaunchKernelGGL(resample_kernel, dim3(gx, njobs), dim3(64), 0, s, jobs_dev, traj_dev);
+}
+
+}  // namespace ga

@@ -1,0 +1,151 @@
+// ga_kernels.hpp -- launch wrappers of the hand-written gfx950 kernels (ga_kernels.hip).
+// Host code (ga_engine.cpp) builds small job tables in pinned memory, uploads them once per chunk and
+// calls these wrappers; every wrapper only enqueues work on `stream` (no allocation, no sync).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ga {
+
+constexpr int kBlock = 128;  // AudioBuffer.FramesPerBlock (AudioBuffer.cs:10)
+constexpr int kBins = 129;   // complexCount for fftSize 256 (PartitionedConvolver.cs:40-41)
+
+// ---- convolver pipeline -----------------------------------------------------------------------------
+// Spectra planes are split re/im float32 like the reference's _delayReal/_delayImag (PartitionedConvolver.cs:23-24)
+// but laid out [bin k][block t][row r] with the row (channel-instance) index fastest, so that one MFMA operand
+// fragment is one coalesced LDS/HBM line of rows.
+struct ConvPlanes {
+  float* xr;       // [kBins][tx][rp]  forward spectra incl. (P-1) history rows at the front
+  float* xi;
+  float* yr;       // [kBins][ty][rp]  accumulated spectra
+  float* yi;
+  int tx;          // allocated block extent of x planes
+  int ty;          // allocated block extent of y planes
+  int rp;          // padded row count (multiple of 128)
+};
+
+// one row (convolver channel-instance) of a group: where its time-domain input / output for this chunk live.
+struct ConvRowIO {
+  const float* in;   // chunk-frame indexed input (in[f], f in [0, nblocks*128)); nullptr = silence
+  float* out;        // chunk-frame indexed output slab; nullptr = discard (padding row)
+};
+
+// twiddle tables: w128[j] = exp(-2 pi i j / 128) j<64 ; w256[k] = exp(-2 pi i k / 256) k<=128 (double2 = re, im)
+struct Twiddles {
+  const double2* w128;
+  const double2* w256;
+};
+
+// forward rfft256 of every (row, block): X planes rows [hist + t] for t in [0, nblocks)
+void launch_rfft_fwd(hipStream_t s, const ConvRowIO* rows_dev, int nrows, int nblocks, int hist, ConvPlanes pl, Twiddles tw);
+// shared-IR spectral multiply-accumulate (PartitionedConvolver.cs:154-223 over all blocks of the chunk at once)
+//   Y[k][t][r] = sum_{p<P} X[k][t + (P-1) - p][r] * H[k][p]
+void launch_spectral_mac_shared(hipStream_t s, ConvPlanes pl, const float* hr, const float* hi, int P, int nblocks, int nrows);
+// inverse rfft256 + overlap-add (PartitionedConvolver.cs:130-151); the overlap state [rows][128] persists across
+// chunks and is double buffered (read overlap_in, write overlap_out) because workgroups run in any order
+void launch_irfft_ola(hipStream_t s, const ConvRowIO* rows_dev, int nrows, int nblocks, ConvPlanes pl, const float* overlap_in,
+                      float* overlap_out, Twiddles tw);
+// history: copy n block-rows of every bin plane  dst[k][dst_t0 + i][:] = src[k][src_t0 + i][:]
+void launch_plane_copy(hipStream_t s, float* dst, int dst_t, int dst_t0, const float* src, int src_t, int src_t0, int n, int rp);
+// IR spectra extraction  h[c][k][p] = x[k][p][c]  for c < nch (planes produced by launch_rfft_fwd with hist = 0)
+void launch_extract_ir(hipStream_t s, float* hr, float* hi, const float* xr, const float* xi, int tx, int rp, int P, int nch);
+// out[f] = a[f] + b[f]   (true-stereo pair sum, ConvolverNode.cs:157-164)
+void launch_pair_sum(hipStream_t s, float* out, const float* a, const float* b, int64_t n);
+
+// ---- graph plumbing kernels ------------------------------------------------------------------------
+// out[f0 + i] = ((0 + t0[f0+i]) + t1[f0+i]) + ...  in term order (AudioNodeInput.cs:118-132,182-244)
+struct MixJob {
+  float* out;
+  int term0;      // index of first term in the term table
+  int nterms;
+  int64_t f0;     // first chunk frame
+  int64_t n;      // frames
+};
+void launch_mix(hipStream_t s, const MixJob* jobs_dev, int njobs, const float* const* terms_dev, int64_t max_n, bool vec4);
+
+// down-mix N -> 1: out[f] = (sum_ch in[ch][f]) * scale   (AudioNodeInput.cs:214-228); 'ins' index the term table
+struct DownmixJob {
+  float* out;
+  int term0;
+  int nch;
+  float scale;
+  int64_t f0;
+  int64_t n;
+};
+void launch_downmix(hipStream_t s, const DownmixJob* jobs_dev, int njobs, const float* const* terms_dev, int64_t max_n);
+
+// out = in * gain  (GainNode.cs:48-58); curve != nullptr -> per-sample a-rate values, else constant
+struct GainJob {
+  const float* in;
+  float* out;
+  const float* curve;
+  float gain;
+  int64_t f0;
+  int64_t n;
+};
+void launch_gain(hipStream_t s, const GainJob* jobs_dev, int njobs, int64_t max_n);
+
+// float32 Direct-Form-II biquad with constant coefficients (BiQuadFilterNode.cs:136-141); state = {W1, W2}
+struct BiquadJob {
+  const float* in;
+  float* out;
+  float* state;
+  float b0, b1, b2, a1, a2;
+  int64_t f0;
+  int64_t n;
+};
+void launch_biquad(hipStream_t s, const BiquadJob* jobs_dev, int njobs);
+
+// AudioParam timeline evaluation (AudioParam.cs:114-247)
+struct ParamEvent {
+  int type;  // 0 SetValue, 1 LinearRamp, 2 ExponentialRamp, 3 SetTarget
+  float value;
+  float target;
+  float pad_;
+  double time;
+  double time_constant;
+};
+struct ParamJob {
+  float* out;         // chunk-frame indexed curve
+  int ev0;            // first event in the event table
+  int nev;
+  float value;        // AudioParam._value
+  int arate;          // 1 = per sample, 0 = per block
+  int64_t b0;         // first block (chunk relative)
+  int64_t nblocks;
+};
+void launch_param_curve(hipStream_t s, const ParamJob* jobs_dev, int njobs, const ParamEvent* events_dev,
+                        const double* block_times_dev, double delta_time, int64_t max_blocks);
+
+// Looping rate-1 playback (AudioBufferSourceNode.cs:186-235): out[f] = buf[map(pos0 + f - f0)]
+struct LoopJob {
+  const float* buf;
+  float* out;
+  int64_t pos0;       // _playbackPosition at the first frame of the job
+  int64_t loop_start;
+  int64_t loop_end;
+  int64_t f0;
+  int64_t n;
+};
+void launch_loop_source(hipStream_t s, const LoopJob* jobs_dev, int njobs, int64_t max_n);
+
+// CubicResampler playback (CubicResampler.cs:26-63) driven by a host-computed block trajectory
+struct ResampleBlock {  // state at the start of one 128-frame block
+  int64_t consumed;     // input samples consumed before this block (relative to the start position)
+  double pos;           // CubicResampler.Pos
+  int ready;            // CubicResampler.Ready
+  int produced;         // outputs produced in this block (128 unless the input ran out)
+};
+struct ResampleJob {
+  const float* buf;      // channel data
+  float* out;            // chunk-frame indexed
+  int64_t start_pos;     // buffer index of the first consumed sample
+  int64_t avail;         // number of input samples available from start_pos
+  int traj0;             // index of the trajectory entry for the job's first block
+  double rate;
+  int64_t b0;            // first block (chunk relative)
+  int64_t nblocks;
+};
+void launch_resample(hipStream_t s, const ResampleJob* jobs_dev, int njobs, const ResampleBlock* traj_dev, int64_t max_blocks);
+
+}  // namespace ga

@@ -1,0 +1,111 @@
+"""Graph builders shared by the oracle tests, the GPU parity tests, bench.py and smoke().
+
+Every builder takes a context (HIP product or CPU oracle -- same host classes) and returns (ctx, out_channels).
+Synthetic inputs follow BASELINE.md section 3 / SURVEY.md section 8(d):
+  voices : default_rng(1000+v).standard_normal(n).astype(float32) * 0.25
+  IRs    : default_rng(7+ch).standard_normal(taps) * exp(-6.9 * n / taps), float32, Normalize = true
+"""
+import numpy as np
+
+from graphaudio_amd import (AudioBufferSourceNode, BiQuadFilterNode, ConvolverNode, FilterType, GainNode,
+                            PlayableAudioBuffer)
+
+
+def voice(v, n, scale=0.25):
+    return (np.random.default_rng(1000 + v).standard_normal(n) * scale).astype(np.float32)
+
+
+def synth_ir(ch, taps, seed0=7):
+    n = np.arange(taps)
+    return (np.random.default_rng(seed0 + ch).standard_normal(taps) * np.exp(-6.9 * n / taps)).astype(np.float32)
+
+
+def config1_plumbing(ctx, voices=8, frames=128 * 6, sr=48000):
+    """8 AudioBufferSourceNode -> GainNode(0.125) -> destination, mono (BASELINE.json configs[0])."""
+    ctx.Destination.SetChannelCount(1)
+    g = GainNode(ctx)
+    g.Gain.Value = 0.125
+    g.Inputs[0].SetChannelCount(1)
+    g.Connect(ctx.Destination)
+    for v in range(voices):
+        s = AudioBufferSourceNode(ctx)
+        s.Buffer = PlayableAudioBuffer.FromMonoArray(voice(v, frames), sr)
+        s.Connect(g)
+        s.Start()
+    return 1
+
+
+def config2_biquad(ctx, voices=256, frames=48000, sr=48000, mono=True):
+    """voices -> BiQuadFilterNode(lowpass, f = 200 * 2^(v/32) capped 20 kHz, Q = 0.707) -> Gain(1/16) -> mix."""
+    if mono:
+        ctx.Destination.SetChannelCount(1)
+    for v in range(voices):
+        s = AudioBufferSourceNode(ctx)
+        s.Buffer = PlayableAudioBuffer.FromMonoArray(voice(v, frames), sr)
+        bq = BiQuadFilterNode(ctx)
+        bq.Type = FilterType.Lowpass
+        bq.Frequency.Value = min(20000.0, 200.0 * 2.0 ** (v / 32.0))
+        bq.Q.Value = 0.707
+        g = GainNode(ctx)
+        g.Gain.Value = 1.0 / 16.0
+        if mono:
+            bq.Inputs[0].SetChannelCount(1)
+            g.Inputs[0].SetChannelCount(1)
+        s.Connect(bq).Connect(g).Connect(ctx.Destination)
+        s.Start()
+    return 1 if mono else 2
+
+
+def config3_convolver(ctx, voices=1024, taps=65536, frames=48000, sr=48000, ir_channels=2, shared=True, voice_len=None):
+    """voices -> per-voice ConvolverNode (shared stereo IR) -> destination (2 ch)  (BASELINE.json configs[2])."""
+    vlen = voice_len or (frames + 256)
+    irbuf = PlayableAudioBuffer.FromChannelArrays([synth_ir(c, taps) for c in range(ir_channels)], sr)
+    ctx.Destination.SetChannelCount(ir_channels)
+    for v in range(voices):
+        s = AudioBufferSourceNode(ctx)
+        s.Buffer = PlayableAudioBuffer.FromMonoArray(voice(v, vlen), sr)
+        cv = ConvolverNode(ctx)
+        if shared:
+            cv.Buffer = irbuf
+        else:
+            cv.Buffer = PlayableAudioBuffer.FromChannelArrays(
+                [synth_ir(c, taps, seed0=7 + 100 * (v + 1)) for c in range(ir_channels)], sr)
+        s.Connect(cv).Connect(ctx.Destination)
+        s.Start()
+    return ir_channels
+
+
+def config4_eq(ctx, voices=4096, frames=48000, sr=48000, src_sr=44100):
+    """voices: 44.1k mono buffer -> CubicResampler -> 5-band biquad EQ -> gain automation -> mix."""
+    n_in = int(frames * src_sr / sr) + 2048
+    bands = [(FilterType.Lowshelf, 100.0, 1.0, 6.0), (FilterType.Peaking, 400.0, 1.0, -6.0),
+             (FilterType.Peaking, 1000.0, 1.0, 6.0), (FilterType.Peaking, 4000.0, 1.0, -6.0),
+             (FilterType.Highshelf, 10000.0, 1.0, 6.0)]
+    for v in range(voices):
+        s = AudioBufferSourceNode(ctx)
+        s.Buffer = PlayableAudioBuffer.FromMonoArray(voice(v, n_in), src_sr)
+        node = s
+        for (ft, f, q, gdb) in bands:
+            bq = BiQuadFilterNode(ctx)
+            bq.Type = ft
+            bq.Frequency.Value = f
+            bq.Q.Value = q
+            bq.Gain.Value = gdb
+            node = node.Connect(bq)
+        g = GainNode(ctx)
+        g.Gain.SetValueAtTime(0.0, 0.0)
+        g.Gain.LinearRampToValueAtTime(1.0 / 64.0, 0.5)
+        g.Gain.SetTargetAtTime(0.0, 8.0, 0.3)
+        node.Connect(g).Connect(ctx.Destination)
+        s.Start()
+    return 2
+
+
+def render(ctx, channels, frames):
+    out = np.zeros((channels, frames), dtype=np.float32)
+    ctx.Render(out, frames)
+    return out
+
+
+def rms(a):
+    return float(np.sqrt(np.mean(np.square(a.astype(np.float64)))))
