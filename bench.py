@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- rendered frames/sec @48 kHz on the BASELINE.json headline workload.
+
+Workload (config.workload, BASELINE.json configs[2], SURVEY.md section 8d "Config 3"):
+    1024 mono voices -> per-voice ConvolverNode sharing one 2-channel 65,536-tap IR (P = 512 partitions of
+    128 samples) -> destination (2 ch), 48 kHz, synthetic noise voices + synthetic room-like IR.
+A "step" renders `--seconds` (default 10 s = 480,000 frames = 3,750 blocks) of that graph through the C ABI
+(ga_render); steps continue the same render (DSP state persists), voices loop over a 10 s buffer so inputs stay
+resident in HBM for any number of steps.
+
+Multi-GPU (--gpus N, launched by torch.distributed.run, one rank per GPU): the voices are sharded V/N per rank
+(strong scaling: the job is the same 1024-voice mix), every rank renders its shard with ga_render_device and the
+destination bus is summed with one RCCL reduce per step (torch.distributed backend "nccl" = RCCL over xGMI).
+
+One JSON line on stdout (rank 0).  Besides the contract keys:
+  roofline      -- dominant kernel (time-batched spectral multiply-accumulate on the f32 matrix cores): achieved
+                   algorithmic TFLOP/s (8*P*129 flop per channel-instance per block) / its HIP-event time, against
+                   the dense f32 MFMA peak of MI355X_MICROARCH.md (157.3 TFLOP/s).
+  roofline_hbm_streaming -- the same kernel time priced with SURVEY.md section 8(d)'s per-block STREAMING byte count
+                   (1.086 GB/block for this workload) against 8 TB/s: the time-batched formulation re-uses every
+                   loaded spectrum ~P times from LDS/L2, so this fraction exceeds 1 by design.
+  cpu_baseline  -- the CPU oracle (C++ restatement of the reference's single-threaded render path; .NET cannot run
+                   here) timed on this host on a bounded sample, scaled to the full workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SR = 48000
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: Peak FP32 (matrix)
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak
+
+
+def build_graph(ctx, voices, v0, taps, loop_frames, G):
+    from graphaudio_amd import AudioBufferSourceNode, ConvolverNode, PlayableAudioBuffer
+    irbuf = PlayableAudioBuffer.FromChannelArrays([G.synth_ir(c, taps) for c in range(2)], SR)
+    ctx.Destination.SetChannelCount(2)
+    for v in range(v0, v0 + voices):
+        s = AudioBufferSourceNode(ctx)
+        s.Buffer = PlayableAudioBuffer.FromMonoArray(G.voice(v, loop_frames), SR)
+        s.Loop = True
+        cv = ConvolverNode(ctx)
+        cv.Buffer = irbuf
+        s.Connect(cv).Connect(ctx.Destination)
+        s.Start()
+
+
+def cpu_baseline(voices_full, taps, G):
+    """Time the CPU oracle (1 thread, like the reference) on a bounded sample of the same graph."""
+    from tests._oracle import OracleContext
+    sample_voices, sample_blocks = 64, 375  # 1 s of 64 voices: ~10-30 s of single-thread CPU work at 65,536 taps
+    ctx = OracleContext(SR)
+    frames = sample_blocks * 128
+    build_graph(ctx, sample_voices, 0, taps, frames + 256, G)
+    out = np.zeros((2, frames), np.float32)
+    ctx.Render(out, 128)  # first block outside the timed region (queued commands, lazy allocations)
+    t0 = time.perf_counter()
+    ctx.Render(out, frames - 128, 128)
+    dt = time.perf_counter() - t0
+    ctx.Dispose()
+    fps_sample = (frames - 128) / dt
+    fps_full = fps_sample * sample_voices / voices_full  # cost is linear in the voice count
+    return {
+        "value": fps_full, "unit": "frames/s", "cores": 1, "kind": "port",
+        "sample": f"{sample_voices} voices x {sample_blocks - 1} blocks of the same graph ({taps}-tap stereo IR), "
+                  f"{dt:.1f} s single thread, {fps_sample:.1f} frames/s measured, scaled by {sample_voices}/{voices_full}",
+        "host_cpu": _cpu_name(), "host_cores_available": os.cpu_count(),
+    }
+
+
+def _cpu_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--seconds", type=float, default=10.0, help="audio seconds rendered per step")
+    ap.add_argument("--voices", type=int, default=1024)
+    ap.add_argument("--taps", type=int, default=65536)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n_gpus = args.gpus
+    dist = None
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == n_gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+
+    from graphaudio_amd import OfflineAudioContext
+    from tests import _graphs as G
+
+    frames = int(round(args.seconds * SR)) // 128 * 128
+    voices_total = args.voices
+    shard = voices_total // world
+    v0 = rank * shard
+    if rank == world - 1:
+        shard = voices_total - v0
+
+    ctx = OfflineAudioContext(SR, device=local_rank)
+    ctx.SetOption("profile", 1)
+    ctx.SetOption("max_chunk_blocks", 4096)
+    build_graph(ctx, shard, v0, args.taps, frames, G)
+
+    host_out = np.zeros((2, frames), np.float32)
+    if world > 1:
+        dev_out = torch.zeros((2, frames), dtype=torch.float32, device=f"cuda:{local_rank}")
+
+    def step():
+        if world == 1:
+            ctx.Render(host_out, frames)
+        else:
+            ctx.RenderDevice([dev_out[0].data_ptr(), dev_out[1].data_ptr()], frames)
+            dist.reduce(dev_out, dst=0, op=dist.ReduceOp.SUM)   # the destination-bus sum, RCCL over xGMI
+            if rank == 0:
+                host_out[:] = dev_out.cpu().numpy()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    st0 = ctx.GetStats()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    st1 = ctx.GetStats()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total_frames = frames * args.steps
+        value = total_frames / dt
+        d = {k: st1[k] - st0[k] for k in ("mac_ms_total", "mac_flops_total", "mac_bytes_total", "mac_launches",
+                                           "fft_ms_total", "other_ms_total", "device_ms_total", "kernel_launches")}
+        mac_s = d["mac_ms_total"] * 1e-3
+        ach_tflops = d["mac_flops_total"] / mac_s / 1e12 if mac_s > 0 else 0.0
+        ach_gbs = d["mac_bytes_total"] / mac_s / 1e9 if mac_s > 0 else 0.0
+        blocks = frames // 128
+        rec = {
+            "metric": "rendered frames/sec @48kHz, 1024-voice convolver graph",
+            "value": value, "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{voices_total} voices -> PartitionedConvolver, {args.taps}-tap stereo IR shared by all "
+                                   f"voices (P={(args.taps + 127) // 128}), 128-sample blocks, 48 kHz, {blocks} blocks per step",
+                       "voices": voices_total, "taps": args.taps, "frames_per_step": frames,
+                       "parallelism": f"voice-shard x{world} + RCCL bus reduce" if world > 1 else "single GPU"},
+            "realtime_factor": value / SR,
+            "roofline": {"bound": "mfma", "achieved": ach_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "spectral_mac_shared_kernel (v_mfma_f32_16x16x4_f32)",
+                         "avg_launch_ms": d["mac_ms_total"] / max(d["mac_launches"], 1), "launches": d["mac_launches"],
+                         "formulation": "time-batched banded-Toeplitz GEMM per bin; algorithmic flops = 8*P*129 per channel-instance per block"},
+            "roofline_hbm_streaming": {"bound": "hbm", "achieved": ach_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                       "frac": ach_gbs / PEAK_HBM_GBS, "traffic": None,
+                                       "note": "algorithmic bytes of the reference's per-block streaming formulation (SURVEY 8d) / MAC kernel time"},
+            "kernel_ms_per_step": {"mac": d["mac_ms_total"] / args.steps, "fft": d["fft_ms_total"] / args.steps,
+                                   "other": d["other_ms_total"] / args.steps, "device_total": d["device_ms_total"] / args.steps,
+                                   "launches": d["kernel_launches"] / args.steps},
+            "device_bytes_in_use": st1["device_bytes_in_use"],
+        }
+        if not args.no_cpu_baseline and world == 1:
+            rec["cpu_baseline"] = cpu_baseline(voices_total, args.taps, G)
+            rec["speedup_vs_cpu_1thread"] = value / rec["cpu_baseline"]["value"]
+        else:
+            rec["cpu_baseline"] = None
+        print(json.dumps(rec))
+    ctx.Dispose()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
