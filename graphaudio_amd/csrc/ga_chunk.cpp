@@ -1045,9 +1045,9 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
         }
         rio[idx] = ConvRowIO{in, out};
         if (nd.isTrueStereo) {
-          auto& tt = tsTemps[ns_.first];
-          if (slot == 0) tt = {nullptr, nullptr, nullptr, nullptr};
-          tt[slot] = out;
+          auto it = tsTemps.find(ns_.first);
+          if (it == tsTemps.end()) it = tsTemps.emplace(ns_.first, std::array<float*, 4>{nullptr, nullptr, nullptr, nullptr}).first;
+          it->second[slot] = out;
         }
       }
       ex.flushLevel();
