@@ -992,7 +992,16 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
     }
 
     // ---- convolvers whose inputs are complete (depth d): once per chunk over all blocks ----
-    std::map<ConvGroup*, std::vector<std::pair<int, int>>> active;  // group -> (node, slot)
+    // group -> (node, slot); ordered by (IR buffer, IR channel) so groups fed by the same inputs are adjacent
+    struct GroupLess {
+      bool operator()(const ConvGroup* a, const ConvGroup* b) const {
+        if (a->ir.get() != b->ir.get()) return a->ir.get() < b->ir.get();
+        return a->irCh < b->irCh;
+      }
+    };
+    std::map<ConvGroup*, std::vector<std::pair<int, int>>, GroupLess> active;
+    std::vector<const float*> prevIns;
+    int prevP = -1, prevRp = -1, prevRows = -1;
     for (int id : topo) {
       NodeS& nd = *nodes[id];
       if (nd.type != GA_NODE_CONVOLVER || !nd.ir || nd.depth != d) continue;
@@ -1068,6 +1077,15 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
       float* ovOut = g.overlap[g.ovCur ^ 1];
       g.ovCur ^= 1;
       g.histZero = false;
+      // forward spectra depend only on the inputs: a group fed by exactly the same signals as the previous one (e.g. the
+      // channels of one stereo IR behind mono voices) reuses the X rows that are still in the scratch planes
+      std::vector<const float*> ins(nrows);
+      for (int r = 0; r < nrows; r++) ins[r] = rio[r].in;
+      const bool skipFwd = (prevP == P && prevRp == rp && prevRows == nrows && prevIns == ins);
+      prevIns = ins;
+      prevP = P;
+      prevRp = rp;
+      prevRows = nrows;
       ex.plan.add(LK_FFT, [=](uint8_t* base) {
         // frequency-domain delay line of the previous chunk(s) in front of this chunk's spectra
         if (hist > 0) {
@@ -1078,7 +1096,7 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
         int tail = std::min(tx - (hist + nn), 256);
         launch_plane_copy(st, pl.xr, tx, hist + nn, nullptr, 0, 0, tail, rp);
         launch_plane_copy(st, pl.xi, tx, hist + nn, nullptr, 0, 0, tail, rp);
-        launch_rfft_fwd(st, (const ConvRowIO*)(base + rioOff), nrows, nn, hist, pl, tw);
+        if (!skipFwd) launch_rfft_fwd(st, (const ConvRowIO*)(base + rioOff), nrows, nn, hist, pl, tw);
       });
       ex.plan.add(LK_MAC, [=](uint8_t*) { launch_spectral_mac_shared(st, pl, hr, hi, P, nn, nrows); });
       ex.plan.add(LK_FFT, [=](uint8_t* base) {

@@ -22,133 +22,165 @@ namespace ga {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // =====================================================================================================
-//  256-point real FFT on one wavefront (forward: RealFourierTransform.cs:62-88; inverse: :101-131)
-//  z[n] = x[2n] + i x[2n+1] (n < 128); lane l owns z[l] (slot 0) and z[l+64] (slot 1).
+//  256-point real FFT on one wavefront (forward: RealFourierTransform.cs:62-88; inverse: :101-131), double precision.
+//  z[n] = x[2n] + i x[2n+1] (n < 128); lane l owns z[l] (slot 0) and z[l+64] (slot 1).  One in-lane radix-2 stage
+//  and six cross-lane stages; the cross-lane exchanges are DPP moves (xor 1,2,4,8), ds_swizzle (xor 16) and one
+//  ds_bpermute (xor 32) -- no LDS storage, no barriers.  Butterflies are select-free: every lane evaluates
+//  d = fma(sigma, mine, partner) followed by one complex multiply whose twiddle is (1, 0) on the "lower" lanes.
+//  Each wavefront keeps FFT_ILP independent transforms in flight to hide the exchange latency.
 // =====================================================================================================
-__device__ __forceinline__ double shx(double v, int mask) { return __shfl_xor(v, mask, 64); }
+template <int MASK>
+__device__ __forceinline__ int xchg32(int v) {
+  if constexpr (MASK == 1) return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);           // quad_perm [1,0,3,2]
+  else if constexpr (MASK == 2) return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);      // quad_perm [2,3,0,1]
+  else if constexpr (MASK == 4) {                                                                // xor 7 then xor 3
+    int t = __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true);                                  // row_half_mirror
+    return __builtin_amdgcn_mov_dpp(t, 0x1B, 0xF, 0xF, true);                                    // quad_perm [3,2,1,0]
+  } else if constexpr (MASK == 8) {                                                              // xor 15 then xor 7
+    int t = __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true);                                  // row_mirror
+    return __builtin_amdgcn_mov_dpp(t, 0x141, 0xF, 0xF, true);
+  } else if constexpr (MASK == 16) return __builtin_amdgcn_ds_swizzle(v, 0x401F);                // bit mode: xor 0x10
+  else return __shfl_xor(v, MASK, 64);
+}
+template <int MASK>
+__device__ __forceinline__ double xchg(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  return __hiloint2double(xchg32<MASK>(hi), xchg32<MASK>(lo));
+}
+__device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ int rev6(int l) { return (int)(__brev((unsigned)l) >> 26); }
 
-struct LaneTw {   // per-lane twiddles, loaded once per kernel
-  double c[6], s[6];   // stage twiddles for half = 32,16,8,4,2,1 : W128^{(l & (half-1)) * 64/half}
+struct LaneTw {   // per-lane constants, loaded once per kernel
+  double c[6], s[6];   // stage twiddle for half = 32,16,8,4,2,1: W128^{(l & (half-1)) * 64/half} on upper lanes, (1,0) on lower
+  double sg[6];        // -1 on upper lanes (l & half), +1 on lower lanes
   double c1, s1;       // W128^l  (the in-lane stage)
 };
-
 __device__ __forceinline__ LaneTw load_lane_tw(const double2* __restrict w128, int lane) {
   LaneTw t;
 #pragma unroll
   for (int i = 0; i < 6; i++) {
     int half = 32 >> i;
+    bool up = (lane & half) != 0;
     double2 w = w128[(lane & (half - 1)) * (64 / half)];
-    t.c[i] = w.x;
-    t.s[i] = w.y;
+    t.c[i] = up ? w.x : 1.0;
+    t.s[i] = up ? w.y : 0.0;
+    t.sg[i] = up ? -1.0 : 1.0;
   }
   double2 w = w128[lane];
   t.c1 = w.x;
   t.s1 = w.y;
   return t;
 }
-
-// decimation-in-frequency over the 64 lanes: natural order in, bit-reversed out
+// decimation in frequency: lower <- a + b ; upper <- (a - b) W   (natural order in, bit-reversed out)
 template <int HALF, int IDX>
-__device__ __forceinline__ void dif_stage(double& ar, double& ai, const LaneTw& t, bool up) {
-  double pr = shx(ar, HALF), pi = shx(ai, HALF);
-  double sr = ar + pr, si = ai + pi;
-  double dr = pr - ar, di = pi - ai;
-  double ur = fma(dr, t.c[IDX], -(di * t.s[IDX]));
-  double ui = fma(dr, t.s[IDX], di * t.c[IDX]);
-  ar = up ? ur : sr;
-  ai = up ? ui : si;
+__device__ __forceinline__ void dif_stage(double& ar, double& ai, const LaneTw& t) {
+  double pr = xchg<HALF>(ar), pi = xchg<HALF>(ai);
+  double dr = fma(t.sg[IDX], ar, pr), di = fma(t.sg[IDX], ai, pi);   // lower: mine + partner ; upper: partner - mine
+  ar = fma(dr, t.c[IDX], -(di * t.s[IDX]));
+  ai = fma(dr, t.s[IDX], di * t.c[IDX]);
 }
-// decimation-in-time over the 64 lanes with conjugated twiddles: bit-reversed in, natural out
+// decimation in time with conjugated twiddles: lower <- a + b conj(W) ; upper <- a - b conj(W)  (bit-reversed in, natural out)
 template <int HALF, int IDX>
-__device__ __forceinline__ void dit_stage(double& ar, double& ai, const LaneTw& t, bool up) {
-  double pr = shx(ar, HALF), pi = shx(ai, HALF);
-  double mr = up ? ar : pr, mi = up ? ai : pi;          // the upper element of the pair
-  double c = t.c[IDX], s = -t.s[IDX];                   // conj twiddle
-  double qr = fma(mr, c, -(mi * s));
-  double qi = fma(mr, s, mi * c);
-  ar = up ? (pr - qr) : (ar + qr);
-  ai = up ? (pi - qi) : (ai + qi);
+__device__ __forceinline__ void dit_stage(double& ar, double& ai, const LaneTw& t) {
+  double qr = fma(ar, t.c[IDX], ai * t.s[IDX]);       // mine * conj(tw)   (tw = (1,0) on lower lanes)
+  double qi = fma(ai, t.c[IDX], -(ar * t.s[IDX]));
+  double pr = xchg<HALF>(qr), pi = xchg<HALF>(qi);
+  ar = fma(t.sg[IDX], qr, pr);                         // lower: a + q_partner ; upper: partner - q_mine
+  ai = fma(t.sg[IDX], qi, pi);
 }
 
 constexpr int FFT_ROWS = 32;        // rows (channel-instances) per workgroup
-constexpr int STAGE_LD = FFT_ROWS + 1;
+constexpr int STAGE_LD = 132;       // staging tile is [row][bin], bins fastest, 129 padded to 132 floats
+constexpr int FFT_ILP = 4;          // independent transforms in flight per wavefront
 
 // ---- forward ----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void rfft_fwd_kernel(const ConvRowIO* __restrict rows, int nrows, int nblocks, int hist,
                                                        ConvPlanes pl, Twiddles tw) {
-  __shared__ float st_r[kBins * STAGE_LD];
-  __shared__ float st_i[kBins * STAGE_LD];
-  __shared__ double2 zs[4][128];
+  __shared__ float st_r[FFT_ROWS * STAGE_LD];
+  __shared__ float st_i[FFT_ROWS * STAGE_LD];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rowtile = blockIdx.x;
   const int t = blockIdx.y;
   const LaneTw ltw = load_lane_tw(tw.w128, lane);
-  const double2 wk0 = tw.w256[lane];        // for k = lane
-  const double2 wk1 = tw.w256[lane + 64];   // for k = lane + 64
-  const int zidx = rev6(lane) << 1;
+  // after the DIF stages slot j of lane l holds Z[k], k = 2 m + j, m = rev6(l).  X[k] needs Z[128 - k]:
+  //   j = 0: index 2 ((64 - m) & 63) -> lane rev6((64 - m) & 63) ; j = 1: index 2 (63 - m) + 1 -> lane 63 - l
+  const int m = rev6(lane);
+  const int k0 = 2 * m, k1 = 2 * m + 1;
+  const int src0 = rev6((64 - m) & 63), src1 = 63 - lane;
+  const double2 wk0 = tw.w256[k0];
+  const double2 wk1 = tw.w256[k1];
 
-  for (int q = 0; q < FFT_ROWS / 4; q++) {
-    const int rl = wave * (FFT_ROWS / 4) + q;
-    const int row = rowtile * FFT_ROWS + rl;
-    const float* in = row < nrows ? rows[row].in : nullptr;
-    double s0r = 0.0, s0i = 0.0;
-    if (in) {
-      const float* p = in + (int64_t)t * kBlock + 2 * lane;
-      s0r = (double)p[0];     // float -> double, PartitionedConvolver.cs:106
-      s0i = (double)p[1];
+  for (int q0 = 0; q0 < FFT_ROWS / 4; q0 += FFT_ILP) {
+    double s0r[FFT_ILP], s0i[FFT_ILP], s1r[FFT_ILP], s1i[FFT_ILP];
+#pragma unroll
+    for (int u = 0; u < FFT_ILP; u++) {
+      const int row = rowtile * FFT_ROWS + wave * (FFT_ROWS / 4) + q0 + u;
+      const float* in = row < nrows ? rows[row].in : nullptr;
+      s0r[u] = 0.0;
+      s0i[u] = 0.0;
+      if (in) {
+        const float* p = in + (int64_t)t * kBlock + 2 * lane;
+        s0r[u] = (double)p[0];     // float -> double, PartitionedConvolver.cs:106
+        s0i[u] = (double)p[1];
+      }
+      // in-lane stage with the zero upper half (PartitionedConvolver.cs:107): (a + 0, (a - 0) * W128^l)
+      s1r[u] = fma(s0r[u], ltw.c1, -(s0i[u] * ltw.s1));
+      s1i[u] = fma(s0r[u], ltw.s1, s0i[u] * ltw.c1);
     }
-    // in-lane stage with the zero upper half (PartitionedConvolver.cs:107): (a + 0, (a - 0) * W128^l)
-    double s1r = fma(s0r, ltw.c1, -(s0i * ltw.s1));
-    double s1i = fma(s0r, ltw.s1, s0i * ltw.c1);
-    dif_stage<32, 0>(s0r, s0i, ltw, lane & 32); dif_stage<32, 0>(s1r, s1i, ltw, lane & 32);
-    dif_stage<16, 1>(s0r, s0i, ltw, lane & 16); dif_stage<16, 1>(s1r, s1i, ltw, lane & 16);
-    dif_stage<8, 2>(s0r, s0i, ltw, lane & 8);   dif_stage<8, 2>(s1r, s1i, ltw, lane & 8);
-    dif_stage<4, 3>(s0r, s0i, ltw, lane & 4);   dif_stage<4, 3>(s1r, s1i, ltw, lane & 4);
-    dif_stage<2, 4>(s0r, s0i, ltw, lane & 2);   dif_stage<2, 4>(s1r, s1i, ltw, lane & 2);
-    dif_stage<1, 5>(s0r, s0i, ltw, lane & 1);   dif_stage<1, 5>(s1r, s1i, ltw, lane & 1);
-    // slot j of lane l now holds Z[(rev6(l) << 1) | j]
-    zs[wave][zidx] = make_double2(s0r, s0i);
-    zs[wave][zidx + 1] = make_double2(s1r, s1i);
-    __syncthreads();
-    // real-FFT split: X[k] = E[k] + W256^k * (-i) * D[k]
-    {
-      const int k = lane;
-      double2 a = zs[wave][k];
-      double2 b = zs[wave][(128 - k) & 127];
-      double er = 0.5 * (a.x + b.x), ei = 0.5 * (a.y - b.y);
-      double dr = 0.5 * (a.x - b.x), di = 0.5 * (a.y + b.y);
-      double pr = fma(dr, wk0.x, -(di * wk0.y)), pi = fma(dr, wk0.y, di * wk0.x);
-      float xr = (float)(er + pi), xi = (float)(ei - pr);   // double -> float, PartitionedConvolver.cs:117-118
-      if (k == 0) xi = 0.f;
-      st_r[k * STAGE_LD + rl] = xr;
-      st_i[k * STAGE_LD + rl] = xi;
-      if (k == 0) {  // Nyquist: X[128] = Re Z[0] - Im Z[0], imaginary part zero (RealFourierTransform.cs:76-78)
-        st_r[128 * STAGE_LD + rl] = (float)(a.x - a.y);
-        st_i[128 * STAGE_LD + rl] = 0.f;
+#pragma unroll
+    for (int u = 0; u < FFT_ILP; u++) { dif_stage<32, 0>(s0r[u], s0i[u], ltw); dif_stage<32, 0>(s1r[u], s1i[u], ltw); }
+#pragma unroll
+    for (int u = 0; u < FFT_ILP; u++) { dif_stage<16, 1>(s0r[u], s0i[u], ltw); dif_stage<16, 1>(s1r[u], s1i[u], ltw); }
+#pragma unroll
+    for (int u = 0; u < FFT_ILP; u++) { dif_stage<8, 2>(s0r[u], s0i[u], ltw); dif_stage<8, 2>(s1r[u], s1i[u], ltw); }
+#pragma unroll
+    for (int u = 0; u < FFT_ILP; u++) { dif_stage<4, 3>(s0r[u], s0i[u], ltw); dif_stage<4, 3>(s1r[u], s1i[u], ltw); }
+#pragma unroll
+    for (int u = 0; u < FFT_ILP; u++) { dif_stage<2, 4>(s0r[u], s0i[u], ltw); dif_stage<2, 4>(s1r[u], s1i[u], ltw); }
+#pragma unroll
+    for (int u = 0; u < FFT_ILP; u++) { dif_stage<1, 5>(s0r[u], s0i[u], ltw); dif_stage<1, 5>(s1r[u], s1i[u], ltw); }
+    // real-FFT split: X[k] = E[k] + W256^k * (-i) * D[k],  E = (Z[k] + conj Z[128-k]) / 2,  D = (Z[k] - conj Z[128-k]) / 2
+#pragma unroll
+    for (int u = 0; u < FFT_ILP; u++) {
+      const int rl = wave * (FFT_ROWS / 4) + q0 + u;
+      {
+        double ax = s0r[u], ay = s0i[u];
+        double bx = shfl_d(ax, src0), by = shfl_d(ay, src0);
+        double er = 0.5 * (ax + bx), ei = 0.5 * (ay - by);
+        double dr = 0.5 * (ax - bx), di = 0.5 * (ay + by);
+        double pr = fma(dr, wk0.x, -(di * wk0.y)), pi = fma(dr, wk0.y, di * wk0.x);
+        float xr = (float)(er + pi), xi = (float)(ei - pr);   // double -> float, PartitionedConvolver.cs:117-118
+        if (k0 == 0) {  // lane 0: DC, plus Nyquist X[128] = Re Z[0] - Im Z[0]; both purely real (RealFourierTransform.cs:76-78)
+          xi = 0.f;
+          st_r[rl * STAGE_LD + 128] = (float)(ax - ay);
+          st_i[rl * STAGE_LD + 128] = 0.f;
+        }
+        st_r[rl * STAGE_LD + k0] = xr;
+        st_i[rl * STAGE_LD + k0] = xi;
+      }
+      {
+        double ax = s1r[u], ay = s1i[u];
+        double bx = shfl_d(ax, src1), by = shfl_d(ay, src1);
+        double er = 0.5 * (ax + bx), ei = 0.5 * (ay - by);
+        double dr = 0.5 * (ax - bx), di = 0.5 * (ay + by);
+        double pr = fma(dr, wk1.x, -(di * wk1.y)), pi = fma(dr, wk1.y, di * wk1.x);
+        st_r[rl * STAGE_LD + k1] = (float)(er + pi);
+        st_i[rl * STAGE_LD + k1] = (float)(ei - pr);
       }
     }
-    {
-      const int k = lane + 64;
-      double2 a = zs[wave][k];
-      double2 b = zs[wave][128 - k];
-      double er = 0.5 * (a.x + b.x), ei = 0.5 * (a.y - b.y);
-      double dr = 0.5 * (a.x - b.x), di = 0.5 * (a.y + b.y);
-      double pr = fma(dr, wk1.x, -(di * wk1.y)), pi = fma(dr, wk1.y, di * wk1.x);
-      st_r[k * STAGE_LD + rl] = (float)(er + pi);
-      st_i[k * STAGE_LD + rl] = (float)(ei - pr);
-    }
-    __syncthreads();
   }
-  // coalesced store of the [bin][row] tile: 32 consecutive rows = one 128-byte line per bin
+  __syncthreads();
+  // coalesced 16-byte stores: 8 lanes cover the 32 consecutive rows (one 128-byte line) of one bin
   const size_t plane_t = (size_t)pl.tx * pl.rp;
   const size_t base = (size_t)(hist + t) * pl.rp + (size_t)rowtile * FFT_ROWS;
-  for (int idx = tid; idx < kBins * FFT_ROWS; idx += 256) {
-    int k = idx / FFT_ROWS, r = idx % FFT_ROWS;
-    size_t o = (size_t)k * plane_t + base + r;
-    pl.xr[o] = st_r[k * STAGE_LD + r];
-    pl.xi[o] = st_i[k * STAGE_LD + r];
+  for (int idx = tid; idx < kBins * (FFT_ROWS / 4); idx += 256) {
+    int k = idx / (FFT_ROWS / 4), r4 = (idx % (FFT_ROWS / 4)) * 4;
+    size_t o = (size_t)k * plane_t + base + r4;
+    float4 vr = make_float4(st_r[(r4 + 0) * STAGE_LD + k], st_r[(r4 + 1) * STAGE_LD + k], st_r[(r4 + 2) * STAGE_LD + k], st_r[(r4 + 3) * STAGE_LD + k]);
+    float4 vi = make_float4(st_i[(r4 + 0) * STAGE_LD + k], st_i[(r4 + 1) * STAGE_LD + k], st_i[(r4 + 2) * STAGE_LD + k], st_i[(r4 + 3) * STAGE_LD + k]);
+    *reinterpret_cast<float4*>(pl.xr + o) = vr;
+    *reinterpret_cast<float4*>(pl.xi + o) = vi;
   }
 }
 
@@ -163,8 +195,8 @@ constexpr int OLA_RUN = 16;   // consecutive blocks per workgroup (one extra inv
 
 __global__ __launch_bounds__(256) void irfft_ola_kernel(const ConvRowIO* __restrict rows, int nrows, int nblocks, ConvPlanes pl,
                                                         const float* __restrict overlap_in, float* __restrict overlap_out, Twiddles tw) {
-  __shared__ float ys_r[kBins * STAGE_LD];
-  __shared__ float ys_i[kBins * STAGE_LD];
+  __shared__ float ys_r[FFT_ROWS * STAGE_LD];
+  __shared__ float ys_i[FFT_ROWS * STAGE_LD];
   __shared__ float tail[FFT_ROWS][kBlock];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -188,58 +220,76 @@ __global__ __launch_bounds__(256) void irfft_ola_kernel(const ConvRowIO* __restr
     const bool pre = t < ta;   // only recompute block ta-1 to obtain its second half
     __syncthreads();
     const size_t base = (size_t)t * pl.rp + (size_t)rowtile * FFT_ROWS;
-    for (int idx = tid; idx < kBins * FFT_ROWS; idx += 256) {
-      int k = idx / FFT_ROWS, r = idx % FFT_ROWS;
-      size_t o = (size_t)k * plane_t + base + r;
-      ys_r[k * STAGE_LD + r] = pl.yr[o];
-      ys_i[k * STAGE_LD + r] = pl.yi[o];
+    for (int idx = tid; idx < kBins * (FFT_ROWS / 4); idx += 256) {   // 16-byte loads, 8 lanes per 128-byte bin line
+      int k = idx / (FFT_ROWS / 4), r4 = (idx % (FFT_ROWS / 4)) * 4;
+      size_t o = (size_t)k * plane_t + base + r4;
+      float4 vr = *reinterpret_cast<const float4*>(pl.yr + o);
+      float4 vi = *reinterpret_cast<const float4*>(pl.yi + o);
+      ys_r[(r4 + 0) * STAGE_LD + k] = vr.x; ys_r[(r4 + 1) * STAGE_LD + k] = vr.y;
+      ys_r[(r4 + 2) * STAGE_LD + k] = vr.z; ys_r[(r4 + 3) * STAGE_LD + k] = vr.w;
+      ys_i[(r4 + 0) * STAGE_LD + k] = vi.x; ys_i[(r4 + 1) * STAGE_LD + k] = vi.y;
+      ys_i[(r4 + 2) * STAGE_LD + k] = vi.z; ys_i[(r4 + 3) * STAGE_LD + k] = vi.w;
     }
     __syncthreads();
-    for (int q = 0; q < FFT_ROWS / 4; q++) {
-      const int rl = wave * (FFT_ROWS / 4) + q;
-      const int row = rowtile * FFT_ROWS + rl;
-      if (row >= nrows) continue;   // wave-uniform
+    for (int q0 = 0; q0 < FFT_ROWS / 4; q0 += FFT_ILP) {
+      double s0r[FFT_ILP], s0i[FFT_ILP], s1r[FFT_ILP], s1i[FFT_ILP];
       // Z[k] = (X[k] + conj X[128-k]) + i conj(W256^k) (X[k] - conj X[128-k])   (float -> double, :136)
-      double s0r, s0i, s1r, s1i;
-      {
-        double ar = ys_r[k0 * STAGE_LD + rl], ai = ys_i[k0 * STAGE_LD + rl];
-        double br = ys_r[(128 - k0) * STAGE_LD + rl], bi = -(double)ys_i[(128 - k0) * STAGE_LD + rl];
-        if (k0 == 0) { ai = 0.0; bi = 0.0; }   // rdft ignores Im of DC / Nyquist (RealFourierTransform.cs:120-123)
-        double er = ar + br, ei = ai + bi, dr = ar - br, di = ai - bi;
-        double pr = fma(dr, wk0.x, di * wk0.y), pi = fma(di, wk0.x, -(dr * wk0.y));   // d * conj(w)
-        s0r = er - pi;
-        s0i = ei + pr;
-      }
-      {
-        double ar = ys_r[k1 * STAGE_LD + rl], ai = ys_i[k1 * STAGE_LD + rl];
-        double br = ys_r[(128 - k1) * STAGE_LD + rl], bi = -(double)ys_i[(128 - k1) * STAGE_LD + rl];
-        double er = ar + br, ei = ai + bi, dr = ar - br, di = ai - bi;
-        double pr = fma(dr, wk1.x, di * wk1.y), pi = fma(di, wk1.x, -(dr * wk1.y));
-        s1r = er - pi;
-        s1i = ei + pr;
-      }
-      dit_stage<1, 5>(s0r, s0i, ltw, lane & 1);   dit_stage<1, 5>(s1r, s1i, ltw, lane & 1);
-      dit_stage<2, 4>(s0r, s0i, ltw, lane & 2);   dit_stage<2, 4>(s1r, s1i, ltw, lane & 2);
-      dit_stage<4, 3>(s0r, s0i, ltw, lane & 4);   dit_stage<4, 3>(s1r, s1i, ltw, lane & 4);
-      dit_stage<8, 2>(s0r, s0i, ltw, lane & 8);   dit_stage<8, 2>(s1r, s1i, ltw, lane & 8);
-      dit_stage<16, 1>(s0r, s0i, ltw, lane & 16); dit_stage<16, 1>(s1r, s1i, ltw, lane & 16);
-      dit_stage<32, 0>(s0r, s0i, ltw, lane & 32); dit_stage<32, 0>(s1r, s1i, ltw, lane & 32);
-      // in-lane stage: z[l] = s0 + s1 conj(W128^l), z[l+64] = s0 - s1 conj(W128^l); scale 2/n * 1/2 (:46,129)
-      double qr = fma(s1r, ltw.c1, s1i * ltw.s1), qi = fma(s1i, ltw.c1, -(s1r * ltw.s1));
-      const double scale = 1.0 / 256.0;
-      double h0 = (s0r + qr) * scale, h1 = (s0i + qi) * scale;   // time samples 2l, 2l+1
-      double g0 = (s0r - qr) * scale, g1 = (s0i - qi) * scale;   // time samples 128+2l, 128+2l+1
-      if (!pre) {
-        float* out = rows[row].out;
-        float o0 = (float)h0 + tail[rl][2 * lane];        // (float)y[i] + overlap[i]  (:148)
-        float o1 = (float)h1 + tail[rl][2 * lane + 1];
-        if (out) {
-          float2* op = reinterpret_cast<float2*>(out + (int64_t)t * kBlock + 2 * lane);
-          *op = make_float2(o0, o1);
+#pragma unroll
+      for (int u = 0; u < FFT_ILP; u++) {
+        const int rl = wave * (FFT_ROWS / 4) + q0 + u;
+        {
+          double ar = ys_r[rl * STAGE_LD + k0], ai = ys_i[rl * STAGE_LD + k0];
+          double br = ys_r[rl * STAGE_LD + (128 - k0)], bi = -(double)ys_i[rl * STAGE_LD + (128 - k0)];
+          if (k0 == 0) { ai = 0.0; bi = 0.0; }   // rdft ignores Im of DC / Nyquist (RealFourierTransform.cs:120-123)
+          double er = ar + br, ei = ai + bi, dr = ar - br, di = ai - bi;
+          double pr = fma(dr, wk0.x, di * wk0.y), pi = fma(di, wk0.x, -(dr * wk0.y));   // d * conj(w)
+          s0r[u] = er - pi;
+          s0i[u] = ei + pr;
+        }
+        {
+          double ar = ys_r[rl * STAGE_LD + k1], ai = ys_i[rl * STAGE_LD + k1];
+          double br = ys_r[rl * STAGE_LD + (128 - k1)], bi = -(double)ys_i[rl * STAGE_LD + (128 - k1)];
+          double er = ar + br, ei = ai + bi, dr = ar - br, di = ai - bi;
+          double pr = fma(dr, wk1.x, di * wk1.y), pi = fma(di, wk1.x, -(dr * wk1.y));
+          s1r[u] = er - pi;
+          s1i[u] = ei + pr;
         }
       }
-      tail[rl][2 * lane] = (float)g0;                      // overlap[i] = (float)y[i + 128]  (:149)
-      tail[rl][2 * lane + 1] = (float)g1;
+#pragma unroll
+      for (int u = 0; u < FFT_ILP; u++) { dit_stage<1, 5>(s0r[u], s0i[u], ltw); dit_stage<1, 5>(s1r[u], s1i[u], ltw); }
+#pragma unroll
+      for (int u = 0; u < FFT_ILP; u++) { dit_stage<2, 4>(s0r[u], s0i[u], ltw); dit_stage<2, 4>(s1r[u], s1i[u], ltw); }
+#pragma unroll
+      for (int u = 0; u < FFT_ILP; u++) { dit_stage<4, 3>(s0r[u], s0i[u], ltw); dit_stage<4, 3>(s1r[u], s1i[u], ltw); }
+#pragma unroll
+      for (int u = 0; u < FFT_ILP; u++) { dit_stage<8, 2>(s0r[u], s0i[u], ltw); dit_stage<8, 2>(s1r[u], s1i[u], ltw); }
+#pragma unroll
+      for (int u = 0; u < FFT_ILP; u++) { dit_stage<16, 1>(s0r[u], s0i[u], ltw); dit_stage<16, 1>(s1r[u], s1i[u], ltw); }
+#pragma unroll
+      for (int u = 0; u < FFT_ILP; u++) { dit_stage<32, 0>(s0r[u], s0i[u], ltw); dit_stage<32, 0>(s1r[u], s1i[u], ltw); }
+#pragma unroll
+      for (int u = 0; u < FFT_ILP; u++) {
+        const int rl = wave * (FFT_ROWS / 4) + q0 + u;
+        const int row = rowtile * FFT_ROWS + rl;
+        // in-lane stage: z[l] = s0 + s1 conj(W128^l), z[l+64] = s0 - s1 conj(W128^l); scale 2/n * 1/2 (:46,129)
+        double qr = fma(s1r[u], ltw.c1, s1i[u] * ltw.s1), qi = fma(s1i[u], ltw.c1, -(s1r[u] * ltw.s1));
+        const double scale = 1.0 / 256.0;
+        double h0 = (s0r[u] + qr) * scale, h1 = (s0i[u] + qi) * scale;   // time samples 2l, 2l+1
+        double g0 = (s0r[u] - qr) * scale, g1 = (s0i[u] - qi) * scale;   // time samples 128+2l, 128+2l+1
+        if (row < nrows) {
+          if (!pre) {
+            float* out = rows[row].out;
+            float o0 = (float)h0 + tail[rl][2 * lane];        // (float)y[i] + overlap[i]  (:148)
+            float o1 = (float)h1 + tail[rl][2 * lane + 1];
+            if (out) {
+              float2* op = reinterpret_cast<float2*>(out + (int64_t)t * kBlock + 2 * lane);
+              *op = make_float2(o0, o1);
+            }
+          }
+          tail[rl][2 * lane] = (float)g0;                      // overlap[i] = (float)y[i + 128]  (:149)
+          tail[rl][2 * lane + 1] = (float)g1;
+        }
+      }
     }
   }
   if (tb == nblocks) {
@@ -275,10 +325,66 @@ constexpr int MAC_LD = MAC_ROWS + 16;        // padded row stride: lanes 16..31 
 constexpr int MAC_PSEG = 1024;
 constexpr int MAC_GLEN = MAC_PSEG + 160;
 
+// One 16-step chunk of the banded Toeplitz product for a wave tile (2 M-tiles x 4 N-tiles).
+// N-tile n (blocks 16n..16n+15 of the time tile) is inside the band exactly for chunks [n, n + (Ps+14)/16]: the band
+// edges coincide with chunk boundaries, so activity is decided per (chunk, N-tile) with no wasted MFMA, and the partial
+// edge chunks are covered by the zero padding of the reversed tap table.  A fragments are read once per chunk, B
+// fragments are double buffered one N-tile ahead so their LDS latency hides under the previous tile's 24 MFMAs.
+__device__ __forceinline__ void mac_chunk(const float* __restrict xsr, const float* __restrict xsi, const float* __restrict g0,
+                                          const float* __restrict g1, const float* __restrict g2, int c, int Ps, int wave, int la,
+                                          int lk, f32x4 (&acc1)[2][4], f32x4 (&acc2)[2][4], f32x4 (&acc3)[2][4]) {
+  float ar[4][2], ai[4][2], as[4][2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++)
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+      int off = (ks * 4 + lk) * MAC_LD + wave * 32 + m * 16 + la;
+      ar[ks][m] = xsr[off];
+      ai[ks][m] = xsi[off];
+    }
+  float br[2][4], bi[2][4], bs[2][4];
+  const int gbase = c * MAC_KC + lk - la + 64;
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) {
+    br[0][ks] = g0[gbase + ks * 4];
+    bi[0][ks] = g1[gbase + ks * 4];
+    bs[0][ks] = g2[gbase + ks * 4];
+  }
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++)
+#pragma unroll
+    for (int m = 0; m < 2; m++) as[ks][m] = ar[ks][m] + ai[ks][m];
+  const int last = (Ps + 14) / 16;
+#pragma unroll
+  for (int n = 0; n < 4; n++) {
+    const int cur = n & 1, nxt = cur ^ 1;
+    if (n + 1 < 4) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        int gi = gbase + ks * 4 - 16 * (n + 1);
+        br[nxt][ks] = g0[gi];
+        bi[nxt][ks] = g1[gi];
+        bs[nxt][ks] = g2[gi];
+      }
+    }
+    if (c >= n && c <= n + last) {   // wave uniform
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++)
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+          // (a + ib)(c + id) = (ac - bd) + i(ad + bc)   (PartitionedConvolver.cs:195-204) on the matrix core
+          acc1[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[ks][m], br[cur][ks], acc1[m][n], 0, 0, 0);
+          acc2[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[ks][m], bi[cur][ks], acc2[m][n], 0, 0, 0);
+          acc3[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[ks][m], bs[cur][ks], acc3[m][n], 0, 0, 0);
+        }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void spectral_mac_shared_kernel(ConvPlanes pl, const float* __restrict hr, const float* __restrict hi,
                                                                  int P, int ntt, int nrt, int total) {
   __shared__ __attribute__((aligned(16))) float xs[2][2][MAC_KC * MAC_LD];   // [buffer][re/im][u][row]
-  __shared__ float gs[2][MAC_GLEN];                                           // reversed, zero padded taps (re, im)
+  __shared__ float gs[3][MAC_GLEN];                                           // reversed, zero padded taps: re, im, re + im
 
   // XCD-aware mapping: workgroups b and b+8 share an XCD (round-robin dispatch), give each XCD a contiguous range of
   // (bin, row tile, time tile) so neighbouring time tiles -- which re-read 8/9 of the same X rows -- share one L2.
@@ -296,17 +402,22 @@ __global__ __launch_bounds__(256) void spectral_mac_shared_kernel(ConvPlanes pl,
   const float* __restrict xr = pl.xr + (size_t)k * xplane + row0;
   const float* __restrict xi = pl.xi + (size_t)k * xplane + row0;
 
-  f32x4 accr[2][4], acci[2][4];
+  // Three-multiplication complex product (Gauss): with P1 = sum ar*br, P2 = sum ai*bi, P3 = sum (ar+ai)*(br+bi)
+  //   re = P1 - P2 ,  im = P3 - P1 - P2      -> 3 MFMAs per complex tile step instead of 4.
+  f32x4 acc1[2][4], acc2[2][4], acc3[2][4];
 #pragma unroll
   for (int m = 0; m < 2; m++)
 #pragma unroll
     for (int n = 0; n < 4; n++) {
-      accr[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      acci[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc1[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc2[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc3[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 
-  // global -> LDS staging assignment: thread -> (u = tid/32 and +8, rows 4*(tid%32) .. +3)
-  const int su = tid >> 5, sr4 = (tid & 31) * 4;
+  // global -> LDS staging is WAVE-PRIVATE: wave w only ever reads rows [32w, 32w+32) of a chunk, so it stages exactly
+  // those rows itself (lane -> u = lane/8 and +8, rows 32w + 4*(lane%8) .. +3).  LDS operations of one wave execute in
+  // order, so the main loop needs no workgroup barrier and the four waves drift freely over the shared matrix pipes.
+  const int su = lane >> 3, sr4 = wave * 32 + (lane & 7) * 4;
   const int la = lane & 15, lk = lane >> 4;
 
   for (int pa = 0; pa < P; pa += MAC_PSEG) {
@@ -319,8 +430,11 @@ __global__ __launch_bounds__(256) void spectral_mac_shared_kernel(ConvPlanes pl,
       int m = i - 64;
       bool ok = (m >= 0) && (m < Ps);
       int p = pa + Ps - 1 - m;
-      gs[0][i] = ok ? hr[(size_t)k * P + p] : 0.f;
-      gs[1][i] = ok ? hi[(size_t)k * P + p] : 0.f;
+      float gr_ = ok ? hr[(size_t)k * P + p] : 0.f;
+      float gi_ = ok ? hi[(size_t)k * P + p] : 0.f;
+      gs[0][i] = gr_;
+      gs[1][i] = gi_;
+      gs[2][i] = gr_ + gi_;
     }
     // prologue: chunk 0
     float4 pr0, pr1, pi0, pi1;
@@ -349,35 +463,7 @@ __global__ __launch_bounds__(256) void spectral_mac_shared_kernel(ConvPlanes pl,
         pi0 = *reinterpret_cast<const float4*>(xi + o0);
         pi1 = *reinterpret_cast<const float4*>(xi + o1);
       }
-      const float* __restrict xsr = xs[buf][0];
-      const float* __restrict xsi = xs[buf][1];
-#pragma unroll
-      for (int ks = 0; ks < MAC_KC / 4; ks++) {
-        const int uk = c * MAC_KC + ks * 4;     // first u of this K-step (wave uniform)
-        float ar[2], ai[2], nai[2];
-#pragma unroll
-        for (int m = 0; m < 2; m++) {
-          int off = (ks * 4 + lk) * MAC_LD + wave * 32 + m * 16 + la;
-          ar[m] = xsr[off];
-          ai[m] = xsi[off];
-          nai[m] = -ai[m];
-        }
-#pragma unroll
-        for (int n = 0; n < 4; n++) {
-          // band of N-tile n: u in [16n, 16n + 15 + Ps - 1]; skip K-steps entirely outside (B fragment all zero)
-          if (uk + 3 < 16 * n || uk > 16 * n + 14 + Ps) continue;
-          int gi = uk + lk - (16 * n + la) + 64;
-          float br = gs[0][gi], bi = gs[1][gi];
-#pragma unroll
-          for (int m = 0; m < 2; m++) {
-            // (a + ib)(c + id): re += ac - bd ; im += ad + bc   (PartitionedConvolver.cs:195-204, fused on the matrix core)
-            accr[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[m], br, accr[m][n], 0, 0, 0);
-            accr[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(nai[m], bi, accr[m][n], 0, 0, 0);
-            acci[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[m], bi, acci[m][n], 0, 0, 0);
-            acci[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[m], br, acci[m][n], 0, 0, 0);
-          }
-        }
-      }
+      mac_chunk(xs[buf][0], xs[buf][1], gs[0], gs[1], gs[2], c, Ps, wave, la, lk, acc1, acc2, acc3);
       if (more) {
         const int nb = buf ^ 1;
         *reinterpret_cast<float4*>(&xs[nb][0][su * MAC_LD + sr4]) = pr0;
@@ -385,7 +471,7 @@ __global__ __launch_bounds__(256) void spectral_mac_shared_kernel(ConvPlanes pl,
         *reinterpret_cast<float4*>(&xs[nb][1][su * MAC_LD + sr4]) = pi0;
         *reinterpret_cast<float4*>(&xs[nb][1][(su + 8) * MAC_LD + sr4]) = pi1;
       }
-      __syncthreads();
+      __builtin_amdgcn_wave_barrier();   // scheduling fence only: keep the staging writes ahead of the next chunk's reads
     }
   }
 
@@ -399,8 +485,8 @@ __global__ __launch_bounds__(256) void spectral_mac_shared_kernel(ConvPlanes pl,
     for (int n = 0; n < 4; n++) {
       int t = t0 + 16 * n + la;
       size_t o = (size_t)t * pl.rp + wave * 32 + m * 16 + lk * 4;
-      *reinterpret_cast<f32x4*>(yr + o) = accr[m][n];
-      *reinterpret_cast<f32x4*>(yi + o) = acci[m][n];
+      *reinterpret_cast<f32x4*>(yr + o) = acc1[m][n] - acc2[m][n];
+      *reinterpret_cast<f32x4*>(yi + o) = (acc3[m][n] - acc1[m][n]) - acc2[m][n];
     }
 }
 
