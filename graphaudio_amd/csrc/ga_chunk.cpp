@@ -412,7 +412,8 @@ struct Exec {
   std::vector<MixJob> mixJobs;
   std::vector<DownmixJob> dmJobs;
   std::vector<GainJob> gainJobs;
-  std::vector<BiquadJob> bqJobs;
+  std::vector<BiquadJob> bqJobs[kMaxBiquadSections + 1];  // by cascade length
+  std::vector<BiquadSection> bqSecs;
   std::vector<LoopJob> loopJobs;
   std::vector<ResampleJob> rsJobs;
   std::vector<ResampleBlock> traj;  // per-chunk trajectory table (all rates + custom tail blocks)
@@ -551,17 +552,28 @@ struct Exec {
       hipStream_t st = c.stream;
       plan.add(LK_OTHER, [=](uint8_t* base) { launch_gain(st, (const GainJob*)(base + off), nj, mx); });
     }
-    if (!bqJobs.empty()) {
-      size_t off = plan.putv(bqJobs);
-      int nj = (int)bqJobs.size();
-      hipStream_t st = c.stream;
-      plan.add(LK_OTHER, [=](uint8_t* base) { launch_biquad(st, (const BiquadJob*)(base + off), nj); });
+    {
+      bool any = false;
+      for (int k = 1; k <= kMaxBiquadSections; k++) any = any || !bqJobs[k].empty();
+      if (any) {
+        size_t soff = plan.putv(bqSecs);
+        for (int k = 1; k <= kMaxBiquadSections; k++) {
+          if (bqJobs[k].empty()) continue;
+          size_t off = plan.putv(bqJobs[k]);
+          int nj = (int)bqJobs[k].size();
+          hipStream_t st = c.stream;
+          plan.add(LK_OTHER, [=](uint8_t* base) {
+            launch_biquad(st, (const BiquadJob*)(base + off), nj, (const BiquadSection*)(base + soff), k);
+          });
+        }
+      }
     }
     terms.clear();
     mixJobs.clear();
     dmJobs.clear();
     gainJobs.clear();
-    bqJobs.clear();
+    for (auto& v : bqJobs) v.clear();
+    bqSecs.clear();
     loopJobs.clear();
     rsJobs.clear();
     mixAligned = true;
@@ -861,6 +873,28 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
       for (const NodeSeg& ns : sg.nodes)
         if (nodes[ns.id]->depth == d) todo.push_back(&ns);
       std::stable_sort(todo.begin(), todo.end(), [&](const NodeSeg* a, const NodeSeg* b2) { return nodes[a->id]->level < nodes[b2->id]->level; });
+      // biquad cascade fusion: A is absorbed by B when B's only input term is A, A's only consumer is B and both run
+      // (non-silent) with the same channel count; chains are capped at kMaxBiquadSections
+      std::unordered_map<int, const NodeSeg*> segNode;
+      std::unordered_map<int, int> absorbedBy, chainLen;
+      for (const NodeSeg* nsp : todo) segNode[nsp->id] = nsp;
+      for (const NodeSeg* nsp : todo) {
+        const NodeSeg& b_ = *nsp;
+        if (nodes[b_.id]->type != GA_NODE_BIQUAD || !b_.bqActive) continue;
+        chainLen[b_.id] = 1;
+        if (b_.ins[0].terms.size() != 1) continue;
+        const TermS& t = b_.ins[0].terms[0];
+        auto ia = segNode.find(t.node);
+        if (ia == segNode.end()) continue;
+        const NodeSeg& a_ = *ia->second;
+        NodeS& an = *nodes[a_.id];
+        if (an.type != GA_NODE_BIQUAD || !a_.bqActive || t.ch != b_.ins[0].bufCh || a_.outCh != b_.outCh) continue;
+        if (an.outputs[0].connectedInputs.size() != 1) continue;
+        int la_ = chainLen.count(a_.id) ? chainLen[a_.id] : 1;
+        if (la_ >= kMaxBiquadSections) continue;
+        absorbedBy[a_.id] = b_.id;
+        chainLen[b_.id] = la_ + 1;
+      }
       int curLevel = -1;
       for (const NodeSeg* nsp : todo) {
         const NodeSeg& ns = *nsp;
@@ -942,29 +976,53 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
             break;
           }
           case GA_NODE_BIQUAD: {
-            auto iv = ex.resolveInput((int)si, ns, 0, false, nullptr);
-            if (!ns.bqActive) break;  // silent input: cleared output, state frozen (BiQuadFilterNode.cs:103-108)
-            if (!nd.bqState) {
-              const size_t per = 32 * 2 * sizeof(float);
-              const size_t blk = (size_t)1 << 20;
-              if (bqBlocks.empty() || bqUsed + per > blk) {
-                void* p = dalloc(blk);
-                GA_HIP(hipMemsetAsync(p, 0, blk, stream));
-                bqBlocks.push_back(p);
-                bqUsed = 0;
+            if (!ns.bqActive) {  // silent input: cleared output, state frozen (BiQuadFilterNode.cs:103-108)
+              ex.resolveInput((int)si, ns, 0, false, nullptr);
+              break;
+            }
+            if (absorbedBy.count(ns.id)) break;  // evaluated inside the cascade job of a downstream biquad
+            // chain head ... this node: biquads connected output -> single input with equal channel counts
+            std::vector<const NodeSeg*> chain{&ns};
+            while (true) {
+              const NodeSeg* h = chain.front();
+              if (h->ins[0].terms.size() != 1) break;
+              int up = h->ins[0].terms[0].node;
+              auto ab = absorbedBy.find(up);
+              if (ab == absorbedBy.end() || ab->second != h->id) break;
+              chain.insert(chain.begin(), segNode[up]);
+            }
+            auto iv = ex.resolveInput((int)si, *chain.front(), 0, false, nullptr);
+            for (const NodeSeg* cn : chain) {
+              NodeS& cnd = *nodes[cn->id];
+              if (!cnd.bqState) {
+                const size_t per = 32 * 2 * sizeof(float);
+                const size_t blk = (size_t)1 << 20;
+                if (bqBlocks.empty() || bqUsed + per > blk) {
+                  void* p = dalloc(blk);
+                  GA_HIP(hipMemsetAsync(p, 0, blk, stream));
+                  bqBlocks.push_back(p);
+                  bqUsed = 0;
+                }
+                cnd.bqState = (float*)((char*)bqBlocks.back() + bqUsed);
+                bqUsed += per;
               }
-              nd.bqState = (float*)((char*)bqBlocks.back() + bqUsed);
-              bqUsed += per;
             }
             for (int ch = 0; ch < ns.outCh; ch++) {
               BiquadJob bj;
               bj.in = iv[ch] ? iv[ch] : zeros;
               bj.out = ex.nodeOut(ns.id, ch);
-              bj.state = nd.bqState + 2 * ch;
-              bj.b0 = ns.b0; bj.b1 = ns.b1; bj.b2 = ns.b2; bj.a1 = ns.a1; bj.a2 = ns.a2;
+              bj.sec0 = (int)ex.bqSecs.size();
+              bj.nsec = (int)chain.size();
               bj.f0 = f0;
               bj.n = nf;
-              ex.bqJobs.push_back(bj);
+              for (const NodeSeg* cn : chain) {
+                BiquadSection sc;
+                sc.b0 = cn->b0; sc.b1 = cn->b1; sc.b2 = cn->b2; sc.a1 = cn->a1; sc.a2 = cn->a2;
+                sc.pad_ = 0.f;
+                sc.state = nodes[cn->id]->bqState + 2 * ch;
+                ex.bqSecs.push_back(sc);
+              }
+              ex.bqJobs[bj.nsec].push_back(bj);
               ov[ch] = bj.out;
             }
             break;

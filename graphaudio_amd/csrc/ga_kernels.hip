@@ -625,62 +625,128 @@ void launch_gain(hipStream_t s, const GainJob* jobs_dev, int njobs, int64_t max_
 //  coalesced 256-byte row even though each lane walks its own slab serially.
 // =====================================================================================================
 constexpr int BQ_TILE = 64;
-__global__ __launch_bounds__(64) void biquad_kernel(const BiquadJob* __restrict jobs, int njobs) {
+__device__ __forceinline__ const float* bcast_ptr(const float* p, int srcLane) {
+  unsigned long long v = (unsigned long long)p;
+  unsigned lo = __builtin_amdgcn_readlane((unsigned)v, srcLane), hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), srcLane);
+  return (const float*)(((unsigned long long)hi << 32) | lo);
+}
+template <int NSEC>
+__global__ __launch_bounds__(64) void biquad_kernel(const BiquadJob* __restrict jobs, int njobs, const BiquadSection* __restrict secs) {
   __shared__ float tile[64][BQ_TILE + 1];
   const int lane = threadIdx.x;
   const int j0 = blockIdx.x * 64;
   const int myj = j0 + lane;
   const bool have = myj < njobs;
-  BiquadJob me;
+  // every lane keeps ITS job (cascade coefficients and states) in registers; row pointers are broadcast with v_readlane
+  BiquadJob me{};
   if (have) me = jobs[myj];
-  float w1 = 0.f, w2 = 0.f;
-  int64_t n = 0;
-  if (have) {
-    w1 = me.state[0];
-    w2 = me.state[1];
-    n = me.n;
+  const float* inb = have ? me.in + me.f0 : nullptr;
+  float* outb = have ? me.out + me.f0 : nullptr;
+  float b0[NSEC], b1[NSEC], b2[NSEC], a1[NSEC], a2[NSEC], w1[NSEC], w2[NSEC];
+  float* st[NSEC];
+#pragma unroll
+  for (int q = 0; q < NSEC; q++) {
+    b0[q] = b1[q] = b2[q] = a1[q] = a2[q] = w1[q] = w2[q] = 0.f;
+    st[q] = nullptr;
+    if (have) {
+      const BiquadSection sc = secs[me.sec0 + q];
+      b0[q] = sc.b0; b1[q] = sc.b1; b2[q] = sc.b2; a1[q] = sc.a1; a2[q] = sc.a2;
+      st[q] = sc.state;
+      w1[q] = sc.state[0];
+      w2[q] = sc.state[1];
+    }
   }
+  const int64_t n = have ? me.n : 0;
   int64_t nmax = n;
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) nmax = max(nmax, (int64_t)__shfl_xor((long long)nmax, m, 64));
   const int jcount = min(64, njobs - j0);
-  for (int64_t base = 0; base < nmax; base += BQ_TILE) {
-    // cooperative load: row r of the tile = frames [base, base+64) of job j0 + r
-    for (int r = 0; r < jcount; r++) {
-      const BiquadJob* jr = &jobs[j0 + r];
-      int64_t nr = jr->n;
+
+  float pre[64];   // prefetched tile: pre[r] = frame (base + lane) of job j0 + r   (64 coalesced 256-byte loads in flight)
+  auto fetch = [&](int64_t base) {
+#pragma unroll
+    for (int r = 0; r < 64; r++) {
+      const float* p = bcast_ptr(inb, r);
+      int64_t nr = __builtin_amdgcn_readlane((int)n, r);   // n < 2^31 frames per segment
       int64_t fi = base + lane;
-      tile[r][lane] = fi < nr ? jr->in[jr->f0 + fi] : 0.f;
+      pre[r] = (r < jcount && fi < nr) ? p[fi] : 0.f;
     }
+  };
+  fetch(0);
+  for (int64_t base = 0; base < nmax; base += BQ_TILE) {
+#pragma unroll
+    for (int r = 0; r < 64; r++) tile[r][lane] = pre[r];
     __syncthreads();
-    if (have) {
-      int cnt = (int)min<int64_t>(BQ_TILE, n - base);
-      for (int i = 0; i < cnt; i++) {
+    if (base + BQ_TILE < nmax) fetch(base + BQ_TILE);   // next tile's loads fly during the serial recurrence below
+    const int cnt = (int)max<int64_t>(0, min<int64_t>(BQ_TILE, n - base));
+    if (cnt == BQ_TILE) {
+      // register batches of 16 keep LDS latency off the W1/W2 dependency chains
+#pragma unroll
+      for (int i0 = 0; i0 < BQ_TILE; i0 += 16) {
+        float xv[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) xv[i] = tile[lane][i0 + i];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          float x = xv[i];
+#pragma unroll
+          for (int q = 0; q < NSEC; q++) {
+            float w = x - a1[q] * w1[q] - a2[q] * w2[q];            // BiQuadFilterNode.cs:137
+            float y = b0[q] * w + b1[q] * w1[q] + b2[q] * w2[q];    // :138
+            w2[q] = w1[q];
+            w1[q] = w;
+            x = y;
+          }
+          xv[i] = x;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) tile[lane][i0 + i] = xv[i];
+      }
+    } else {
+      for (int i = 0; i < cnt; i++) {   // the job's last, partial tile
         float x = tile[lane][i];
-        float w = x - me.a1 * w1 - me.a2 * w2;            // (:137)
-        float y = me.b0 * w + me.b1 * w1 + me.b2 * w2;    // (:138)
-        w2 = w1;
-        w1 = w;
-        tile[lane][i] = y;
+#pragma unroll
+        for (int q = 0; q < NSEC; q++) {
+          float w = x - a1[q] * w1[q] - a2[q] * w2[q];
+          float y = b0[q] * w + b1[q] * w1[q] + b2[q] * w2[q];
+          w2[q] = w1[q];
+          w1[q] = w;
+          x = y;
+        }
+        tile[lane][i] = x;
       }
     }
     __syncthreads();
+#pragma unroll 8
     for (int r = 0; r < jcount; r++) {
-      const BiquadJob* jr = &jobs[j0 + r];
-      int64_t nr = jr->n;
+      float* q = (float*)bcast_ptr(outb, r);
+      int64_t nr = __builtin_amdgcn_readlane((int)n, r);
       int64_t fi = base + lane;
-      if (fi < nr) jr->out[jr->f0 + fi] = tile[r][lane];
+      if (fi < nr) q[fi] = tile[r][lane];
     }
     __syncthreads();
   }
   if (have) {
-    me.state[0] = w1;
-    me.state[1] = w2;
+#pragma unroll
+    for (int q = 0; q < NSEC; q++) {
+      st[q][0] = w1[q];
+      st[q][1] = w2[q];
+    }
   }
 }
-void launch_biquad(hipStream_t s, const BiquadJob* jobs_dev, int njobs) {
+void launch_biquad(hipStream_t s, const BiquadJob* jobs_dev, int njobs, const BiquadSection* secs_dev, int nsec) {
   if (njobs <= 0) return;
-  hipLaunchKernelGGL(biquad_kernel, dim3((njobs + 63) / 64), dim3(64), 0, s, jobs_dev, njobs);
+  dim3 g((njobs + 63) / 64), b(64);
+  switch (nsec) {
+    case 1: hipLaunchKernelGGL(biquad_kernel<1>, g, b, 0, s, jobs_dev, njobs, secs_dev); break;
+    case 2: hipLaunchKernelGGL(biquad_kernel<2>, g, b, 0, s, jobs_dev, njobs, secs_dev); break;
+    case 3: hipLaunchKernelGGL(biquad_kernel<3>, g, b, 0, s, jobs_dev, njobs, secs_dev); break;
+    case 4: hipLaunchKernelGGL(biquad_kernel<4>, g, b, 0, s, jobs_dev, njobs, secs_dev); break;
+    case 5: hipLaunchKernelGGL(biquad_kernel<5>, g, b, 0, s, jobs_dev, njobs, secs_dev); break;
+    case 6: hipLaunchKernelGGL(biquad_kernel<6>, g, b, 0, s, jobs_dev, njobs, secs_dev); break;
+    case 7: hipLaunchKernelGGL(biquad_kernel<7>, g, b, 0, s, jobs_dev, njobs, secs_dev); break;
+    default: hipLaunchKernelGGL(biquad_kernel<8>, g, b, 0, s, jobs_dev, njobs, secs_dev); break;
+  }
 }
 
 // =====================================================================================================

@@ -85,16 +85,24 @@ struct GainJob {
 };
 void launch_gain(hipStream_t s, const GainJob* jobs_dev, int njobs, int64_t max_n);
 
-// float32 Direct-Form-II biquad with constant coefficients (BiQuadFilterNode.cs:136-141); state = {W1, W2}
+// float32 Direct-Form-II biquad cascade with constant coefficients (BiQuadFilterNode.cs:136-141).  A job is a chain of
+// 1..8 BiQuadFilterNodes connected output -> single input (the planner fuses them): every section is evaluated with
+// exactly the per-node arithmetic, its float32 output feeding the next section, so results equal node-by-node processing.
+constexpr int kMaxBiquadSections = 8;
+struct BiquadSection {
+  float b0, b1, b2, a1, a2;
+  float pad_;
+  float* state;   // {W1, W2} of this (node, channel)
+};
 struct BiquadJob {
   const float* in;
   float* out;
-  float* state;
-  float b0, b1, b2, a1, a2;
+  int sec0;       // first section in the section table
+  int nsec;
   int64_t f0;
   int64_t n;
 };
-void launch_biquad(hipStream_t s, const BiquadJob* jobs_dev, int njobs);
+void launch_biquad(hipStream_t s, const BiquadJob* jobs_dev, int njobs, const BiquadSection* secs_dev, int nsec);
 
 // AudioParam timeline evaluation (AudioParam.cs:114-247)
 struct ParamEvent {

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Render the other BASELINE.json configurations at full size on the HIP path and report frames/s (not bench lines:
+bench.py measures configs[2]; these are parity-test cases, timed here to find performance bugs)."""
+import os, sys, time, json
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from graphaudio_amd import OfflineAudioContext
+from tests import _graphs as G
+
+SR = 48000
+which = sys.argv[1] if len(sys.argv) > 1 else "2"
+seconds = float(sys.argv[2]) if len(sys.argv) > 2 else 10.0
+frames = int(seconds * SR) // 128 * 128
+ctx = OfflineAudioContext(SR)
+ctx.SetOption("profile", 1)
+t0 = time.time()
+if which == "2":
+    ch = G.config2_biquad(ctx, voices=256, frames=frames + 256)
+elif which == "4":
+    ch = G.config4_eq(ctx, voices=int(sys.argv[3]) if len(sys.argv) > 3 else 4096, frames=frames)
+elif which == "3u":
+    ch = G.config3_convolver(ctx, voices=int(sys.argv[3]) if len(sys.argv) > 3 else 64, taps=65536, frames=frames, shared=False)
+else:
+    raise SystemExit("unknown config")
+print(f"build {time.time() - t0:.1f} s")
+out = np.zeros((ch, frames), np.float32)
+for rep in range(2):
+    t0 = time.time()
+    ctx.Render(out, frames // 2, 0 if rep == 0 else frames // 2)
+    dt = time.time() - t0
+    print(f"render half {rep}: {dt * 1e3:.1f} ms -> {frames / 2 / dt / 1e6:.2f} M frames/s")
+st = ctx.GetStats()
+print(json.dumps({k: st[k] for k in ("chunks", "segments", "kernel_launches", "device_ms_total", "mac_ms_total", "fft_ms_total", "other_ms_total", "device_bytes_in_use")}))
+print("rms", G.rms(out))
