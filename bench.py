@@ -55,7 +55,7 @@ def build_graph(ctx, voices, v0, taps, loop_frames, G):
 def cpu_baseline(voices_full, taps, G):
     """Time the CPU oracle (1 thread, like the reference) on a bounded sample of the same graph."""
     from tests._oracle import OracleContext
-    sample_voices, sample_blocks = 64, 375  # 1 s of 64 voices: ~10-30 s of single-thread CPU work at 65,536 taps
+    sample_voices, sample_blocks = 128, 751  # 2 s of 128 voices: ~10-20 s of single-thread CPU work at 65,536 taps
     ctx = OracleContext(SR)
     frames = sample_blocks * 128
     build_graph(ctx, sample_voices, 0, taps, frames + 256, G)
@@ -166,6 +166,15 @@ def main():
         ach_tflops = d["mac_flops_total"] / mac_s / 1e12 if mac_s > 0 else 0.0
         ach_gbs = d["mac_bytes_total"] / mac_s / 1e9 if mac_s > 0 else 0.0
         blocks = frames // 128
+        # HBM bytes per MAC launch from rocprofv3 PMC passes of this exact workload (profiles/r01_pmc_hbm_traffic.json:
+        # separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md); null for other shapes
+        traffic = None
+        try:
+            if world == 1 and voices_total == 1024 and args.taps == 65536 and blocks == 3750:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+                traffic = pm["spectral_mac_shared_kernel_hbm_bytes_per_launch"]["total"]
+        except (OSError, KeyError, ValueError):
+            traffic = None
         rec = {
             "metric": "rendered frames/sec @48kHz, 1024-voice convolver graph",
             "value": value, "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
@@ -177,12 +186,13 @@ def main():
                        "parallelism": f"voice-shard x{world} + RCCL bus reduce" if world > 1 else "single GPU"},
             "realtime_factor": value / SR,
             "roofline": {"bound": "mfma", "achieved": ach_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "frac": ach_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                          "kernel": "spectral_mac_shared_kernel (v_mfma_f32_16x16x4_f32)",
                          "avg_launch_ms": d["mac_ms_total"] / max(d["mac_launches"], 1), "launches": d["mac_launches"],
                          "formulation": "time-batched banded-Toeplitz GEMM per bin; algorithmic flops = 8*P*129 per channel-instance per block"},
             "roofline_hbm_streaming": {"bound": "hbm", "achieved": ach_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                       "frac": ach_gbs / PEAK_HBM_GBS, "traffic": None,
+                                       "frac": ach_gbs / PEAK_HBM_GBS, "traffic": traffic,
+                                       "algorithmic_bytes_per_launch": d["mac_bytes_total"] / max(d["mac_launches"], 1),
                                        "note": "algorithmic bytes of the reference's per-block streaming formulation (SURVEY 8d) / MAC kernel time"},
             "kernel_ms_per_step": {"mac": d["mac_ms_total"] / args.steps, "fft": d["fft_ms_total"] / args.steps,
                                    "other": d["other_ms_total"] / args.steps, "device_total": d["device_ms_total"] / args.steps,
