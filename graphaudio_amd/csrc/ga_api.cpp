@@ -118,6 +118,9 @@ void Context::render(float* const* out, int channels, int64_t frameCount, int64_
         int convRowsMax = 0;
         for (auto& g : groups) convRowsMax = std::max(convRowsMax, (int)((g->rows.size() + 127) / 128 * 128));
         perBlock += (double)convRowsMax * kBins * 4.0 * 4.0;
+        for (auto& np : nodes)   // private-IR convolvers (formulation B): x rows + y rows
+          if (np->type == GA_NODE_CONVOLVER && np->ir && np->convPath != 1)
+            perBlock += (double)(np->ir->nch + (np->isTrueStereo ? 2 : np->ir->nch)) * kBins * 8.0;
         perBlock += ((double)nodes.size() * 2.0 + 64.0) * kBlock * 4.0;
         double budget = ((double)freeB + (double)slabBlocks.size() * (double)((size_t)1 << 30) * 0.0) * memBudgetFraction;
         // memory already held by slabs / planes is reused, so add it back to the budget
@@ -550,11 +553,9 @@ int ga_convolver_set_buffer(ga_context* ctx, int node, int buffer_id) {
     if (buffer_id < 0) {
       c.post([cp, node]() {
         NodeS& nd = *cp->nodes[node];
+        cp->releaseConvState(nd);
         nd.irBuf = -1;
         nd.ir.reset();
-        for (auto& r : nd.convRows)
-          if (r.group) r.group->rows[r.idx] = {-1, 0};
-        nd.convRows.clear();
         nd.effectiveOutCh = 0;
         nd.isTrueStereo = false;
         nd.inputs[0].mode = GA_COUNT_MODE_MAX;
@@ -568,10 +569,9 @@ int ga_convolver_set_buffer(ga_context* ctx, int node, int buffer_id) {
     std::shared_ptr<IrSpectra> sp = c.irSpectra(buffer_id, n->normalize);
     c.post([cp, node, buffer_id, sp]() {
       NodeS& nd = *cp->nodes[node];
-      // new PartitionedConvolver instances: fresh (zero) delay line and overlap
-      for (auto& r : nd.convRows)
-        if (r.group) r.group->rows[r.idx] = {-1, 0};
-      nd.convRows.clear();
+      // new PartitionedConvolver instances: fresh (zero) delay line and overlap; the formulation (shared-IR rows or
+      // private state) is chosen at the next render, when it is known how many nodes share this impulse response
+      cp->releaseConvState(nd);
       nd.irBuf = buffer_id;
       nd.ir = sp;
       int channels = sp->nch;
@@ -580,35 +580,6 @@ int ga_convolver_set_buffer(ga_context* ctx, int node, int buffer_id) {
       nd.inputs[0].channelCount = nd.isTrueStereo ? 2 : channels;
       nd.inputs[0].dirty = true;
       nd.inputs[0].mode = GA_COUNT_MODE_EXPLICIT;
-      for (int ch = 0; ch < channels; ch++) {
-        auto key = std::make_pair(sp.get(), ch);
-        ConvGroup* g;
-        auto it = cp->groupOf.find(key);
-        if (it == cp->groupOf.end()) {
-          auto ng = std::make_unique<ConvGroup>();
-          ng->ir = sp;
-          ng->irCh = ch;
-          ng->P = sp->P;
-          g = ng.get();
-          cp->groups.push_back(std::move(ng));
-          cp->groupOf[key] = g;
-        } else {
-          g = it->second;
-        }
-        // rows are append-only while a group holds live state: a freed row would need its delay line cleared
-        int idx = (int)g->rows.size();
-        g->rows.push_back({node, ch});
-        if (idx < g->rp && g->histR) {  // the column may hold stale scratch data: a new convolver starts from zero state
-          const int hist = g->P - 1;
-          if (hist > 0) {
-            GA_HIP(hipMemset2DAsync(g->histR + idx, (size_t)g->rp * 4, 0, 4, (size_t)kBins * hist, cp->stream));
-            GA_HIP(hipMemset2DAsync(g->histI + idx, (size_t)g->rp * 4, 0, 4, (size_t)kBins * hist, cp->stream));
-          }
-          GA_HIP(hipMemsetAsync(g->overlap[0] + (size_t)idx * kBlock, 0, kBlock * 4, cp->stream));
-          GA_HIP(hipMemsetAsync(g->overlap[1] + (size_t)idx * kBlock, 0, kBlock * 4, cp->stream));
-        }
-        nd.convRows.push_back(ConvRowRef{g, idx});
-      }
     });
   });
 }

@@ -841,11 +841,19 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
 
   // ---- convolver scratch planes are shared by all groups: size them for the largest group BEFORE any recorded
   //      launch captures their address ----
+  assignConvPaths(topo);
+  int bHistMax = 0;
   {
     size_t xMax = 0, yMax = 0;
+    size_t bx = 0, by = 0;
     for (int id : topo) {
       NodeS& nd = *nodes[id];
       if (nd.type != GA_NODE_CONVOLVER || !nd.ir) continue;
+      if (nd.convPath == 2) {
+        bx += nd.bInCh;
+        by += nd.bSlots;
+        bHistMax = std::max(bHistMax, nd.ir->P - 1);
+      }
       for (auto& rr : nd.convRows) {
         ConvGroup& g = *rr.group;
         ensureGroupState(*this, g);
@@ -859,6 +867,13 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
       ensure(planes[1], xMax);
       ensure(planes[2], yMax);
       ensure(planes[3], yMax);
+    }
+    if (bx) {  // formulation B scratch: [row][bin][block]
+      const size_t txb = (size_t)roundup(bHistMax, 4) + roundup(n, 16) + 16, tyb = (size_t)roundup(n, 256);
+      ensure(planesB[0], bx * kBins * txb * sizeof(float));
+      ensure(planesB[1], bx * kBins * txb * sizeof(float));
+      ensure(planesB[2], by * kBins * tyb * sizeof(float));
+      ensure(planesB[3], by * kBins * tyb * sizeof(float));
     }
   }
 
@@ -1060,10 +1075,15 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
     std::map<ConvGroup*, std::vector<std::pair<int, int>>, GroupLess> active;
     std::vector<const float*> prevIns;
     int prevP = -1, prevRp = -1, prevRows = -1;
+    std::vector<int> bNodes;  // formulation B nodes of this depth
     for (int id : topo) {
       NodeS& nd = *nodes[id];
       if (nd.type != GA_NODE_CONVOLVER || !nd.ir || nd.depth != d) continue;
       if (ex.convIn.find(id) == ex.convIn.end()) continue;
+      if (nd.convPath == 2) {
+        bNodes.push_back(id);
+        continue;
+      }
       for (int slot = 0; slot < (int)nd.convRows.size(); slot++) active[nd.convRows[slot].group].push_back({id, slot});
     }
     std::unordered_map<int, std::array<float*, 4>> tsTemps;  // true-stereo temp outputs per node
@@ -1168,6 +1188,147 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
       // streaming-formulation bytes: per channel-instance per block FDL read + write + input, IR once per block per channel
       stats.mac_bytes_total += ((double)P * kBins * 8.0 + kBins * 8.0 + 512.0) * (double)kv.second.size() * (double)n +
                                (double)P * kBins * 8.0 * (double)n;
+      stats.mac_launches += 1;
+    }
+    // ---- formulation B: nodes with a private impulse response ----
+    if (!bNodes.empty()) {
+      const int hist = (int)roundup(bHistMax, 4);   // plane time origin, 16-byte aligned rows
+      const int txb = hist + (int)roundup(n, 16) + 16, tyb = (int)roundup(n, 256);
+      ConvPlanesB plb{(float*)planesB[0].p, (float*)planesB[1].p, (float*)planesB[2].p, (float*)planesB[3].p, txb, tyb};
+      std::vector<ConvRowIO> xrows, yrows;
+      std::vector<ConvSetB> sets;
+      std::vector<HistJobB> restore, save;
+      std::vector<const float*> ovIn;
+      std::vector<float*> ovOut;
+      double flops = 0;
+      for (int id : bNodes) {
+        NodeS& nd = *nodes[id];
+        const int P = nd.ir->P, h = P - 1;
+        auto& ci = ex.convIn[id];
+        // chunk-long input pointer of every input channel (stable view, or a materialised copy)
+        std::vector<const float*> chIn(nd.bInCh, nullptr);
+        for (int c = 0; c < nd.bInCh; c++) {
+          const float* stable = nullptr;
+          bool same = true, first = true;
+          for (size_t si = 0; si < segs.size(); si++) {
+            const float* v = (ci[si].empty() || c >= (int)ci[si].size()) ? nullptr : ci[si][c];
+            if (first) { stable = v; first = false; } else if (v != stable) same = false;
+          }
+          if (same) {
+            chIn[c] = stable;
+          } else {
+            float* slab = getSlab(*this);
+            for (size_t si = 0; si < segs.size(); si++) {
+              const float* v = (ci[si].empty() || c >= (int)ci[si].size()) ? nullptr : ci[si][c];
+              MixJob mj;
+              mj.out = slab;
+              mj.term0 = (int)ex.terms.size();
+              mj.nterms = v ? 1 : 0;
+              mj.f0 = segs[si].b0 * kBlock;
+              mj.n = (segs[si].b1 - segs[si].b0) * kBlock;
+              if (v) {
+                ex.terms.push_back(v);
+                ex.noteAlign(v, mj.f0);
+              }
+              ex.mixJobs.push_back(mj);
+            }
+            chIn[c] = slab;
+          }
+        }
+        bool allSame = true;
+        for (int c = 1; c < nd.bInCh; c++) allSame = allSame && (chIn[c] == chIn[0]);
+        const size_t hstride = (size_t)kBins * std::max(h, 1);
+        if (nd.bShared && !allSame) {
+          // the channels start to differ: every channel inherits the (so far common) history of channel 0
+          if (!nd.bHistZero && h > 0)
+            for (int c = 1; c < nd.bInCh; c++) {
+              GA_HIP(hipMemcpyAsync(nd.bHistR + c * hstride, nd.bHistR, hstride * 4, hipMemcpyDeviceToDevice, stream));
+              GA_HIP(hipMemcpyAsync(nd.bHistI + c * hstride, nd.bHistI, hstride * 4, hipMemcpyDeviceToDevice, stream));
+            }
+          nd.bShared = false;
+        }
+        const int nxr = nd.bShared ? 1 : nd.bInCh;
+        const int x0 = (int)xrows.size();
+        for (int c = 0; c < nxr; c++) {
+          const int xi = x0 + c;
+          xrows.push_back(ConvRowIO{chIn[c], nullptr});
+          float* xr_row = plb.xr + (size_t)xi * kBins * txb;
+          float* xi_row = plb.xi + (size_t)xi * kBins * txb;
+          // [0, hist - h) zeros, [hist - h, hist) this channel's history, rows after the chunk zero (K padding reads them)
+          if (hist - h > 0) {
+            restore.push_back(HistJobB{xr_row, nullptr, txb, 0, hist - h, 0});
+            restore.push_back(HistJobB{xi_row, nullptr, txb, 0, hist - h, 0});
+          }
+          if (h > 0) {
+            restore.push_back(HistJobB{xr_row + (hist - h), nd.bHistZero ? nullptr : nd.bHistR + c * hstride, txb, h, h, 0});
+            restore.push_back(HistJobB{xi_row + (hist - h), nd.bHistZero ? nullptr : nd.bHistI + c * hstride, txb, h, h, 0});
+            save.push_back(HistJobB{nd.bHistR + c * hstride, xr_row + (hist + (int)n - h), h, txb, h, 0});
+            save.push_back(HistJobB{nd.bHistI + c * hstride, xi_row + (hist + (int)n - h), h, txb, h, 0});
+          }
+          const int tailn = txb - (hist + (int)n);
+          restore.push_back(HistJobB{xr_row + hist + (int)n, nullptr, txb, 0, tailn, 0});
+          restore.push_back(HistJobB{xi_row + hist + (int)n, nullptr, txb, 0, tailn, 0});
+        }
+        // slots: discrete -> slot c reads input c, IR channel c ; true stereo -> (L,h0) (L,h1) (R,h2) (R,h3)
+        std::vector<float*> slotOut(nd.bSlots, nullptr);
+        for (int slot = 0; slot < nd.bSlots; slot++) {
+          if (nd.isTrueStereo) {
+            float* tmp = getSlab(*this);
+            slotOut[slot] = tmp;
+            auto it = tsTemps.find(id);
+            if (it == tsTemps.end()) it = tsTemps.emplace(id, std::array<float*, 4>{nullptr, nullptr, nullptr, nullptr}).first;
+            it->second[slot] = tmp;
+          } else {
+            slotOut[slot] = ex.nodeOut(id, slot);
+          }
+        }
+        // sets: columns grouped by the x-row they read, at most 16 per set, y rows consecutive per set
+        for (int xc = 0; xc < nxr; xc++) {
+          std::vector<int> cols;
+          for (int slot = 0; slot < nd.bSlots; slot++) {
+            int inc = nd.isTrueStereo ? (slot >> 1) : slot;
+            if (nd.bShared || inc == xc) cols.push_back(slot);
+          }
+          for (size_t c0 = 0; c0 < cols.size(); c0 += 16) {
+            ConvSetB st{};
+            st.x = x0 + xc;
+            st.y0 = (int)yrows.size();
+            st.ncol = (int)std::min<size_t>(16, cols.size() - c0);
+            st.P = P;
+            for (int j = 0; j < st.ncol; j++) {
+              int slot = cols[c0 + j];
+              st.hr[j] = nd.ir->hr + (size_t)slot * kBins * P;   // slot index == IR channel index in both modes
+              st.hi[j] = nd.ir->hi + (size_t)slot * kBins * P;
+              yrows.push_back(ConvRowIO{nullptr, slotOut[slot]});
+              ovIn.push_back(nd.bOverlap + ((size_t)slot * 2 + nd.bOvCur) * kBlock);
+              ovOut.push_back(nd.bOverlap + ((size_t)slot * 2 + (nd.bOvCur ^ 1)) * kBlock);
+            }
+            sets.push_back(st);
+          }
+        }
+        nd.bOvCur ^= 1;
+        nd.bHistZero = false;
+        flops += 8.0 * P * kBins * (double)nd.bSlots * (double)n;
+      }
+      ex.flushLevel();
+      size_t xo = ex.plan.putv(xrows), yo = ex.plan.putv(yrows), so = ex.plan.putv(sets), ro = ex.plan.putv(restore),
+             sv = ex.plan.putv(save), oi = ex.plan.putv(ovIn), oo = ex.plan.putv(ovOut);
+      const int nx = (int)xrows.size(), ny = (int)yrows.size(), ns_ = (int)sets.size(), nr = (int)restore.size(), nsv = (int)save.size();
+      hipStream_t st = stream;
+      Twiddles tw{w128, w256};
+      const int nn = (int)n;
+      const int maxn = std::max(hist, txb - hist - nn);
+      ex.plan.add(LK_FFT, [=](uint8_t* base) {
+        launch_hist_copy_b(st, (const HistJobB*)(base + ro), nr, std::max(maxn, 1));
+        launch_rfft_fwd_b(st, (const ConvRowIO*)(base + xo), nx, nn, hist, plb, tw);
+      });
+      ex.plan.add(LK_MAC, [=](uint8_t* base) { launch_spectral_mac_b(st, (const ConvSetB*)(base + so), ns_, nn, hist, plb); });
+      ex.plan.add(LK_FFT, [=](uint8_t* base) {
+        launch_irfft_ola_b(st, (const ConvRowIO*)(base + yo), ny, nn, plb, (const float* const*)(base + oi), (float* const*)(base + oo), tw);
+        launch_hist_copy_b(st, (const HistJobB*)(base + sv), nsv, std::max(hist, 1));
+      });
+      stats.mac_flops_total += flops;
+      stats.mac_bytes_total += flops;   // streaming formulation with private IRs: 2 * P * 129 * 8 B per 8 * P * 129 flop
       stats.mac_launches += 1;
     }
     // true stereo: outL = conv0(L) + conv2(R) ; outR = conv1(L) + conv3(R)  (ConvolverNode.cs:127-144)

@@ -75,6 +75,13 @@ Context::~Context() {
   }
   for (auto& a : planes)
     if (a.p) (void)hipFree(a.p);
+  for (auto& a : planesB)
+    if (a.p) (void)hipFree(a.p);
+  for (auto& np : nodes) {
+    if (np && np->bHistR) (void)hipFree(np->bHistR);
+    if (np && np->bHistI) (void)hipFree(np->bHistI);
+    if (np && np->bOverlap) (void)hipFree(np->bOverlap);
+  }
   if (tables.p) (void)hipFree(tables.p);
   if (tablesHost) (void)hipHostFree(tablesHost);
   for (void* p : slabBlocks) (void)hipFree(p);
@@ -203,9 +210,98 @@ void Context::doDispose(int id) {
   if (n.type == GA_NODE_CONVOLVER) {                   // ConvolverNode.cs:166-175
     n.ir.reset();
     n.irBuf = -1;
-    for (auto& r : n.convRows)
-      if (r.group) r.group->rows[r.idx] = {-1, 0};
-    n.convRows.clear();
+    releaseConvState(n);
+  }
+}
+
+// a node loses its PartitionedConvolver instances (Buffer reassigned / disposed): rows and private state are released
+void Context::releaseConvState(NodeS& n) {
+  for (auto& r : n.convRows)
+    if (r.group) r.group->rows[r.idx] = {-1, 0};
+  n.convRows.clear();
+  if (n.bHistR || n.bOverlap) {
+    if (stream) (void)hipStreamSynchronize(stream);
+    if (n.ir) {
+      size_t hb = (size_t)n.bInCh * kBins * std::max(n.ir->P - 1, 1) * sizeof(float);
+      dfree(n.bHistR, hb);
+      dfree(n.bHistI, hb);
+    } else {
+      (void)hipFree(n.bHistR);
+      (void)hipFree(n.bHistI);
+    }
+    dfree(n.bOverlap, (size_t)n.bSlots * 2 * kBlock * sizeof(float));
+  }
+  n.bHistR = n.bHistI = n.bOverlap = nullptr;
+  n.convPath = 0;
+  n.bShared = true;
+  n.bHistZero = true;
+  n.bOvCur = 0;
+}
+
+// Decide, for convolver nodes that do not have DSP state yet, which formulation serves them: nodes sharing an impulse
+// response with at least 7 others become rows of the shared-IR GEMM (A); nodes with a (nearly) private IR use the
+// per-node formulation (B), whose state is O(P) per input channel instead of O(P * 128 rows) per IR channel.
+void Context::assignConvPaths(const std::vector<int>& topo) {
+  std::map<IrSpectra*, int> users;
+  std::map<IrSpectra*, bool> hasA;
+  for (int id : topo) {
+    NodeS& nd = *nodes[id];
+    if (nd.type != GA_NODE_CONVOLVER || !nd.ir) continue;
+    users[nd.ir.get()]++;
+    if (nd.convPath == 1) hasA[nd.ir.get()] = true;
+  }
+  for (int id : topo) {
+    NodeS& nd = *nodes[id];
+    if (nd.type != GA_NODE_CONVOLVER || !nd.ir || nd.convPath != 0) continue;
+    IrSpectra* ir = nd.ir.get();
+    const int channels = ir->nch;
+    const bool pathA = hasA[ir] || users[ir] >= 8;
+    if (pathA) {
+      for (int ch = 0; ch < channels; ch++) {
+        auto key = std::make_pair(ir, ch);
+        ConvGroup* g;
+        auto it = groupOf.find(key);
+        if (it == groupOf.end()) {
+          auto ng = std::make_unique<ConvGroup>();
+          ng->ir = nd.ir;
+          ng->irCh = ch;
+          ng->P = ir->P;
+          g = ng.get();
+          groups.push_back(std::move(ng));
+          groupOf[key] = g;
+        } else {
+          g = it->second;
+        }
+        int idx = (int)g->rows.size();   // rows are append-only while a group holds live state
+        g->rows.push_back({id, ch});
+        if (idx < g->rp && g->histR) {   // the column may hold stale scratch data: a new convolver starts from zero state
+          const int hist = g->P - 1;
+          if (hist > 0) {
+            GA_HIP(hipMemset2DAsync(g->histR + idx, (size_t)g->rp * 4, 0, 4, (size_t)kBins * hist, stream));
+            GA_HIP(hipMemset2DAsync(g->histI + idx, (size_t)g->rp * 4, 0, 4, (size_t)kBins * hist, stream));
+          }
+          GA_HIP(hipMemsetAsync(g->overlap[0] + (size_t)idx * kBlock, 0, kBlock * 4, stream));
+          GA_HIP(hipMemsetAsync(g->overlap[1] + (size_t)idx * kBlock, 0, kBlock * 4, stream));
+        }
+        nd.convRows.push_back(ConvRowRef{g, idx});
+      }
+      nd.convPath = 1;
+    } else {
+      nd.bInCh = nd.isTrueStereo ? 2 : channels;
+      nd.bSlots = nd.isTrueStereo ? 4 : channels;
+      size_t hb = (size_t)nd.bInCh * kBins * std::max(ir->P - 1, 1) * sizeof(float);
+      size_t ob = (size_t)nd.bSlots * 2 * kBlock * sizeof(float);
+      nd.bHistR = (float*)dalloc(hb);
+      nd.bHistI = (float*)dalloc(hb);
+      nd.bOverlap = (float*)dalloc(ob);
+      GA_HIP(hipMemsetAsync(nd.bHistR, 0, hb, stream));
+      GA_HIP(hipMemsetAsync(nd.bHistI, 0, hb, stream));
+      GA_HIP(hipMemsetAsync(nd.bOverlap, 0, ob, stream));
+      nd.bShared = true;
+      nd.bHistZero = true;
+      nd.bOvCur = 0;
+      nd.convPath = 2;
+    }
   }
 }
 

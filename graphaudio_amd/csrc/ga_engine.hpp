@@ -143,6 +143,15 @@ struct NodeS {
   int effectiveOutCh = 0;
   bool isTrueStereo = false, normalize = true, enableTrueStereo = true;
   std::vector<ConvRowRef> convRows;
+  // convolution path: 0 = not assigned yet, 1 = shared-IR groups (formulation A), 2 = private IR (formulation B)
+  int convPath = 0;
+  int bInCh = 0, bSlots = 0;       // formulation B: input channels / (input channel, IR channel) slots
+  float* bHistR = nullptr;         // [bInCh][129][P-1] spectra history of every input channel
+  float* bHistI = nullptr;
+  float* bOverlap = nullptr;       // [bSlots][2][128] double-buffered overlap
+  int bOvCur = 0;
+  bool bShared = true;             // all input channels have carried identical signals so far (one x-row serves all)
+  bool bHistZero = true;
 };
 
 // one evaluated control state of a node within a segment
@@ -229,6 +238,7 @@ struct Context {
   float* zeros = nullptr;  // zero page (chunk frames)
   int64_t zerosLen = 0;
   DevArena planes[4];      // xr, xi, yr, yi scratch shared by all groups
+  DevArena planesB[4];     // formulation B scratch
   DevArena tables;         // per-chunk job tables
   void* tablesHost = nullptr;
   size_t tablesHostBytes = 0;
@@ -268,6 +278,8 @@ struct Context {
   void doDispose(int id);
 
   std::shared_ptr<IrSpectra> irSpectra(int bufId, bool normalize);
+  void releaseConvState(NodeS& n);
+  void assignConvPaths(const std::vector<int>& topo);
   void updateBiquadCoefficients(NodeS& n, float frequency, float q, float gain);
 
   void render(float* const* out, int channels, int64_t frames, int64_t start, bool deviceOut);

@@ -499,6 +499,316 @@ void launch_spectral_mac_shared(hipStream_t s, ConvPlanes pl, const float* hr, c
   hipLaunchKernelGGL(spectral_mac_shared_kernel, dim3(grid), dim3(256), 0, s, pl, hr, hi, P, ntt, nrt, total);
 }
 
+// =====================================================================================================
+//  Formulation B kernels (see ga_kernels.hpp): planes [row][bin][block], block index fastest.
+// =====================================================================================================
+constexpr int FB_RUN = 16;            // blocks per workgroup in the B-layout FFT kernels
+constexpr int FB_LD = FB_RUN + 4;     // staging row: [bin][16 blocks] padded to 20 floats (16-byte aligned rows)
+
+// forward: workgroup = (x-row, run of 16 blocks); wave w transforms blocks t0 + w + 4u, u = 0..3 (4 in flight)
+__global__ __launch_bounds__(256) void rfft_fwd_b_kernel(const ConvRowIO* __restrict xrows, int nx, int nblocks, int hist,
+                                                         ConvPlanesB pl, Twiddles tw) {
+  __shared__ __attribute__((aligned(16))) float st_r[kBins * FB_LD];
+  __shared__ __attribute__((aligned(16))) float st_i[kBins * FB_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int xrow = blockIdx.x;
+  const int t0 = blockIdx.y * FB_RUN;
+  const LaneTw ltw = load_lane_tw(tw.w128, lane);
+  const int m = rev6(lane);
+  const int k0 = 2 * m, k1 = 2 * m + 1;
+  const int src0 = rev6((64 - m) & 63), src1 = 63 - lane;
+  const double2 wk0 = tw.w256[k0];
+  const double2 wk1 = tw.w256[k1];
+  const float* in = xrows[xrow].in;
+
+  double s0r[4], s0i[4], s1r[4], s1i[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int t = t0 + wave + 4 * u;
+    s0r[u] = 0.0;
+    s0i[u] = 0.0;
+    if (in && t < nblocks) {
+      const float* p = in + (int64_t)t * kBlock + 2 * lane;
+      s0r[u] = (double)p[0];
+      s0i[u] = (double)p[1];
+    }
+    s1r[u] = fma(s0r[u], ltw.c1, -(s0i[u] * ltw.s1));
+    s1i[u] = fma(s0r[u], ltw.s1, s0i[u] * ltw.c1);
+  }
+#pragma unroll
+  for (int u = 0; u < 4; u++) { dif_stage<32, 0>(s0r[u], s0i[u], ltw); dif_stage<32, 0>(s1r[u], s1i[u], ltw); }
+#pragma unroll
+  for (int u = 0; u < 4; u++) { dif_stage<16, 1>(s0r[u], s0i[u], ltw); dif_stage<16, 1>(s1r[u], s1i[u], ltw); }
+#pragma unroll
+  for (int u = 0; u < 4; u++) { dif_stage<8, 2>(s0r[u], s0i[u], ltw); dif_stage<8, 2>(s1r[u], s1i[u], ltw); }
+#pragma unroll
+  for (int u = 0; u < 4; u++) { dif_stage<4, 3>(s0r[u], s0i[u], ltw); dif_stage<4, 3>(s1r[u], s1i[u], ltw); }
+#pragma unroll
+  for (int u = 0; u < 4; u++) { dif_stage<2, 4>(s0r[u], s0i[u], ltw); dif_stage<2, 4>(s1r[u], s1i[u], ltw); }
+#pragma unroll
+  for (int u = 0; u < 4; u++) { dif_stage<1, 5>(s0r[u], s0i[u], ltw); dif_stage<1, 5>(s1r[u], s1i[u], ltw); }
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int tl = wave + 4 * u;   // block within the run
+    {
+      double ax = s0r[u], ay = s0i[u];
+      double bx = shfl_d(ax, src0), by = shfl_d(ay, src0);
+      double er = 0.5 * (ax + bx), ei = 0.5 * (ay - by);
+      double dr = 0.5 * (ax - bx), di = 0.5 * (ay + by);
+      double pr = fma(dr, wk0.x, -(di * wk0.y)), pi = fma(dr, wk0.y, di * wk0.x);
+      float xr = (float)(er + pi), xi = (float)(ei - pr);
+      if (k0 == 0) {
+        xi = 0.f;
+        st_r[128 * FB_LD + tl] = (float)(ax - ay);
+        st_i[128 * FB_LD + tl] = 0.f;
+      }
+      st_r[k0 * FB_LD + tl] = xr;
+      st_i[k0 * FB_LD + tl] = xi;
+    }
+    {
+      double ax = s1r[u], ay = s1i[u];
+      double bx = shfl_d(ax, src1), by = shfl_d(ay, src1);
+      double er = 0.5 * (ax + bx), ei = 0.5 * (ay - by);
+      double dr = 0.5 * (ax - bx), di = 0.5 * (ay + by);
+      double pr = fma(dr, wk1.x, -(di * wk1.y)), pi = fma(dr, wk1.y, di * wk1.x);
+      st_r[k1 * FB_LD + tl] = (float)(er + pi);
+      st_i[k1 * FB_LD + tl] = (float)(ei - pr);
+    }
+  }
+  __syncthreads();
+  // store: per bin 16 consecutive blocks = 64 bytes, 4 lanes x 16 B
+  const size_t rowbase = (size_t)xrow * kBins * pl.tx + hist + t0;
+  for (int idx = tid; idx < kBins * 4; idx += 256) {
+    int k = idx >> 2, q = (idx & 3) * 4;
+    if (t0 + q >= nblocks) continue;
+    size_t o = rowbase + (size_t)k * pl.tx + q;
+    *reinterpret_cast<float4*>(pl.xr + o) = *reinterpret_cast<const float4*>(&st_r[k * FB_LD + q]);
+    *reinterpret_cast<float4*>(pl.xi + o) = *reinterpret_cast<const float4*>(&st_i[k * FB_LD + q]);
+  }
+}
+void launch_rfft_fwd_b(hipStream_t s, const ConvRowIO* xrows_dev, int nx, int nblocks, int hist, ConvPlanesB pl, Twiddles tw) {
+  if (nx <= 0 || nblocks <= 0) return;
+  dim3 grid(nx, (nblocks + FB_RUN - 1) / FB_RUN);
+  hipLaunchKernelGGL(rfft_fwd_b_kernel, grid, dim3(256), 0, s, xrows_dev, nx, nblocks, hist, pl, tw);
+}
+
+// MAC B: workgroup = (set, bin, 256-block time tile); wave = 64 blocks (4 M-tiles) x 16 columns; taps in segments of 256
+constexpr int MB_TW = 256;
+constexpr int MB_PSEG = 256;
+constexpr int MB_HLD = MB_PSEG + 2;            // column stride: 2j + kk distinct banks for lanes (j, kk)
+constexpr int MB_XLEN = MB_TW + MB_PSEG + 8;
+
+__global__ __launch_bounds__(256) void spectral_mac_b_kernel(const ConvSetB* __restrict sets, int nblocks, int hist, ConvPlanesB pl,
+                                                             int ntt) {
+  __shared__ float hs[3][16 * MB_HLD];   // taps re, im, re+im  [column][p]
+  __shared__ float xw[3][MB_XLEN];       // input spectra window re, im, re+im : xw[i] = X[t0 - pa - (Ps-1) + i ... ]
+  const ConvSetB* __restrict Sp = &sets[blockIdx.z];   // accessed in place: a by-value copy (32 pointers) would go to scratch
+  struct { int x, y0, ncol, P; } S = {Sp->x, Sp->y0, Sp->ncol, Sp->P};
+  const int k = blockIdx.y;
+  const int tt = blockIdx.x;
+  const int t0 = tt * MB_TW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int la = lane & 15, lk = lane >> 4;
+  const int P = S.P;
+  const float* __restrict xr = pl.xr + ((size_t)S.x * kBins + k) * pl.tx;
+  const float* __restrict xi = pl.xi + ((size_t)S.x * kBins + k) * pl.tx;
+
+  f32x4 acc1[4], acc2[4], acc3[4];
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    acc1[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc2[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc3[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  for (int pa = 0; pa < P; pa += MB_PSEG) {
+    const int Ps = min(MB_PSEG, P - pa);
+    const int Ps4 = (Ps + 3) & ~3;
+    __syncthreads();
+    // taps of this segment, zero padded to a multiple of 4 (and unused columns zero)
+    for (int i = tid; i < 16 * MB_HLD; i += 256) {
+      int j = i / MB_HLD, p = i % MB_HLD;
+      float vr = 0.f, vi = 0.f;
+      if (j < S.ncol && p < Ps) {
+        vr = Sp->hr[j][(size_t)k * P + pa + p];
+        vi = Sp->hi[j][(size_t)k * P + pa + p];
+      }
+      hs[0][i] = vr;
+      hs[1][i] = vi;
+      hs[2][i] = vr + vi;
+    }
+    // window: plane index of block t is hist + t; tap p needs block t - p.  xw[i] <-> block  t0 - pa - (Ps4 - 1) + i
+    const int wlen = MB_TW + Ps4 - 1;
+    const int b0 = t0 - pa - (Ps4 - 1);
+    for (int i = tid; i < wlen; i += 256) {
+      int blk = b0 + i;            // may be < -hist (before any history): zero
+      float vr = 0.f, vi = 0.f;
+      if (blk >= -hist && blk < nblocks) {
+        vr = xr[hist + blk];
+        vi = xi[hist + blk];
+      }
+      xw[0][i] = vr;
+      xw[1][i] = vi;
+      xw[2][i] = vr + vi;
+    }
+    __syncthreads();
+    // Y[t] += sum_p X[t - p] H[p];  A[i][kk] = X[t0w + 16m + i - (p0 + kk)] -> xw index (Ps4 - 1) + 64w + 16m + i - p0 - kk
+    const int abase = (Ps4 - 1) + wave * 64 + la - lk;
+    for (int p0 = 0; p0 < Ps4; p0 += 4) {
+      const int hoff = la * MB_HLD + p0 + lk;
+      float br = hs[0][hoff], bi = hs[1][hoff], bs = hs[2][hoff];
+#pragma unroll
+      for (int m = 0; m < 4; m++) {
+        const int xo = abase + 16 * m - p0;
+        float ar = xw[0][xo], ai = xw[1][xo], as = xw[2][xo];
+        acc1[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar, br, acc1[m], 0, 0, 0);
+        acc2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, bi, acc2[m], 0, 0, 0);
+        acc3[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(as, bs, acc3[m], 0, 0, 0);
+      }
+    }
+  }
+  // D layout: column (IR channel) = lane & 15, row (block) = 4 * (lane >> 4) + reg -> four consecutive blocks per lane
+  if (la < S.ncol) {
+    float* __restrict yr = pl.yr + ((size_t)(S.y0 + la) * kBins + k) * pl.ty;
+    float* __restrict yi = pl.yi + ((size_t)(S.y0 + la) * kBins + k) * pl.ty;
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      int t = t0 + wave * 64 + 16 * m + 4 * lk;
+      if (t < pl.ty) {
+        *reinterpret_cast<f32x4*>(yr + t) = acc1[m] - acc2[m];
+        *reinterpret_cast<f32x4*>(yi + t) = (acc3[m] - acc1[m]) - acc2[m];
+      }
+    }
+  }
+}
+void launch_spectral_mac_b(hipStream_t s, const ConvSetB* sets_dev, int nsets, int nblocks, int hist, ConvPlanesB pl) {
+  if (nsets <= 0 || nblocks <= 0) return;
+  int ntt = (nblocks + MB_TW - 1) / MB_TW;
+  for (int z0 = 0; z0 < nsets; z0 += 32768) {   // gridDim.z limit
+    int nz = std::min(32768, nsets - z0);
+    hipLaunchKernelGGL(spectral_mac_b_kernel, dim3(ntt, kBins, nz), dim3(256), 0, s, sets_dev + z0, nblocks, hist, pl, ntt);
+  }
+}
+
+// inverse + overlap-add, B layout: workgroup = 4 y-rows (one per wave) x run of 16 blocks (+1 to recover the incoming tail)
+__global__ __launch_bounds__(256) void irfft_ola_b_kernel(const ConvRowIO* __restrict yrows, int ny, int nblocks, ConvPlanesB pl,
+                                                          const float* const* __restrict overlap_in, float* const* __restrict overlap_out,
+                                                          Twiddles tw) {
+  __shared__ float ys_r[4][kBins * FB_LD];
+  __shared__ float ys_i[4][kBins * FB_LD];
+  __shared__ float tail[4][kBlock];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  const int ta = blockIdx.y * FB_RUN;
+  const int tb = min(ta + FB_RUN, nblocks);
+  const LaneTw ltw = load_lane_tw(tw.w128, lane);
+  const int k0 = rev6(lane) << 1, k1 = k0 | 1;
+  const double2 wk0 = tw.w256[k0];
+  const double2 wk1 = tw.w256[k1];
+  if (row >= ny) return;   // whole wave; no workgroup barriers below (everything is wave-private)
+  const float* ov = overlap_in[row];
+  float* ovo = overlap_out[row];
+  float* out = yrows[row].out;
+  const float* __restrict yr = pl.yr + (size_t)row * kBins * pl.ty;
+  const float* __restrict yi = pl.yi + (size_t)row * kBins * pl.ty;
+  float* sr = ys_r[wave];
+  float* si = ys_i[wave];
+  // stage blocks [ta - 1, tb) of this row: column c of the staging tile <-> block ta - 1 + c   (c = 0 unused when ta == 0)
+  const int c0 = (ta == 0) ? 1 : 0;
+  const int ncols = tb - ta + 1;
+  for (int idx = lane; idx < kBins * FB_LD; idx += 64) {
+    int k = idx / FB_LD, c = idx % FB_LD;
+    float vr = 0.f, vi = 0.f;
+    if (c >= c0 && c < ncols) {
+      size_t o = (size_t)k * pl.ty + (ta - 1 + c);
+      vr = yr[o];
+      vi = yi[o];
+    }
+    sr[idx] = vr;
+    si[idx] = vi;
+  }
+  if (ta == 0) {
+    tail[wave][2 * lane] = ov[2 * lane];
+    tail[wave][2 * lane + 1] = ov[2 * lane + 1];
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int cbase = c0; cbase < ncols; cbase += 4) {
+    double s0r[4], s0i[4], s1r[4], s1i[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int c = min(cbase + u, ncols - 1);
+      {
+        double ar = sr[k0 * FB_LD + c], ai = si[k0 * FB_LD + c];
+        double br = sr[(128 - k0) * FB_LD + c], bi = -(double)si[(128 - k0) * FB_LD + c];
+        if (k0 == 0) { ai = 0.0; bi = 0.0; }
+        double er = ar + br, ei = ai + bi, dr = ar - br, di = ai - bi;
+        double pr = fma(dr, wk0.x, di * wk0.y), pi = fma(di, wk0.x, -(dr * wk0.y));
+        s0r[u] = er - pi;
+        s0i[u] = ei + pr;
+      }
+      {
+        double ar = sr[k1 * FB_LD + c], ai = si[k1 * FB_LD + c];
+        double br = sr[(128 - k1) * FB_LD + c], bi = -(double)si[(128 - k1) * FB_LD + c];
+        double er = ar + br, ei = ai + bi, dr = ar - br, di = ai - bi;
+        double pr = fma(dr, wk1.x, di * wk1.y), pi = fma(di, wk1.x, -(dr * wk1.y));
+        s1r[u] = er - pi;
+        s1i[u] = ei + pr;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) { dit_stage<1, 5>(s0r[u], s0i[u], ltw); dit_stage<1, 5>(s1r[u], s1i[u], ltw); }
+#pragma unroll
+    for (int u = 0; u < 4; u++) { dit_stage<2, 4>(s0r[u], s0i[u], ltw); dit_stage<2, 4>(s1r[u], s1i[u], ltw); }
+#pragma unroll
+    for (int u = 0; u < 4; u++) { dit_stage<4, 3>(s0r[u], s0i[u], ltw); dit_stage<4, 3>(s1r[u], s1i[u], ltw); }
+#pragma unroll
+    for (int u = 0; u < 4; u++) { dit_stage<8, 2>(s0r[u], s0i[u], ltw); dit_stage<8, 2>(s1r[u], s1i[u], ltw); }
+#pragma unroll
+    for (int u = 0; u < 4; u++) { dit_stage<16, 1>(s0r[u], s0i[u], ltw); dit_stage<16, 1>(s1r[u], s1i[u], ltw); }
+#pragma unroll
+    for (int u = 0; u < 4; u++) { dit_stage<32, 0>(s0r[u], s0i[u], ltw); dit_stage<32, 0>(s1r[u], s1i[u], ltw); }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int c = cbase + u;
+      if (c >= ncols) break;   // wave uniform
+      const int t = ta - 1 + c;
+      double qr = fma(s1r[u], ltw.c1, s1i[u] * ltw.s1), qi = fma(s1i[u], ltw.c1, -(s1r[u] * ltw.s1));
+      const double scale = 1.0 / 256.0;
+      double h0 = (s0r[u] + qr) * scale, h1 = (s0i[u] + qi) * scale;
+      double g0 = (s0r[u] - qr) * scale, g1 = (s0i[u] - qi) * scale;
+      if (t >= ta) {
+        float o0 = (float)h0 + tail[wave][2 * lane];
+        float o1 = (float)h1 + tail[wave][2 * lane + 1];
+        if (out) *reinterpret_cast<float2*>(out + (int64_t)t * kBlock + 2 * lane) = make_float2(o0, o1);
+      }
+      tail[wave][2 * lane] = (float)g0;
+      tail[wave][2 * lane + 1] = (float)g1;
+    }
+  }
+  if (tb == nblocks) {   // persistent overlap for the next chunk (double buffered: another workgroup may still read overlap_in)
+    ovo[2 * lane] = tail[wave][2 * lane];
+    ovo[2 * lane + 1] = tail[wave][2 * lane + 1];
+  }
+}
+void launch_irfft_ola_b(hipStream_t s, const ConvRowIO* yrows_dev, int ny, int nblocks, ConvPlanesB pl,
+                        const float* const* overlap_in_dev, float* const* overlap_out_dev, Twiddles tw) {
+  if (ny <= 0 || nblocks <= 0) return;
+  dim3 grid((ny + 3) / 4, (nblocks + FB_RUN - 1) / FB_RUN);
+  hipLaunchKernelGGL(irfft_ola_b_kernel, grid, dim3(256), 0, s, yrows_dev, ny, nblocks, pl, overlap_in_dev, overlap_out_dev, tw);
+}
+
+__global__ void hist_copy_b_kernel(const HistJobB* __restrict jobs) {
+  const HistJobB j = jobs[blockIdx.y];
+  const int k = blockIdx.x;
+  for (int i = threadIdx.x; i < j.n; i += blockDim.x) j.dst[(size_t)k * j.dst_stride + i] = j.src ? j.src[(size_t)k * j.src_stride + i] : 0.f;
+}
+void launch_hist_copy_b(hipStream_t s, const HistJobB* jobs_dev, int njobs, int max_n) {
+  if (njobs <= 0 || max_n <= 0) return;
+  for (int j0 = 0; j0 < njobs; j0 += 32768) {
+    int nj = std::min(32768, njobs - j0);
+    hipLaunchKernelGGL(hist_copy_b_kernel, dim3(kBins, nj), dim3(128), 0, s, jobs_dev + j0);
+  }
+}
+
 // ---- plane utilities ----------------------------------------------------------------------------------
 __global__ void plane_copy_kernel(float* __restrict dst, int dst_t, int dst_t0, const float* __restrict src, int src_t, int src_t0,
                                   int n, int rp) {

@@ -52,6 +52,37 @@ void launch_extract_ir(hipStream_t s, float* hr, float* hi, const float* xr, con
 // out[f] = a[f] + b[f]   (true-stereo pair sum, ConvolverNode.cs:157-164)
 void launch_pair_sum(hipStream_t s, float* out, const float* a, const float* b, int64_t n);
 
+// ---- convolver pipeline, formulation B: one input against up to 16 IR channels ("private IR" nodes) ----------------
+// Used when few nodes share an impulse response (unique IR per voice, multi-channel HRTF-style IRs): rows of the
+// shared-IR GEMM would be empty.  Here one input spectrum sequence X[k][t] (an "x-row") is multiplied with the spectra of
+// up to 16 (slot -> IR channel) columns:  Y[col][k][t] = sum_p X[k][t - p] * H[col][k][p]   -- M = time, N = columns, K = taps.
+// Planes are [row][bin][block] with the block index fastest.
+struct ConvPlanesB {
+  float* xr;   // [nx][kBins][tx]   tx = hist + chunk blocks (padded)
+  float* xi;
+  float* yr;   // [ny][kBins][ty]
+  float* yi;
+  int tx, ty;
+};
+struct ConvSetB {          // one MAC problem: x-row `x` against `ncol` columns
+  int x;                   // x-row index
+  int y0;                  // first y-row index (columns are consecutive y rows)
+  int ncol;                // 1..16
+  int P;
+  const float* hr[16];     // per column: spectra [kBins][P] (re)
+  const float* hi[16];
+};
+struct HistJobB {          // history save / restore of one x-row: kBins runs of `n` floats
+  float* dst;
+  const float* src;        // nullptr = fill with zeros
+  int dst_stride, src_stride, n, pad_;
+};
+void launch_rfft_fwd_b(hipStream_t s, const ConvRowIO* xrows_dev, int nx, int nblocks, int hist, ConvPlanesB pl, Twiddles tw);
+void launch_spectral_mac_b(hipStream_t s, const ConvSetB* sets_dev, int nsets, int nblocks, int hist, ConvPlanesB pl);
+void launch_irfft_ola_b(hipStream_t s, const ConvRowIO* yrows_dev, int ny, int nblocks, ConvPlanesB pl,
+                        const float* const* overlap_in_dev, float* const* overlap_out_dev, Twiddles tw);
+void launch_hist_copy_b(hipStream_t s, const HistJobB* jobs_dev, int njobs, int max_n);
+
 // ---- graph plumbing kernels ------------------------------------------------------------------------
 // out[f0 + i] = ((0 + t0[f0+i]) + t1[f0+i]) + ...  in term order (AudioNodeInput.cs:118-132,182-244)
 struct MixJob {

@@ -98,3 +98,61 @@ def test_render_too_many_channels_raises():
     out = np.zeros((2, 256), np.float32)
     with pytest.raises(ArgumentOutOfRangeException):
         ctx.Render(out, 256)
+
+
+def test_private_ir_per_voice():
+    """Unique IR per voice (config 3 variant): served by the per-node formulation (time x IR-channels MFMA tiles)."""
+    ref, got = both(G.config3_convolver, 128 * 40, voices=5, taps=3000, frames=128 * 40, shared=False)
+    err = G.rms(ref - got)
+    assert err <= TOL_RMS and err / G.rms(ref) < 2e-6
+
+
+def _config5(ctx, sources=4, taps=2000, frames=128 * 30, ir_channels=16):
+    """sources x 16-channel PartitionedConvolver (HRTF-style multi-IR), destination 16 ch (BASELINE.json configs[4])."""
+    ctx.Destination.SetChannelCount(ir_channels)
+    for v in range(sources):
+        s = AudioBufferSourceNode(ctx)
+        s.Buffer = PlayableAudioBuffer.FromMonoArray(G.voice(v, frames + 256), 48000)
+        cv = ConvolverNode(ctx)
+        cv.Buffer = PlayableAudioBuffer.FromChannelArrays([G.synth_ir(c, taps, seed0=7 + 100 * v) for c in range(ir_channels)], 48000)
+        s.Connect(cv).Connect(ctx.Destination)
+        s.Start()
+    return ir_channels
+
+
+def test_config5_multichannel_ir():
+    ref, got = both(_config5, 128 * 30)
+    assert ref.shape[0] == 16
+    err = G.rms(ref - got)
+    assert err <= TOL_RMS and err / G.rms(ref) < 2e-6
+
+
+def test_private_ir_stereo_source_and_chunked_state():
+    """Stereo source into a private 2-channel IR (distinct inputs per channel) rendered in uneven pieces."""
+    frames = 128 * 50
+
+    def build(ctx):
+        l, r = G.voice(70, frames + 256), G.voice(71, frames + 256)
+        s = AudioBufferSourceNode(ctx)
+        s.Buffer = PlayableAudioBuffer.FromStereoArrays(l, r, 48000)
+        cv = ConvolverNode(ctx)
+        cv.Buffer = PlayableAudioBuffer.FromChannelArrays([G.synth_ir(c, 5000) for c in range(2)], 48000)
+        s.Connect(cv).Connect(ctx.Destination)
+        s.Start()
+        return 2
+
+    o = OracleContext(48000)
+    build(o)
+    ref = G.render(o, 2, frames)
+    h = OfflineAudioContext(48000)
+    h.SetOption("max_chunk_blocks", 13)
+    build(h)
+    got = np.zeros_like(ref)
+    pos = 0
+    for n in (300, 128 * 7 + 5, 128 * 20, frames):
+        n = min(n, frames - pos)
+        if n > 0:
+            h.Render(got, n, pos)
+            pos += n
+    err = G.rms(ref - got)
+    assert err <= TOL_RMS and err / G.rms(ref) < 2e-6
