@@ -311,6 +311,22 @@ struct Sim {
     NodeSeg ns;
     ns.id = id;
     ns.ins.resize(n_.inputs.size());
+    // params first: ComputeValues pulls the modulation input (1 channel, explicit) before the node's inputs (:167-175)
+    ns.pins.resize(n_.params.size());
+    for (int p = 0; p < (int)n_.params.size(); p++) {
+      auto& mod = n_.params[p].modulation;
+      InSeg& is = ns.pins[p];
+      is.bufCh = 1;
+      is.silent = true;
+      for (auto& m : mod) {
+        evalNode(m.first);
+        OutputS& o = c.nodes[m.first]->outputs[m.second];
+        if (o.bufCh != 0 && !o.silent) {
+          is.terms.push_back(TermS{m.first, m.second, o.bufCh});
+          is.silent = false;
+        }
+      }
+    }
     for (int i = 0; i < (int)n_.inputs.size(); i++) pull(n_, i, ns.ins[i]);
     process(n_, ns);
     n_.isProcessing = false;
@@ -331,7 +347,10 @@ struct Sim {
       case GA_NODE_BIQUAD: {  // BiQuadFilterNode.cs:87-147
         n_.outputs[0].bufCh = ns.ins[0].bufCh;
         n_.outputs[0].silent = ns.ins[0].silent;
-        if (!ns.ins[0].silent) {
+        ns.bqDynamic = !n_.params[0].events.empty() || !n_.params[1].events.empty() || !n_.params[2].events.empty();
+        if (!ns.ins[0].silent && ns.bqDynamic) {
+          ns.bqActive = true;   // coefficients are refreshed per sample on the device
+        } else if (!ns.ins[0].silent) {
           float nyq = c.sampleRate / 2.f;
           float f = n_.params[0].value;
           f = f < 1.f ? 1.f : (f > nyq ? nyq : f);
@@ -392,6 +411,8 @@ struct Sim {
         h = hmix(h, ((uint64_t)is.bufCh << 1) | (is.silent ? 1 : 0));
         for (const TermS& t : is.terms) h = hmix(h, ((uint64_t)t.node << 16) | ((uint64_t)t.out << 8) | (uint64_t)t.ch);
       }
+      for (const InSeg& is : ns.pins)
+        for (const TermS& t : is.terms) h = hmix(h, 0x5151ull ^ (((uint64_t)t.node << 16) | ((uint64_t)t.out << 8) | (uint64_t)t.ch));
     }
     return h;
   }
@@ -414,6 +435,7 @@ struct Exec {
   std::vector<GainJob> gainJobs;
   std::vector<BiquadJob> bqJobs[kMaxBiquadSections + 1];  // by cascade length
   std::vector<BiquadSection> bqSecs;
+  std::vector<BiquadDynJob> bqDynJobs;
   std::vector<LoopJob> loopJobs;
   std::vector<ResampleJob> rsJobs;
   std::vector<ResampleBlock> traj;  // per-chunk trajectory table (all rates + custom tail blocks)
@@ -439,8 +461,11 @@ struct Exec {
 
   // AudioNodeInput.Pull + MixBuffer (AudioNodeInput.cs:100-138,182-244) for one input over one segment
   std::vector<const float*> resolveInput(int si, const NodeSeg& ns, int i, bool force, float* const* forcedSlabs) {
+    return resolveInSeg(si, ns.id, i, ns.ins[i], force, forcedSlabs);
+  }
+  // i >= 0: node input i ; i < 0: modulation input of param (-1 - i)
+  std::vector<const float*> resolveInSeg(int si, int nodeId, int i, const InSeg& is, bool force, float* const* forcedSlabs) {
     const Segment& sg = segs[si];
-    const InSeg& is = ns.ins[i];
     const int dstCh = is.bufCh;
     const int64_t f0 = sg.b0 * kBlock, nf = (sg.b1 - sg.b0) * kBlock;
     std::vector<std::vector<const float*>> lists(dstCh);
@@ -481,7 +506,7 @@ struct Exec {
           continue;
         }
       }
-      float* out = forcedSlabs ? forcedSlabs[ch] : inMixed(ns.id, i, ch);
+      float* out = forcedSlabs ? forcedSlabs[ch] : inMixed(nodeId, i + 64, ch);
       if (!out) continue;
       MixJob mj;
       mj.out = out;
@@ -568,6 +593,13 @@ struct Exec {
         }
       }
     }
+    if (!bqDynJobs.empty()) {
+      size_t off = plan.putv(bqDynJobs);
+      int nj = (int)bqDynJobs.size();
+      hipStream_t st = c.stream;
+      plan.add(LK_OTHER, [=](uint8_t* base) { launch_biquad_dynamic(st, (const BiquadDynJob*)(base + off), nj); });
+    }
+    bqDynJobs.clear();
     terms.clear();
     mixJobs.clear();
     dmJobs.clear();
@@ -667,10 +699,18 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
       color[id] = 1;
       NodeS& nd = *nodes[id];
       nd.reachable = true;
-      for (auto& p : nd.params)
-        if (!p.modulation.empty())
-          fail(GA_ERR_UNSUPPORTED, "audio-rate AudioParam modulation is not on the device path yet");
       int lvl = 0, dep = 0;
+      for (auto& p : nd.params)
+        if (!p.modulation.empty()) {
+          if (nd.type != GA_NODE_GAIN)
+            fail(GA_ERR_UNSUPPORTED, "audio-rate AudioParam modulation is only on the device path for GainNode.gain");
+          for (auto& m : p.modulation) {
+            dfs(m.first);
+            NodeS& up = *nodes[m.first];
+            lvl = std::max(lvl, up.level + 1);
+            dep = std::max(dep, up.depth + ((up.type == GA_NODE_CONVOLVER && up.ir) ? 1 : 0));
+          }
+        }
       for (auto& in : nd.inputs)
         for (const Conn& cn : in.connected) {
           dfs(cn.node);
@@ -692,9 +732,18 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
     NodeS& nd = *nodes[id];
     if (nd.type == GA_NODE_BUFFER_SOURCE && !nd.params[0].events.empty())
       fail(GA_ERR_UNSUPPORTED, "playbackRate automation is not on the device path yet");
-    if (nd.type == GA_NODE_BIQUAD)
-      for (auto& p : nd.params)
-        if (!p.events.empty()) fail(GA_ERR_UNSUPPORTED, "BiQuadFilterNode parameter automation is not on the device path yet");
+    if (nd.type == GA_NODE_BIQUAD && nd.coefOnDevice && nd.bqDyn) {
+      bool automated = false;
+      for (auto& p : nd.params) automated = automated || !p.events.empty();
+      if (!automated) {  // back to constant parameters: fetch the coefficients the automated run left on the device
+        BiquadDynState tmp;
+        GA_HIP(hipStreamSynchronize(stream));
+        GA_HIP(hipMemcpy(&tmp, nd.bqDyn, 24, hipMemcpyDeviceToHost));
+        nd.b0 = tmp.b0; nd.b1 = tmp.b1; nd.b2 = tmp.b2; nd.a1 = tmp.a1; nd.a2 = tmp.a2;
+        nd.coefDirty = tmp.dirty != 0;
+        nd.coefOnDevice = false;
+      }
+    }
   }
 
   // ---- block clock (accumulated, AudioContextBase.cs:78-79) ----
@@ -809,20 +858,21 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
     for (int id : topo) {
       NodeS& nd = *nodes[id];
       for (auto& p : nd.params) p.curve = nullptr;
-      if (nd.type != GA_NODE_GAIN) continue;
-      ParamS& p = nd.params[0];
-      if (p.events.empty()) continue;
-      p.curve = getSlab(*this);
-      ParamJob pj;
-      pj.out = p.curve;
-      pj.ev0 = (int)events.size();
-      pj.nev = (int)p.events.size();
-      pj.value = p.value;
-      pj.arate = p.arate ? 1 : 0;
-      pj.b0 = 0;
-      pj.nblocks = n;
-      events.insert(events.end(), p.events.begin(), p.events.end());
-      pjobs.push_back(pj);
+      if (nd.type != GA_NODE_GAIN && nd.type != GA_NODE_BIQUAD) continue;
+      for (ParamS& p : nd.params) {
+        if (p.events.empty()) continue;
+        p.curve = getSlab(*this);
+        ParamJob pj;
+        pj.out = p.curve;
+        pj.ev0 = (int)events.size();
+        pj.nev = (int)p.events.size();
+        pj.value = p.value;
+        pj.arate = p.arate ? 1 : 0;
+        pj.b0 = 0;
+        pj.nblocks = n;
+        events.insert(events.end(), p.events.begin(), p.events.end());
+        pjobs.push_back(pj);
+      }
     }
     if (!pjobs.empty()) {
       size_t jo = ex.plan.putv(pjobs), eo = ex.plan.putv(events), bo = ex.plan.putv(bt);
@@ -877,6 +927,20 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
     }
   }
 
+  auto ensureBiquadState = [&](NodeS& bn) {
+    if (bn.bqDyn) return;
+    const size_t per = (sizeof(BiquadDynState) + 31) & ~(size_t)31;
+    const size_t blk = (size_t)1 << 20;
+    if (bqBlocks.empty() || bqUsed + per > blk) {
+      void* p = dalloc(blk);
+      GA_HIP(hipMemsetAsync(p, 0, blk, stream));
+      bqBlocks.push_back(p);
+      bqUsed = 0;
+    }
+    bn.bqDyn = (BiquadDynState*)((char*)bqBlocks.back() + bqUsed);
+    bn.bqState = (float*)((char*)bn.bqDyn + 24);
+    bqUsed += per;
+  };
   // ---- stages: convolver depth d ; inside a stage every segment is executed level by level ----
   for (int d = 0; d <= maxDepth; d++) {
     for (size_t si = 0; si < segs.size(); si++) {
@@ -895,7 +959,7 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
       for (const NodeSeg* nsp : todo) segNode[nsp->id] = nsp;
       for (const NodeSeg* nsp : todo) {
         const NodeSeg& b_ = *nsp;
-        if (nodes[b_.id]->type != GA_NODE_BIQUAD || !b_.bqActive) continue;
+        if (nodes[b_.id]->type != GA_NODE_BIQUAD || !b_.bqActive || b_.bqDynamic) continue;
         chainLen[b_.id] = 1;
         if (b_.ins[0].terms.size() != 1) continue;
         const TermS& t = b_.ins[0].terms[0];
@@ -903,7 +967,7 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
         if (ia == segNode.end()) continue;
         const NodeSeg& a_ = *ia->second;
         NodeS& an = *nodes[a_.id];
-        if (an.type != GA_NODE_BIQUAD || !a_.bqActive || t.ch != b_.ins[0].bufCh || a_.outCh != b_.outCh) continue;
+        if (an.type != GA_NODE_BIQUAD || !a_.bqActive || a_.bqDynamic || t.ch != b_.ins[0].bufCh || a_.outCh != b_.outCh) continue;
         if (an.outputs[0].connectedInputs.size() != 1) continue;
         int la_ = chainLen.count(a_.id) ? chainLen[a_.id] : 1;
         if (la_ >= kMaxBiquadSections) continue;
@@ -974,6 +1038,8 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
             break;
           }
           case GA_NODE_GAIN: {
+            const float* gmod = nullptr;   // audio-rate modulation of gain: mixed to 1 channel (AudioParam.cs:68-70,123-135)
+            if (!ns.pins.empty() && !ns.pins[0].silent) gmod = ex.resolveInSeg((int)si, ns.id, -1, ns.pins[0], false, nullptr)[0];
             auto iv = ex.resolveInput((int)si, ns, 0, false, nullptr);
             if (ns.ins[0].silent) break;  // cleared output (GainNode.cs:41-46)
             for (int ch = 0; ch < ns.outCh; ch++) {
@@ -982,6 +1048,9 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
               gj.in = iv[ch];
               gj.out = ex.nodeOut(ns.id, ch);
               gj.curve = nd.params[0].curve;
+              gj.mod = gmod;
+              gj.vmin = nd.params[0].minv;
+              gj.vmax = nd.params[0].maxv;
               gj.gain = nd.params[0].value;
               gj.f0 = f0;
               gj.n = nf;
@@ -993,6 +1062,39 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
           case GA_NODE_BIQUAD: {
             if (!ns.bqActive) {  // silent input: cleared output, state frozen (BiQuadFilterNode.cs:103-108)
               ex.resolveInput((int)si, ns, 0, false, nullptr);
+              break;
+            }
+            if (ns.bqDynamic) {  // automated parameters: per-sample coefficient refresh on the device
+              auto iv = ex.resolveInput((int)si, ns, 0, false, nullptr);
+              ensureBiquadState(nd);
+              BiquadDynJob dj{};
+              for (int ch = 0; ch < ns.outCh && ch < 32; ch++) {
+                dj.in[ch] = iv[ch];
+                dj.out[ch] = ex.nodeOut(ns.id, ch);
+                ov[ch] = dj.out[ch];
+              }
+              dj.fcurve = nd.params[0].curve;
+              dj.qcurve = nd.params[1].curve;
+              dj.gcurve = nd.params[2].curve;
+              dj.fval = nd.params[0].value;
+              dj.qval = nd.params[1].value;
+              dj.gval = nd.params[2].value;
+              dj.channels = ns.outCh;
+              dj.filter_type = nd.filterType;
+              dj.nyquist = sampleRate / 2.f;
+              dj.sample_rate = (float)sampleRate;
+              dj.state = nd.bqDyn;
+              dj.b0 = sg.b0;
+              dj.nblocks = nb;
+              if (!nd.coefOnDevice) {  // hand the host-side coefficient state (constant-parameter runs) to the device once
+                BiquadDynState init{};
+                init.b0 = nd.b0; init.b1 = nd.b1; init.b2 = nd.b2; init.a1 = nd.a1; init.a2 = nd.a2;
+                init.dirty = nd.coefDirty ? 1 : 0;
+                GA_HIP(hipMemcpyAsync(nd.bqDyn, &init, 24, hipMemcpyHostToDevice, stream));
+                GA_HIP(hipStreamSynchronize(stream));
+                nd.coefOnDevice = true;
+              }
+              ex.bqDynJobs.push_back(dj);
               break;
             }
             if (absorbedBy.count(ns.id)) break;  // evaluated inside the cascade job of a downstream biquad
@@ -1009,18 +1111,7 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
             auto iv = ex.resolveInput((int)si, *chain.front(), 0, false, nullptr);
             for (const NodeSeg* cn : chain) {
               NodeS& cnd = *nodes[cn->id];
-              if (!cnd.bqState) {
-                const size_t per = 32 * 2 * sizeof(float);
-                const size_t blk = (size_t)1 << 20;
-                if (bqBlocks.empty() || bqUsed + per > blk) {
-                  void* p = dalloc(blk);
-                  GA_HIP(hipMemsetAsync(p, 0, blk, stream));
-                  bqBlocks.push_back(p);
-                  bqUsed = 0;
-                }
-                cnd.bqState = (float*)((char*)bqBlocks.back() + bqUsed);
-                bqUsed += per;
-              }
+              ensureBiquadState(cnd);
             }
             for (int ch = 0; ch < ns.outCh; ch++) {
               BiquadJob bj;

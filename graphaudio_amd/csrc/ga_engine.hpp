@@ -136,7 +136,9 @@ struct NodeS {
   int filterType = GA_FILTER_LOWPASS;
   float b0 = 0, b1 = 0, b2 = 0, a1 = 0, a2 = 0;
   bool coefDirty = true;
-  float* bqState = nullptr;  // device [32][2]
+  BiquadDynState* bqDyn = nullptr;  // device: coefficients + dirty flag + {W1, W2} per channel
+  float* bqState = nullptr;         // = bqDyn->w
+  bool coefOnDevice = false;        // the device copy of the coefficients is newer than b0..a2 above (automated run)
   // ConvolverNode (ConvolverNode.cs:12-16,87,95)
   int irBuf = -1;
   std::shared_ptr<IrSpectra> ir;
@@ -166,6 +168,8 @@ struct InSeg {
 struct NodeSeg {
   int id = 0;
   std::vector<InSeg> ins;
+  std::vector<InSeg> pins;  // AudioParam modulation inputs (AudioParam.cs:97-101), one per param
+  bool bqDynamic = false;   // biquad with automated parameters
   int outCh = 0;
   bool outSilent = true;
   int srcPhase = SRC_IDLE;

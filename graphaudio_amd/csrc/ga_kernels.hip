@@ -920,6 +920,10 @@ __global__ __launch_bounds__(256) void gain_kernel(const GainJob* __restrict job
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < job.n; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t f = job.f0 + i;
     float g = job.curve ? job.curve[f] : job.gain;
+    if (job.mod) {   // Math.Clamp(intrinsicValue + modulation, min, max), AudioParam.cs:129
+      g = g + job.mod[f];
+      g = g < job.vmin ? job.vmin : (g > job.vmax ? job.vmax : g);
+    }
     job.out[f] = job.in[f] * g;
   }
 }
@@ -1057,6 +1061,106 @@ void launch_biquad(hipStream_t s, const BiquadJob* jobs_dev, int njobs, const Bi
     case 7: hipLaunchKernelGGL(biquad_kernel<7>, g, b, 0, s, jobs_dev, njobs, secs_dev); break;
     default: hipLaunchKernelGGL(biquad_kernel<8>, g, b, 0, s, jobs_dev, njobs, secs_dev); break;
   }
+}
+
+// ---- BiQuadFilterNode with automated parameters --------------------------------------------------------
+__device__ void biquad_update_coefficients(int type, float frequency, float q, float gain, float sample_rate, float& b0, float& b1,
+                                           float& b2, float& a1, float& a2) {   // BiQuadFilterNode.cs:149-258
+  const float PI = 3.14159274f;
+  float w0 = 2.f * PI * frequency / sample_rate;
+  float cosW0 = cosf(w0);
+  float sinW0 = sinf(w0);
+  float alpha = sinW0 / (2.f * q);
+  float a0, A1, A2, B0, B1, B2;
+  switch (type) {
+    case 0: B0 = (1.f - cosW0) / 2.f; B1 = 1.f - cosW0; B2 = (1.f - cosW0) / 2.f; a0 = 1.f + alpha; A1 = -2.f * cosW0; A2 = 1.f - alpha; break;
+    case 1: B0 = (1.f + cosW0) / 2.f; B1 = -(1.f + cosW0); B2 = (1.f + cosW0) / 2.f; a0 = 1.f + alpha; A1 = -2.f * cosW0; A2 = 1.f - alpha; break;
+    case 2: B0 = alpha; B1 = 0.f; B2 = -alpha; a0 = 1.f + alpha; A1 = -2.f * cosW0; A2 = 1.f - alpha; break;
+    case 3: B0 = 1.f; B1 = -2.f * cosW0; B2 = 1.f; a0 = 1.f + alpha; A1 = -2.f * cosW0; A2 = 1.f - alpha; break;
+    case 4: B0 = 1.f - alpha; B1 = -2.f * cosW0; B2 = 1.f + alpha; a0 = 1.f + alpha; A1 = -2.f * cosW0; A2 = 1.f - alpha; break;
+    case 5: {
+      float A = powf(10.f, gain / 40.f);
+      B0 = 1.f + alpha * A; B1 = -2.f * cosW0; B2 = 1.f - alpha * A; a0 = 1.f + alpha / A; A1 = -2.f * cosW0; A2 = 1.f - alpha / A;
+      break;
+    }
+    case 6: {
+      float A = powf(10.f, gain / 40.f);
+      float beta = sqrtf(A) / q;
+      B0 = A * ((A + 1.f) - (A - 1.f) * cosW0 + beta * sinW0);
+      B1 = 2.f * A * ((A - 1.f) - (A + 1.f) * cosW0);
+      B2 = A * ((A + 1.f) - (A - 1.f) * cosW0 - beta * sinW0);
+      a0 = (A + 1.f) + (A - 1.f) * cosW0 + beta * sinW0;
+      A1 = -2.f * ((A - 1.f) + (A + 1.f) * cosW0);
+      A2 = (A + 1.f) + (A - 1.f) * cosW0 - beta * sinW0;
+      break;
+    }
+    case 7: {
+      float A = powf(10.f, gain / 40.f);
+      float beta = sqrtf(A) / q;
+      B0 = A * ((A + 1.f) + (A - 1.f) * cosW0 + beta * sinW0);
+      B1 = -2.f * A * ((A - 1.f) + (A + 1.f) * cosW0);
+      B2 = A * ((A + 1.f) + (A - 1.f) * cosW0 - beta * sinW0);
+      a0 = (A + 1.f) - (A - 1.f) * cosW0 + beta * sinW0;
+      A1 = 2.f * ((A - 1.f) - (A + 1.f) * cosW0);
+      A2 = (A + 1.f) - (A - 1.f) * cosW0 - beta * sinW0;
+      break;
+    }
+    default: B0 = 1.f; B1 = 0.f; B2 = 0.f; a0 = 1.f; A1 = 0.f; A2 = 0.f; break;
+  }
+  b0 = B0 / a0;
+  b1 = B1 / a0;
+  b2 = B2 / a0;
+  a1 = A1 / a0;
+  a2 = A2 / a0;
+}
+__global__ __launch_bounds__(64) void biquad_dynamic_kernel(const BiquadDynJob* __restrict jobs, int njobs) {
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  if (j >= njobs) return;
+  const BiquadDynJob* __restrict job = &jobs[j];
+  BiquadDynState* st = job->state;
+  float b0 = st->b0, b1 = st->b1, b2 = st->b2, a1 = st->a1, a2 = st->a2;
+  bool dirty = st->dirty != 0;
+  const int C = job->channels;
+  const int type = job->filter_type;
+  const float nyq = job->nyquist, sr = job->sample_rate;
+  for (int64_t b = 0; b < job->nblocks; b++) {
+    const int64_t f0 = (job->b0 + b) * kBlock;
+    const float gainDb = job->gcurve ? job->gcurve[f0] : job->gval;
+    float lb0 = b0, lb1 = b1, lb2 = b2, la1 = a1, la2 = a2;   // lastB0 ... (:110)
+    float usedFreq = 1000.f, usedQ = 1.0f;                     // _lastFrequency / _lastQ never change (:13-14,111-112)
+    for (int ch = 0; ch < C; ch++) {
+      const float* in = job->in[ch];
+      float* out = job->out[ch];
+      float w1 = st->w[2 * ch], w2 = st->w[2 * ch + 1];
+      for (int i = 0; i < kBlock; i++) {
+        float f = job->fcurve ? job->fcurve[f0 + i] : job->fval;
+        f = f < 1.f ? 1.f : (f > nyq ? nyq : f);
+        float q = job->qcurve ? job->qcurve[f0 + i] : job->qval;
+        q = q > 0.001f ? q : 0.001f;
+        if (dirty || fabsf(f - usedFreq) > 0.001f || fabsf(q - usedQ) > 0.0001f) {   // usedGain == gainDb always (:113,126)
+          biquad_update_coefficients(type, f, q, gainDb, sr, b0, b1, b2, a1, a2);
+          usedFreq = f;
+          usedQ = q;
+          dirty = false;
+          lb0 = b0; lb1 = b1; lb2 = b2; la1 = a1; la2 = a2;
+        }
+        float x = in ? in[f0 + i] : 0.f;
+        float w = x - la1 * w1 - la2 * w2;
+        float y = lb0 * w + lb1 * w1 + lb2 * w2;
+        w2 = w1;
+        w1 = w;
+        out[f0 + i] = y;
+      }
+      st->w[2 * ch] = w1;
+      st->w[2 * ch + 1] = w2;
+    }
+  }
+  st->b0 = b0; st->b1 = b1; st->b2 = b2; st->a1 = a1; st->a2 = a2;
+  st->dirty = dirty ? 1 : 0;
+}
+void launch_biquad_dynamic(hipStream_t s, const BiquadDynJob* jobs_dev, int njobs) {
+  if (njobs <= 0) return;
+  hipLaunchKernelGGL(biquad_dynamic_kernel, dim3((njobs + 63) / 64), dim3(64), 0, s, jobs_dev, njobs);
 }
 
 // =====================================================================================================

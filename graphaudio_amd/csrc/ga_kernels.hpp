@@ -110,7 +110,9 @@ struct GainJob {
   const float* in;
   float* out;
   const float* curve;
+  const float* mod;     // audio-rate modulation (AudioParam.cs:123-135): value = clamp(intrinsic + mod, min, max); nullptr = none
   float gain;
+  float vmin, vmax;
   int64_t f0;
   int64_t n;
 };
@@ -134,6 +136,31 @@ struct BiquadJob {
   int64_t n;
 };
 void launch_biquad(hipStream_t s, const BiquadJob* jobs_dev, int njobs, const BiquadSection* secs_dev, int nsec);
+
+// BiQuadFilterNode with automated parameters (BiQuadFilterNode.cs:87-147): one lane per NODE walks block by block and
+// channel by channel exactly like the reference, refreshing the coefficients whenever the per-sample frequency / Q move
+// by more than 1e-3 Hz / 1e-4 (usedFreq / usedQ restart at 1000 / 1.0 every block, :111-112,126).
+struct BiquadDynState {   // persistent per node
+  float b0, b1, b2, a1, a2;
+  int dirty;
+  float w[64];            // {W1, W2} per channel (32 channels)
+};
+struct BiquadDynJob {
+  const float* in[32];    // per channel, chunk-frame indexed; nullptr = zeros
+  float* out[32];
+  const float* fcurve;    // per-sample frequency curve or nullptr
+  const float* qcurve;
+  const float* gcurve;    // k-rate gain (dB) curve or nullptr
+  float fval, qval, gval;
+  int channels;
+  int filter_type;
+  float nyquist;
+  float sample_rate;
+  BiquadDynState* state;
+  int64_t b0;             // first block (chunk relative)
+  int64_t nblocks;
+};
+void launch_biquad_dynamic(hipStream_t s, const BiquadDynJob* jobs_dev, int njobs);
 
 // AudioParam timeline evaluation (AudioParam.cs:114-247)
 struct ParamEvent {

@@ -156,3 +156,54 @@ def test_private_ir_stereo_source_and_chunked_state():
             pos += n
     err = G.rms(ref - got)
     assert err <= TOL_RMS and err / G.rms(ref) < 2e-6
+
+
+def _automated_biquad(ctx):
+    from graphaudio_amd import BiQuadFilterNode, FilterType
+    n = 128 * 60
+    for v, ft in enumerate([FilterType.Lowpass, FilterType.Peaking, FilterType.Highshelf]):
+        s = AudioBufferSourceNode(ctx)
+        s.Buffer = PlayableAudioBuffer.FromMonoArray(G.voice(300 + v, n + 256), 48000)
+        bq = BiQuadFilterNode(ctx)
+        bq.Type = ft
+        bq.Frequency.SetValueAtTime(300.0, 0.0)
+        bq.Frequency.ExponentialRampToValueAtTime(6000.0, 0.1)
+        bq.Q.SetValueAtTime(0.7, 0.0)
+        bq.Q.LinearRampToValueAtTime(4.0, 0.05)
+        bq.Gain.SetValueAtTime(-6.0, 0.0)
+        bq.Gain.SetValueAtTime(6.0, 0.06)
+        s.Connect(bq).Connect(ctx.Destination)   # default input: mono source up-mixed to 2 channels (trigger state spans channels)
+        s.Start()
+    return 2
+
+
+def test_biquad_parameter_automation():
+    """a-rate frequency / Q with the per-sample coefficient refresh of BiQuadFilterNode.cs:123-134 (device sinf/cosf/powf)."""
+    ref, got = both(_automated_biquad, 128 * 60)
+    assert G.rms(ref) > 1e-3
+    err = G.rms(ref - got)
+    assert err <= TOL_RMS and err / G.rms(ref) < 2e-5, err
+
+
+def _modulated_gain(ctx):
+    n = 128 * 20
+    ctx.Destination.SetChannelCount(1)
+    carrier = AudioBufferSourceNode(ctx)
+    carrier.Buffer = PlayableAudioBuffer.FromMonoArray(G.voice(400, n + 256), 48000)
+    lfo = AudioBufferSourceNode(ctx)
+    t = np.arange(n + 256) / 48000.0
+    lfo.Buffer = PlayableAudioBuffer.FromStereoArrays((0.8 * np.sin(2 * np.pi * 50 * t)).astype(np.float32),
+                                                      (0.8 * np.cos(2 * np.pi * 30 * t)).astype(np.float32), 48000)
+    g = GainNode(ctx)
+    g.Inputs[0].SetChannelCount(1)
+    g.Gain.Value = 0.5
+    lfo.Connect(g.Gain)            # stereo LFO -> 1-channel param input: (L + R) / sqrt(2), then clamp(intrinsic + mod)
+    carrier.Connect(g).Connect(ctx.Destination)
+    carrier.Start()
+    lfo.Start(128 * 3 / 48000.0 + 1e-9)   # modulation starts three blocks in
+    return 1
+
+
+def test_gain_audio_rate_modulation_bit_exact():
+    ref, got = both(_modulated_gain, 128 * 20)
+    assert np.array_equal(ref, got)

@@ -293,3 +293,20 @@ def test_argument_validation():
     g = GainNode(ctx)
     with pytest.raises(ArgumentException):
         g.Gain.ExponentialRampToValueAtTime(0.0, 1.0)
+
+
+def test_audio_rate_param_modulation_semantics():
+    """value[i] = clamp(intrinsic + modulation[i]) when the modulation input is non-silent (AudioParam.cs:123-135)."""
+    ctx = mono_ctx()
+    g = GainNode(ctx)
+    g.Inputs[0].SetChannelCount(1)
+    g.Gain.Value = 0.25
+    g.Connect(ctx.Destination)
+    src(ctx, np.ones(2048), connect=g)
+    mod = np.linspace(-1, 1, 2048).astype(np.float32)
+    m = AudioBufferSourceNode(ctx)
+    m.Buffer = PlayableAudioBuffer.FromMonoArray(mod, SR)
+    m.Connect(g.Gain)
+    m.Start()
+    out = render1(ctx, 1024)[0]
+    assert np.array_equal(out, np.float32(0.25) + mod[:1024])

@@ -20,6 +20,23 @@ elif which == "4":
     ch = G.config4_eq(ctx, voices=int(sys.argv[3]) if len(sys.argv) > 3 else 4096, frames=frames)
 elif which == "3u":
     ch = G.config3_convolver(ctx, voices=int(sys.argv[3]) if len(sys.argv) > 3 else 64, taps=65536, frames=frames, shared=False)
+elif which == "5":
+    from graphaudio_amd import AudioBufferSourceNode, ConvolverNode, PlayableAudioBuffer
+    nsrc = int(sys.argv[3]) if len(sys.argv) > 3 else 512
+    taps, C = 32768, 16
+    ctx.Destination.SetChannelCount(C)
+    n = np.arange(taps)
+    env = np.exp(-6.9 * n / taps).astype(np.float32)
+    for v in range(nsrc):
+        s = AudioBufferSourceNode(ctx)
+        s.Buffer = PlayableAudioBuffer.FromMonoArray(G.voice(v, frames + 256), SR)
+        rng = np.random.default_rng(7 + 100 * v)
+        irs = [(rng.standard_normal(taps, dtype=np.float32) * env) for c in range(C)]
+        cv = ConvolverNode(ctx)
+        cv.Buffer = PlayableAudioBuffer.FromChannelArrays(irs, SR)
+        s.Connect(cv).Connect(ctx.Destination)
+        s.Start()
+    ch = C
 else:
     raise SystemExit("unknown config")
 print(f"build {time.time() - t0:.1f} s")
