@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--voices", type=int, default=1024)
     ap.add_argument("--taps", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="exercise the process-group / RCCL reduce path even with one rank")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -102,10 +103,13 @@ def main():
     n_gpus = args.gpus
     dist = None
     import torch
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     assert world == n_gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
 
     from graphaudio_amd import OfflineAudioContext
@@ -124,11 +128,11 @@ def main():
     build_graph(ctx, shard, v0, args.taps, frames, G)
 
     host_out = np.zeros((2, frames), np.float32)
-    if world > 1:
+    if use_dist:
         dev_out = torch.zeros((2, frames), dtype=torch.float32, device=f"cuda:{local_rank}")
 
     def step():
-        if world == 1:
+        if not use_dist:
             ctx.Render(host_out, frames)
         else:
             ctx.RenderDevice([dev_out[0].data_ptr(), dev_out[1].data_ptr()], frames)
@@ -138,7 +142,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -152,7 +156,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     st1 = ctx.GetStats()
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -206,7 +210,7 @@ def main():
             rec["cpu_baseline"] = None
         print(json.dumps(rec))
     ctx.Dispose()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

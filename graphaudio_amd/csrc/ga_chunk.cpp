@@ -899,7 +899,7 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
     for (int id : topo) {
       NodeS& nd = *nodes[id];
       if (nd.type != GA_NODE_CONVOLVER || !nd.ir) continue;
-      if (nd.convPath == 2) {
+      if (nd.convPath >= 2) {
         bx += nd.bInCh;
         by += nd.bSlots;
         bHistMax = std::max(bHistMax, nd.ir->P - 1);
@@ -1171,7 +1171,7 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
       NodeS& nd = *nodes[id];
       if (nd.type != GA_NODE_CONVOLVER || !nd.ir || nd.depth != d) continue;
       if (ex.convIn.find(id) == ex.convIn.end()) continue;
-      if (nd.convPath == 2) {
+      if (nd.convPath >= 2) {
         bNodes.push_back(id);
         continue;
       }
@@ -1288,6 +1288,7 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
       ConvPlanesB plb{(float*)planesB[0].p, (float*)planesB[1].p, (float*)planesB[2].p, (float*)planesB[3].p, txb, tyb};
       std::vector<ConvRowIO> xrows, yrows;
       std::vector<ConvSetB> sets;
+      std::map<int, std::vector<ConvSetC>> setsC;   // by P: one launch per distinct segment length
       std::vector<HistJobB> restore, save;
       std::vector<const float*> ovIn;
       std::vector<float*> ovOut;
@@ -1386,15 +1387,21 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
             st.y0 = (int)yrows.size();
             st.ncol = (int)std::min<size_t>(16, cols.size() - c0);
             st.P = P;
+            ConvSetC sc{};
+            sc.x = st.x;
+            sc.y0 = st.y0;
+            sc.ncol = st.ncol;
+            sc.P = P;
             for (int j = 0; j < st.ncol; j++) {
               int slot = cols[c0 + j];
               st.hr[j] = nd.ir->hr + (size_t)slot * kBins * P;   // slot index == IR channel index in both modes
               st.hi[j] = nd.ir->hi + (size_t)slot * kBins * P;
+              if (nd.convPath == 3) sc.hs[j] = nd.ir->hspec + (size_t)slot * kBins * nd.ir->N2;
               yrows.push_back(ConvRowIO{nullptr, slotOut[slot]});
               ovIn.push_back(nd.bOverlap + ((size_t)slot * 2 + nd.bOvCur) * kBlock);
               ovOut.push_back(nd.bOverlap + ((size_t)slot * 2 + (nd.bOvCur ^ 1)) * kBlock);
             }
-            sets.push_back(st);
+            if (nd.convPath == 3) setsC[P].push_back(sc); else sets.push_back(st);
           }
         }
         nd.bOvCur ^= 1;
@@ -1413,13 +1420,38 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
         launch_hist_copy_b(st, (const HistJobB*)(base + ro), nr, std::max(maxn, 1));
         launch_rfft_fwd_b(st, (const ConvRowIO*)(base + xo), nx, nn, hist, plb, tw);
       });
-      ex.plan.add(LK_MAC, [=](uint8_t* base) { launch_spectral_mac_b(st, (const ConvSetB*)(base + so), ns_, nn, hist, plb); });
+      if (ns_ > 0) ex.plan.add(LK_MAC, [=](uint8_t* base) { launch_spectral_mac_b(st, (const ConvSetB*)(base + so), ns_, nn, hist, plb); });
+      for (auto& kv : setsC) {
+        const int Pc = kv.first;
+        int N2 = 1;
+        while (N2 < Pc) N2 <<= 1;
+        N2 *= 4;
+        const int Lc = N2 - (Pc - 1);
+        const int nseg = (nn + Lc - 1) / Lc;
+        size_t co = ex.plan.putv(kv.second);
+        const int nc = (int)kv.second.size();
+        const float2* twc = twiddlesC(N2);
+        ex.plan.add(LK_MAC, [=](uint8_t* base) { launch_tconv(st, (const ConvSetC*)(base + co), nc, nn, hist, plb, N2, twc, nseg); });
+      }
       ex.plan.add(LK_FFT, [=](uint8_t* base) {
         launch_irfft_ola_b(st, (const ConvRowIO*)(base + yo), ny, nn, plb, (const float* const*)(base + oi), (float* const*)(base + oo), tw);
         launch_hist_copy_b(st, (const HistJobB*)(base + sv), nsv, std::max(hist, 1));
       });
       stats.mac_flops_total += flops;
-      stats.mac_bytes_total += flops;   // streaming formulation with private IRs: 2 * P * 129 * 8 B per 8 * P * 129 flop
+      // streaming-formulation bytes: per channel-instance per block FDL read + write + input; every distinct
+      // IR channel is counted once per block however many nodes share it
+      {
+        std::map<std::pair<IrSpectra*, int>, int> distinct;
+        double bytes = 0;
+        for (int id : bNodes) {
+          NodeS& nd = *nodes[id];
+          const int P = nd.ir->P;
+          bytes += ((double)P * kBins * 8.0 + kBins * 8.0 + 512.0) * nd.bSlots * (double)n;
+          for (int sl = 0; sl < nd.bSlots; sl++) distinct[{nd.ir.get(), sl}] = P;
+        }
+        for (auto& kv : distinct) bytes += (double)kv.second * kBins * 8.0 * (double)n;
+        stats.mac_bytes_total += bytes;
+      }
       stats.mac_launches += 1;
     }
     // true stereo: outL = conv0(L) + conv2(R) ; outR = conv1(L) + conv3(R)  (ConvolverNode.cs:127-144)

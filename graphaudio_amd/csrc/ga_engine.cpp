@@ -65,6 +65,7 @@ Context::~Context() {
     if (kv.second) {
       if (kv.second->hr) (void)hipFree(kv.second->hr);
       if (kv.second->hi) (void)hipFree(kv.second->hi);
+      if (kv.second->hspec) (void)hipFree(kv.second->hspec);
     }
   }
   for (auto& g : groups) {
@@ -90,6 +91,7 @@ Context::~Context() {
   if (zeros) (void)hipFree(zeros);
   if (w128) (void)hipFree(w128);
   if (w256) (void)hipFree(w256);
+  for (auto& kv : twC) (void)hipFree(kv.second);
   if (cacheDev) (void)hipFree(cacheDev);
   if (stream && ownStream) (void)hipStreamDestroy(stream);
 }
@@ -255,7 +257,8 @@ void Context::assignConvPaths(const std::vector<int>& topo) {
     if (nd.type != GA_NODE_CONVOLVER || !nd.ir || nd.convPath != 0) continue;
     IrSpectra* ir = nd.ir.get();
     const int channels = ir->nch;
-    const bool pathA = hasA[ir] || users[ir] >= 8;
+    const bool pathC = useTimeFft && ir->P > 64 && ir->P <= 1024;   // FFT along the block axis (N2 <= 4096)
+    const bool pathA = !pathC && (hasA[ir] || users[ir] >= 8);
     if (pathA) {
       for (int ch = 0; ch < channels; ch++) {
         auto key = std::make_pair(ir, ch);
@@ -300,7 +303,8 @@ void Context::assignConvPaths(const std::vector<int>& topo) {
       nd.bShared = true;
       nd.bHistZero = true;
       nd.bOvCur = 0;
-      nd.convPath = 2;
+      nd.convPath = pathC ? 3 : 2;
+      if (pathC) ensureTapSpectra(*nd.ir);
     }
   }
 }
@@ -452,6 +456,32 @@ std::shared_ptr<IrSpectra> Context::irSpectra(int bufId, bool normalize) {
   dfree(rowsDev, sizeof(ConvRowIO) * nch);
   irCache[key] = sp;
   return sp;
+}
+
+const float2* Context::twiddlesC(int N2) {
+  auto it = twC.find(N2);
+  if (it != twC.end()) return it->second;
+  const double pi = 3.14159265358979323846264338327950288;
+  std::vector<float2> t(N2);
+  for (int j = 0; j < N2; j++) t[j] = make_float2((float)std::cos(2.0 * pi * j / N2), (float)-std::sin(2.0 * pi * j / N2));
+  float2* d = (float2*)dalloc(sizeof(float2) * N2);
+  GA_HIP(hipMemcpy(d, t.data(), sizeof(float2) * N2, hipMemcpyHostToDevice));
+  twC[N2] = d;
+  return d;
+}
+// N2 = 4 * 2^ceil(log2 P): segment efficiency (N2 - P + 1) / N2 >= 75 %
+static int tapFftSize(int P) {
+  int n = 1;
+  while (n < P) n <<= 1;
+  return 4 * n;
+}
+void Context::ensureTapSpectra(IrSpectra& ir) {
+  if (ir.hspec) return;
+  ir.N2 = tapFftSize(ir.P);
+  size_t bytes = (size_t)ir.nch * kBins * ir.N2 * sizeof(float2);
+  ir.hspec = (float2*)dalloc(bytes);
+  launch_tap_spectra(stream, ir.hspec, ir.hr, ir.hi, ir.nch, ir.P, ir.N2, twiddlesC(ir.N2));
+  GA_HIP(hipGetLastError());
 }
 
 // host replay of the CubicResampler position recurrence for unbounded input (CubicResampler.cs:31-60)

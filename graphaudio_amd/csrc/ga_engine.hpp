@@ -93,6 +93,9 @@ struct IrSpectra {  // P zero-padded 256-point spectra per IR channel (Partition
   int nch = 0;
   float* hr = nullptr;  // [nch][129][P]
   float* hi = nullptr;
+  // formulation C: N2-point spectra of the taps along the partition axis, [nch][129][N2]
+  int N2 = 0;
+  float2* hspec = nullptr;
 };
 
 struct ConvGroup;   // rows sharing one IR channel's spectra
@@ -239,6 +242,7 @@ struct Context {
   // device resources
   double2* w128 = nullptr;
   double2* w256 = nullptr;
+  std::map<int, float2*> twC;   // float32 twiddles exp(-2 pi i j / N2) for the block-axis FFTs
   float* zeros = nullptr;  // zero page (chunk frames)
   int64_t zerosLen = 0;
   DevArena planes[4];      // xr, xi, yr, yi scratch shared by all groups
@@ -284,6 +288,9 @@ struct Context {
   std::shared_ptr<IrSpectra> irSpectra(int bufId, bool normalize);
   void releaseConvState(NodeS& n);
   void assignConvPaths(const std::vector<int>& topo);
+  const float2* twiddlesC(int N2);
+  void ensureTapSpectra(IrSpectra& ir);
+  bool useTimeFft = true;        // option "time_fft": formulation C for 64 < P <= 1024
   void updateBiquadCoefficients(NodeS& n, float frequency, float q, float gain);
 
   void render(float* const* out, int channels, int64_t frames, int64_t start, bool deviceOut);

@@ -502,10 +502,10 @@ void launch_spectral_mac_shared(hipStream_t s, ConvPlanes pl, const float* hr, c
 // =====================================================================================================
 //  Formulation B kernels (see ga_kernels.hpp): planes [row][bin][block], block index fastest.
 // =====================================================================================================
-constexpr int FB_RUN = 16;            // blocks per workgroup in the B-layout FFT kernels
-constexpr int FB_LD = FB_RUN + 4;     // staging row: [bin][16 blocks] padded to 20 floats (16-byte aligned rows)
+constexpr int FB_RUN = 32;            // blocks per workgroup in the B-layout FFT kernels: 32 blocks = one 128-byte line per bin
+constexpr int FB_LD = FB_RUN + 4;     // staging row [bin][32 blocks] padded to 36 floats (16-byte aligned rows)
 
-// forward: workgroup = (x-row, run of 16 blocks); wave w transforms blocks t0 + w + 4u, u = 0..3 (4 in flight)
+// forward: workgroup = (x-row, run of 32 blocks); wave w transforms blocks w, w+4, ..., w+28 of the run, 4 in flight
 __global__ __launch_bounds__(256) void rfft_fwd_b_kernel(const ConvRowIO* __restrict xrows, int nx, int nblocks, int hist,
                                                          ConvPlanesB pl, Twiddles tw) {
   __shared__ __attribute__((aligned(16))) float st_r[kBins * FB_LD];
@@ -521,65 +521,67 @@ __global__ __launch_bounds__(256) void rfft_fwd_b_kernel(const ConvRowIO* __rest
   const double2 wk1 = tw.w256[k1];
   const float* in = xrows[xrow].in;
 
-  double s0r[4], s0i[4], s1r[4], s1i[4];
+  for (int bq = 0; bq < FB_RUN / 16; bq++) {
+    double s0r[4], s0i[4], s1r[4], s1i[4];
 #pragma unroll
-  for (int u = 0; u < 4; u++) {
-    const int t = t0 + wave + 4 * u;
-    s0r[u] = 0.0;
-    s0i[u] = 0.0;
-    if (in && t < nblocks) {
-      const float* p = in + (int64_t)t * kBlock + 2 * lane;
-      s0r[u] = (double)p[0];
-      s0i[u] = (double)p[1];
-    }
-    s1r[u] = fma(s0r[u], ltw.c1, -(s0i[u] * ltw.s1));
-    s1i[u] = fma(s0r[u], ltw.s1, s0i[u] * ltw.c1);
-  }
-#pragma unroll
-  for (int u = 0; u < 4; u++) { dif_stage<32, 0>(s0r[u], s0i[u], ltw); dif_stage<32, 0>(s1r[u], s1i[u], ltw); }
-#pragma unroll
-  for (int u = 0; u < 4; u++) { dif_stage<16, 1>(s0r[u], s0i[u], ltw); dif_stage<16, 1>(s1r[u], s1i[u], ltw); }
-#pragma unroll
-  for (int u = 0; u < 4; u++) { dif_stage<8, 2>(s0r[u], s0i[u], ltw); dif_stage<8, 2>(s1r[u], s1i[u], ltw); }
-#pragma unroll
-  for (int u = 0; u < 4; u++) { dif_stage<4, 3>(s0r[u], s0i[u], ltw); dif_stage<4, 3>(s1r[u], s1i[u], ltw); }
-#pragma unroll
-  for (int u = 0; u < 4; u++) { dif_stage<2, 4>(s0r[u], s0i[u], ltw); dif_stage<2, 4>(s1r[u], s1i[u], ltw); }
-#pragma unroll
-  for (int u = 0; u < 4; u++) { dif_stage<1, 5>(s0r[u], s0i[u], ltw); dif_stage<1, 5>(s1r[u], s1i[u], ltw); }
-#pragma unroll
-  for (int u = 0; u < 4; u++) {
-    const int tl = wave + 4 * u;   // block within the run
-    {
-      double ax = s0r[u], ay = s0i[u];
-      double bx = shfl_d(ax, src0), by = shfl_d(ay, src0);
-      double er = 0.5 * (ax + bx), ei = 0.5 * (ay - by);
-      double dr = 0.5 * (ax - bx), di = 0.5 * (ay + by);
-      double pr = fma(dr, wk0.x, -(di * wk0.y)), pi = fma(dr, wk0.y, di * wk0.x);
-      float xr = (float)(er + pi), xi = (float)(ei - pr);
-      if (k0 == 0) {
-        xi = 0.f;
-        st_r[128 * FB_LD + tl] = (float)(ax - ay);
-        st_i[128 * FB_LD + tl] = 0.f;
+    for (int u = 0; u < 4; u++) {
+      const int t = t0 + wave + 4 * (bq * 4 + u);
+      s0r[u] = 0.0;
+      s0i[u] = 0.0;
+      if (in && t < nblocks) {
+        const float* p = in + (int64_t)t * kBlock + 2 * lane;
+        s0r[u] = (double)p[0];
+        s0i[u] = (double)p[1];
       }
-      st_r[k0 * FB_LD + tl] = xr;
-      st_i[k0 * FB_LD + tl] = xi;
+      s1r[u] = fma(s0r[u], ltw.c1, -(s0i[u] * ltw.s1));
+      s1i[u] = fma(s0r[u], ltw.s1, s0i[u] * ltw.c1);
     }
-    {
-      double ax = s1r[u], ay = s1i[u];
-      double bx = shfl_d(ax, src1), by = shfl_d(ay, src1);
-      double er = 0.5 * (ax + bx), ei = 0.5 * (ay - by);
-      double dr = 0.5 * (ax - bx), di = 0.5 * (ay + by);
-      double pr = fma(dr, wk1.x, -(di * wk1.y)), pi = fma(dr, wk1.y, di * wk1.x);
-      st_r[k1 * FB_LD + tl] = (float)(er + pi);
-      st_i[k1 * FB_LD + tl] = (float)(ei - pr);
+#pragma unroll
+    for (int u = 0; u < 4; u++) { dif_stage<32, 0>(s0r[u], s0i[u], ltw); dif_stage<32, 0>(s1r[u], s1i[u], ltw); }
+#pragma unroll
+    for (int u = 0; u < 4; u++) { dif_stage<16, 1>(s0r[u], s0i[u], ltw); dif_stage<16, 1>(s1r[u], s1i[u], ltw); }
+#pragma unroll
+    for (int u = 0; u < 4; u++) { dif_stage<8, 2>(s0r[u], s0i[u], ltw); dif_stage<8, 2>(s1r[u], s1i[u], ltw); }
+#pragma unroll
+    for (int u = 0; u < 4; u++) { dif_stage<4, 3>(s0r[u], s0i[u], ltw); dif_stage<4, 3>(s1r[u], s1i[u], ltw); }
+#pragma unroll
+    for (int u = 0; u < 4; u++) { dif_stage<2, 4>(s0r[u], s0i[u], ltw); dif_stage<2, 4>(s1r[u], s1i[u], ltw); }
+#pragma unroll
+    for (int u = 0; u < 4; u++) { dif_stage<1, 5>(s0r[u], s0i[u], ltw); dif_stage<1, 5>(s1r[u], s1i[u], ltw); }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int tl = wave + 4 * (bq * 4 + u);   // block within the run
+      {
+        double ax = s0r[u], ay = s0i[u];
+        double bx = shfl_d(ax, src0), by = shfl_d(ay, src0);
+        double er = 0.5 * (ax + bx), ei = 0.5 * (ay - by);
+        double dr = 0.5 * (ax - bx), di = 0.5 * (ay + by);
+        double pr = fma(dr, wk0.x, -(di * wk0.y)), pi = fma(dr, wk0.y, di * wk0.x);
+        float xr = (float)(er + pi), xi = (float)(ei - pr);
+        if (k0 == 0) {
+          xi = 0.f;
+          st_r[128 * FB_LD + tl] = (float)(ax - ay);
+          st_i[128 * FB_LD + tl] = 0.f;
+        }
+        st_r[k0 * FB_LD + tl] = xr;
+        st_i[k0 * FB_LD + tl] = xi;
+      }
+      {
+        double ax = s1r[u], ay = s1i[u];
+        double bx = shfl_d(ax, src1), by = shfl_d(ay, src1);
+        double er = 0.5 * (ax + bx), ei = 0.5 * (ay - by);
+        double dr = 0.5 * (ax - bx), di = 0.5 * (ay + by);
+        double pr = fma(dr, wk1.x, -(di * wk1.y)), pi = fma(dr, wk1.y, di * wk1.x);
+        st_r[k1 * FB_LD + tl] = (float)(er + pi);
+        st_i[k1 * FB_LD + tl] = (float)(ei - pr);
+      }
     }
   }
   __syncthreads();
-  // store: per bin 16 consecutive blocks = 64 bytes, 4 lanes x 16 B
+  // store: per bin 32 consecutive blocks = 128 bytes, 8 lanes x 16 B
   const size_t rowbase = (size_t)xrow * kBins * pl.tx + hist + t0;
-  for (int idx = tid; idx < kBins * 4; idx += 256) {
-    int k = idx >> 2, q = (idx & 3) * 4;
+  for (int idx = tid; idx < kBins * 8; idx += 256) {
+    int k = idx >> 3, q = (idx & 7) * 4;
     if (t0 + q >= nblocks) continue;
     size_t o = rowbase + (size_t)k * pl.tx + q;
     *reinterpret_cast<float4*>(pl.xr + o) = *reinterpret_cast<const float4*>(&st_r[k * FB_LD + q]);
@@ -689,56 +691,65 @@ void launch_spectral_mac_b(hipStream_t s, const ConvSetB* sets_dev, int nsets, i
   }
 }
 
-// inverse + overlap-add, B layout: workgroup = 4 y-rows (one per wave) x run of 16 blocks (+1 to recover the incoming tail)
+// inverse + overlap-add, B layout: workgroup = (y-row, run of 32 blocks).  All 33 inverse transforms of the run (the extra
+// one recovers the tail of the block before the run) are independent: 4 waves x up to 3 batches of 4.  Heads and tails land
+// in LDS, then out[t] = (float)head[t] + tail[t-1] is written as one contiguous, fully coalesced 16 KB range.
 __global__ __launch_bounds__(256) void irfft_ola_b_kernel(const ConvRowIO* __restrict yrows, int ny, int nblocks, ConvPlanesB pl,
                                                           const float* const* __restrict overlap_in, float* const* __restrict overlap_out,
                                                           Twiddles tw) {
-  __shared__ float ys_r[4][kBins * FB_LD];
-  __shared__ float ys_i[4][kBins * FB_LD];
-  __shared__ float tail[4][kBlock];
+  // staging tile [bin][33 columns]: column c <-> block ta - 1 + c ; later reused for the head/tail tiles
+  constexpr int LD = FB_RUN + 4;                        // 36
+  __shared__ __attribute__((aligned(16))) float smem[2 * kBins * LD];   // 9288 floats >= (33 + 33) * 128 = 8448
+  float* sr = smem;
+  float* si = smem + kBins * LD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int row = blockIdx.x * 4 + wave;
+  const int row = blockIdx.x;
   const int ta = blockIdx.y * FB_RUN;
   const int tb = min(ta + FB_RUN, nblocks);
+  const int nrun = tb - ta;
   const LaneTw ltw = load_lane_tw(tw.w128, lane);
   const int k0 = rev6(lane) << 1, k1 = k0 | 1;
   const double2 wk0 = tw.w256[k0];
   const double2 wk1 = tw.w256[k1];
-  if (row >= ny) return;   // whole wave; no workgroup barriers below (everything is wave-private)
-  const float* ov = overlap_in[row];
-  float* ovo = overlap_out[row];
-  float* out = yrows[row].out;
   const float* __restrict yr = pl.yr + (size_t)row * kBins * pl.ty;
   const float* __restrict yi = pl.yi + (size_t)row * kBins * pl.ty;
-  float* sr = ys_r[wave];
-  float* si = ys_i[wave];
-  // stage blocks [ta - 1, tb) of this row: column c of the staging tile <-> block ta - 1 + c   (c = 0 unused when ta == 0)
-  const int c0 = (ta == 0) ? 1 : 0;
-  const int ncols = tb - ta + 1;
-  for (int idx = lane; idx < kBins * FB_LD; idx += 64) {
-    int k = idx / FB_LD, c = idx % FB_LD;
-    float vr = 0.f, vi = 0.f;
-    if (c >= c0 && c < ncols) {
-      size_t o = (size_t)k * pl.ty + (ta - 1 + c);
-      vr = yr[o];
-      vi = yi[o];
+  // columns 1..nrun <- blocks ta .. tb-1 (16-byte loads, 8 lanes per 128-byte bin line); column 0 <- block ta - 1
+  for (int idx = tid; idx < kBins * 8; idx += 256) {
+    int k = idx >> 3, q = (idx & 7) * 4;
+    float4 vr = make_float4(0.f, 0.f, 0.f, 0.f), vi = vr;
+    if (ta + q < nblocks) {
+      vr = *reinterpret_cast<const float4*>(yr + (size_t)k * pl.ty + ta + q);
+      vi = *reinterpret_cast<const float4*>(yi + (size_t)k * pl.ty + ta + q);
     }
-    sr[idx] = vr;
-    si[idx] = vi;
+    float* dr = &sr[k * LD + 1 + q];
+    float* di = &si[k * LD + 1 + q];
+    dr[0] = vr.x; dr[1] = vr.y; dr[2] = vr.z; dr[3] = vr.w;
+    di[0] = vi.x; di[1] = vi.y; di[2] = vi.z; di[3] = vi.w;
   }
-  if (ta == 0) {
-    tail[wave][2 * lane] = ov[2 * lane];
-    tail[wave][2 * lane + 1] = ov[2 * lane + 1];
+  if (tid < kBins) {
+    float vr = 0.f, vi = 0.f;
+    if (ta > 0) {
+      vr = yr[(size_t)tid * pl.ty + ta - 1];
+      vi = yi[(size_t)tid * pl.ty + ta - 1];
+    }
+    sr[tid * LD] = vr;
+    si[tid * LD] = vi;
   }
-  __builtin_amdgcn_wave_barrier();
-  for (int cbase = c0; cbase < ncols; cbase += 4) {
+  __syncthreads();
+  // transform columns c = 0..nrun (c = 0 only when ta > 0); results kept in registers until the staging tile is dead
+  float hd[3][4][2], tl[3][4][2];
+  int cc[3][4];
+#pragma unroll
+  for (int bq = 0; bq < 3; bq++) {
     double s0r[4], s0i[4], s1r[4], s1i[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-      const int c = min(cbase + u, ncols - 1);
+      int c = (bq * 4 + u) * 4 + wave;
+      cc[bq][u] = c;
+      const int cl = min(c, FB_RUN);
       {
-        double ar = sr[k0 * FB_LD + c], ai = si[k0 * FB_LD + c];
-        double br = sr[(128 - k0) * FB_LD + c], bi = -(double)si[(128 - k0) * FB_LD + c];
+        double ar = sr[k0 * LD + cl], ai = si[k0 * LD + cl];
+        double br = sr[(128 - k0) * LD + cl], bi = -(double)si[(128 - k0) * LD + cl];
         if (k0 == 0) { ai = 0.0; bi = 0.0; }
         double er = ar + br, ei = ai + bi, dr = ar - br, di = ai - bi;
         double pr = fma(dr, wk0.x, di * wk0.y), pi = fma(di, wk0.x, -(dr * wk0.y));
@@ -746,53 +757,69 @@ __global__ __launch_bounds__(256) void irfft_ola_b_kernel(const ConvRowIO* __res
         s0i[u] = ei + pr;
       }
       {
-        double ar = sr[k1 * FB_LD + c], ai = si[k1 * FB_LD + c];
-        double br = sr[(128 - k1) * FB_LD + c], bi = -(double)si[(128 - k1) * FB_LD + c];
+        double ar = sr[k1 * LD + cl], ai = si[k1 * LD + cl];
+        double br = sr[(128 - k1) * LD + cl], bi = -(double)si[(128 - k1) * LD + cl];
         double er = ar + br, ei = ai + bi, dr = ar - br, di = ai - bi;
         double pr = fma(dr, wk1.x, di * wk1.y), pi = fma(di, wk1.x, -(dr * wk1.y));
         s1r[u] = er - pi;
         s1i[u] = ei + pr;
       }
     }
+    if (bq * 16 <= nrun) {   // wave uniform: skip batches entirely beyond the run
 #pragma unroll
-    for (int u = 0; u < 4; u++) { dit_stage<1, 5>(s0r[u], s0i[u], ltw); dit_stage<1, 5>(s1r[u], s1i[u], ltw); }
+      for (int u = 0; u < 4; u++) { dit_stage<1, 5>(s0r[u], s0i[u], ltw); dit_stage<1, 5>(s1r[u], s1i[u], ltw); }
 #pragma unroll
-    for (int u = 0; u < 4; u++) { dit_stage<2, 4>(s0r[u], s0i[u], ltw); dit_stage<2, 4>(s1r[u], s1i[u], ltw); }
+      for (int u = 0; u < 4; u++) { dit_stage<2, 4>(s0r[u], s0i[u], ltw); dit_stage<2, 4>(s1r[u], s1i[u], ltw); }
 #pragma unroll
-    for (int u = 0; u < 4; u++) { dit_stage<4, 3>(s0r[u], s0i[u], ltw); dit_stage<4, 3>(s1r[u], s1i[u], ltw); }
+      for (int u = 0; u < 4; u++) { dit_stage<4, 3>(s0r[u], s0i[u], ltw); dit_stage<4, 3>(s1r[u], s1i[u], ltw); }
 #pragma unroll
-    for (int u = 0; u < 4; u++) { dit_stage<8, 2>(s0r[u], s0i[u], ltw); dit_stage<8, 2>(s1r[u], s1i[u], ltw); }
+      for (int u = 0; u < 4; u++) { dit_stage<8, 2>(s0r[u], s0i[u], ltw); dit_stage<8, 2>(s1r[u], s1i[u], ltw); }
 #pragma unroll
-    for (int u = 0; u < 4; u++) { dit_stage<16, 1>(s0r[u], s0i[u], ltw); dit_stage<16, 1>(s1r[u], s1i[u], ltw); }
+      for (int u = 0; u < 4; u++) { dit_stage<16, 1>(s0r[u], s0i[u], ltw); dit_stage<16, 1>(s1r[u], s1i[u], ltw); }
 #pragma unroll
-    for (int u = 0; u < 4; u++) { dit_stage<32, 0>(s0r[u], s0i[u], ltw); dit_stage<32, 0>(s1r[u], s1i[u], ltw); }
+      for (int u = 0; u < 4; u++) { dit_stage<32, 0>(s0r[u], s0i[u], ltw); dit_stage<32, 0>(s1r[u], s1i[u], ltw); }
+    }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-      const int c = cbase + u;
-      if (c >= ncols) break;   // wave uniform
-      const int t = ta - 1 + c;
       double qr = fma(s1r[u], ltw.c1, s1i[u] * ltw.s1), qi = fma(s1i[u], ltw.c1, -(s1r[u] * ltw.s1));
       const double scale = 1.0 / 256.0;
-      double h0 = (s0r[u] + qr) * scale, h1 = (s0i[u] + qi) * scale;
-      double g0 = (s0r[u] - qr) * scale, g1 = (s0i[u] - qi) * scale;
-      if (t >= ta) {
-        float o0 = (float)h0 + tail[wave][2 * lane];
-        float o1 = (float)h1 + tail[wave][2 * lane + 1];
-        if (out) *reinterpret_cast<float2*>(out + (int64_t)t * kBlock + 2 * lane) = make_float2(o0, o1);
-      }
-      tail[wave][2 * lane] = (float)g0;
-      tail[wave][2 * lane + 1] = (float)g1;
+      hd[bq][u][0] = (float)((s0r[u] + qr) * scale);   // time samples 2l, 2l+1
+      hd[bq][u][1] = (float)((s0i[u] + qi) * scale);
+      tl[bq][u][0] = (float)((s0r[u] - qr) * scale);   // time samples 128+2l, 128+2l+1
+      tl[bq][u][1] = (float)((s0i[u] - qi) * scale);
     }
   }
-  if (tb == nblocks) {   // persistent overlap for the next chunk (double buffered: another workgroup may still read overlap_in)
-    ovo[2 * lane] = tail[wave][2 * lane];
-    ovo[2 * lane + 1] = tail[wave][2 * lane + 1];
+  __syncthreads();   // every wave is done reading the staging tile: reuse it as head[33][128] | tail[33][128]
+  float* head = smem;
+  float* tail = smem + 33 * kBlock;
+#pragma unroll
+  for (int bq = 0; bq < 3; bq++)
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int c = cc[bq][u];
+      if (c <= nrun && (c > 0 || ta > 0)) {
+        *reinterpret_cast<float2*>(&head[c * kBlock + 2 * lane]) = make_float2(hd[bq][u][0], hd[bq][u][1]);
+        *reinterpret_cast<float2*>(&tail[c * kBlock + 2 * lane]) = make_float2(tl[bq][u][0], tl[bq][u][1]);
+      }
+    }
+  if (ta == 0 && tid < kBlock) tail[tid] = overlap_in[row][tid];   // incoming overlap of the chunk's first block
+  __syncthreads();
+  float* out = yrows[row].out;
+  if (out) {
+    float4* o4 = reinterpret_cast<float4*>(out + (int64_t)ta * kBlock);
+    for (int idx = tid; idx < nrun * (kBlock / 4); idx += 256) {
+      const int c = idx / (kBlock / 4) + 1, s4 = (idx % (kBlock / 4)) * 4;
+      const float4 h = *reinterpret_cast<const float4*>(&head[c * kBlock + s4]);
+      const float4 t = *reinterpret_cast<const float4*>(&tail[(c - 1) * kBlock + s4]);
+      o4[idx] = make_float4(h.x + t.x, h.y + t.y, h.z + t.z, h.w + t.w);   // (float)y[i] + overlap[i]  (:148)
+    }
   }
+  if (tb == nblocks && tid < kBlock) overlap_out[row][tid] = tail[nrun * kBlock + tid];   // overlap[i] = (float)y[i+128]  (:149)
 }
 void launch_irfft_ola_b(hipStream_t s, const ConvRowIO* yrows_dev, int ny, int nblocks, ConvPlanesB pl,
                         const float* const* overlap_in_dev, float* const* overlap_out_dev, Twiddles tw) {
   if (ny <= 0 || nblocks <= 0) return;
-  dim3 grid((ny + 3) / 4, (nblocks + FB_RUN - 1) / FB_RUN);
+  dim3 grid(ny, (nblocks + FB_RUN - 1) / FB_RUN);
   hipLaunchKernelGGL(irfft_ola_b_kernel, grid, dim3(256), 0, s, yrows_dev, ny, nblocks, pl, overlap_in_dev, overlap_out_dev, tw);
 }
 
@@ -806,6 +833,176 @@ void launch_hist_copy_b(hipStream_t s, const HistJobB* jobs_dev, int njobs, int 
   for (int j0 = 0; j0 < njobs; j0 += 32768) {
     int nj = std::min(32768, njobs - j0);
     hipLaunchKernelGGL(hist_copy_b_kernel, dim3(kBins, nj), dim3(128), 0, s, jobs_dev + j0);
+  }
+}
+
+// =====================================================================================================
+//  Formulation C: FFT convolution along the block axis (see ga_kernels.hpp).  One workgroup of 256 threads owns one
+//  N2-point complex sequence in LDS; Stockham autosort passes of radix 8 / 4 (natural order in and out), float32.
+// =====================================================================================================
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul_mi(float2 a) { return make_float2(a.y, -a.x); }   // a * (-i)
+
+__device__ __forceinline__ void dft4(float2& a0, float2& a1, float2& a2, float2& a3) {   // forward, natural order
+  float2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = cmul_mi(csub(a1, a3));
+  a0 = cadd(t0, t2);
+  a2 = csub(t0, t2);
+  a1 = cadd(t1, t3);
+  a3 = csub(t1, t3);
+}
+__device__ __forceinline__ void dft8(float2 (&v)[8]) {   // forward 8-point DFT, natural order in / out
+  const float h = 0.70710678118654752440f;
+  float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+  float2 o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+  dft4(e0, e1, e2, e3);
+  dft4(o0, o1, o2, o3);
+  // odd part times W8^q
+  float2 w1 = make_float2(h * (o1.x + o1.y), h * (o1.y - o1.x));      // o1 * (1 - i)/sqrt2
+  float2 w2 = cmul_mi(o2);                                            // o2 * (-i)
+  float2 w3 = make_float2(h * (o3.y - o3.x), -h * (o3.x + o3.y));     // o3 * (-1 - i)/sqrt2
+  v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
+  v[1] = cadd(e1, w1); v[5] = csub(e1, w1);
+  v[2] = cadd(e2, w2); v[6] = csub(e2, w2);
+  v[3] = cadd(e3, w3); v[7] = csub(e3, w3);
+}
+
+// LDS index padding: one extra float2 every 16 keeps the strided writes of the early passes off a single bank pair
+__device__ __forceinline__ int PADI(int i) { return i + (i >> 4); }
+#define TC_PADDED(n) ((n) + ((n) >> 4))
+
+// one Stockham pass of radix R over the N-point sequence in `buf` (in place: read, barrier, write, barrier)
+template <int N, int R>
+__device__ __forceinline__ void stockham_pass(float2* __restrict buf, const float2* __restrict tw, int Ns, int tid) {
+  constexpr int NB = N / R;                 // butterflies
+  constexpr int PER = (NB + 255) / 256;     // per thread
+  float2 v[PER][R];
+#pragma unroll
+  for (int u = 0; u < PER; u++) {
+    const int j = tid + u * 256;
+    if (NB % 256 == 0 || j < NB) {
+      const int kk = j % Ns;
+#pragma unroll
+      for (int m = 0; m < R; m++) {
+        float2 x = buf[PADI(j + m * NB)];
+        if (m > 0) x = cmul(x, tw[(kk * m) * (N / (Ns * R))]);
+        v[u][m] = x;
+      }
+      if constexpr (R == 8) {
+        dft8(v[u]);
+      } else {
+        dft4(v[u][0], v[u][1], v[u][2], v[u][3]);
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < PER; u++) {
+    const int j = tid + u * 256;
+    if (NB % 256 == 0 || j < NB) {
+      const int kk = j % Ns;
+      const int j0 = (j / Ns) * Ns * R + kk;
+#pragma unroll
+      for (int m = 0; m < R; m++) buf[PADI(j0 + m * Ns)] = v[u][m];
+    }
+  }
+  __syncthreads();
+}
+template <int N>
+__device__ __forceinline__ void fft_lds(float2* buf, const float2* tw, int tid) {   // forward N-point FFT in place
+  if (N == 1024) {
+    stockham_pass<N, 8>(buf, tw, 1, tid);
+    stockham_pass<N, 8>(buf, tw, 8, tid);
+    stockham_pass<N, 4>(buf, tw, 64, tid);
+    stockham_pass<N, 4>(buf, tw, 256, tid);
+  } else if (N == 2048) {
+    stockham_pass<N, 8>(buf, tw, 1, tid);
+    stockham_pass<N, 8>(buf, tw, 8, tid);
+    stockham_pass<N, 8>(buf, tw, 64, tid);
+    stockham_pass<N, 4>(buf, tw, 512, tid);
+  } else {
+    stockham_pass<N, 8>(buf, tw, 1, tid);
+    stockham_pass<N, 8>(buf, tw, 8, tid);
+    stockham_pass<N, 8>(buf, tw, 64, tid);
+    stockham_pass<N, 8>(buf, tw, 512, tid);
+  }
+}
+
+template <int N2>
+__global__ __launch_bounds__(256) void tap_spectra_kernel(float2* __restrict hs, const float* __restrict hr, const float* __restrict hi,
+                                                          int P, const float2* __restrict tw) {
+  __shared__ float2 buf[TC_PADDED(N2)];
+  const int k = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
+  const size_t src = ((size_t)c * kBins + k) * P;
+  for (int i = tid; i < N2; i += 256) buf[PADI(i)] = i < P ? make_float2(hr[src + i], hi[src + i]) : make_float2(0.f, 0.f);
+  __syncthreads();
+  fft_lds<N2>(buf, tw, tid);
+  float2* dst = hs + ((size_t)c * kBins + k) * N2;
+  for (int i = tid; i < N2; i += 256) dst[i] = buf[PADI(i)];
+}
+void launch_tap_spectra(hipStream_t s, float2* hs, const float* hr, const float* hi, int nch, int P, int N2, const float2* tw) {
+  dim3 g(kBins, nch), b(256);
+  if (N2 == 1024) hipLaunchKernelGGL(tap_spectra_kernel<1024>, g, b, 0, s, hs, hr, hi, P, tw);
+  else if (N2 == 2048) hipLaunchKernelGGL(tap_spectra_kernel<2048>, g, b, 0, s, hs, hr, hi, P, tw);
+  else hipLaunchKernelGGL(tap_spectra_kernel<4096>, g, b, 0, s, hs, hr, hi, P, tw);
+}
+
+// workgroup = (segment, bin, set): window of N2 block-spectra of the x-row -> FFT -> per column: * taps spectrum,
+// inverse FFT (conjugation trick), store the N2 - P + 1 valid blocks of the y-row
+template <int N2>
+__global__ __launch_bounds__(256) void tconv_kernel(const ConvSetC* __restrict sets, int nblocks, int hist, ConvPlanesB pl,
+                                                    const float2* __restrict tw) {
+  extern __shared__ float2 lds[];
+  float2* xf = lds;          // spectrum of the window (kept for every column)
+  float2* wk = lds + TC_PADDED(N2);     // work buffer
+  const ConvSetC* __restrict S = &sets[blockIdx.z];
+  const int k = blockIdx.y, seg = blockIdx.x, tid = threadIdx.x;
+  const int P = S->P, ncol = S->ncol;
+  const int L = N2 - (P - 1);
+  const int t0 = seg * L;                      // first output block of this segment
+  if (t0 >= nblocks) return;
+  const float* __restrict xr = pl.xr + ((size_t)S->x * kBins + k) * pl.tx;
+  const float* __restrict xi = pl.xi + ((size_t)S->x * kBins + k) * pl.tx;
+  const int b0 = t0 - (P - 1);                 // block of window element 0
+  for (int i = tid; i < N2; i += 256) {
+    const int blk = b0 + i;
+    float2 v = make_float2(0.f, 0.f);
+    if (blk >= -hist && blk < nblocks) v = make_float2(xr[hist + blk], xi[hist + blk]);
+    xf[PADI(i)] = v;
+  }
+  __syncthreads();
+  fft_lds<N2>(xf, tw, tid);
+  const float scale = 1.0f / N2;
+  const int nvalid = min(L, nblocks - t0);
+  for (int j = 0; j < ncol; j++) {
+    const float2* __restrict hs = S->hs[j] + (size_t)k * N2;
+    for (int i = tid; i < N2; i += 256) {
+      float2 p = cmul(xf[PADI(i)], hs[i]);
+      wk[PADI(i)] = make_float2(p.x, -p.y);          // conj: ifft(y) = conj(fft(conj(y))) / N
+    }
+    __syncthreads();
+    fft_lds<N2>(wk, tw, tid);
+    float* __restrict yr = pl.yr + ((size_t)(S->y0 + j) * kBins + k) * pl.ty + t0;
+    float* __restrict yi = pl.yi + ((size_t)(S->y0 + j) * kBins + k) * pl.ty + t0;
+    for (int i = tid; i < nvalid; i += 256) {
+      float2 v = wk[PADI(P - 1 + i)];
+      yr[i] = v.x * scale;
+      yi[i] = -v.y * scale;
+    }
+    __syncthreads();
+  }
+}
+void launch_tconv(hipStream_t s, const ConvSetC* sets_dev, int nsets, int nblocks, int hist, ConvPlanesB pl, int N2, const float2* tw,
+                  int nseg) {
+  if (nsets <= 0 || nblocks <= 0) return;
+  size_t lds = (size_t)2 * TC_PADDED(N2) * sizeof(float2);
+  for (int z0 = 0; z0 < nsets; z0 += 32768) {
+    int nz = std::min(32768, nsets - z0);
+    // the host guarantees every set of one launch has the same P, hence the same segment length L = N2 - P + 1
+    if (N2 == 1024) hipLaunchKernelGGL(tconv_kernel<1024>, dim3(nseg, kBins, nz), dim3(256), lds, s, sets_dev + z0, nblocks, hist, pl, tw);
+    else if (N2 == 2048) hipLaunchKernelGGL(tconv_kernel<2048>, dim3(nseg, kBins, nz), dim3(256), lds, s, sets_dev + z0, nblocks, hist, pl, tw);
+    else hipLaunchKernelGGL(tconv_kernel<4096>, dim3(nseg, kBins, nz), dim3(256), lds, s, sets_dev + z0, nblocks, hist, pl, tw);
   }
 }
 

@@ -83,6 +83,24 @@ void launch_irfft_ola_b(hipStream_t s, const ConvRowIO* yrows_dev, int ny, int n
                         const float* const* overlap_in_dev, float* const* overlap_out_dev, Twiddles tw);
 void launch_hist_copy_b(hipStream_t s, const HistJobB* jobs_dev, int njobs, int max_n);
 
+// ---- convolver pipeline, formulation C: the partition sum as an FFT convolution ALONG THE BLOCK AXIS -----------------
+// For one (row, bin) the reference's  acc[t] = sum_{p<P} X[t-p] H[p]  (PartitionedConvolver.cs:154-223) is a length-P
+// linear convolution over the block index t.  With all blocks of a chunk known it is evaluated by overlap-save with
+// complex FFTs of N2 = 4 * 2^ceil(log2 P) points (float32): forward FFT of the spectra window, product with the
+// precomputed N2-point spectrum of the taps, inverse FFT, keep the last N2 - P + 1 outputs.  ~20x fewer flops than the
+// direct sum, so the stage becomes HBM-bound.  Same [row][bin][block] planes, sets and histories as formulation B.
+struct ConvSetC {
+  int x;                   // x-row index
+  int y0;                  // first y-row (columns consecutive)
+  int ncol;                // 1..16
+  int P;
+  const float2* hs[16];    // per column: [kBins][N2] spectrum of the taps along the partition axis
+};
+// spectra of the taps: hs[c][k][0..N2) = FFT_N2( H[c][k][0..P) zero padded )
+void launch_tap_spectra(hipStream_t s, float2* hs, const float* hr, const float* hi, int nch, int P, int N2, const float2* tw);
+void launch_tconv(hipStream_t s, const ConvSetC* sets_dev, int nsets, int nblocks, int hist, ConvPlanesB pl, int N2, const float2* tw,
+                  int nseg);
+
 // ---- graph plumbing kernels ------------------------------------------------------------------------
 // out[f0 + i] = ((0 + t0[f0+i]) + t1[f0+i]) + ...  in term order (AudioNodeInput.cs:118-132,182-244)
 struct MixJob {

@@ -33,12 +33,14 @@ def build(ctx, voices, frames, delay_blocks=0, ir=None):
     return 2
 
 
-def test_steady_state_parity_at_full_tap_count():
+@pytest.mark.parametrize("time_fft", [0, 1])
+def test_steady_state_parity_at_full_tap_count(time_fft):
     blocks = 640
     frames = blocks * 128
     outs = []
     for mk in (OracleContext, OfflineAudioContext):
         ctx = mk(SR)
+        ctx.SetOption("time_fft", time_fft)
         build(ctx, range(3), frames)
         outs.append(G.render(ctx, 2, frames))
     ref, got = outs
@@ -48,12 +50,23 @@ def test_steady_state_parity_at_full_tap_count():
     assert err / G.rms(ref[:, tail]) < 2e-6
 
 
-def test_chunk_invariance_bit_exact():
+def close(a, b, exact):
+    """Direct-sum formulations (A/B) are order-deterministic -> bit-exact; the block-axis FFT formulation (C) places its
+    overlap-save segments relative to the chunk start, so re-chunking changes float32 rounding only."""
+    if exact:
+        return np.array_equal(a, b)
+    return G.rms(a - b) <= 1e-6 * G.rms(a)
+
+
+@pytest.mark.parametrize("time_fft", [0, 1])
+def test_chunk_invariance(time_fft):
     frames = 128 * 700
     a = OfflineAudioContext(SR)
+    a.SetOption("time_fft", time_fft)
     build(a, range(48), frames)
     one = G.render(a, 2, frames)
     b = OfflineAudioContext(SR)
+    b.SetOption("time_fft", time_fft)
     b.SetOption("max_chunk_blocks", 96)
     build(b, range(48), frames)
     many = np.zeros_like(one)
@@ -64,23 +77,28 @@ def test_chunk_invariance_bit_exact():
             b.Render(many, n, pos)
             pos += n
     assert b.GetStats()["chunks"] > 6
-    assert np.array_equal(one, many)
+    assert close(one, many, exact=not time_fft)
 
 
-def test_superposition_and_time_invariance():
+@pytest.mark.parametrize("time_fft", [0, 1])
+def test_superposition_and_time_invariance(time_fft):
     frames = 128 * 600
     full = OfflineAudioContext(SR)
+    full.SetOption("time_fft", time_fft)
     build(full, range(32), frames)
     bus = G.render(full, 2, frames)
     parts = np.zeros_like(bus, dtype=np.float64)
     for half in (range(0, 16), range(16, 32)):
         c = OfflineAudioContext(SR)
+        c.SetOption("time_fft", time_fft)
         build(c, half, frames)
         parts += G.render(c, 2, frames)
     assert G.rms(bus - parts) <= 4e-7 * G.rms(bus)   # float32 summation order only
     k = 7
     d = OfflineAudioContext(SR)
+    d.SetOption("time_fft", time_fft)
     build(d, range(32), frames, delay_blocks=k)
     delayed = G.render(d, 2, frames)
-    assert np.abs(delayed[:, : k * 128]).max() == 0.0
-    assert np.array_equal(delayed[:, k * 128:], bus[:, : frames - k * 128])
+    # FFT-based formulations leave ~1e-9 of circular-convolution rounding where the direct sum gives exact zeros
+    assert np.abs(delayed[:, : k * 128]).max() <= (1e-6 if time_fft else 0.0)
+    assert close(delayed[:, k * 128:], bus[:, : frames - k * 128], exact=not time_fft)
