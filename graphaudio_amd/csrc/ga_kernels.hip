@@ -948,55 +948,164 @@ void launch_tap_spectra(hipStream_t s, float2* hs, const float* hr, const float*
   else hipLaunchKernelGGL(tap_spectra_kernel<4096>, g, b, 0, s, hs, hr, hi, P, tw);
 }
 
+// ---- register/LDS hybrid FFT for the tconv kernel -------------------------------------------------------------------
+// Every thread owns the PT = N/256 points {tid + 256 m}.  With the radix plans below these are exactly the inputs of the
+// FIRST Stockham pass (butterfly j = tid + 256u reads j + (N/R1) m) and the outputs of the LAST one (j + (N/RL) m), so
+// a forward FFT, a pointwise product and an inverse FFT chain through registers; only the middle passes go through LDS
+// (ping-pong buffers, one barrier per pass).   N = 1024: radices 4,8,8,4   N = 2048: 8,8,8,4   N = 4096: 8,8,8,8
+template <int R>
+__device__ __forceinline__ void dftR(float2 (&v)[R]) {
+  if constexpr (R == 8) dft8(v);
+  else dft4(v[0], v[1], v[2], v[3]);
+}
+template <int N, int R>
+__device__ __forceinline__ void first_pass(const float2 (&own)[N / 256], float2* __restrict dst, int tid) {
+  constexpr int NBT = (N / R) / 256;   // butterflies per thread
+#pragma unroll
+  for (int u = 0; u < NBT; u++) {
+    const int j = tid + 256 * u;
+    float2 v[R];
+#pragma unroll
+    for (int m = 0; m < R; m++) v[m] = own[u + NBT * m];
+    dftR<R>(v);
+#pragma unroll
+    for (int m = 0; m < R; m++) dst[PADI(j * R + m)] = v[m];   // Ns = 1: j0 = j * R
+  }
+}
+template <int N, int R, int Ns>
+__device__ __forceinline__ void mid_pass(const float2* __restrict src, float2* __restrict dst, const float2* __restrict tw, int tid) {
+  constexpr int NB = N / R;
+  constexpr int PER = (NB + 255) / 256;
+#pragma unroll
+  for (int u = 0; u < PER; u++) {
+    const int j = tid + 256 * u;
+    if (NB % 256 == 0 || j < NB) {
+      const int kk = j % Ns;
+      float2 v[R];
+#pragma unroll
+      for (int m = 0; m < R; m++) {
+        float2 x = src[PADI(j + m * NB)];
+        if (m > 0) x = cmul(x, tw[(kk * m) * (N / (Ns * R))]);
+        v[m] = x;
+      }
+      dftR<R>(v);
+      const int j0 = (j / Ns) * Ns * R + kk;
+#pragma unroll
+      for (int m = 0; m < R; m++) dst[PADI(j0 + m * Ns)] = v[m];
+    }
+  }
+}
+template <int N, int R>
+__device__ __forceinline__ void last_pass(const float2* __restrict src, float2 (&own)[N / 256], const float2* __restrict tw, int tid) {
+  constexpr int NB = N / R, Ns = N / R;   // last pass: Ns * R == N
+  constexpr int NBT = NB / 256;
+#pragma unroll
+  for (int u = 0; u < NBT; u++) {
+    const int j = tid + 256 * u;           // j < Ns: kk = j, j0 = j
+    float2 v[R];
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+      float2 x = src[PADI(j + m * NB)];
+      if (m > 0) x = cmul(x, tw[j * m]);
+      v[m] = x;
+    }
+    dftR<R>(v);
+#pragma unroll
+    for (int m = 0; m < R; m++) own[u + (Ns / 256) * m] = v[m];   // position j + m * Ns = tid + 256 (u + (Ns/256) m)
+  }
+}
+// forward FFT of the thread-owned points; `a` is written first.  One barrier per pass.
+template <int N>
+__device__ __forceinline__ void fft_own(float2 (&own)[N / 256], float2* a, float2* b, const float2* tw, int tid) {
+  if constexpr (N == 1024) {
+    first_pass<N, 4>(own, a, tid);
+    __syncthreads();
+    mid_pass<N, 8, 4>(a, b, tw, tid);
+    __syncthreads();
+    mid_pass<N, 8, 32>(b, a, tw, tid);
+    __syncthreads();
+    last_pass<N, 4>(a, own, tw, tid);
+  } else if constexpr (N == 2048) {
+    first_pass<N, 8>(own, a, tid);
+    __syncthreads();
+    mid_pass<N, 8, 8>(a, b, tw, tid);
+    __syncthreads();
+    mid_pass<N, 8, 64>(b, a, tw, tid);
+    __syncthreads();
+    last_pass<N, 4>(a, own, tw, tid);
+  } else {
+    first_pass<N, 8>(own, a, tid);
+    __syncthreads();
+    mid_pass<N, 8, 8>(a, b, tw, tid);
+    __syncthreads();
+    mid_pass<N, 8, 64>(b, a, tw, tid);
+    __syncthreads();
+    last_pass<N, 8>(a, own, tw, tid);
+  }
+}
+
 // workgroup = (segment, bin, set): window of N2 block-spectra of the x-row -> FFT -> per column: * taps spectrum,
 // inverse FFT (conjugation trick), store the N2 - P + 1 valid blocks of the y-row
 template <int N2>
 __global__ __launch_bounds__(256) void tconv_kernel(const ConvSetC* __restrict sets, int nblocks, int hist, ConvPlanesB pl,
-                                                    const float2* __restrict tw) {
+                                                    const float2* __restrict twg) {
+  constexpr int PT = N2 / 256;
   extern __shared__ float2 lds[];
-  float2* xf = lds;          // spectrum of the window (kept for every column)
-  float2* wk = lds + TC_PADDED(N2);     // work buffer
+  float2* bufA = lds;
+  float2* bufB = lds + TC_PADDED(N2);
+  float2* tw = lds + 2 * TC_PADDED(N2);      // twiddle table exp(-2 pi i j / N2) in LDS
   const ConvSetC* __restrict S = &sets[blockIdx.z];
   const int k = blockIdx.y, seg = blockIdx.x, tid = threadIdx.x;
   const int P = S->P, ncol = S->ncol;
   const int L = N2 - (P - 1);
   const int t0 = seg * L;                      // first output block of this segment
   if (t0 >= nblocks) return;
+  for (int i = tid; i < N2; i += 256) tw[i] = twg[i];
   const float* __restrict xr = pl.xr + ((size_t)S->x * kBins + k) * pl.tx;
   const float* __restrict xi = pl.xi + ((size_t)S->x * kBins + k) * pl.tx;
   const int b0 = t0 - (P - 1);                 // block of window element 0
-  for (int i = tid; i < N2; i += 256) {
-    const int blk = b0 + i;
-    float2 v = make_float2(0.f, 0.f);
-    if (blk >= -hist && blk < nblocks) v = make_float2(xr[hist + blk], xi[hist + blk]);
-    xf[PADI(i)] = v;
+  float2 xf[PT];
+#pragma unroll
+  for (int m = 0; m < PT; m++) {
+    const int blk = b0 + tid + 256 * m;
+    xf[m] = make_float2(0.f, 0.f);
+    if (blk >= -hist && blk < nblocks) xf[m] = make_float2(xr[hist + blk], xi[hist + blk]);
   }
-  __syncthreads();
-  fft_lds<N2>(xf, tw, tid);
+  __syncthreads();                             // twiddles visible
+  fft_own<N2>(xf, bufA, bufB, tw, tid);        // xf[m] = spectrum at tid + 256 m ; last pass read bufA
   const float scale = 1.0f / N2;
   const int nvalid = min(L, nblocks - t0);
   for (int j = 0; j < ncol; j++) {
     const float2* __restrict hs = S->hs[j] + (size_t)k * N2;
-    for (int i = tid; i < N2; i += 256) {
-      float2 p = cmul(xf[PADI(i)], hs[i]);
-      wk[PADI(i)] = make_float2(p.x, -p.y);          // conj: ifft(y) = conj(fft(conj(y))) / N
+    float2 y[PT];
+#pragma unroll
+    for (int m = 0; m < PT; m++) {
+      float2 p = cmul(xf[m], hs[tid + 256 * m]);
+      y[m] = make_float2(p.x, -p.y);           // conj: ifft(v) = conj(fft(conj(v))) / N
     }
-    __syncthreads();
-    fft_lds<N2>(wk, tw, tid);
+    // alternate the first buffer so this transform never overwrites what slower threads still read in their last pass
+    if (j & 1) fft_own<N2>(y, bufA, bufB, tw, tid); else fft_own<N2>(y, bufB, bufA, tw, tid);
     float* __restrict yr = pl.yr + ((size_t)(S->y0 + j) * kBins + k) * pl.ty + t0;
     float* __restrict yi = pl.yi + ((size_t)(S->y0 + j) * kBins + k) * pl.ty + t0;
-    for (int i = tid; i < nvalid; i += 256) {
-      float2 v = wk[PADI(P - 1 + i)];
-      yr[i] = v.x * scale;
-      yi[i] = -v.y * scale;
+#pragma unroll
+    for (int m = 0; m < PT; m++) {
+      const int i = tid + 256 * m - (P - 1);   // output block index within the segment
+      if (i >= 0 && i < nvalid) {
+        yr[i] = y[m].x * scale;
+        yi[i] = -y[m].y * scale;
+      }
     }
-    __syncthreads();
   }
 }
 void launch_tconv(hipStream_t s, const ConvSetC* sets_dev, int nsets, int nblocks, int hist, ConvPlanesB pl, int N2, const float2* tw,
                   int nseg) {
   if (nsets <= 0 || nblocks <= 0) return;
-  size_t lds = (size_t)2 * TC_PADDED(N2) * sizeof(float2);
+  size_t lds = ((size_t)2 * TC_PADDED(N2) + N2) * sizeof(float2);
+  static bool attr_set = false;
+  if (!attr_set) {   // N2 = 4096 needs 100 KB of dynamic LDS (gfx950 has 160 KB per CU)
+    (void)hipFuncSetAttribute((const void*)tconv_kernel<4096>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+    attr_set = true;
+  }
   for (int z0 = 0; z0 < nsets; z0 += 32768) {
     int nz = std::min(32768, nsets - z0);
     // the host guarantees every set of one launch has the same P, hence the same segment length L = N2 - P + 1
