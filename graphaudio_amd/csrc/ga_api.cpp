@@ -214,6 +214,7 @@ int ga_set_option(ga_context* ctx, const char* key, double value) {
     if (k == "max_chunk_blocks") c.maxChunkBlocks = std::max<int64_t>(1, std::min<int64_t>(32768, (int64_t)value));
     else if (k == "profile") c.profile = value != 0;
     else if (k == "time_fft") c.useTimeFft = value != 0;
+    else if (k == "fft64") c.fft64 = value != 0;
     else if (k == "mem_budget_fraction") c.memBudgetFraction = std::min(0.95, std::max(0.05, value));
     else fail(GA_ERR_INVALID_ARGUMENT, "unknown option " + k);
   });

@@ -992,6 +992,9 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
             if (g.effectiveRate == 1.0 && !nd.loop) {
               // zero-copy: the node's output for these blocks IS the buffer (AudioBufferSourceNode.cs:186-222)
               for (int ch = 0; ch < pb.channels; ch++) ov[ch] = pb.dev + (size_t)ch * pb.stride + ns.srcPos - f0;
+            } else if (g.effectiveRate == 1.0 && ns.srcPos < g.loopEndFrame && ns.srcPos + nf <= g.loopEndFrame) {
+              // looping, but these blocks do not reach the loop end: still a plain window of the buffer (zero-copy)
+              for (int ch = 0; ch < pb.channels; ch++) ov[ch] = pb.dev + (size_t)ch * pb.stride + ns.srcPos - f0;
             } else if (g.effectiveRate == 1.0) {
               for (int ch = 0; ch < pb.channels; ch++) {
                 LoopJob lj;
@@ -1416,9 +1419,10 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
       Twiddles tw{w128, w256};
       const int nn = (int)n;
       const int maxn = std::max(hist, txb - hist - nn);
+      const bool f64 = fft64;
       ex.plan.add(LK_FFT, [=](uint8_t* base) {
         launch_hist_copy_b(st, (const HistJobB*)(base + ro), nr, std::max(maxn, 1));
-        launch_rfft_fwd_b(st, (const ConvRowIO*)(base + xo), nx, nn, hist, plb, tw);
+        launch_rfft_fwd_b(st, (const ConvRowIO*)(base + xo), nx, nn, hist, plb, tw, f64);
       });
       if (ns_ > 0) ex.plan.add(LK_MAC, [=](uint8_t* base) { launch_spectral_mac_b(st, (const ConvSetB*)(base + so), ns_, nn, hist, plb); });
       for (auto& kv : setsC) {
@@ -1434,7 +1438,7 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
         ex.plan.add(LK_MAC, [=](uint8_t* base) { launch_tconv(st, (const ConvSetC*)(base + co), nc, nn, hist, plb, N2, twc, nseg); });
       }
       ex.plan.add(LK_FFT, [=](uint8_t* base) {
-        launch_irfft_ola_b(st, (const ConvRowIO*)(base + yo), ny, nn, plb, (const float* const*)(base + oi), (float* const*)(base + oo), tw);
+        launch_irfft_ola_b(st, (const ConvRowIO*)(base + yo), ny, nn, plb, (const float* const*)(base + oi), (float* const*)(base + oo), tw, f64);
         launch_hist_copy_b(st, (const HistJobB*)(base + sv), nsv, std::max(hist, 1));
       });
       stats.mac_flops_total += flops;

@@ -290,6 +290,7 @@ struct Context {
   void assignConvPaths(const std::vector<int>& topo);
   const float2* twiddlesC(int N2);
   void ensureTapSpectra(IrSpectra& ir);
+  bool fft64 = false;            // option "fft64": double-precision 256-point transforms in the B-layout kernels (reference-like)
   bool useTimeFft = true;        // option "time_fft": formulation C for 64 < P <= 1024
   void updateBiquadCoefficients(NodeS& n, float frequency, float q, float gain);
 

@@ -47,45 +47,55 @@ __device__ __forceinline__ double xchg(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
   return __hiloint2double(xchg32<MASK>(hi), xchg32<MASK>(lo));
 }
+template <int MASK>
+__device__ __forceinline__ float xchg(float v) { return __int_as_float(xchg32<MASK>(__float_as_int(v))); }
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ float shfl_d(float v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ int rev6(int l) { return (int)(__brev((unsigned)l) >> 26); }
 
-struct LaneTw {   // per-lane constants, loaded once per kernel
-  double c[6], s[6];   // stage twiddle for half = 32,16,8,4,2,1: W128^{(l & (half-1)) * 64/half} on upper lanes, (1,0) on lower
-  double sg[6];        // -1 on upper lanes (l & half), +1 on lower lanes
-  double c1, s1;       // W128^l  (the in-lane stage)
+// T = double reproduces the reference's double-precision FftFlat transform (spectra equal after the float32 cast with
+// overwhelming probability); T = float is the default fast path: the transform error (~1e-7 relative) stays an order of
+// magnitude inside the float32 accumulation noise of the partition sum that follows.
+template <class T>
+struct LaneTwT {   // per-lane constants, loaded once per kernel
+  T c[6], s[6];    // stage twiddle for half = 32,16,8,4,2,1: W128^{(l & (half-1)) * 64/half} on upper lanes, (1,0) on lower
+  T sg[6];         // -1 on upper lanes (l & half), +1 on lower lanes
+  T c1, s1;        // W128^l  (the in-lane stage)
 };
-__device__ __forceinline__ LaneTw load_lane_tw(const double2* __restrict w128, int lane) {
-  LaneTw t;
+using LaneTw = LaneTwT<double>;
+template <class T>
+__device__ __forceinline__ LaneTwT<T> load_lane_tw_t(const double2* __restrict w128, int lane) {
+  LaneTwT<T> t;
 #pragma unroll
   for (int i = 0; i < 6; i++) {
     int half = 32 >> i;
     bool up = (lane & half) != 0;
     double2 w = w128[(lane & (half - 1)) * (64 / half)];
-    t.c[i] = up ? w.x : 1.0;
-    t.s[i] = up ? w.y : 0.0;
-    t.sg[i] = up ? -1.0 : 1.0;
+    t.c[i] = up ? (T)w.x : (T)1.0;
+    t.s[i] = up ? (T)w.y : (T)0.0;
+    t.sg[i] = up ? (T)-1.0 : (T)1.0;
   }
   double2 w = w128[lane];
-  t.c1 = w.x;
-  t.s1 = w.y;
+  t.c1 = (T)w.x;
+  t.s1 = (T)w.y;
   return t;
 }
+__device__ __forceinline__ LaneTw load_lane_tw(const double2* __restrict w128, int lane) { return load_lane_tw_t<double>(w128, lane); }
 // decimation in frequency: lower <- a + b ; upper <- (a - b) W   (natural order in, bit-reversed out)
-template <int HALF, int IDX>
-__device__ __forceinline__ void dif_stage(double& ar, double& ai, const LaneTw& t) {
-  double pr = xchg<HALF>(ar), pi = xchg<HALF>(ai);
-  double dr = fma(t.sg[IDX], ar, pr), di = fma(t.sg[IDX], ai, pi);   // lower: mine + partner ; upper: partner - mine
+template <int HALF, int IDX, class T>
+__device__ __forceinline__ void dif_stage(T& ar, T& ai, const LaneTwT<T>& t) {
+  T pr = xchg<HALF>(ar), pi = xchg<HALF>(ai);
+  T dr = fma(t.sg[IDX], ar, pr), di = fma(t.sg[IDX], ai, pi);   // lower: mine + partner ; upper: partner - mine
   ar = fma(dr, t.c[IDX], -(di * t.s[IDX]));
   ai = fma(dr, t.s[IDX], di * t.c[IDX]);
 }
 // decimation in time with conjugated twiddles: lower <- a + b conj(W) ; upper <- a - b conj(W)  (bit-reversed in, natural out)
-template <int HALF, int IDX>
-__device__ __forceinline__ void dit_stage(double& ar, double& ai, const LaneTw& t) {
-  double qr = fma(ar, t.c[IDX], ai * t.s[IDX]);       // mine * conj(tw)   (tw = (1,0) on lower lanes)
-  double qi = fma(ai, t.c[IDX], -(ar * t.s[IDX]));
-  double pr = xchg<HALF>(qr), pi = xchg<HALF>(qi);
-  ar = fma(t.sg[IDX], qr, pr);                         // lower: a + q_partner ; upper: partner - q_mine
+template <int HALF, int IDX, class T>
+__device__ __forceinline__ void dit_stage(T& ar, T& ai, const LaneTwT<T>& t) {
+  T qr = fma(ar, t.c[IDX], ai * t.s[IDX]);       // mine * conj(tw)   (tw = (1,0) on lower lanes)
+  T qi = fma(ai, t.c[IDX], -(ar * t.s[IDX]));
+  T pr = xchg<HALF>(qr), pi = xchg<HALF>(qi);
+  ar = fma(t.sg[IDX], qr, pr);                   // lower: a + q_partner ; upper: partner - q_mine
   ai = fma(t.sg[IDX], qi, pi);
 }
 
@@ -503,35 +513,38 @@ void launch_spectral_mac_shared(hipStream_t s, ConvPlanes pl, const float* hr, c
 //  Formulation B kernels (see ga_kernels.hpp): planes [row][bin][block], block index fastest.
 // =====================================================================================================
 constexpr int FB_RUN = 32;            // blocks per workgroup in the B-layout FFT kernels: 32 blocks = one 128-byte line per bin
-constexpr int FB_LD = FB_RUN + 4;     // staging row [bin][32 blocks] padded to 36 floats (16-byte aligned rows)
+constexpr int FB_KP = 130;            // staging pitch of a [block][bin] tile: 129 bins + 1, even, == 2 (mod 32)
 
 // forward: workgroup = (x-row, run of 32 blocks); wave w transforms blocks w, w+4, ..., w+28 of the run, 4 in flight
+template <class T>
 __global__ __launch_bounds__(256) void rfft_fwd_b_kernel(const ConvRowIO* __restrict xrows, int nx, int nblocks, int hist,
                                                          ConvPlanesB pl, Twiddles tw) {
-  __shared__ __attribute__((aligned(16))) float st_r[kBins * FB_LD];
-  __shared__ __attribute__((aligned(16))) float st_i[kBins * FB_LD];
+  // staging tile [block of the run][bin], pitch FB_KP = 130 floats: a lane's bins (k0, k0 + 1) are one aligned 8-byte
+  // access and the 32 lanes of a group land on distinct bank pairs (2-way at worst); same for the transposed reads below
+  __shared__ __attribute__((aligned(16))) float st_r[FB_RUN * FB_KP];
+  __shared__ __attribute__((aligned(16))) float st_i[FB_RUN * FB_KP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int xrow = blockIdx.x;
   const int t0 = blockIdx.y * FB_RUN;
-  const LaneTw ltw = load_lane_tw(tw.w128, lane);
+  const LaneTwT<T> ltw = load_lane_tw_t<T>(tw.w128, lane);
   const int m = rev6(lane);
   const int k0 = 2 * m, k1 = 2 * m + 1;
   const int src0 = rev6((64 - m) & 63), src1 = 63 - lane;
-  const double2 wk0 = tw.w256[k0];
-  const double2 wk1 = tw.w256[k1];
+  const T wk0x = (T)tw.w256[k0].x, wk0y = (T)tw.w256[k0].y;
+  const T wk1x = (T)tw.w256[k1].x, wk1y = (T)tw.w256[k1].y;
   const float* in = xrows[xrow].in;
 
   for (int bq = 0; bq < FB_RUN / 16; bq++) {
-    double s0r[4], s0i[4], s1r[4], s1i[4];
+    T s0r[4], s0i[4], s1r[4], s1i[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const int t = t0 + wave + 4 * (bq * 4 + u);
-      s0r[u] = 0.0;
-      s0i[u] = 0.0;
+      s0r[u] = (T)0.0;
+      s0i[u] = (T)0.0;
       if (in && t < nblocks) {
         const float* p = in + (int64_t)t * kBlock + 2 * lane;
-        s0r[u] = (double)p[0];
-        s0i[u] = (double)p[1];
+        s0r[u] = (T)p[0];
+        s0i[u] = (T)p[1];
       }
       s1r[u] = fma(s0r[u], ltw.c1, -(s0i[u] * ltw.s1));
       s1i[u] = fma(s0r[u], ltw.s1, s0i[u] * ltw.c1);
@@ -551,29 +564,30 @@ __global__ __launch_bounds__(256) void rfft_fwd_b_kernel(const ConvRowIO* __rest
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const int tl = wave + 4 * (bq * 4 + u);   // block within the run
+      float x0r, x0i;
       {
-        double ax = s0r[u], ay = s0i[u];
-        double bx = shfl_d(ax, src0), by = shfl_d(ay, src0);
-        double er = 0.5 * (ax + bx), ei = 0.5 * (ay - by);
-        double dr = 0.5 * (ax - bx), di = 0.5 * (ay + by);
-        double pr = fma(dr, wk0.x, -(di * wk0.y)), pi = fma(dr, wk0.y, di * wk0.x);
+        T ax = s0r[u], ay = s0i[u];
+        T bx = shfl_d(ax, src0), by = shfl_d(ay, src0);
+        T er = (T)0.5 * (ax + bx), ei = (T)0.5 * (ay - by);
+        T dr = (T)0.5 * (ax - bx), di = (T)0.5 * (ay + by);
+        T pr = fma(dr, wk0x, -(di * wk0y)), pi = fma(dr, wk0y, di * wk0x);
         float xr = (float)(er + pi), xi = (float)(ei - pr);
         if (k0 == 0) {
           xi = 0.f;
-          st_r[128 * FB_LD + tl] = (float)(ax - ay);
-          st_i[128 * FB_LD + tl] = 0.f;
+          st_r[tl * FB_KP + 128] = (float)(ax - ay);
+          st_i[tl * FB_KP + 128] = 0.f;
         }
-        st_r[k0 * FB_LD + tl] = xr;
-        st_i[k0 * FB_LD + tl] = xi;
+        x0r = xr;
+        x0i = xi;
       }
       {
-        double ax = s1r[u], ay = s1i[u];
-        double bx = shfl_d(ax, src1), by = shfl_d(ay, src1);
-        double er = 0.5 * (ax + bx), ei = 0.5 * (ay - by);
-        double dr = 0.5 * (ax - bx), di = 0.5 * (ay + by);
-        double pr = fma(dr, wk1.x, -(di * wk1.y)), pi = fma(dr, wk1.y, di * wk1.x);
-        st_r[k1 * FB_LD + tl] = (float)(er + pi);
-        st_i[k1 * FB_LD + tl] = (float)(ei - pr);
+        T ax = s1r[u], ay = s1i[u];
+        T bx = shfl_d(ax, src1), by = shfl_d(ay, src1);
+        T er = (T)0.5 * (ax + bx), ei = (T)0.5 * (ay - by);
+        T dr = (T)0.5 * (ax - bx), di = (T)0.5 * (ay + by);
+        T pr = fma(dr, wk1x, -(di * wk1y)), pi = fma(dr, wk1y, di * wk1x);
+        *reinterpret_cast<float2*>(&st_r[tl * FB_KP + k0]) = make_float2(x0r, (float)(er + pi));
+        *reinterpret_cast<float2*>(&st_i[tl * FB_KP + k0]) = make_float2(x0i, (float)(ei - pr));
       }
     }
   }
@@ -584,14 +598,15 @@ __global__ __launch_bounds__(256) void rfft_fwd_b_kernel(const ConvRowIO* __rest
     int k = idx >> 3, q = (idx & 7) * 4;
     if (t0 + q >= nblocks) continue;
     size_t o = rowbase + (size_t)k * pl.tx + q;
-    *reinterpret_cast<float4*>(pl.xr + o) = *reinterpret_cast<const float4*>(&st_r[k * FB_LD + q]);
-    *reinterpret_cast<float4*>(pl.xi + o) = *reinterpret_cast<const float4*>(&st_i[k * FB_LD + q]);
+    *reinterpret_cast<float4*>(pl.xr + o) = make_float4(st_r[q * FB_KP + k], st_r[(q + 1) * FB_KP + k], st_r[(q + 2) * FB_KP + k], st_r[(q + 3) * FB_KP + k]);
+    *reinterpret_cast<float4*>(pl.xi + o) = make_float4(st_i[q * FB_KP + k], st_i[(q + 1) * FB_KP + k], st_i[(q + 2) * FB_KP + k], st_i[(q + 3) * FB_KP + k]);
   }
 }
-void launch_rfft_fwd_b(hipStream_t s, const ConvRowIO* xrows_dev, int nx, int nblocks, int hist, ConvPlanesB pl, Twiddles tw) {
+void launch_rfft_fwd_b(hipStream_t s, const ConvRowIO* xrows_dev, int nx, int nblocks, int hist, ConvPlanesB pl, Twiddles tw, bool fp64) {
   if (nx <= 0 || nblocks <= 0) return;
   dim3 grid(nx, (nblocks + FB_RUN - 1) / FB_RUN);
-  hipLaunchKernelGGL(rfft_fwd_b_kernel, grid, dim3(256), 0, s, xrows_dev, nx, nblocks, hist, pl, tw);
+  if (fp64) hipLaunchKernelGGL(rfft_fwd_b_kernel<double>, grid, dim3(256), 0, s, xrows_dev, nx, nblocks, hist, pl, tw);
+  else hipLaunchKernelGGL(rfft_fwd_b_kernel<float>, grid, dim3(256), 0, s, xrows_dev, nx, nblocks, hist, pl, tw);
 }
 
 // MAC B: workgroup = (set, bin, 256-block time tile); wave = 64 blocks (4 M-tiles) x 16 columns; taps in segments of 256
@@ -694,23 +709,25 @@ void launch_spectral_mac_b(hipStream_t s, const ConvSetB* sets_dev, int nsets, i
 // inverse + overlap-add, B layout: workgroup = (y-row, run of 32 blocks).  All 33 inverse transforms of the run (the extra
 // one recovers the tail of the block before the run) are independent: 4 waves x up to 3 batches of 4.  Heads and tails land
 // in LDS, then out[t] = (float)head[t] + tail[t-1] is written as one contiguous, fully coalesced 16 KB range.
+template <class T>
 __global__ __launch_bounds__(256) void irfft_ola_b_kernel(const ConvRowIO* __restrict yrows, int ny, int nblocks, ConvPlanesB pl,
                                                           const float* const* __restrict overlap_in, float* const* __restrict overlap_out,
                                                           Twiddles tw) {
-  // staging tile [bin][33 columns]: column c <-> block ta - 1 + c ; later reused for the head/tail tiles
-  constexpr int LD = FB_RUN + 4;                        // 36
-  __shared__ __attribute__((aligned(16))) float smem[2 * kBins * LD];   // 9288 floats >= (33 + 33) * 128 = 8448
+  // staging tile [33 columns][bin] (pitch 130, see the forward kernel): column c <-> block ta - 1 + c ; the memory is
+  // reused for the head/tail tiles afterwards
+  constexpr int NC = FB_RUN + 1;
+  __shared__ __attribute__((aligned(16))) float smem[2 * NC * FB_KP];   // 8580 floats >= (33 + 33) * 128 = 8448
   float* sr = smem;
-  float* si = smem + kBins * LD;
+  float* si = smem + NC * FB_KP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row = blockIdx.x;
   const int ta = blockIdx.y * FB_RUN;
   const int tb = min(ta + FB_RUN, nblocks);
   const int nrun = tb - ta;
-  const LaneTw ltw = load_lane_tw(tw.w128, lane);
+  const LaneTwT<T> ltw = load_lane_tw_t<T>(tw.w128, lane);
   const int k0 = rev6(lane) << 1, k1 = k0 | 1;
-  const double2 wk0 = tw.w256[k0];
-  const double2 wk1 = tw.w256[k1];
+  const T wk0x = (T)tw.w256[k0].x, wk0y = (T)tw.w256[k0].y;
+  const T wk1x = (T)tw.w256[k1].x, wk1y = (T)tw.w256[k1].y;
   const float* __restrict yr = pl.yr + (size_t)row * kBins * pl.ty;
   const float* __restrict yi = pl.yi + (size_t)row * kBins * pl.ty;
   // columns 1..nrun <- blocks ta .. tb-1 (16-byte loads, 8 lanes per 128-byte bin line); column 0 <- block ta - 1
@@ -721,10 +738,8 @@ __global__ __launch_bounds__(256) void irfft_ola_b_kernel(const ConvRowIO* __res
       vr = *reinterpret_cast<const float4*>(yr + (size_t)k * pl.ty + ta + q);
       vi = *reinterpret_cast<const float4*>(yi + (size_t)k * pl.ty + ta + q);
     }
-    float* dr = &sr[k * LD + 1 + q];
-    float* di = &si[k * LD + 1 + q];
-    dr[0] = vr.x; dr[1] = vr.y; dr[2] = vr.z; dr[3] = vr.w;
-    di[0] = vi.x; di[1] = vi.y; di[2] = vi.z; di[3] = vi.w;
+    sr[(1 + q) * FB_KP + k] = vr.x; sr[(2 + q) * FB_KP + k] = vr.y; sr[(3 + q) * FB_KP + k] = vr.z; sr[(4 + q) * FB_KP + k] = vr.w;
+    si[(1 + q) * FB_KP + k] = vi.x; si[(2 + q) * FB_KP + k] = vi.y; si[(3 + q) * FB_KP + k] = vi.z; si[(4 + q) * FB_KP + k] = vi.w;
   }
   if (tid < kBins) {
     float vr = 0.f, vi = 0.f;
@@ -732,8 +747,8 @@ __global__ __launch_bounds__(256) void irfft_ola_b_kernel(const ConvRowIO* __res
       vr = yr[(size_t)tid * pl.ty + ta - 1];
       vi = yi[(size_t)tid * pl.ty + ta - 1];
     }
-    sr[tid * LD] = vr;
-    si[tid * LD] = vi;
+    sr[tid] = vr;
+    si[tid] = vi;
   }
   __syncthreads();
   // transform columns c = 0..nrun (c = 0 only when ta > 0); results kept in registers until the staging tile is dead
@@ -741,26 +756,31 @@ __global__ __launch_bounds__(256) void irfft_ola_b_kernel(const ConvRowIO* __res
   int cc[3][4];
 #pragma unroll
   for (int bq = 0; bq < 3; bq++) {
-    double s0r[4], s0i[4], s1r[4], s1i[4];
+    T s0r[4], s0i[4], s1r[4], s1i[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       int c = (bq * 4 + u) * 4 + wave;
       cc[bq][u] = c;
       const int cl = min(c, FB_RUN);
+      float x1r, x1i;
       {
-        double ar = sr[k0 * LD + cl], ai = si[k0 * LD + cl];
-        double br = sr[(128 - k0) * LD + cl], bi = -(double)si[(128 - k0) * LD + cl];
-        if (k0 == 0) { ai = 0.0; bi = 0.0; }
-        double er = ar + br, ei = ai + bi, dr = ar - br, di = ai - bi;
-        double pr = fma(dr, wk0.x, di * wk0.y), pi = fma(di, wk0.x, -(dr * wk0.y));
+        const float2 pr2 = *reinterpret_cast<const float2*>(&sr[cl * FB_KP + k0]);   // bins k0, k0 + 1
+        const float2 pi2 = *reinterpret_cast<const float2*>(&si[cl * FB_KP + k0]);
+        x1r = pr2.y;
+        x1i = pi2.y;
+        T ar = pr2.x, ai = pi2.x;
+        T br = sr[cl * FB_KP + (128 - k0)], bi = -(T)si[cl * FB_KP + (128 - k0)];
+        if (k0 == 0) { ai = (T)0.0; bi = (T)0.0; }
+        T er = ar + br, ei = ai + bi, dr = ar - br, di = ai - bi;
+        T pr = fma(dr, wk0x, di * wk0y), pi = fma(di, wk0x, -(dr * wk0y));
         s0r[u] = er - pi;
         s0i[u] = ei + pr;
       }
       {
-        double ar = sr[k1 * LD + cl], ai = si[k1 * LD + cl];
-        double br = sr[(128 - k1) * LD + cl], bi = -(double)si[(128 - k1) * LD + cl];
-        double er = ar + br, ei = ai + bi, dr = ar - br, di = ai - bi;
-        double pr = fma(dr, wk1.x, di * wk1.y), pi = fma(di, wk1.x, -(dr * wk1.y));
+        T ar = x1r, ai = x1i;
+        T br = sr[cl * FB_KP + (128 - k1)], bi = -(T)si[cl * FB_KP + (128 - k1)];
+        T er = ar + br, ei = ai + bi, dr = ar - br, di = ai - bi;
+        T pr = fma(dr, wk1x, di * wk1y), pi = fma(di, wk1x, -(dr * wk1y));
         s1r[u] = er - pi;
         s1i[u] = ei + pr;
       }
@@ -781,8 +801,8 @@ __global__ __launch_bounds__(256) void irfft_ola_b_kernel(const ConvRowIO* __res
     }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-      double qr = fma(s1r[u], ltw.c1, s1i[u] * ltw.s1), qi = fma(s1i[u], ltw.c1, -(s1r[u] * ltw.s1));
-      const double scale = 1.0 / 256.0;
+      T qr = fma(s1r[u], ltw.c1, s1i[u] * ltw.s1), qi = fma(s1i[u], ltw.c1, -(s1r[u] * ltw.s1));
+      const T scale = (T)(1.0 / 256.0);
       hd[bq][u][0] = (float)((s0r[u] + qr) * scale);   // time samples 2l, 2l+1
       hd[bq][u][1] = (float)((s0i[u] + qi) * scale);
       tl[bq][u][0] = (float)((s0r[u] - qr) * scale);   // time samples 128+2l, 128+2l+1
@@ -817,10 +837,11 @@ __global__ __launch_bounds__(256) void irfft_ola_b_kernel(const ConvRowIO* __res
   if (tb == nblocks && tid < kBlock) overlap_out[row][tid] = tail[nrun * kBlock + tid];   // overlap[i] = (float)y[i+128]  (:149)
 }
 void launch_irfft_ola_b(hipStream_t s, const ConvRowIO* yrows_dev, int ny, int nblocks, ConvPlanesB pl,
-                        const float* const* overlap_in_dev, float* const* overlap_out_dev, Twiddles tw) {
+                        const float* const* overlap_in_dev, float* const* overlap_out_dev, Twiddles tw, bool fp64) {
   if (ny <= 0 || nblocks <= 0) return;
   dim3 grid(ny, (nblocks + FB_RUN - 1) / FB_RUN);
-  hipLaunchKernelGGL(irfft_ola_b_kernel, grid, dim3(256), 0, s, yrows_dev, ny, nblocks, pl, overlap_in_dev, overlap_out_dev, tw);
+  if (fp64) hipLaunchKernelGGL(irfft_ola_b_kernel<double>, grid, dim3(256), 0, s, yrows_dev, ny, nblocks, pl, overlap_in_dev, overlap_out_dev, tw);
+  else hipLaunchKernelGGL(irfft_ola_b_kernel<float>, grid, dim3(256), 0, s, yrows_dev, ny, nblocks, pl, overlap_in_dev, overlap_out_dev, tw);
 }
 
 __global__ void hist_copy_b_kernel(const HistJobB* __restrict jobs) {
@@ -985,7 +1006,7 @@ __device__ __forceinline__ void mid_pass(const float2* __restrict src, float2* _
 #pragma unroll
       for (int m = 0; m < R; m++) {
         float2 x = src[PADI(j + m * NB)];
-        if (m > 0) x = cmul(x, tw[(kk * m) * (N / (Ns * R))]);
+        if (m > 0) x = cmul(x, tw[PADI((kk * m) * (N / (Ns * R)))]);
         v[m] = x;
       }
       dftR<R>(v);
@@ -1006,7 +1027,7 @@ __device__ __forceinline__ void last_pass(const float2* __restrict src, float2 (
 #pragma unroll
     for (int m = 0; m < R; m++) {
       float2 x = src[PADI(j + m * NB)];
-      if (m > 0) x = cmul(x, tw[j * m]);
+      if (m > 0) x = cmul(x, tw[PADI(j * m)]);
       v[m] = x;
     }
     dftR<R>(v);
@@ -1060,7 +1081,7 @@ __global__ __launch_bounds__(256) void tconv_kernel(const ConvSetC* __restrict s
   const int L = N2 - (P - 1);
   const int t0 = seg * L;                      // first output block of this segment
   if (t0 >= nblocks) return;
-  for (int i = tid; i < N2; i += 256) tw[i] = twg[i];
+  for (int i = tid; i < N2; i += 256) tw[PADI(i)] = twg[i];
   const float* __restrict xr = pl.xr + ((size_t)S->x * kBins + k) * pl.tx;
   const float* __restrict xi = pl.xi + ((size_t)S->x * kBins + k) * pl.tx;
   const int b0 = t0 - (P - 1);                 // block of window element 0
@@ -1100,7 +1121,7 @@ __global__ __launch_bounds__(256) void tconv_kernel(const ConvSetC* __restrict s
 void launch_tconv(hipStream_t s, const ConvSetC* sets_dev, int nsets, int nblocks, int hist, ConvPlanesB pl, int N2, const float2* tw,
                   int nseg) {
   if (nsets <= 0 || nblocks <= 0) return;
-  size_t lds = ((size_t)2 * TC_PADDED(N2) + N2) * sizeof(float2);
+  size_t lds = ((size_t)3 * TC_PADDED(N2)) * sizeof(float2);
   static bool attr_set = false;
   if (!attr_set) {   // N2 = 4096 needs 100 KB of dynamic LDS (gfx950 has 160 KB per CU)
     (void)hipFuncSetAttribute((const void*)tconv_kernel<4096>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);

@@ -77,10 +77,10 @@ struct HistJobB {          // history save / restore of one x-row: kBins runs of
   const float* src;        // nullptr = fill with zeros
   int dst_stride, src_stride, n, pad_;
 };
-void launch_rfft_fwd_b(hipStream_t s, const ConvRowIO* xrows_dev, int nx, int nblocks, int hist, ConvPlanesB pl, Twiddles tw);
+void launch_rfft_fwd_b(hipStream_t s, const ConvRowIO* xrows_dev, int nx, int nblocks, int hist, ConvPlanesB pl, Twiddles tw, bool fp64);
 void launch_spectral_mac_b(hipStream_t s, const ConvSetB* sets_dev, int nsets, int nblocks, int hist, ConvPlanesB pl);
 void launch_irfft_ola_b(hipStream_t s, const ConvRowIO* yrows_dev, int ny, int nblocks, ConvPlanesB pl,
-                        const float* const* overlap_in_dev, float* const* overlap_out_dev, Twiddles tw);
+                        const float* const* overlap_in_dev, float* const* overlap_out_dev, Twiddles tw, bool fp64);
 void launch_hist_copy_b(hipStream_t s, const HistJobB* jobs_dev, int njobs, int max_n);
 
 // ---- convolver pipeline, formulation C: the partition sum as an FFT convolution ALONG THE BLOCK AXIS -----------------
