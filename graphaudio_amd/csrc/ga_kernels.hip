@@ -1075,8 +1075,10 @@ __global__ __launch_bounds__(256) void tconv_kernel(const ConvSetC* __restrict s
   float2* bufA = lds;
   float2* bufB = lds + TC_PADDED(N2);
   float2* tw = lds + 2 * TC_PADDED(N2);      // twiddle table exp(-2 pi i j / N2) in LDS
-  const ConvSetC* __restrict S = &sets[blockIdx.z];
-  const int k = blockIdx.y, seg = blockIdx.x, tid = threadIdx.x;
+  // grid = (segment, set, bin): the bin is the slowest index so that all rows of one bin run back to back and the bin's
+  // tap spectra (N2 * 8 B per column) stay in L2 instead of being re-fetched by every workgroup
+  const ConvSetC* __restrict S = &sets[blockIdx.y];
+  const int k = blockIdx.z, seg = blockIdx.x, tid = threadIdx.x;
   const int P = S->P, ncol = S->ncol;
   const int L = N2 - (P - 1);
   const int t0 = seg * L;                      // first output block of this segment
@@ -1130,9 +1132,9 @@ void launch_tconv(hipStream_t s, const ConvSetC* sets_dev, int nsets, int nblock
   for (int z0 = 0; z0 < nsets; z0 += 32768) {
     int nz = std::min(32768, nsets - z0);
     // the host guarantees every set of one launch has the same P, hence the same segment length L = N2 - P + 1
-    if (N2 == 1024) hipLaunchKernelGGL(tconv_kernel<1024>, dim3(nseg, kBins, nz), dim3(256), lds, s, sets_dev + z0, nblocks, hist, pl, tw);
-    else if (N2 == 2048) hipLaunchKernelGGL(tconv_kernel<2048>, dim3(nseg, kBins, nz), dim3(256), lds, s, sets_dev + z0, nblocks, hist, pl, tw);
-    else hipLaunchKernelGGL(tconv_kernel<4096>, dim3(nseg, kBins, nz), dim3(256), lds, s, sets_dev + z0, nblocks, hist, pl, tw);
+    if (N2 == 1024) hipLaunchKernelGGL(tconv_kernel<1024>, dim3(nseg, nz, kBins), dim3(256), lds, s, sets_dev + z0, nblocks, hist, pl, tw);
+    else if (N2 == 2048) hipLaunchKernelGGL(tconv_kernel<2048>, dim3(nseg, nz, kBins), dim3(256), lds, s, sets_dev + z0, nblocks, hist, pl, tw);
+    else hipLaunchKernelGGL(tconv_kernel<4096>, dim3(nseg, nz, kBins), dim3(256), lds, s, sets_dev + z0, nblocks, hist, pl, tw);
   }
 }
 
