@@ -13,12 +13,14 @@ Multi-GPU (--gpus N, launched by torch.distributed.run, one rank per GPU): the v
 destination bus is summed with one RCCL reduce per step (torch.distributed backend "nccl" = RCCL over xGMI).
 
 One JSON line on stdout (rank 0).  Besides the contract keys:
-  roofline      -- dominant kernel (time-batched spectral multiply-accumulate on the f32 matrix cores): achieved
-                   algorithmic TFLOP/s (8*P*129 flop per channel-instance per block) / its HIP-event time, against
-                   the dense f32 MFMA peak of MI355X_MICROARCH.md (157.3 TFLOP/s).
-  roofline_hbm_streaming -- the same kernel time priced with SURVEY.md section 8(d)'s per-block STREAMING byte count
-                   (1.086 GB/block for this workload) against 8 TB/s: the time-batched formulation re-uses every
-                   loaded spectrum ~P times from LDS/L2, so this fraction exceeds 1 by design.
+  roofline      -- dominant kernel.  Default path ("formulation C"): the partition sum runs as an overlap-save
+                   FFT convolution along the block axis (tconv_kernel), an HBM-bound stage.  `achieved` follows the
+                   contract (SURVEY.md 8(d) per-block STREAMING bytes, 1.086 GB/block here, x blocks per launch / HIP-event
+                   launch time) and therefore exceeds the 8 TB/s peak by construction; `traffic` is the HBM bytes per
+                   launch measured with rocprofv3 PMC passes (profiles/), and
+  roofline_measured_traffic prices the same launch with those measured bytes (the honest distance to the HBM roofline).
+  roofline_flops -- the MAC stage in algorithmic TFLOP/s (8*P*129 flop per channel-instance per block) against the f32
+                   matrix/vector peak (157.3 TFLOP/s); with --direct (time-batched MFMA GEMM) this is the binding roofline.
   cpu_baseline  -- the CPU oracle (C++ restatement of the reference's single-threaded render path; .NET cannot run
                    here) timed on this host on a bounded sample, scaled to the full workload.
 """
@@ -94,6 +96,7 @@ def main():
     ap.add_argument("--voices", type=int, default=1024)
     ap.add_argument("--taps", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--direct", action="store_true", help="use the direct (matrix-core) partition sum instead of the block-axis FFT")
     ap.add_argument("--force-dist", action="store_true", help="exercise the process-group / RCCL reduce path even with one rank")
     args = ap.parse_args()
 
@@ -125,6 +128,8 @@ def main():
     ctx = OfflineAudioContext(SR, device=local_rank)
     ctx.SetOption("profile", 1)
     ctx.SetOption("max_chunk_blocks", 4096)
+    if args.direct:
+        ctx.SetOption("time_fft", 0)
     build_graph(ctx, shard, v0, args.taps, frames, G)
 
     host_out = np.zeros((2, frames), np.float32)
@@ -170,15 +175,30 @@ def main():
         ach_tflops = d["mac_flops_total"] / mac_s / 1e12 if mac_s > 0 else 0.0
         ach_gbs = d["mac_bytes_total"] / mac_s / 1e9 if mac_s > 0 else 0.0
         blocks = frames // 128
-        # HBM bytes per MAC launch from rocprofv3 PMC passes of this exact workload (profiles/r01_pmc_hbm_traffic.json:
-        # separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md); null for other shapes
+        # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes of this exact workload
+        # (profiles/r01_pmc_hbm_traffic_v2_timefft.json: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per
+        # MI355X_MICROARCH.md after calibration on a known byte count); null for other shapes
         traffic = None
         try:
-            if world == 1 and voices_total == 1024 and args.taps == 65536 and blocks == 3750:
+            if world == 1 and voices_total == 1024 and args.taps == 65536 and blocks == 3750 and not args.direct:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_v2_timefft.json")))
+                traffic = pm["tconv_kernel_hbm_bytes_per_launch"]["total"]
+            elif world == 1 and voices_total == 1024 and args.taps == 65536 and blocks == 3750:
                 pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
                 traffic = pm["spectral_mac_shared_kernel_hbm_bytes_per_launch"]["total"]
         except (OSError, KeyError, ValueError):
             traffic = None
+        launches = max(d["mac_launches"], 1)
+        avg_ms = d["mac_ms_total"] / launches
+        alg_bytes = d["mac_bytes_total"] / launches
+        if args.direct:
+            kernel = "spectral_mac_shared_kernel (v_mfma_f32_16x16x4_f32, banded-Toeplitz GEMM per bin)"
+            form = ("direct partition sum, time-batched on the f32 matrix cores; dense f32 MFMA peak 157.3 TFLOP/s is the "
+                    "binding roofline: see roofline_flops")
+        else:
+            kernel = "tconv_kernel<2048> (overlap-save FFT convolution along the block axis, Stockham radix-8/4 in LDS)"
+            form = ("partition sum evaluated as an FFT convolution over the block index (formulation C, DESIGN.md): ~20x "
+                    "fewer flops than the direct sum, so the stage is bound by HBM traffic of the spectra planes")
         rec = {
             "metric": "rendered frames/sec @48kHz, 1024-voice convolver graph",
             "value": value, "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
@@ -189,16 +209,22 @@ def main():
                        "voices": voices_total, "taps": args.taps, "frames_per_step": frames,
                        "parallelism": f"voice-shard x{world} + RCCL bus reduce" if world > 1 else "single GPU"},
             "realtime_factor": value / SR,
-            "roofline": {"bound": "mfma", "achieved": ach_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                         "kernel": "spectral_mac_shared_kernel (v_mfma_f32_16x16x4_f32)",
-                         "avg_launch_ms": d["mac_ms_total"] / max(d["mac_launches"], 1), "launches": d["mac_launches"],
-                         "formulation": "time-batched banded-Toeplitz GEMM per bin; algorithmic flops = 8*P*129 per channel-instance per block"},
-            "roofline_hbm_streaming": {"bound": "hbm", "achieved": ach_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                       "frac": ach_gbs / PEAK_HBM_GBS, "traffic": traffic,
-                                       "algorithmic_bytes_per_launch": d["mac_bytes_total"] / max(d["mac_launches"], 1),
-                                       "note": "algorithmic bytes of the reference's per-block streaming formulation (SURVEY 8d) / MAC kernel time"},
-            "kernel_ms_per_step": {"mac": d["mac_ms_total"] / args.steps, "fft": d["fft_ms_total"] / args.steps,
+            # `achieved` follows the contract: ALGORITHMIC bytes of the reference's per-block streaming formulation
+            # (1.086 GB/block for this workload) x blocks per launch / average launch duration (HIP events on
+            # the context's stream).  It exceeds the HBM peak by construction: every spectrum loaded once serves P outputs.
+            "roofline": {"bound": "hbm", "achieved": alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
+                         "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": (alg_bytes / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if avg_ms > 0 else 0.0,
+                         "traffic": traffic, "kernel": kernel, "avg_launch_ms": avg_ms, "launches": d["mac_launches"],
+                         "algorithmic_bytes_per_launch": alg_bytes, "formulation": form},
+            # the same launch priced with the HBM bytes it actually moved (PMC): the honest distance to the 8 TB/s roofline
+            "roofline_measured_traffic": ({"bound": "hbm", "achieved": traffic / (avg_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
+                                           "unit": "GB/s", "frac": traffic / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
+                                          if traffic and avg_ms > 0 else None),
+            "roofline_flops": {"bound": "mfma" if args.direct else "valu", "achieved": ach_tflops, "peak": PEAK_F32_MFMA_TFLOPS,
+                               "unit": "TFLOP/s", "frac": ach_tflops / PEAK_F32_MFMA_TFLOPS,
+                               "note": "algorithmic flops (8*P*129 per channel-instance per block) / MAC-stage kernel time"},
+            "kernel_ms_per_step": {"mac_stage": d["mac_ms_total"] / args.steps, "rfft256_fwd_inv": d["fft_ms_total"] / args.steps,
                                    "other": d["other_ms_total"] / args.steps, "device_total": d["device_ms_total"] / args.steps,
                                    "launches": d["kernel_launches"] / args.steps},
             "device_bytes_in_use": st1["device_bytes_in_use"],
