@@ -1,6 +1,10 @@
 // ga_chunk.cpp -- control-plane simulation and the per-chunk device executor (see ga_engine.hpp).
+#include <time.h>
+
 #include <algorithm>
 #include <array>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <unordered_map>
 
@@ -677,7 +681,15 @@ static void ensureGroupState(Context& c, ConvGroup& g) {
 // ======================================================================================================
 // runChunk
 // ======================================================================================================
+static double nowMs() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
 void Context::runChunk(int64_t n, float* const* /*unused*/) {
+  static const bool timing = getenv("GA_TIMING") != nullptr;
+  const double tm0 = nowMs();
+  double tmSim = 0, tmPlan = 0, tmLaunch = 0;
   GA_HIP(hipSetDevice(device));
   if (disposed) fail(GA_ERR_DISPOSED, "context disposed");
   drain();  // AudioContextBase.cs:57
@@ -822,6 +834,7 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
   }
   chunkMinDestCh = minDestCh;
   const int64_t frames = n * kBlock;
+  tmSim = nowMs();
 
   // ---- device resources for this chunk ----
   resetSlabs(*this, frames);
@@ -1470,6 +1483,7 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
     }
   }
 
+  tmPlan = nowMs();
   // ---- upload tables, run ----
   ex.trajOffFinal = ex.plan.putv(ex.traj);
   size_t tbytes = ex.plan.host.size();
@@ -1511,7 +1525,11 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
   }
   if (profile) GA_HIP(hipEventRecord(evEnd, stream));
   GA_HIP(hipGetLastError());
+  tmLaunch = nowMs();
   GA_HIP(hipStreamSynchronize(stream));
+  if (timing)
+    fprintf(stderr, "[ga] chunk %lld blocks: sim %.2f ms, plan %.2f ms, enqueue %.2f ms, wait %.2f ms\n", (long long)n, tmSim - tm0,
+            tmPlan - tmSim, tmLaunch - tmPlan, nowMs() - tmLaunch);
   if (profile) {
     float ms = 0;
     GA_HIP(hipEventElapsedTime(&ms, evBegin, evEnd));

@@ -534,18 +534,26 @@ __global__ __launch_bounds__(256) void rfft_fwd_b_kernel(const ConvRowIO* __rest
   const T wk1x = (T)tw.w256[k1].x, wk1y = (T)tw.w256[k1].y;
   const float* in = xrows[xrow].in;
 
+  // all eight input blocks of this wave are requested up front: their HBM latency overlaps the first batch of transforms
+  float inr[FB_RUN / 4], ini[FB_RUN / 4];
+#pragma unroll
+  for (int q = 0; q < FB_RUN / 4; q++) {
+    const int t = t0 + wave + 4 * q;
+    inr[q] = 0.f;
+    ini[q] = 0.f;
+    if (in && t < nblocks) {
+      const float* p = in + (int64_t)t * kBlock + 2 * lane;
+      inr[q] = p[0];
+      ini[q] = p[1];
+    }
+  }
+#pragma unroll
   for (int bq = 0; bq < FB_RUN / 16; bq++) {
     T s0r[4], s0i[4], s1r[4], s1i[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-      const int t = t0 + wave + 4 * (bq * 4 + u);
-      s0r[u] = (T)0.0;
-      s0i[u] = (T)0.0;
-      if (in && t < nblocks) {
-        const float* p = in + (int64_t)t * kBlock + 2 * lane;
-        s0r[u] = (T)p[0];
-        s0i[u] = (T)p[1];
-      }
+      s0r[u] = (T)inr[bq * 4 + u];   // float -> T, PartitionedConvolver.cs:106
+      s0i[u] = (T)ini[bq * 4 + u];
       s1r[u] = fma(s0r[u], ltw.c1, -(s0i[u] * ltw.s1));
       s1i[u] = fma(s0r[u], ltw.s1, s0i[u] * ltw.c1);
     }
@@ -861,7 +869,9 @@ void launch_hist_copy_b(hipStream_t s, const HistJobB* jobs_dev, int njobs, int 
 //  Formulation C: FFT convolution along the block axis (see ga_kernels.hpp).  One workgroup of 256 threads owns one
 //  N2-point complex sequence in LDS; Stockham autosort passes of radix 8 / 4 (natural order in and out), float32.
 // =====================================================================================================
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {   // explicit fma: 4 instructions, one rounding less per component
+  return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
+}
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 cmul_mi(float2 a) { return make_float2(a.y, -a.x); }   // a * (-i)
