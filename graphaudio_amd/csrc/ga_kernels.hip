@@ -1075,59 +1075,80 @@ __device__ __forceinline__ void fft_own(float2 (&own)[N / 256], float2* a, float
   }
 }
 
-// workgroup = (segment, bin, set): window of N2 block-spectra of the x-row -> FFT -> per column: * taps spectrum,
-// inverse FFT (conjugation trick), store the N2 - P + 1 valid blocks of the y-row
+// Persistent workgroups: grid = (TC_GROUPS, bins).  A workgroup owns one bin and walks over its share of the
+// (set, overlap-save segment) items: window of N2 block-spectra of the x-row -> FFT -> per column: * taps spectrum, inverse
+// FFT (conjugation trick), store the N2 - P + 1 valid blocks of the y-row.  The twiddle table is brought into LDS once
+// per workgroup, the bin's taps spectra stay in L2 (every concurrently running workgroup of the bin reads the same ones),
+// and the NEXT item's window is prefetched into registers while the current item is transformed.
+constexpr int TC_GROUPS = 17;   // 17 x 129 workgroups = 2.9 rounds of the 768 resident slots (3 per CU)
 template <int N2>
-__global__ __launch_bounds__(256) void tconv_kernel(const ConvSetC* __restrict sets, int nblocks, int hist, ConvPlanesB pl,
-                                                    const float2* __restrict twg) {
+__global__ __launch_bounds__(256) void tconv_kernel(const ConvSetC* __restrict sets, int nsets, int nseg, int nblocks, int hist,
+                                                    ConvPlanesB pl, const float2* __restrict twg) {
   constexpr int PT = N2 / 256;
   extern __shared__ float2 lds[];
   float2* bufA = lds;
   float2* bufB = lds + TC_PADDED(N2);
   float2* tw = lds + 2 * TC_PADDED(N2);      // twiddle table exp(-2 pi i j / N2) in LDS
-  // grid = (segment, set, bin): the bin is the slowest index so that all rows of one bin run back to back and the bin's
-  // tap spectra (N2 * 8 B per column) stay in L2 instead of being re-fetched by every workgroup
-  const ConvSetC* __restrict S = &sets[blockIdx.y];
-  const int k = blockIdx.z, seg = blockIdx.x, tid = threadIdx.x;
-  const int P = S->P, ncol = S->ncol;
-  const int L = N2 - (P - 1);
-  const int t0 = seg * L;                      // first output block of this segment
-  if (t0 >= nblocks) return;
+  const int k = blockIdx.y, tid = threadIdx.x;
+  const int total = nsets * nseg;
   for (int i = tid; i < N2; i += 256) tw[PADI(i)] = twg[i];
-  const float* __restrict xr = pl.xr + ((size_t)S->x * kBins + k) * pl.tx;
-  const float* __restrict xi = pl.xi + ((size_t)S->x * kBins + k) * pl.tx;
-  const int b0 = t0 - (P - 1);                 // block of window element 0
-  float2 xf[PT];
-#pragma unroll
-  for (int m = 0; m < PT; m++) {
-    const int blk = b0 + tid + 256 * m;
-    xf[m] = make_float2(0.f, 0.f);
-    if (blk >= -hist && blk < nblocks) xf[m] = make_float2(xr[hist + blk], xi[hist + blk]);
-  }
-  __syncthreads();                             // twiddles visible
-  fft_own<N2>(xf, bufA, bufB, tw, tid);        // xf[m] = spectrum at tid + 256 m ; last pass read bufA
-  const float scale = 1.0f / N2;
-  const int nvalid = min(L, nblocks - t0);
-  for (int j = 0; j < ncol; j++) {
-    const float2* __restrict hs = S->hs[j] + (size_t)k * N2;
-    float2 y[PT];
+
+  auto load_window = [&](int item, float2 (&w)[PT]) {
+    const ConvSetC* __restrict S = &sets[item / nseg];
+    const int seg = item % nseg;
+    const int P = S->P;
+    const int b0 = seg * (N2 - (P - 1)) - (P - 1);     // block of window element 0
+    const float* __restrict xr = pl.xr + ((size_t)S->x * kBins + k) * pl.tx;
+    const float* __restrict xi = pl.xi + ((size_t)S->x * kBins + k) * pl.tx;
 #pragma unroll
     for (int m = 0; m < PT; m++) {
-      float2 p = cmul(xf[m], hs[tid + 256 * m]);
-      y[m] = make_float2(p.x, -p.y);           // conj: ifft(v) = conj(fft(conj(v))) / N
+      const int blk = b0 + tid + 256 * m;
+      w[m] = make_float2(0.f, 0.f);
+      if (blk >= -hist && blk < nblocks) w[m] = make_float2(xr[hist + blk], xi[hist + blk]);
     }
-    // alternate the first buffer so this transform never overwrites what slower threads still read in their last pass
-    if (j & 1) fft_own<N2>(y, bufA, bufB, tw, tid); else fft_own<N2>(y, bufB, bufA, tw, tid);
-    float* __restrict yr = pl.yr + ((size_t)(S->y0 + j) * kBins + k) * pl.ty + t0;
-    float* __restrict yi = pl.yi + ((size_t)(S->y0 + j) * kBins + k) * pl.ty + t0;
+  };
+
+  int item = blockIdx.x;
+  __syncthreads();                             // twiddles visible
+  int flip = 0;
+  while (item < total) {
+    const ConvSetC* __restrict S = &sets[item / nseg];
+    const int seg = item % nseg;
+    const int P = S->P, ncol = S->ncol;
+    const int L = N2 - (P - 1);
+    const int t0 = seg * L;                    // first output block of this segment
+    float2 xf[PT];
+    load_window(item, xf);
+    const int next = item + gridDim.x;
+    if (t0 < nblocks) {
+      // buffers alternate between consecutive transforms so that a fast thread never overwrites what a slower one still reads
+      if (flip) fft_own<N2>(xf, bufB, bufA, tw, tid); else fft_own<N2>(xf, bufA, bufB, tw, tid);
+      flip ^= 1;
+      const float scale = 1.0f / N2;
+      const int nvalid = min(L, nblocks - t0);
+      for (int j = 0; j < ncol; j++) {
+        const float2* __restrict hs = S->hs[j] + (size_t)k * N2;
+        float2 y[PT];
 #pragma unroll
-    for (int m = 0; m < PT; m++) {
-      const int i = tid + 256 * m - (P - 1);   // output block index within the segment
-      if (i >= 0 && i < nvalid) {
-        yr[i] = y[m].x * scale;
-        yi[i] = -y[m].y * scale;
+        for (int m = 0; m < PT; m++) {
+          float2 p = cmul(xf[m], hs[tid + 256 * m]);
+          y[m] = make_float2(p.x, -p.y);       // conj: ifft(v) = conj(fft(conj(v))) / N
+        }
+        if (flip) fft_own<N2>(y, bufB, bufA, tw, tid); else fft_own<N2>(y, bufA, bufB, tw, tid);
+        flip ^= 1;
+        float* __restrict yr = pl.yr + ((size_t)(S->y0 + j) * kBins + k) * pl.ty + t0;
+        float* __restrict yi = pl.yi + ((size_t)(S->y0 + j) * kBins + k) * pl.ty + t0;
+#pragma unroll
+        for (int m = 0; m < PT; m++) {
+          const int i = tid + 256 * m - (P - 1);   // output block index within the segment
+          if (i >= 0 && i < nvalid) {
+            yr[i] = y[m].x * scale;
+            yi[i] = -y[m].y * scale;
+          }
+        }
       }
     }
+    item = next;
   }
 }
 void launch_tconv(hipStream_t s, const ConvSetC* sets_dev, int nsets, int nblocks, int hist, ConvPlanesB pl, int N2, const float2* tw,
@@ -1135,17 +1156,17 @@ void launch_tconv(hipStream_t s, const ConvSetC* sets_dev, int nsets, int nblock
   if (nsets <= 0 || nblocks <= 0) return;
   size_t lds = ((size_t)3 * TC_PADDED(N2)) * sizeof(float2);
   static bool attr_set = false;
-  if (!attr_set) {   // N2 = 4096 needs 100 KB of dynamic LDS (gfx950 has 160 KB per CU)
+  if (!attr_set) {   // N2 = 4096 needs 104 KB of dynamic LDS (gfx950 has 160 KB per CU)
     (void)hipFuncSetAttribute((const void*)tconv_kernel<4096>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
     attr_set = true;
   }
-  for (int z0 = 0; z0 < nsets; z0 += 32768) {
-    int nz = std::min(32768, nsets - z0);
-    // the host guarantees every set of one launch has the same P, hence the same segment length L = N2 - P + 1
-    if (N2 == 1024) hipLaunchKernelGGL(tconv_kernel<1024>, dim3(nseg, nz, kBins), dim3(256), lds, s, sets_dev + z0, nblocks, hist, pl, tw);
-    else if (N2 == 2048) hipLaunchKernelGGL(tconv_kernel<2048>, dim3(nseg, nz, kBins), dim3(256), lds, s, sets_dev + z0, nblocks, hist, pl, tw);
-    else hipLaunchKernelGGL(tconv_kernel<4096>, dim3(nseg, nz, kBins), dim3(256), lds, s, sets_dev + z0, nblocks, hist, pl, tw);
-  }
+  // every set of one launch has the same P, hence the same segment length L = N2 - P + 1
+  const long long total = (long long)nsets * nseg;
+  const int gx = (int)std::min<long long>(total, TC_GROUPS);
+  dim3 grid(gx, kBins), block(256);
+  if (N2 == 1024) hipLaunchKernelGGL(tconv_kernel<1024>, grid, block, lds, s, sets_dev, nsets, nseg, nblocks, hist, pl, tw);
+  else if (N2 == 2048) hipLaunchKernelGGL(tconv_kernel<2048>, grid, block, lds, s, sets_dev, nsets, nseg, nblocks, hist, pl, tw);
+  else hipLaunchKernelGGL(tconv_kernel<4096>, grid, block, lds, s, sets_dev, nsets, nseg, nblocks, hist, pl, tw);
 }
 
 // ---- plane utilities ----------------------------------------------------------------------------------
