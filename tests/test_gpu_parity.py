@@ -207,3 +207,25 @@ def _modulated_gain(ctx):
 def test_gain_audio_rate_modulation_bit_exact():
     ref, got = both(_modulated_gain, 128 * 20)
     assert np.array_equal(ref, got)
+
+
+@pytest.mark.parametrize("taps,voices,time_fft", [
+    (20000, 3, 1),     # P = 157  -> block-axis FFT with N2 = 1024
+    (100000, 2, 1),    # P = 782  -> N2 = 4096 (104 KB of LDS)
+    (40000, 3, 0),     # P = 313  -> formulation B, two tap segments of 256
+    (140000, 9, 0),    # P = 1094 -> formulation A (9 voices share the IR), two tap segments of 1024
+    (140000, 2, 1),    # P = 1094 -> outside the block-axis FFT range: formulation B
+])
+def test_convolver_formulations_and_tap_ranges(taps, voices, time_fft):
+    frames = 128 * 150
+    outs = []
+    for mk in (OracleContext, OfflineAudioContext):
+        ctx = mk(48000)
+        ctx.SetOption("time_fft", time_fft)
+        ch = G.config3_convolver(ctx, voices=voices, taps=taps, frames=frames)
+        outs.append(G.render(ctx, ch, frames))
+        ctx.Dispose()
+    ref, got = outs
+    err = G.rms(ref - got)
+    assert G.rms(ref) > 1e-4
+    assert err <= TOL_RMS and err / G.rms(ref) < 2e-6, (err, err / G.rms(ref))
