@@ -1304,14 +1304,17 @@ __device__ __forceinline__ const float* bcast_ptr(const float* p, int srcLane) {
   unsigned lo = __builtin_amdgcn_readlane((unsigned)v, srcLane), hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), srcLane);
   return (const float*)(((unsigned long long)hi << 32) | lo);
 }
-template <int NSEC>
+// JPW = cascades (jobs) per wavefront.  The recurrence is latency/issue bound, not lane bound: with few jobs it is far
+// better to spread them thinly (4..16 lanes busy per wave, every SIMD of the chip working) than to fill 64 lanes of a
+// handful of waves.  All 64 lanes still cooperate on the coalesced 256-byte row loads / stores of the JPW x 64 tile.
+template <int NSEC, int JPW>
 __global__ __launch_bounds__(64) void biquad_kernel(const BiquadJob* __restrict jobs, int njobs, const BiquadSection* __restrict secs) {
-  __shared__ float tile[64][BQ_TILE + 1];
+  __shared__ float tile[JPW][BQ_TILE + 1];
   const int lane = threadIdx.x;
-  const int j0 = blockIdx.x * 64;
+  const int j0 = blockIdx.x * JPW;
   const int myj = j0 + lane;
-  const bool have = myj < njobs;
-  // every lane keeps ITS job (cascade coefficients and states) in registers; row pointers are broadcast with v_readlane
+  const bool have = lane < JPW && myj < njobs;
+  // every compute lane keeps ITS job (cascade coefficients and states) in registers; row pointers are broadcast with v_readlane
   BiquadJob me{};
   if (have) me = jobs[myj];
   const float* inb = have ? me.in + me.f0 : nullptr;
@@ -1334,12 +1337,12 @@ __global__ __launch_bounds__(64) void biquad_kernel(const BiquadJob* __restrict 
   int64_t nmax = n;
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) nmax = max(nmax, (int64_t)__shfl_xor((long long)nmax, m, 64));
-  const int jcount = min(64, njobs - j0);
+  const int jcount = min(JPW, njobs - j0);
 
-  float pre[64];   // prefetched tile: pre[r] = frame (base + lane) of job j0 + r   (64 coalesced 256-byte loads in flight)
+  float pre[JPW];   // prefetched tile: pre[r] = frame (base + lane) of job j0 + r
   auto fetch = [&](int64_t base) {
 #pragma unroll
-    for (int r = 0; r < 64; r++) {
+    for (int r = 0; r < JPW; r++) {
       const float* p = bcast_ptr(inb, r);
       int64_t nr = __builtin_amdgcn_readlane((int)n, r);   // n < 2^31 frames per segment
       int64_t fi = base + lane;
@@ -1349,54 +1352,58 @@ __global__ __launch_bounds__(64) void biquad_kernel(const BiquadJob* __restrict 
   fetch(0);
   for (int64_t base = 0; base < nmax; base += BQ_TILE) {
 #pragma unroll
-    for (int r = 0; r < 64; r++) tile[r][lane] = pre[r];
+    for (int r = 0; r < JPW; r++) tile[r][lane] = pre[r];
     __syncthreads();
     if (base + BQ_TILE < nmax) fetch(base + BQ_TILE);   // next tile's loads fly during the serial recurrence below
     const int cnt = (int)max<int64_t>(0, min<int64_t>(BQ_TILE, n - base));
-    if (cnt == BQ_TILE) {
-      // register batches of 16 keep LDS latency off the W1/W2 dependency chains
+    if (lane < JPW) {
+      if (cnt == BQ_TILE) {
+        // register batches of 16 keep LDS latency off the W1/W2 dependency chains
 #pragma unroll
-      for (int i0 = 0; i0 < BQ_TILE; i0 += 16) {
-        float xv[16];
+        for (int i0 = 0; i0 < BQ_TILE; i0 += 16) {
+          float xv[16];
 #pragma unroll
-        for (int i = 0; i < 16; i++) xv[i] = tile[lane][i0 + i];
+          for (int i = 0; i < 16; i++) xv[i] = tile[lane][i0 + i];
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-          float x = xv[i];
+          for (int i = 0; i < 16; i++) {
+            float x = xv[i];
+#pragma unroll
+            for (int q = 0; q < NSEC; q++) {
+              float w = x - a1[q] * w1[q] - a2[q] * w2[q];            // BiQuadFilterNode.cs:137
+              float y = b0[q] * w + b1[q] * w1[q] + b2[q] * w2[q];    // :138
+              w2[q] = w1[q];
+              w1[q] = w;
+              x = y;
+            }
+            xv[i] = x;
+          }
+#pragma unroll
+          for (int i = 0; i < 16; i++) tile[lane][i0 + i] = xv[i];
+        }
+      } else {
+        for (int i = 0; i < cnt; i++) {   // the job's last, partial tile
+          float x = tile[lane][i];
 #pragma unroll
           for (int q = 0; q < NSEC; q++) {
-            float w = x - a1[q] * w1[q] - a2[q] * w2[q];            // BiQuadFilterNode.cs:137
-            float y = b0[q] * w + b1[q] * w1[q] + b2[q] * w2[q];    // :138
+            float w = x - a1[q] * w1[q] - a2[q] * w2[q];
+            float y = b0[q] * w + b1[q] * w1[q] + b2[q] * w2[q];
             w2[q] = w1[q];
             w1[q] = w;
             x = y;
           }
-          xv[i] = x;
+          tile[lane][i] = x;
         }
-#pragma unroll
-        for (int i = 0; i < 16; i++) tile[lane][i0 + i] = xv[i];
-      }
-    } else {
-      for (int i = 0; i < cnt; i++) {   // the job's last, partial tile
-        float x = tile[lane][i];
-#pragma unroll
-        for (int q = 0; q < NSEC; q++) {
-          float w = x - a1[q] * w1[q] - a2[q] * w2[q];
-          float y = b0[q] * w + b1[q] * w1[q] + b2[q] * w2[q];
-          w2[q] = w1[q];
-          w1[q] = w;
-          x = y;
-        }
-        tile[lane][i] = x;
       }
     }
     __syncthreads();
-#pragma unroll 8
-    for (int r = 0; r < jcount; r++) {
-      float* q = (float*)bcast_ptr(outb, r);
-      int64_t nr = __builtin_amdgcn_readlane((int)n, r);
-      int64_t fi = base + lane;
-      if (fi < nr) q[fi] = tile[r][lane];
+#pragma unroll
+    for (int r = 0; r < JPW; r++) {
+      if (r < jcount) {
+        float* q = (float*)bcast_ptr(outb, r);
+        int64_t nr = __builtin_amdgcn_readlane((int)n, r);
+        int64_t fi = base + lane;
+        if (fi < nr) q[fi] = tile[r][lane];
+      }
     }
     __syncthreads();
   }
@@ -1408,19 +1415,26 @@ __global__ __launch_bounds__(64) void biquad_kernel(const BiquadJob* __restrict 
     }
   }
 }
+template <int JPW>
+static void launch_biquad_jpw(hipStream_t s, const BiquadJob* jobs_dev, int njobs, const BiquadSection* secs_dev, int nsec) {
+  dim3 g((njobs + JPW - 1) / JPW), b(64);
+  switch (nsec) {
+    case 1: hipLaunchKernelGGL((biquad_kernel<1, JPW>), g, b, 0, s, jobs_dev, njobs, secs_dev); break;
+    case 2: hipLaunchKernelGGL((biquad_kernel<2, JPW>), g, b, 0, s, jobs_dev, njobs, secs_dev); break;
+    case 3: hipLaunchKernelGGL((biquad_kernel<3, JPW>), g, b, 0, s, jobs_dev, njobs, secs_dev); break;
+    case 4: hipLaunchKernelGGL((biquad_kernel<4, JPW>), g, b, 0, s, jobs_dev, njobs, secs_dev); break;
+    case 5: hipLaunchKernelGGL((biquad_kernel<5, JPW>), g, b, 0, s, jobs_dev, njobs, secs_dev); break;
+    case 6: hipLaunchKernelGGL((biquad_kernel<6, JPW>), g, b, 0, s, jobs_dev, njobs, secs_dev); break;
+    case 7: hipLaunchKernelGGL((biquad_kernel<7, JPW>), g, b, 0, s, jobs_dev, njobs, secs_dev); break;
+    default: hipLaunchKernelGGL((biquad_kernel<8, JPW>), g, b, 0, s, jobs_dev, njobs, secs_dev); break;
+  }
+}
 void launch_biquad(hipStream_t s, const BiquadJob* jobs_dev, int njobs, const BiquadSection* secs_dev, int nsec) {
   if (njobs <= 0) return;
-  dim3 g((njobs + 63) / 64), b(64);
-  switch (nsec) {
-    case 1: hipLaunchKernelGGL(biquad_kernel<1>, g, b, 0, s, jobs_dev, njobs, secs_dev); break;
-    case 2: hipLaunchKernelGGL(biquad_kernel<2>, g, b, 0, s, jobs_dev, njobs, secs_dev); break;
-    case 3: hipLaunchKernelGGL(biquad_kernel<3>, g, b, 0, s, jobs_dev, njobs, secs_dev); break;
-    case 4: hipLaunchKernelGGL(biquad_kernel<4>, g, b, 0, s, jobs_dev, njobs, secs_dev); break;
-    case 5: hipLaunchKernelGGL(biquad_kernel<5>, g, b, 0, s, jobs_dev, njobs, secs_dev); break;
-    case 6: hipLaunchKernelGGL(biquad_kernel<6>, g, b, 0, s, jobs_dev, njobs, secs_dev); break;
-    case 7: hipLaunchKernelGGL(biquad_kernel<7>, g, b, 0, s, jobs_dev, njobs, secs_dev); break;
-    default: hipLaunchKernelGGL(biquad_kernel<8>, g, b, 0, s, jobs_dev, njobs, secs_dev); break;
-  }
+  // aim at >= 4 waves per SIMD-quad (1024 SIMDs on the chip) before packing more jobs into a wave
+  if (njobs <= 4096 * 4) launch_biquad_jpw<4>(s, jobs_dev, njobs, secs_dev, nsec);
+  else if (njobs <= 4096 * 16) launch_biquad_jpw<16>(s, jobs_dev, njobs, secs_dev, nsec);
+  else launch_biquad_jpw<64>(s, jobs_dev, njobs, secs_dev, nsec);
 }
 
 // ---- BiQuadFilterNode with automated parameters --------------------------------------------------------
