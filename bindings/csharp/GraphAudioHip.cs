@@ -66,6 +66,9 @@ internal static unsafe partial class GraphAudioHip
     [LibraryImport(Lib, EntryPoint = "ga_node_has_ended")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]
     public static partial int ga_node_has_ended(IntPtr ctx, int node);
 
+    [LibraryImport(Lib, EntryPoint = "ga_poll_ended")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]
+    public static partial int ga_poll_ended(IntPtr ctx, int* outNodeIds, int capacity);
+
     [LibraryImport(Lib, EntryPoint = "ga_input_set_channel_count")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]
     public static partial int ga_input_set_channel_count(IntPtr ctx, int node, int input, int count);
     [LibraryImport(Lib, EntryPoint = "ga_input_set_channel_count_mode")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]

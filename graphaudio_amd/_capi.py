@@ -105,6 +105,7 @@ SIGNATURES = {
     "node_connect_param": (_i, [_vp, _i, _i, _i, _i]),
     "node_disconnect_param": (_i, [_vp, _i, _i, _i, _i]),
     "node_has_ended": (_i, [_vp, _i]),
+    "poll_ended": (_i, [_vp, C.POINTER(_i), _i]),
     "input_set_channel_count": (_i, [_vp, _i, _i, _i]),
     "input_set_channel_count_mode": (_i, [_vp, _i, _i, _i]),
     "input_set_channel_interpretation": (_i, [_vp, _i, _i, _i]),

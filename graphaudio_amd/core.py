@@ -377,12 +377,20 @@ class AudioContextBase:
         return st.as_dict()
 
     def _raise_ended(self):
-        for nid, node in list(self._nodes.items()):
-            if isinstance(node, AudioBufferSourceNode) and nid not in self._ended_seen:
-                if self._api.node_has_ended(self._h, nid) == 1:
-                    self._ended_seen.add(nid)
-                    for cb in node.Ended:
+        """Raise the Ended event (AudioBufferSourceNode.cs:378-389) of sources that finished during the last render."""
+        buf = (C.c_int * 256)()
+        while True:
+            n = self._api.poll_ended(self._h, buf, 256)
+            if n <= 0:
+                break
+            for i in range(n):
+                node = self._nodes.get(buf[i])
+                if node is not None and buf[i] not in self._ended_seen:
+                    self._ended_seen.add(buf[i])
+                    for cb in getattr(node, "Ended", []):
                         cb(node)
+            if n < 256:
+                break
 
     def Dispose(self):  # :243-260
         if self._h:

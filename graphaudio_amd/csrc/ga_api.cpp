@@ -373,6 +373,18 @@ int ga_node_has_ended(ga_context* ctx, int node) {
   return rc < 0 ? rc : r;
 }
 
+int ga_poll_ended(ga_context* ctx, int* out_ids, int capacity) {
+  int n = 0;
+  int rc = guard(ctx, [&](Context& c) {
+    if (!out_ids || capacity < 0) fail(GA_ERR_INVALID_ARGUMENT, "bad buffer");
+    while (n < capacity && !c.endedQueue.empty()) {
+      out_ids[n++] = c.endedQueue.front();
+      c.endedQueue.pop_front();
+    }
+  });
+  return rc < 0 ? rc : n;
+}
+
 int ga_input_set_channel_count(ga_context* ctx, int node, int input_index, int count) {
   return guard(ctx, [&](Context& c) {
     NodeS* n = c.node(node);

@@ -1578,6 +1578,7 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
       s.hasStopped = true;
     }
     if (po.gone && po.goneAt <= n) {
+      if (!s.endedRaised) endedQueue.push_back(srcIds[i]);
       s.endedRaised = true;
       if (po.goneAt == n) pending.push_back([this, id = srcIds[i]]() { doDispose(id); });  // runs in the next block's drain
     }

@@ -299,6 +299,7 @@ struct Context {
 
   int64_t busCapFrames = 0;
   std::vector<float*> busSlabs;
+  std::deque<int> endedQueue;  // sources whose Ended was raised and not yet reported through ga_poll_ended
   uint64_t lastHash = 0;       // control-state hash of the last block of the previous chunk
   int chunkMinDestCh = 0;      // smallest destination channel count over the blocks of the last chunk
   int64_t chunkBlocksDone = 0; // blocks actually executed by the last runChunk

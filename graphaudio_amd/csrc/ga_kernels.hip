@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace ga {
 
@@ -1431,9 +1432,15 @@ static void launch_biquad_jpw(hipStream_t s, const BiquadJob* jobs_dev, int njob
 }
 void launch_biquad(hipStream_t s, const BiquadJob* jobs_dev, int njobs, const BiquadSection* secs_dev, int nsec) {
   if (njobs <= 0) return;
-  // aim at >= 4 waves per SIMD-quad (1024 SIMDs on the chip) before packing more jobs into a wave
-  if (njobs <= 4096 * 4) launch_biquad_jpw<4>(s, jobs_dev, njobs, secs_dev, nsec);
-  else if (njobs <= 4096 * 16) launch_biquad_jpw<16>(s, jobs_dev, njobs, secs_dev, nsec);
+  // measured on MI355X (config 4, 8,192 cascades of 5 sections): ~512 waves on the chip (one per two SIMDs) is the sweet
+  // spot -- 4 / 8 / 16 / 32 jobs per wave took 81 / 65 / 47 / 54 ms.  A wave issues one VALU instruction per ~4 cycles
+  // however many lanes are busy, so fewer, fuller waves only pay once that many waves exist.
+  int per = (njobs + 511) / 512;
+  if (const char* e = getenv("GA_BQ_JPW")) per = atoi(e);   // tuning override
+  if (per <= 4) launch_biquad_jpw<4>(s, jobs_dev, njobs, secs_dev, nsec);
+  else if (per <= 8) launch_biquad_jpw<8>(s, jobs_dev, njobs, secs_dev, nsec);
+  else if (per <= 16) launch_biquad_jpw<16>(s, jobs_dev, njobs, secs_dev, nsec);
+  else if (per <= 32) launch_biquad_jpw<32>(s, jobs_dev, njobs, secs_dev, nsec);
   else launch_biquad_jpw<64>(s, jobs_dev, njobs, secs_dev, nsec);
 }
 

@@ -114,6 +114,9 @@ GA_EXPORT int GA_FN(node_connect_param)(ga_context* ctx, int src, int dst_node, 
 GA_EXPORT int GA_FN(node_disconnect_param)(ga_context* ctx, int src, int dst_node, int dst_param, int output_index);
 /* 1 once a scheduled source has raised Ended (AudioBufferSourceNode.cs:378-389); the host raises the event */
 GA_EXPORT int GA_FN(node_has_ended)(ga_context* ctx, int node);
+/* Bulk form for hosts with thousands of sources: writes the ids of sources whose Ended was raised since the previous
+ * call (at most `capacity`) and returns how many were written; call again while it returns `capacity`. */
+GA_EXPORT int GA_FN(poll_ended)(ga_context* ctx, int* out_node_ids, int capacity);
 
 /* AudioNodeInput.SetChannelCount / SetChannelCountMode / SetChannelInterpretation (AudioNodeInput.cs:41-58) */
 GA_EXPORT int GA_FN(input_set_channel_count)(ga_context* ctx, int node, int input_index, int count);

@@ -1050,7 +1050,7 @@ struct ConvolverNode : Node {
 // ---- AudioBufferSourceNode (Nodes/AudioBufferSourceNode.cs:13-415) ----
 struct SourceNode : Node {
   PlayableBuffer* buffer = nullptr;
-  bool hasStarted = false, hasStopped = false, endedRaised = false;
+  bool hasStarted = false, hasStopped = false, endedRaised = false, endedReported = false;
   double startTime = std::nan(""), stopTime = std::nan("");
   double offset = 0, duration = std::numeric_limits<double>::infinity();
   int64_t playbackPosition = 0;
@@ -1437,6 +1437,23 @@ int gao_node_has_ended(ga_context* ctx, int node) {
     if (n->type == GA_NODE_BUFFER_SOURCE) r = static_cast<SourceNode*>(n)->endedRaised ? 1 : 0;
   });
   return rc < 0 ? rc : r;
+}
+
+int gao_poll_ended(ga_context* ctx, int* out_ids, int capacity) {
+  int n = 0;
+  int rc = guard(ctx, [&](Context& c) {
+    if (!out_ids || capacity < 0) fail(GA_ERR_INVALID_ARGUMENT, "bad buffer");
+    for (auto& np : c.nodes) {
+      if (n >= capacity) break;
+      if (np->type != GA_NODE_BUFFER_SOURCE) continue;
+      auto* s = static_cast<SourceNode*>(np.get());
+      if (s->endedRaised && !s->endedReported) {
+        s->endedReported = true;
+        out_ids[n++] = np->id;
+      }
+    }
+  });
+  return rc < 0 ? rc : n;
 }
 
 int gao_input_set_channel_count(ga_context* ctx, int node, int input_index, int count) {
