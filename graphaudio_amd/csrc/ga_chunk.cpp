@@ -184,15 +184,16 @@ static SrcPlanOut planSource(Context& c, NodeS& s, int64_t n, const std::vector<
     int64_t avail = g.durationEndFrame - s.rsStartPos;
     int64_t need = s.rsBlocks + (n - bs) + 2;
     rs.extend(need + 1);
-    // first trajectory block whose unbounded consumption would exceed the available input
+    // first trajectory block that consumes the LAST available input sample (or would need more): a block that ends with
+    // _playbackPosition == durationEndFrame is already cleared by the reference (AudioBufferSourceNode.cs:360)
     int64_t jx = s.rsBlocks;
     {
       int64_t lo = s.rsBlocks, hi = need - 1;  // consumed at the END of block j = blocks[j+1].consumed
       while (lo < hi) {
         int64_t mid = (lo + hi) >> 1;
-        if (rs.blocks[mid + 1].consumed > avail) hi = mid; else lo = mid + 1;
+        if (rs.blocks[mid + 1].consumed >= avail) hi = mid; else lo = mid + 1;
       }
-      jx = (rs.blocks[lo + 1].consumed > avail) ? lo : INF;
+      jx = (rs.blocks[lo + 1].consumed >= avail) ? lo : INF;
     }
     if (avail <= 0) {
       kData = 0;
@@ -216,7 +217,15 @@ static SrcPlanOut planSource(Context& c, NodeS& s, int64_t n, const std::vector<
   int64_t playEnd = std::min(kData, kGone == INF ? INF : kGone + 1);  // exclusive
   int64_t rel = 0;
   if (playEnd > 0) {
-    s.spans.push_back(SrcSpan{bs, SRC_PLAY, pos, s.rsBlocks});
+    if (s.loop && rate1 && pos >= g.loopEndFrame && g.loopEndFrame > g.loopStartFrame) {
+      // start offset beyond the loop end: the first block restarts exactly at loopStart (`pos = loopStartFrame`,
+      // AudioBufferSourceNode.cs:197-200) whereas _playbackPosition itself wraps modulo the loop length afterwards
+      // (:226-234).  Reading from `loopEnd` makes the loop kernel's modular map start at loopStart for that block.
+      s.spans.push_back(SrcSpan{bs, SRC_PLAY, g.loopEndFrame, s.rsBlocks});
+      if (playEnd > 1 && bs + 1 < n) s.spans.push_back(SrcSpan{bs + 1, SRC_PLAY, pos + kBlock, s.rsBlocks + 1});
+    } else {
+      s.spans.push_back(SrcSpan{bs, SRC_PLAY, pos, s.rsBlocks});
+    }
     rel = playEnd;
   }
   if (kData < (kGone == INF ? INF : kGone + 1) && bs + kData < n) {
@@ -626,22 +635,9 @@ struct Exec {
 // ======================================================================================================
 // convolver rows <-> groups
 // ======================================================================================================
-static ConvGroup* groupFor(Context& c, const std::shared_ptr<IrSpectra>& ir, int ch) {
-  auto key = std::make_pair(ir.get(), ch);
-  auto it = c.groupOf.find(key);
-  if (it != c.groupOf.end()) return it->second;
-  auto g = std::make_unique<ConvGroup>();
-  g->ir = ir;
-  g->irCh = ch;
-  g->P = ir->P;
-  ConvGroup* gp = g.get();
-  c.groups.push_back(std::move(g));
-  c.groupOf[key] = gp;
-  return gp;
-}
-
 // make sure the group's state arrays cover all rows; new rows start from zero state
-static void ensureGroupState(Context& c, ConvGroup& g) {
+void Context::ensureGroupState(ConvGroup& g) {
+  Context& c = *this;
   int need = (int)roundup(std::max<size_t>(g.rows.size(), 1), 128);
   if (need <= g.rp) return;
   const int hist = g.P - 1;
@@ -919,7 +915,7 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
       }
       for (auto& rr : nd.convRows) {
         ConvGroup& g = *rr.group;
-        ensureGroupState(*this, g);
+        ensureGroupState(g);
         const int ty_ = (int)roundup(n, 64), tx_ = ty_ + g.P + 128;
         xMax = std::max(xMax, (size_t)kBins * tx_ * g.rp * sizeof(float));
         yMax = std::max(yMax, (size_t)kBins * ty_ * g.rp * sizeof(float));
@@ -1176,7 +1172,8 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
     struct GroupLess {
       bool operator()(const ConvGroup* a, const ConvGroup* b) const {
         if (a->ir.get() != b->ir.get()) return a->ir.get() < b->ir.get();
-        return a->irCh < b->irCh;
+        if (a->irCh != b->irCh) return a->irCh < b->irCh;
+        return a->depth < b->depth;
       }
     };
     std::map<ConvGroup*, std::vector<std::pair<int, int>>, GroupLess> active;

@@ -240,6 +240,37 @@ void Context::releaseConvState(NodeS& n) {
   n.bOvCur = 0;
 }
 
+// one row (= one PartitionedConvolver instance) in the shared-IR group of (IR, IR channel, convolver depth)
+ConvRowRef Context::addGroupRow(const std::shared_ptr<IrSpectra>& ir, int ch, int depth, int nodeId) {
+  auto key = std::make_tuple(ir.get(), ch, depth);
+  ConvGroup* g;
+  auto it = groupOf.find(key);
+  if (it == groupOf.end()) {
+    auto ng = std::make_unique<ConvGroup>();
+    ng->ir = ir;
+    ng->irCh = ch;
+    ng->depth = depth;
+    ng->P = ir->P;
+    g = ng.get();
+    groups.push_back(std::move(ng));
+    groupOf[key] = g;
+  } else {
+    g = it->second;
+  }
+  int idx = (int)g->rows.size();   // rows are append-only while a group holds live state
+  g->rows.push_back({nodeId, ch});
+  if (idx < g->rp && g->histR) {   // the column may hold stale scratch data: a new convolver starts from zero state
+    const int hist = g->P - 1;
+    if (hist > 0) {
+      GA_HIP(hipMemset2DAsync(g->histR + idx, (size_t)g->rp * 4, 0, 4, (size_t)kBins * hist, stream));
+      GA_HIP(hipMemset2DAsync(g->histI + idx, (size_t)g->rp * 4, 0, 4, (size_t)kBins * hist, stream));
+    }
+    GA_HIP(hipMemsetAsync(g->overlap[0] + (size_t)idx * kBlock, 0, kBlock * 4, stream));
+    GA_HIP(hipMemsetAsync(g->overlap[1] + (size_t)idx * kBlock, 0, kBlock * 4, stream));
+  }
+  return ConvRowRef{g, idx};
+}
+
 // Decide, for convolver nodes that do not have DSP state yet, which formulation serves them: nodes sharing an impulse
 // response with at least 7 others become rows of the shared-IR GEMM (A); nodes with a (nearly) private IR use the
 // per-node formulation (B), whose state is O(P) per input channel instead of O(P * 128 rows) per IR channel.
@@ -250,7 +281,32 @@ void Context::assignConvPaths(const std::vector<int>& topo) {
     NodeS& nd = *nodes[id];
     if (nd.type != GA_NODE_CONVOLVER || !nd.ir) continue;
     users[nd.ir.get()]++;
-    if (nd.convPath == 1) hasA[nd.ir.get()] = true;
+    if (nd.convPath == 1) {
+      hasA[nd.ir.get()] = true;
+      // a group is executed once per chunk at ONE convolver depth; a graph edit that moved this node to another depth
+      // moves its rows (FDL column + overlap tail) to the group of that depth
+      for (size_t slot = 0; slot < nd.convRows.size(); slot++) {
+        ConvRowRef old = nd.convRows[slot];
+        if (old.group->depth == nd.depth) continue;
+        ConvRowRef nw = addGroupRow(nd.ir, old.group->irCh, nd.depth, id);
+        ensureGroupState(*nw.group);
+        ConvGroup& og = *old.group;
+        ConvGroup& ng = *nw.group;
+        const int hist = og.P - 1;
+        if (hist > 0 && !og.histZero && og.histR) {
+          GA_HIP(hipMemcpy2DAsync(ng.histR + nw.idx, (size_t)ng.rp * 4, og.histR + old.idx, (size_t)og.rp * 4, 4,
+                                  (size_t)kBins * hist, hipMemcpyDeviceToDevice, stream));
+          GA_HIP(hipMemcpy2DAsync(ng.histI + nw.idx, (size_t)ng.rp * 4, og.histI + old.idx, (size_t)og.rp * 4, 4,
+                                  (size_t)kBins * hist, hipMemcpyDeviceToDevice, stream));
+          ng.histZero = false;   // (a fresh group's arrays are zero-filled, so the other columns stay correct)
+        }
+        if (og.overlap[og.ovCur])
+          GA_HIP(hipMemcpyAsync(ng.overlap[ng.ovCur] + (size_t)nw.idx * kBlock, og.overlap[og.ovCur] + (size_t)old.idx * kBlock,
+                                kBlock * 4, hipMemcpyDeviceToDevice, stream));
+        og.rows[old.idx] = {-1, 0};
+        nd.convRows[slot] = nw;
+      }
+    }
   }
   for (int id : topo) {
     NodeS& nd = *nodes[id];
@@ -260,34 +316,7 @@ void Context::assignConvPaths(const std::vector<int>& topo) {
     const bool pathC = useTimeFft && ir->P > 64 && ir->P <= 1024;   // FFT along the block axis (N2 <= 4096)
     const bool pathA = !pathC && (hasA[ir] || users[ir] >= 8);
     if (pathA) {
-      for (int ch = 0; ch < channels; ch++) {
-        auto key = std::make_pair(ir, ch);
-        ConvGroup* g;
-        auto it = groupOf.find(key);
-        if (it == groupOf.end()) {
-          auto ng = std::make_unique<ConvGroup>();
-          ng->ir = nd.ir;
-          ng->irCh = ch;
-          ng->P = ir->P;
-          g = ng.get();
-          groups.push_back(std::move(ng));
-          groupOf[key] = g;
-        } else {
-          g = it->second;
-        }
-        int idx = (int)g->rows.size();   // rows are append-only while a group holds live state
-        g->rows.push_back({id, ch});
-        if (idx < g->rp && g->histR) {   // the column may hold stale scratch data: a new convolver starts from zero state
-          const int hist = g->P - 1;
-          if (hist > 0) {
-            GA_HIP(hipMemset2DAsync(g->histR + idx, (size_t)g->rp * 4, 0, 4, (size_t)kBins * hist, stream));
-            GA_HIP(hipMemset2DAsync(g->histI + idx, (size_t)g->rp * 4, 0, 4, (size_t)kBins * hist, stream));
-          }
-          GA_HIP(hipMemsetAsync(g->overlap[0] + (size_t)idx * kBlock, 0, kBlock * 4, stream));
-          GA_HIP(hipMemsetAsync(g->overlap[1] + (size_t)idx * kBlock, 0, kBlock * 4, stream));
-        }
-        nd.convRows.push_back(ConvRowRef{g, idx});
-      }
+      for (int ch = 0; ch < channels; ch++) nd.convRows.push_back(addGroupRow(nd.ir, ch, nd.depth, id));
       nd.convPath = 1;
     } else {
       nd.bInCh = nd.isTrueStereo ? 2 : channels;

@@ -18,6 +18,7 @@
 #include <functional>
 #include <limits>
 #include <map>
+#include <tuple>
 #include <memory>
 #include <string>
 #include <unordered_map>
@@ -191,6 +192,7 @@ struct Segment {
 struct ConvGroup {
   std::shared_ptr<IrSpectra> ir;
   int irCh = 0;
+  int depth = 0;                          // convolver depth the group is executed at (one pass per chunk)
   int P = 0;
   std::vector<std::pair<int, int>> rows;  // (node id, row slot) ; node id < 0 = free row
   int rp = 0;                             // allocated (padded) rows of the state arrays
@@ -231,7 +233,7 @@ struct Context {
   std::vector<std::unique_ptr<PlayBuf>> buffers;
   std::map<std::pair<int, int>, std::shared_ptr<IrSpectra>> irCache;  // (buffer id, normalize)
   std::vector<std::unique_ptr<ConvGroup>> groups;
-  std::map<std::pair<IrSpectra*, int>, ConvGroup*> groupOf;
+  std::map<std::tuple<IrSpectra*, int, int>, ConvGroup*> groupOf;   // (IR, IR channel, depth)
   std::map<uint64_t, std::unique_ptr<Resampler>> resamplers;          // keyed by rate bits
   std::string lastError;
   ga_stats stats{};
@@ -288,6 +290,8 @@ struct Context {
   std::shared_ptr<IrSpectra> irSpectra(int bufId, bool normalize);
   void releaseConvState(NodeS& n);
   void assignConvPaths(const std::vector<int>& topo);
+  ConvRowRef addGroupRow(const std::shared_ptr<IrSpectra>& ir, int ch, int depth, int nodeId);
+  void ensureGroupState(ConvGroup& g);
   const float2* twiddlesC(int N2);
   void ensureTapSpectra(IrSpectra& ir);
   bool fft64 = false;            // option "fft64": double-precision 256-point transforms in the B-layout kernels (reference-like)

@@ -229,3 +229,70 @@ def test_convolver_formulations_and_tap_ranges(taps, voices, time_fft):
     err = G.rms(ref - got)
     assert G.rms(ref) > 1e-4
     assert err <= TOL_RMS and err / G.rms(ref) < 2e-6, (err, err / G.rms(ref))
+
+
+def _chained_shared_ir(ctx, voices=10, taps=700, frames=128 * 40, hold=None):
+    """`voices` sources, each through TWO convolvers in series that all share one impulse response (the shared-IR
+    formulation then holds rows of one IR at two convolver depths)."""
+    rng = np.random.default_rng(77)
+    ctx.Destination.SetChannelCount(2)
+    ir = PlayableAudioBuffer.FromChannelArrays([(rng.standard_normal(taps) * 0.05).astype(np.float32) for _ in range(2)], 48000)
+    for v in range(voices):
+        s = AudioBufferSourceNode(ctx)
+        s.Buffer = PlayableAudioBuffer.FromChannelArrays([(rng.standard_normal(frames) * 0.25).astype(np.float32)], 48000)
+        c1 = ConvolverNode(ctx)
+        c1.Buffer = ir
+        c2 = ConvolverNode(ctx)
+        c2.Buffer = ir
+        s.Connect(c1)
+        c1.Connect(c2)
+        c2.Connect(ctx.Destination)
+        s.Start(0.0)
+        if hold is not None:
+            hold.append((s, c1, c2))
+    return 2
+
+
+@pytest.mark.parametrize("chunk", [0, 7])
+def test_shared_ir_convolvers_in_series(chunk):
+    frames = 128 * 40
+    outs = []
+    for mk in (OracleContext, OfflineAudioContext):
+        ctx = mk(48000)
+        ctx.SetOption("time_fft", 0)
+        if chunk:
+            ctx.SetOption("max_chunk_blocks", chunk)
+        ch = _chained_shared_ir(ctx, frames=frames)
+        outs.append(G.render(ctx, ch, frames))
+        ctx.Dispose()
+    ref, got = outs
+    err = G.rms(ref - got)
+    assert G.rms(ref) > 1e-4
+    assert err <= TOL_RMS and err / G.rms(ref) < 2e-6, (err, err / G.rms(ref))
+
+
+def test_shared_ir_row_follows_depth_change():
+    """A graph edit between renders puts a convolver behind another one: its filter state must move with it."""
+    frames = 128 * 30
+    outs = []
+    for mk in (OracleContext, OfflineAudioContext):
+        ctx = mk(48000)
+        ctx.SetOption("time_fft", 0)
+        hold = []
+        ch = _chained_shared_ir(ctx, frames=frames, hold=hold)
+        out = np.zeros((ch, frames), np.float32)
+        ctx.Render(out, 128 * 12, 0)
+        # voice 0: source -> c1 -> c2   becomes   source -> c2 -> c1 (c1 depth 0 -> 1, c2 depth 1 -> 0)
+        s, c1, c2 = hold[0]
+        s.Disconnect(c1)
+        c1.Disconnect(c2)
+        c2.Disconnect(ctx.Destination)
+        s.Connect(c2)
+        c2.Connect(c1)
+        c1.Connect(ctx.Destination)
+        ctx.Render(out, frames - 128 * 12, 128 * 12)
+        outs.append(out)
+        ctx.Dispose()
+    ref, got = outs
+    err = G.rms(ref - got)
+    assert err <= TOL_RMS and err / G.rms(ref) < 2e-6, (err, err / G.rms(ref))
