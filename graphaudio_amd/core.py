@@ -278,8 +278,7 @@ class ConvolverNode(AudioNode):  # Nodes/ConvolverNode.cs:10-176
 
     @Buffer.setter
     def Buffer(self, value: Optional[PlayableAudioBuffer]):  # :25-79
-        if value is self._buffer:
-            return
+        # the `_buffer == value` early-out (:30) is decided natively: it compares with the last EXECUTED swap
         bid = -1 if value is None else value._native_id(self.Context)
         self.Context._call("convolver_set_buffer", self._id, bid)
         self._buffer = value

@@ -564,6 +564,12 @@ int ga_convolver_set_buffer(ga_context* ctx, int node, int buffer_id) {
   return guard(ctx, [&](Context& c) {  // ConvolverNode.Buffer setter, ConvolverNode.cs:25-79
     NodeS* n = typed(c, node, GA_NODE_CONVOLVER);
     Context* cp = &c;
+    // `if (_buffer == value) return;` (:30) compares with the buffer of the last EXECUTED swap: a swap that is still
+    // queued does not count, so A -> B -> A between two blocks ends on B
+    if (n->irBuf == (buffer_id < 0 ? -1 : buffer_id)) {
+      if (buffer_id >= 0) (void)c.buffer(buffer_id);
+      return;
+    }
     if (buffer_id < 0) {
       c.post([cp, node]() {
         NodeS& nd = *cp->nodes[node];

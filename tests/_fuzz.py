@@ -1,13 +1,13 @@
 """Random graph generator shared by the fuzz tests: builds the SAME random graph on any context."""
 import numpy as np
 
-from graphaudio_amd import (AudioBufferSourceNode, BiQuadFilterNode, ChannelCountMode, ConvolverNode, FilterType,
-                            GainNode, PlayableAudioBuffer)
+from graphaudio_amd import (AudioBufferSourceNode, BiQuadFilterNode, ChannelCountMode, ChannelInterpretation, ConvolverNode,
+                            FilterType, GainNode, PlayableAudioBuffer)
 
 SR = 48000
 
 
-def build_random_graph(ctx, seed, frames, keep=None):
+def build_random_graph(ctx, seed, frames, keep=None, handles=None):
     """Sources -> random chains (gain / biquad / convolver) -> optional shared bus nodes -> destination."""
     rng = np.random.default_rng(seed)
     dest_ch = int(rng.choice([1, 2, 2, 4]))
@@ -44,6 +44,8 @@ def build_random_graph(ctx, seed, frames, keep=None):
             s.PlaybackRate.Value = float(rng.choice([0.5, 1.25]))
             s.Loop = False
         node = s
+        if handles is not None:
+            handles.setdefault("sources", []).append(s)
         for _ in range(int(rng.integers(0, 4))):
             kind = rng.choice(["gain", "gain_auto", "biquad", "biquad", "conv_shared", "conv_private"])
             if kind == "gain":
@@ -77,6 +79,8 @@ def build_random_graph(ctx, seed, frames, keep=None):
                 n.Inputs[0].SetChannelCountMode(ChannelCountMode(int(rng.integers(0, 3))))
             node.Connect(n)
             node = n
+            if handles is not None:
+                handles.setdefault(type(n).__name__, []).append(n)
         target = buses[int(rng.integers(0, len(buses)))] if buses and rng.random() < 0.6 else ctx.Destination
         live = keep is None or v in keep  # (minimiser hook: unconnected voices are never pulled)
         if live:
@@ -90,4 +94,142 @@ def build_random_graph(ctx, seed, frames, keep=None):
             s.Start(when)
         if rng.random() < 0.2:
             s.Stop(float(rng.uniform(when, frames / SR)))
+    if handles is not None:
+        handles.update(buses=buses, shared_ir=shared_ir)
     return dest_ch
+
+
+def run_random_session(ctx, seed, frames=128 * 48, max_piece=128 * 9):
+    """Render a random graph in random pieces and EDIT it between the pieces (parameter writes and automation, stop,
+    new voices, dispose, rewiring, impulse-response swaps, audio-rate modulation, channel settings).  The same seed
+    replays the same session on any context.  Returns (output, log of (piece, action, exception type or None))."""
+    h = {}
+    ch = build_random_graph(ctx, seed, frames, handles=h)
+    rng = np.random.default_rng(seed ^ 0x5EED)
+    out = np.zeros((ch, frames), np.float32)
+    log = []
+    gains = h.get("GainNode", []) + h["buses"]
+    biquads = h.get("BiQuadFilterNode", [])
+    convs = h.get("ConvolverNode", [])
+    sources = h.get("sources", [])
+    everything = lambda: gains + biquads + convs + sources
+    dead = set()
+
+    def pick(lst):
+        lst = [x for x in lst if id(x) not in dead]
+        return lst[int(rng.integers(0, len(lst)))] if lst else None
+
+    def new_voice(now):
+        s = AudioBufferSourceNode(ctx)
+        n = int(rng.integers(200, 3000))
+        s.Buffer = PlayableAudioBuffer.FromChannelArrays(
+            [(rng.standard_normal(n) * 0.2).astype(np.float32) for _ in range(int(rng.choice([1, 2])))], SR)
+        if rng.random() < 0.5:
+            s.Loop = True
+        tail = s
+        if rng.random() < 0.5:
+            g = GainNode(ctx)
+            g.Gain.Value = float(rng.uniform(0.1, 1.0))
+            s.Connect(g)
+            gains.append(g)
+            tail = g
+        tgt = pick(h["buses"]) if rng.random() < 0.5 else None
+        tail.Connect(tgt if tgt is not None else ctx.Destination)
+        s.Start(now + float(rng.choice([0.0, rng.uniform(0, 0.02)])))
+        sources.append(s)
+
+    def act(now):
+        kind = str(rng.choice(["gain_value", "gain_sched", "gain_cancel", "bq_value", "bq_type", "bq_ramp", "stop", "voice",
+                               "dispose", "rewire", "ir_swap", "modulate", "dest_ch", "interp", "loop_toggle"]))
+        if kind == "gain_value":
+            g = pick(gains)
+            if g: g.Gain.Value = float(rng.uniform(0, 1.2))
+        elif kind == "gain_sched":
+            g = pick(gains)
+            if g:
+                t = now + float(rng.uniform(0, 0.02))
+                m = int(rng.integers(0, 4))
+                if m == 0: g.Gain.SetValueAtTime(float(rng.uniform(0, 1)), t)
+                elif m == 1: g.Gain.LinearRampToValueAtTime(float(rng.uniform(0, 1)), t + 0.01)
+                elif m == 2:
+                    g.Gain.SetValueAtTime(float(rng.uniform(0.1, 1)), t)
+                    g.Gain.ExponentialRampToValueAtTime(float(rng.uniform(0.05, 1)), t + float(rng.uniform(0.003, 0.03)))
+                else: g.Gain.SetTargetAtTime(float(rng.uniform(0, 1)), t, float(rng.uniform(0.001, 0.02)))
+        elif kind == "gain_cancel":
+            g = pick(gains)
+            if g: g.Gain.CancelScheduledValues(now + float(rng.uniform(0, 0.02)))
+        elif kind == "bq_value":
+            b = pick(biquads)
+            if b:
+                b.Frequency.Value = float(rng.uniform(300, 12000))
+                if rng.random() < 0.5: b.Q.Value = float(rng.uniform(0.3, 3))
+        elif kind == "bq_type":
+            b = pick(biquads)
+            if b: b.Type = FilterType(int(rng.integers(0, 8)))
+        elif kind == "bq_ramp":
+            b = pick(biquads)
+            if b:
+                b.Frequency.SetValueAtTime(float(rng.uniform(300, 8000)), now)
+                b.Frequency.LinearRampToValueAtTime(float(rng.uniform(300, 8000)), now + float(rng.uniform(0.005, 0.03)))
+        elif kind == "stop":
+            s = pick(sources)
+            if s: s.Stop(now + float(rng.choice([0.0, rng.uniform(0, 0.02)])))
+        elif kind == "voice":
+            new_voice(now)
+        elif kind == "dispose":
+            n = pick(everything())
+            if n and not any(n is b for b in h["buses"]):
+                n.Dispose()
+                dead.add(id(n))
+        elif kind == "rewire":
+            n = pick(gains + biquads + convs)
+            if n and not any(n is b for b in h["buses"]):
+                n.Disconnect()
+                tgt = pick(h["buses"]) if rng.random() < 0.5 else None
+                n.Connect(tgt if tgt is not None else ctx.Destination)
+        elif kind == "ir_swap":
+            c = pick(convs)
+            if c:
+                if rng.random() < 0.4:
+                    c.Buffer = h["shared_ir"]
+                else:
+                    taps = int(rng.integers(10, 900))
+                    c.Buffer = PlayableAudioBuffer.FromChannelArrays(
+                        [(rng.standard_normal(taps) * 0.1).astype(np.float32) for _ in range(int(rng.choice([1, 2])))], SR)
+        elif kind == "modulate":
+            g = pick(gains)
+            if g:
+                lfo = AudioBufferSourceNode(ctx)
+                lfo.Buffer = PlayableAudioBuffer.FromMonoArray((rng.standard_normal(700) * 0.3).astype(np.float32), SR)
+                lfo.Loop = True
+                lfo.Connect(g.Gain)
+                lfo.Start(now)
+                sources.append(lfo)
+        elif kind == "dest_ch":
+            ctx.Destination.SetChannelCount(int(rng.integers(ch, 5)))
+        elif kind == "interp":
+            n = pick(gains + biquads)
+            if n: n.Inputs[0].SetChannelInterpretation(ChannelInterpretation(int(rng.integers(0, 2))))
+        elif kind == "loop_toggle":
+            s = pick(sources)
+            if s and s.Buffer is not None and s.Buffer.SampleRate == SR and s.PlaybackRate.Value == 1.0:
+                s.Loop = not s.Loop
+        return kind
+
+    global last_pieces
+    last_pieces = []
+    pos = 0
+    piece = 0
+    while pos < frames:
+        n = int(min(frames - pos, rng.integers(1, max_piece)))
+        ctx.Render(out, n, pos)
+        pos += n
+        piece += 1
+        last_pieces.append(pos)
+        for _ in range(int(rng.integers(0, 4))):
+            try:
+                k = act(ctx.CurrentTime)
+                log.append((piece, k, None))
+            except Exception as e:  # the other implementation must raise the same exception type at the same point
+                log.append((piece, "?", type(e).__name__))
+    return out, log

@@ -48,3 +48,27 @@ def test_random_graph_matches_oracle(seed):
     err = G.rms(ref - got)
     scale = max(G.rms(ref), 1e-3)
     assert err <= 1e-5 and err <= 2e-5 * scale, (seed, err, scale)   # north_star: <= 1e-5 RMS per sample
+
+
+def _session_pair(seed, chunk=11):
+    from tests._fuzz import run_random_session
+    o = OracleContext(48000)
+    ref, ref_log = run_random_session(o, seed)
+    h = OfflineAudioContext(48000)
+    h.SetOption("max_chunk_blocks", chunk)
+    got, got_log = run_random_session(h, seed)
+    return ref, ref_log, got, got_log
+
+
+@pytest.mark.parametrize("seed", list(range(60)))
+def test_random_edit_session_matches_oracle(seed):
+    """The graph is edited between render pieces (parameter writes, automation, stop, new voices, dispose, rewiring,
+    impulse-response swaps, audio-rate modulation, channel settings): same output and the same exceptions."""
+    try:
+        ref, ref_log, got, got_log = _session_pair(seed)
+    except NotSupportedException as e:
+        pytest.skip(f"session uses a feature outside the device path: {e}")
+    assert ref_log == got_log
+    err = G.rms(ref - got)
+    scale = max(G.rms(ref), 1e-3)
+    assert err <= 1e-5 and err <= 2e-5 * scale, (seed, err, scale)

@@ -296,3 +296,32 @@ def test_shared_ir_row_follows_depth_change():
     ref, got = outs
     err = G.rms(ref - got)
     assert err <= TOL_RMS and err / G.rms(ref) < 2e-6, (err, err / G.rms(ref))
+
+
+def test_convolver_buffer_swap_back_while_queued_is_ignored():
+    """ConvolverNode.cs:30 compares with the buffer of the last EXECUTED swap: A -> B -> A between two blocks ends on B."""
+    rng = np.random.default_rng(5)
+    irA = PlayableAudioBuffer.FromMonoArray((rng.standard_normal(300) * 0.1).astype(np.float32), 48000)
+    irB = PlayableAudioBuffer.FromMonoArray((rng.standard_normal(500) * 0.1).astype(np.float32), 48000)
+    x = (rng.standard_normal(128 * 20) * 0.25).astype(np.float32)
+    outs = []
+    for mk in (OracleContext, OfflineAudioContext):
+        ctx = mk(48000)
+        ctx.Destination.SetChannelCount(1)
+        s = AudioBufferSourceNode(ctx)
+        s.Buffer = PlayableAudioBuffer.FromMonoArray(x, 48000)
+        c = ConvolverNode(ctx)
+        c.Buffer = irA
+        s.Connect(c)
+        c.Connect(ctx.Destination)
+        s.Start(0.0)
+        out = np.zeros((1, 128 * 16), np.float32)
+        ctx.Render(out, 128 * 6, 0)
+        c.Buffer = irB
+        c.Buffer = irA   # ignored: the executed buffer is still irA
+        ctx.Render(out, 128 * 10, 128 * 6)
+        outs.append(out)
+        ctx.Dispose()
+    ref, got = outs
+    assert G.rms(ref[:, 128 * 8:]) > 1e-4
+    assert G.rms(ref - got) <= 2e-6 * G.rms(ref)
