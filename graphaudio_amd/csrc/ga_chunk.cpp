@@ -85,7 +85,7 @@ struct SrcGeom {
 };
 static SrcGeom sourceGeom(Context& c, NodeS& s, PlayBuf& b) {
   SrcGeom g;
-  float playbackRate = s.params[0].value;  // k-rate, no automation on the device path yet
+  float playbackRate = s.params[0].value;  // k-rate; a timeline on it is handled by the general replay (gsrReplayBlock)
   double sampleRateRatio = b.sampleRate / (double)c.sampleRate;
   g.effectiveRate = sampleRateRatio * playbackRate;
   g.loopStartFrame = (int64_t)(s.loopStart * b.sampleRate);
@@ -112,7 +112,8 @@ static Resampler& resamplerFor(Context& c, double rate) {
 }
 
 // bounded replay of ONE block of CubicResampler.Process (CubicResampler.cs:26-63) from a trajectory state
-static void resampleBlockBounded(const ResampleBlock& st, double rate, int64_t avail, int& produced, int64_t& consumedAfter) {
+static void resampleBlockBounded(const ResampleBlock& st, double rate, int64_t avail, int& produced, int64_t& consumedAfter,
+                                 double* posAfter = nullptr, int* readyAfter = nullptr) {
   int64_t in = st.consumed;
   double Pos = st.pos;
   int ready = st.ready;
@@ -132,6 +133,134 @@ static void resampleBlockBounded(const ResampleBlock& st, double rate, int64_t a
     }
   }
   consumedAfter = in;
+  if (posAfter) *posAfter = Pos;
+  if (readyAfter) *readyAfter = ready;
+}
+
+// ---- general source replay: AudioBufferSourceNode.Process for ONE block on indices only (see GsrBlock) ----
+struct GsrState {
+  int64_t w[4];
+  double pos;
+  int ready;
+  int64_t pp;
+};
+static inline void gsrFeed(GsrState& st, int64_t idx) {  // CubicResampler.Shift, :91-97
+  st.w[0] = st.w[1];
+  st.w[1] = st.w[2];
+  st.w[2] = st.w[3];
+  st.w[3] = idx;
+}
+// CubicResampler.Process (:26-63) on an index stream at(k), k < inLen
+template <class At>
+static void gsrProcess(GsrState& st, At at, int inLen, int outLen, double rate, int& consumed, int& produced) {
+  int inPos = 0, outPos = 0;
+  while (st.ready < 4 && inPos < inLen) {
+    gsrFeed(st, at(inPos++));
+    st.ready++;
+  }
+  if (st.ready < 4) {
+    consumed = inPos;
+    produced = 0;
+    return;
+  }
+  while (outPos < outLen) {
+    int consume = (int)st.pos;
+    if (inPos + consume > inLen) break;
+    for (int i = 0; i < consume; i++) gsrFeed(st, at(inPos++));
+    st.pos -= consume;
+    outPos++;
+    st.pos += rate;
+  }
+  consumed = inPos;
+  produced = outPos;
+}
+// returns true when the block is an END block (`!hasMoreData || (!_loop && _playbackPosition >= durationEndFrame)`, :360)
+static bool gsrReplayBlock(NodeS& s, const SrcGeom& g, PlayBuf& b, Context& c, float playbackRate, GsrState& st, GsrBlock& d) {
+  const double effectiveRate = (b.sampleRate / (double)c.sampleRate) * playbackRate;
+  const int64_t loopStart = g.loopStartFrame, loopEnd = g.loopEndFrame, durEnd = g.durationEndFrame, len = b.length;
+  const bool loop = s.loop;
+  bool hasMore = false;
+  int64_t first = -1;
+  int outIdx = 0;
+  d.pp = st.pp;
+  d.rate = effectiveRate;
+  d.pad_ = 0;
+  auto snap = [&]() {
+    for (int k = 0; k < 4; k++) d.w[k] = st.w[k];
+    d.pos = st.pos;
+    d.ready = st.ready;
+  };
+  if (effectiveRate == 1.0) {  // :186-235
+    d.copy = 1;
+    snap();
+    int64_t pos = st.pp;
+    while (outIdx < kBlock) {
+      if (loop && pos >= loopEnd) pos = loopStart;
+      if (pos >= durEnd && !loop) break;
+      int64_t endFrame = loop ? loopEnd : std::min(durEnd, len);
+      int available = (int)std::min<int64_t>(endFrame - pos, kBlock - outIdx);
+      if (available <= 0) break;
+      if (first < 0) first = pos;
+      pos += available;
+      outIdx += available;
+      hasMore = true;
+    }
+    st.pp += kBlock;
+  } else {  // :236-358
+    d.copy = 0;
+    if (s.rsChannels != b.channels) {  // `_resamplers` (re)created and cleared (:238-245)
+      st.w[0] = st.w[1] = st.w[2] = st.w[3] = -1;
+      st.pos = 0.0;
+      st.ready = 0;
+      s.rsChannels = b.channels;
+    }
+    snap();
+    int64_t pos = st.pp, consumedThis = 0;
+    int guard = 0;
+    while (outIdx < kBlock) {
+      if (++guard > 4096) fail(GA_ERR_UNSUPPORTED, "source loop of zero length with resampling never finishes a block in the reference");
+      if (loop && pos >= loopEnd) pos = loopStart;
+      if (pos >= durEnd && !loop) break;
+      int64_t endFrame = loop ? loopEnd : std::min(durEnd, len);
+      int available = (int)std::min<int64_t>(endFrame - pos, len - pos);
+      if (available <= 0) {
+        if (loop) {
+          pos = loopStart;
+          consumedThis = pos - st.pp;
+          continue;
+        }
+        break;
+      }
+      if (first < 0) first = pos;
+      int consumed = 0, produced = 0;
+      if (loop && pos + available >= loopEnd - 4) {  // the 512-sample wrap buffer (:297-314)
+        const int64_t loopLength = loopEnd - loopStart;
+        const int fromEnd = (int)(loopEnd - pos);
+        const int needed = std::min(kBlock - outIdx + 4, 512);
+        const int head = std::min(fromEnd, needed);
+        const int tail = (int)std::min<int64_t>(std::max(needed - head, 0), loopLength);
+        gsrProcess(st, [&](int k) { return k < head ? pos + k : loopStart + (k - head); }, head + tail, kBlock - outIdx,
+                   effectiveRate, consumed, produced);
+      } else {
+        gsrProcess(st, [&](int k) { return pos + k; }, available, kBlock - outIdx, effectiveRate, consumed, produced);
+      }
+      if (produced > 0) hasMore = true;
+      int64_t newPos = pos + consumed;
+      if (loop && newPos >= loopEnd) newPos = loopStart + (newPos - loopEnd);
+      consumedThis += (newPos >= pos) ? (newPos - pos) : (loopEnd - pos + newPos - loopStart);
+      pos = newPos;
+      outIdx += produced;
+      if (consumed == 0 && produced == 0) break;
+    }
+    st.pp += consumedThis;
+  }
+  if (loop && st.pp >= loopEnd) {  // :226-234, :349-357
+    int64_t loopLength = loopEnd - loopStart;
+    if (loopLength > 0) st.pp = loopStart + ((st.pp - loopEnd) % loopLength);
+  }
+  d.next = first < 0 ? 0 : first;
+  d.produced = outIdx;
+  return !hasMore || (!loop && st.pp >= durEnd);
 }
 
 struct SrcPlanOut {
@@ -171,8 +300,98 @@ static SrcPlanOut planSource(Context& c, NodeS& s, int64_t n, const std::vector<
   int64_t kData = INF;
   const bool rate1 = g.effectiveRate == 1.0;
   int64_t pos = s.playbackPosition;
-  if (s.loop) {
-    if (!rate1) fail(GA_ERR_UNSUPPORTED, "looping playback with resampling is not on the device path yet");
+  const bool hasTimeline = !s.params[0].events.empty();
+  const bool resamplerLive = s.gsr ? s.gsrReady > 0 : s.rsBlocks > 0;
+  if (resamplerLive && s.rsBufId != s.bufId)
+    fail(GA_ERR_UNSUPPORTED, "the Buffer of a source was replaced while its resampler holds samples of the old one");
+  if (!resamplerLive) s.rsBufId = s.bufId;
+  bool wantGsr = s.gsr || hasTimeline || (s.loop && !rate1) || (s.rsBlocks > 0 && g.effectiveRate != s.rsRate);
+  if (wantGsr) {
+    if (!s.gsr) {  // leave trajectory mode: the state after rsBlocks blocks becomes explicit
+      if (s.rsBlocks > 0) {
+        Resampler& rs = resamplerFor(c, s.rsRate);
+        rs.extend(s.rsBlocks + 2);
+        ResampleBlock rb = rs.blocks[s.rsBlocks];
+        // the trajectory assumes unbounded input: if the data ran out in an earlier block the true state is that block's
+        // bounded replay (later END blocks find nothing to consume, AudioBufferSourceNode.cs:267-271)
+        const int64_t avail0 = std::max<int64_t>(g.durationEndFrame - s.rsStartPos, 0);
+        if (rb.consumed >= avail0) {
+          int64_t lo = 0, hi = s.rsBlocks - 1;
+          while (lo < hi) {
+            int64_t mid = (lo + hi) >> 1;
+            if (rs.blocks[mid + 1].consumed >= avail0) hi = mid; else lo = mid + 1;
+          }
+          int produced;
+          int64_t consumedAfter;
+          double posAfter;
+          int readyAfter;
+          resampleBlockBounded(rs.blocks[lo], s.rsRate, avail0, produced, consumedAfter, &posAfter, &readyAfter);
+          rb.consumed = consumedAfter;
+          rb.pos = posAfter;
+          rb.ready = readyAfter;
+        }
+        s.gsrPos = rb.pos;
+        s.gsrReady = rb.ready;
+        for (int k = 0; k < 4; k++) s.gsrW[3 - k] = k < rb.ready ? s.rsStartPos + rb.consumed - 1 - k : -1;
+        s.playbackPosition = s.rsStartPos + rb.consumed;  // `_playbackPosition += totalInputConsumed` (:347)
+        s.rsChannels = b->channels;
+        s.rsBlocks = 0;
+      }
+      s.gsr = true;
+    }
+    GsrState st;
+    for (int k = 0; k < 4; k++) st.w[k] = s.gsrW[k];
+    st.pos = s.gsrPos;
+    st.ready = s.gsrReady;
+    st.pp = s.playbackPosition;
+    s.gsrBlocks.clear();
+    s.gsrUploaded = false;
+    int64_t maxRel = n - bs;
+    if (kTime != INF) maxRel = std::min(maxRel, kTime + 1);
+    for (int64_t rel = 0; rel < maxRel; rel++) {
+      float pr = hasTimeline ? param_value_at(s.params[0].events.data(), (int)s.params[0].events.size(), s.params[0].value, bt[bs + rel])
+                             : s.params[0].value;  // k-rate: GetValues()[0] at the block start (AudioParam.cs:146-165)
+      GsrBlock d;
+      bool end = gsrReplayBlock(s, g, *b, c, pr, st, d);
+      s.gsrBlocks.push_back(d);
+      // END blocks keep being processed until the stop time (their state still moves: `_playbackPosition += 128` on the
+      // copy path), and with unchanged controls an END block is followed by END blocks only
+      if (end && kData == INF) kData = rel;
+      if (!end && kData != INF) fail(GA_ERR_UNSUPPORTED, "a source resumed after an end block inside one render chunk");
+    }
+    // every index the device will touch is checked here, on the host: a wrong descriptor must be an error, not a GPU fault
+    for (size_t bi = 0; bi < s.gsrBlocks.size(); bi++) {
+      const GsrBlock& d = s.gsrBlocks[bi];
+      if (kData != INF && (int64_t)bi >= kData) break;  // END blocks: cleared, no device reads
+      int64_t ip = d.next;
+      int64_t feeds = 0;
+      if (d.copy) {
+        feeds = d.produced;
+      } else if (d.produced > 0) {
+        for (int k = 0; k < 4; k++)
+          if (d.w[k] < -1 || d.w[k] >= b->length) fail(GA_ERR_DEVICE, "internal: source replay window index out of range");
+        feeds = 4 - d.ready;
+        double P = d.pos;
+        for (int o = 0; o < d.produced; o++) {
+          int consume = (int)P;
+          if (consume > 0) feeds += consume;
+          P -= consume;
+          P += d.rate;
+        }
+      }
+      for (int64_t f = 0; f < feeds; f++) {
+        if (ip < 0 || ip >= b->length) fail(GA_ERR_DEVICE, "internal: source replay feed index out of range");
+        ip++;
+        if (s.loop && ip >= g.loopEndFrame) ip = g.loopStartFrame;
+      }
+    }
+    GsrBlock tail{};  // state after the last replayed block
+    tail.pp = st.pp;
+    for (int k = 0; k < 4; k++) tail.w[k] = st.w[k];
+    tail.pos = st.pos;
+    tail.ready = st.ready;
+    s.gsrBlocks.push_back(tail);
+  } else if (s.loop) {
     int64_t loopLen = g.loopEndFrame - g.loopStartFrame;
     if (loopLen <= 0) kData = 0;  // available <= 0 on the first iteration: hasMoreData stays false
   } else if (rate1) {
@@ -180,7 +399,10 @@ static SrcPlanOut planSource(Context& c, NodeS& s, int64_t n, const std::vector<
     kData = rem <= 0 ? 0 : (rem + kBlock - 1) / kBlock - 1;
   } else {
     Resampler& rs = resamplerFor(c, g.effectiveRate);
-    if (s.rsBlocks == 0) s.rsStartPos = pos;
+    if (s.rsBlocks == 0) {
+      s.rsStartPos = pos;
+      s.rsRate = g.effectiveRate;
+    }
     int64_t avail = g.durationEndFrame - s.rsStartPos;
     int64_t need = s.rsBlocks + (n - bs) + 2;
     rs.extend(need + 1);
@@ -217,7 +439,9 @@ static SrcPlanOut planSource(Context& c, NodeS& s, int64_t n, const std::vector<
   int64_t playEnd = std::min(kData, kGone == INF ? INF : kGone + 1);  // exclusive
   int64_t rel = 0;
   if (playEnd > 0) {
-    if (s.loop && rate1 && pos >= g.loopEndFrame && g.loopEndFrame > g.loopStartFrame) {
+    if (s.gsr) {
+      s.spans.push_back(SrcSpan{bs, SRC_PLAY, pos, 0});  // blkIdx indexes gsrBlocks
+    } else if (s.loop && rate1 && pos >= g.loopEndFrame && g.loopEndFrame > g.loopStartFrame) {
       // start offset beyond the loop end: the first block restarts exactly at loopStart (`pos = loopStartFrame`,
       // AudioBufferSourceNode.cs:197-200) whereas _playbackPosition itself wraps modulo the loop length afterwards
       // (:226-234).  Reading from `loopEnd` makes the loop kernel's modular map start at loopStart for that block.
@@ -451,6 +675,7 @@ struct Exec {
   std::vector<BiquadDynJob> bqDynJobs;
   std::vector<LoopJob> loopJobs;
   std::vector<ResampleJob> rsJobs;
+  std::vector<GsrJob> gsrJobs;
   std::vector<ResampleBlock> traj;  // per-chunk trajectory table (all rates + custom tail blocks)
   bool mixAligned = true;
   // conv inputs: node -> slot -> per segment view
@@ -582,6 +807,14 @@ struct Exec {
         launch_resample(st, (const ResampleJob*)(base + r.off), r.nj, (const ResampleBlock*)(base + trajOffFinal), r.mx);
       });
     }
+    if (!gsrJobs.empty()) {
+      size_t off = plan.putv(gsrJobs);
+      int nj = (int)gsrJobs.size();
+      int64_t mx = 0;
+      for (auto& j : gsrJobs) mx = std::max(mx, j.nblocks);
+      hipStream_t st = c.stream;
+      plan.add(LK_OTHER, [=](uint8_t* base) { launch_gsr(st, (const GsrJob*)(base + off), nj, base, mx); });
+    }
     if (!gainJobs.empty()) {
       size_t off = plan.putv(gainJobs);
       int nj = (int)gainJobs.size();
@@ -621,6 +854,7 @@ struct Exec {
     bqSecs.clear();
     loopJobs.clear();
     rsJobs.clear();
+    gsrJobs.clear();
     mixAligned = true;
   }
   struct RsLaunch {
@@ -738,8 +972,6 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
     maxDepth = std::max(maxDepth, nodes[id]->depth);
     maxLevel = std::max(maxLevel, nodes[id]->level);
     NodeS& nd = *nodes[id];
-    if (nd.type == GA_NODE_BUFFER_SOURCE && !nd.params[0].events.empty())
-      fail(GA_ERR_UNSUPPORTED, "playbackRate automation is not on the device path yet");
     if (nd.type == GA_NODE_BIQUAD && nd.coefOnDevice && nd.bqDyn) {
       bool automated = false;
       for (auto& p : nd.params) automated = automated || !p.events.empty();
@@ -998,7 +1230,28 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
             if (ns.srcPhase != SRC_PLAY) break;  // silent: ZERO views
             PlayBuf& pb = *buffers[ns.srcBuf];
             SrcGeom g = sourceGeom(*this, nd, pb);
-            if (g.effectiveRate == 1.0 && !nd.loop) {
+            if (nd.gsr) {  // general replay: one host-made descriptor per block
+              if (!nd.gsrUploaded) {
+                nd.gsrDevOff = ex.plan.putv(nd.gsrBlocks);
+                nd.gsrUploaded = true;
+              }
+              for (int ch = 0; ch < pb.channels; ch++) {
+                GsrJob gj;
+                gj.buf = pb.dev + (size_t)ch * pb.stride;
+                gj.out = ex.nodeOut(ns.id, ch);
+                gj.desc_off = nd.gsrDevOff + (uint64_t)ns.srcBlk * sizeof(GsrBlock);
+                gj.b0 = sg.b0;
+                gj.nblocks = nb;
+                gj.loop_start = g.loopStartFrame;
+                gj.loop_end = g.loopEndFrame;
+                gj.loop = nd.loop ? 1 : 0;
+                gj.pad_ = 0;
+                ex.gsrJobs.push_back(gj);
+                ov[ch] = gj.out;
+              }
+            } else if (g.effectiveRate == 1.0 && (ns.srcPos < 0 || (nd.loop ? g.loopEndFrame : ns.srcPos + nf) > pb.length)) {
+              fail(GA_ERR_DEVICE, "internal: source window beyond the buffer");
+            } else if (g.effectiveRate == 1.0 && !nd.loop) {
               // zero-copy: the node's output for these blocks IS the buffer (AudioBufferSourceNode.cs:186-222)
               for (int ch = 0; ch < pb.channels; ch++) ov[ch] = pb.dev + (size_t)ch * pb.stride + ns.srcPos - f0;
             } else if (g.effectiveRate == 1.0 && ns.srcPos < g.loopEndFrame && ns.srcPos + nf <= g.loopEndFrame) {
@@ -1033,6 +1286,12 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
                   traj0 = (int)ex.traj.size();
                   ex.traj.push_back(rb);
                 }
+              {  // host-side bound of the device reads of this job: a wrong plan must be an error, not a GPU fault
+                const bool partial = ex.traj[traj0].produced != kBlock;
+                if (nd.rsStartPos < 0 || avail < 0 || nd.rsStartPos + avail > pb.length ||
+                    (!partial && rs.blocks[ns.srcBlk + nb].consumed > avail))
+                  fail(GA_ERR_DEVICE, "internal: resampler job reads beyond the source buffer");
+              }
               for (int ch = 0; ch < pb.channels; ch++) {
                 ResampleJob rj;
                 rj.buf = pb.dev + (size_t)ch * pb.stride;
@@ -1559,7 +1818,15 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
     PlayBuf* pb = s.bufId >= 0 ? buffers[s.bufId].get() : nullptr;
     bool rate1 = true;
     if (pb) rate1 = sourceGeom(*this, s, *pb).effectiveRate == 1.0;
-    if (rate1) {
+    if (s.gsr) {
+      if (!s.gsrBlocks.empty()) {  // the state at the start of block `played` (END blocks leave nothing to resume)
+        const GsrBlock& e = s.gsrBlocks[std::min<size_t>((size_t)played, s.gsrBlocks.size() - 1)];
+        s.playbackPosition = e.pp;
+        for (int k = 0; k < 4; k++) s.gsrW[k] = e.w[k];
+        s.gsrPos = e.pos;
+        s.gsrReady = e.ready;
+      }
+    } else if (rate1) {
       s.playbackPosition += played * kBlock;
       if (s.loop && pb) {
         SrcGeom g = sourceGeom(*this, s, *pb);

@@ -136,6 +136,17 @@ struct NodeS {
   int64_t rsBlocks = 0;          // resampler: blocks played so far (index into the trajectory)
   int64_t rsStartPos = 0;        // resampler: buffer index where consumption started
   std::vector<SrcSpan> spans;    // per-chunk plan
+  // general replay mode (GsrBlock): entered -- for good -- when the source loops while resampling or its rate moves
+  bool gsr = false;
+  double rsRate = 0.0;           // trajectory mode: the effective rate the trajectory belongs to
+  int rsBufId = -1;              // buffer the resampler window refers to
+  int rsChannels = 0;            // `_resamplers.Length` (AudioBufferSourceNode.cs:238-245)
+  int64_t gsrW[4] = {-1, -1, -1, -1};
+  double gsrPos = 0.0;
+  int gsrReady = 0;
+  std::vector<GsrBlock> gsrBlocks;  // per chunk: one per processed block from the first played block, + the end state
+  uint64_t gsrDevOff = 0;
+  bool gsrUploaded = false;
   // BiQuadFilterNode (BiQuadFilterNode.cs:12-19)
   int filterType = GA_FILTER_LOWPASS;
   float b0 = 0, b1 = 0, b2 = 0, a1 = 0, a2 = 0;

@@ -1548,45 +1548,6 @@ void launch_biquad_dynamic(hipStream_t s, const BiquadDynJob* jobs_dev, int njob
 //  AudioParam timeline (AudioParam.ComputeValueAtTime and helpers, AudioParam.cs:169-247), double precision,
 //  no contraction: sampleTime = blockTime + i * deltaTime (:116-120); k-rate samples at block start (:146).
 // =====================================================================================================
-__device__ float param_interp_linear(float v0, double t0, float v1, double t1, double t) {
-  double u = (t - t0) / (t1 - t0);
-  u = u < 0.0 ? 0.0 : (u > 1.0 ? 1.0 : u);
-  float d = v1 - v0;
-  return (float)((double)v0 + (double)d * u);
-}
-__device__ float param_interp_exp(float v0, double t0, float v1, double t1, double t) {
-  if (v0 <= 0 || v1 <= 0) return param_interp_linear(v0, t0, v1, t1, t);
-  double u = (t - t0) / (t1 - t0);
-  u = u < 0.0 ? 0.0 : (u > 1.0 ? 1.0 : u);
-  float ratio = v1 / v0;
-  return (float)((double)v0 * pow((double)ratio, u));
-}
-__device__ float param_set_target(const ParamEvent& e, float baseline, double time) {
-  double elapsed = time - e.time;
-  if (elapsed <= 0) return baseline;
-  double tc = e.time_constant > 0.001 ? e.time_constant : 0.001;
-  float d = baseline - e.target;
-  return (float)((double)e.target + (double)d * exp(-elapsed / tc));
-}
-__device__ float param_value_at(const ParamEvent* __restrict ev, int count, float value, double time) {
-  if (count == 0) return value;
-  float boundary = value;
-  for (int i = 0; i < count; i++) {
-    const ParamEvent& e = ev[i];
-    if (time < e.time) {
-      if (i == 0) return boundary;
-      const ParamEvent& prev = ev[i - 1];
-      if (e.type == 1) return param_interp_linear(prev.value, prev.time, e.value, e.time, time);
-      if (e.type == 2) return param_interp_exp(prev.value, prev.time, e.value, e.time, time);
-      if (prev.type == 3) return param_set_target(prev, boundary, time);
-      return prev.value;
-    }
-    if (e.type != 3) boundary = e.value;
-  }
-  const ParamEvent& last = ev[count - 1];
-  if (last.type == 3) return param_set_target(last, boundary, time);
-  return last.value;
-}
 __global__ __launch_bounds__(128) void param_curve_kernel(const ParamJob* __restrict jobs, const ParamEvent* __restrict events,
                                                           const double* __restrict block_times, double delta_time) {
   const ParamJob job = jobs[blockIdx.y];
@@ -1676,6 +1637,67 @@ void launch_resample(hipStream_t s, const ResampleJob* jobs_dev, int njobs, cons
   if (njobs <= 0 || max_blocks <= 0) return;
   int gx = (int)((max_blocks + 63) / 64);
   hipLaunchKernelGGL(resample_kernel, dim3(gx, njobs), dim3(64), 0, s, jobs_dev, traj_dev);
+}
+
+
+// =====================================================================================================
+//  General source replay (see GsrBlock): one lane per block, fed samples gathered by index with the loop wrap rule
+//  `pos >= loopEnd -> loopStart` (AudioBufferSourceNode.cs:262-265,297-314).  A rare path (looping + resampling,
+//  moving playbackRate): gathers are uncoalesced, stores go through LDS like resample_kernel.
+// =====================================================================================================
+__global__ __launch_bounds__(64) void gsr_kernel(const GsrJob* __restrict jobs, const uint8_t* __restrict base) {
+  __shared__ float tile[64][kBlock + 1];
+  const GsrJob job = jobs[blockIdx.y];
+  const int lane = threadIdx.x;
+  const int64_t bl0 = (int64_t)blockIdx.x * 64;
+  if (bl0 >= job.nblocks) return;
+  const int64_t b = bl0 + lane;
+  if (b < job.nblocks) {
+    const GsrBlock d = ((const GsrBlock*)(base + job.desc_off))[b];
+    const float* __restrict in = job.buf;
+    int64_t ip = d.next;
+    auto feed = [&]() {
+      float v = in[ip++];
+      if (job.loop && ip >= job.loop_end) ip = job.loop_start;
+      return v;
+    };
+    int outp = 0;
+    if (d.copy) {
+      for (; outp < d.produced; outp++) tile[lane][outp] = feed();
+    } else {
+      float S0 = d.w[0] >= 0 ? in[d.w[0]] : 0.f, S1 = d.w[1] >= 0 ? in[d.w[1]] : 0.f;
+      float S2 = d.w[2] >= 0 ? in[d.w[2]] : 0.f, S3 = d.w[3] >= 0 ? in[d.w[3]] : 0.f;
+      double Pos = d.pos;
+      int ready = d.ready;
+      if (d.produced > 0) {
+        while (ready < 4) {   // priming (CubicResampler.cs:31-35); the host has checked that the inputs exist
+          S0 = S1; S1 = S2; S2 = S3; S3 = feed();
+          ready++;
+        }
+        for (; outp < d.produced; outp++) {
+          int consume = (int)Pos;
+          for (int i = 0; i < consume; i++) { S0 = S1; S1 = S2; S2 = S3; S3 = feed(); }
+          Pos -= consume;
+          float t = (float)Pos;
+          tile[lane][outp] = S1 + t * (0.5f * (S2 - S0) + t * ((S0 - 2.5f * S1 + 2.f * S2 - 0.5f * S3) + t * (0.5f * (S3 - S0) + 1.5f * (S1 - S2))));
+          Pos += d.rate;
+        }
+      }
+    }
+    for (; outp < kBlock; outp++) tile[lane][outp] = 0.f;
+  }
+  __syncthreads();
+  const int nb = (int)min<int64_t>(64, job.nblocks - bl0);
+  float* __restrict out = job.out + (job.b0 + bl0) * kBlock;
+  for (int r = 0; r < nb; r++) {
+    out[(int64_t)r * kBlock + lane] = tile[r][lane];
+    out[(int64_t)r * kBlock + 64 + lane] = tile[r][64 + lane];
+  }
+}
+void launch_gsr(hipStream_t s, const GsrJob* jobs_dev, int njobs, const uint8_t* plan_base_dev, int64_t max_blocks) {
+  if (njobs <= 0 || max_blocks <= 0) return;
+  int gx = (int)((max_blocks + 63) / 64);
+  hipLaunchKernelGGL(gsr_kernel, dim3(gx, njobs), dim3(64), 0, s, jobs_dev, plan_base_dev);
 }
 
 }  // namespace ga

@@ -198,6 +198,47 @@ struct ParamJob {
   int64_t b0;         // first block (chunk relative)
   int64_t nblocks;
 };
+// AudioParam.ComputeValueAtTime and helpers (AudioParam.cs:169-247), double precision, no contraction.  Host + device:
+// the device evaluates a-rate / k-rate curves; the host evaluates the k-rate playbackRate that steers source replay.
+__host__ __device__ inline float param_interp_linear(float v0, double t0, float v1, double t1, double t) {
+  double u = (t - t0) / (t1 - t0);
+  u = u < 0.0 ? 0.0 : (u > 1.0 ? 1.0 : u);
+  float d = v1 - v0;
+  return (float)((double)v0 + (double)d * u);
+}
+__host__ __device__ inline float param_interp_exp(float v0, double t0, float v1, double t1, double t) {
+  if (v0 <= 0 || v1 <= 0) return param_interp_linear(v0, t0, v1, t1, t);
+  double u = (t - t0) / (t1 - t0);
+  u = u < 0.0 ? 0.0 : (u > 1.0 ? 1.0 : u);
+  float ratio = v1 / v0;
+  return (float)((double)v0 * pow((double)ratio, u));
+}
+__host__ __device__ inline float param_set_target(const ParamEvent& e, float baseline, double time) {
+  double elapsed = time - e.time;
+  if (elapsed <= 0) return baseline;
+  double tc = e.time_constant > 0.001 ? e.time_constant : 0.001;
+  float d = baseline - e.target;
+  return (float)((double)e.target + (double)d * exp(-elapsed / tc));
+}
+__host__ __device__ inline float param_value_at(const ParamEvent* ev, int count, float value, double time) {
+  if (count == 0) return value;
+  float boundary = value;
+  for (int i = 0; i < count; i++) {
+    const ParamEvent& e = ev[i];
+    if (time < e.time) {
+      if (i == 0) return boundary;
+      const ParamEvent& prev = ev[i - 1];
+      if (e.type == 1) return param_interp_linear(prev.value, prev.time, e.value, e.time, time);
+      if (e.type == 2) return param_interp_exp(prev.value, prev.time, e.value, e.time, time);
+      if (prev.type == 3) return param_set_target(prev, boundary, time);
+      return prev.value;
+    }
+    if (e.type != 3) boundary = e.value;
+  }
+  const ParamEvent& last = ev[count - 1];
+  if (last.type == 3) return param_set_target(last, boundary, time);
+  return last.value;
+}
 void launch_param_curve(hipStream_t s, const ParamJob* jobs_dev, int njobs, const ParamEvent* events_dev,
                         const double* block_times_dev, double delta_time, int64_t max_blocks);
 
@@ -231,5 +272,32 @@ struct ResampleJob {
   int64_t nblocks;
 };
 void launch_resample(hipStream_t s, const ResampleJob* jobs_dev, int njobs, const ResampleBlock* traj_dev, int64_t max_blocks);
+
+// General source replay: the host replays AudioBufferSourceNode.Process block by block (AudioBufferSourceNode.cs:165-358:
+// k-rate playbackRate per block, loop wrap, the copy path when the effective rate is exactly 1, the resampler's window
+// carried as buffer INDICES) and hands the device one descriptor per block; the device does the per-sample arithmetic.
+// Used for looping playback with resampling and for a playbackRate that changes while the source plays.
+struct GsrBlock {        // state at the start of one processed block
+  int64_t pp;            // _playbackPosition (host bookkeeping)
+  int64_t next;          // buffer index of the first sample fed in this block
+  int64_t w[4];          // buffer indices held in S0..S3 (-1: never fed -> 0.0f)
+  double pos;            // CubicResampler.Pos
+  double rate;           // effective rate of this block
+  int ready;             // CubicResampler.Ready
+  int produced;          // outputs produced; the rest of the block is cleared
+  int copy;              // 1: effective rate == 1.0 -> plain copy path (:186-222), resampler untouched
+  int pad_;
+};
+struct GsrJob {
+  const float* buf;      // channel data
+  float* out;            // chunk-frame indexed
+  uint64_t desc_off;     // byte offset of the first GsrBlock in the plan buffer
+  int64_t b0;            // first block (chunk relative)
+  int64_t nblocks;
+  int64_t loop_start, loop_end;
+  int loop;
+  int pad_;
+};
+void launch_gsr(hipStream_t s, const GsrJob* jobs_dev, int njobs, const uint8_t* plan_base_dev, int64_t max_blocks);
 
 }  // namespace ga

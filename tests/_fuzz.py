@@ -10,6 +10,7 @@ SR = 48000
 def build_random_graph(ctx, seed, frames, keep=None, handles=None):
     """Sources -> random chains (gain / biquad / convolver) -> optional shared bus nodes -> destination."""
     rng = np.random.default_rng(seed)
+    rng2 = np.random.default_rng(seed + 7777)   # later additions draw from their own stream: old seeds keep their graphs
     dest_ch = int(rng.choice([1, 2, 2, 4]))
     ctx.Destination.SetChannelCount(dest_ch)
     if rng.random() < 0.3:
@@ -43,6 +44,18 @@ def build_random_graph(ctx, seed, frames, keep=None, handles=None):
         if src_sr == SR and rng.random() < 0.2:
             s.PlaybackRate.Value = float(rng.choice([0.5, 1.25]))
             s.Loop = False
+        # looping while resampling, odd rates, and a playbackRate timeline (k-rate, sampled at block starts)
+        if rng2.random() < 0.2:
+            s.Loop = True
+            if rng2.random() < 0.6:
+                s.LoopStart = float(rng2.integers(0, length // 3)) / src_sr
+                s.LoopEnd = float(rng2.integers(length // 2, length)) / src_sr
+        if rng2.random() < 0.15:
+            s.PlaybackRate.Value = float(rng2.choice([0.75, 2.0, 3.7, 1.0]))
+        if rng2.random() < 0.15:
+            s.PlaybackRate.SetValueAtTime(float(rng2.uniform(0.5, 2.0)), float(rng2.uniform(0, frames / SR * 0.5)))
+            if rng2.random() < 0.6:
+                s.PlaybackRate.LinearRampToValueAtTime(float(rng2.uniform(0.5, 2.0)), float(rng2.uniform(frames / SR * 0.5, frames / SR)))
         node = s
         if handles is not None:
             handles.setdefault("sources", []).append(s)
@@ -99,12 +112,12 @@ def build_random_graph(ctx, seed, frames, keep=None, handles=None):
     return dest_ch
 
 
-def run_random_session(ctx, seed, frames=128 * 48, max_piece=128 * 9):
+def run_random_session(ctx, seed, frames=128 * 48, max_piece=128 * 9, keep=None):
     """Render a random graph in random pieces and EDIT it between the pieces (parameter writes and automation, stop,
     new voices, dispose, rewiring, impulse-response swaps, audio-rate modulation, channel settings).  The same seed
     replays the same session on any context.  Returns (output, log of (piece, action, exception type or None))."""
     h = {}
-    ch = build_random_graph(ctx, seed, frames, handles=h)
+    ch = build_random_graph(ctx, seed, frames, keep=keep, handles=h)
     rng = np.random.default_rng(seed ^ 0x5EED)
     out = np.zeros((ch, frames), np.float32)
     log = []
@@ -138,9 +151,16 @@ def run_random_session(ctx, seed, frames=128 * 48, max_piece=128 * 9):
         s.Start(now + float(rng.choice([0.0, rng.uniform(0, 0.02)])))
         sources.append(s)
 
+    detail = []
+
+    def nid(x):
+        return getattr(x, '_id', None)
+
     def act(now):
+        detail.clear()
         kind = str(rng.choice(["gain_value", "gain_sched", "gain_cancel", "bq_value", "bq_type", "bq_ramp", "stop", "voice",
-                               "dispose", "rewire", "ir_swap", "modulate", "dest_ch", "interp", "loop_toggle"]))
+                               "dispose", "rewire", "ir_swap", "modulate", "dest_ch", "interp", "loop_toggle", "rate_value",
+                               "rate_sched"]))
         if kind == "gain_value":
             g = pick(gains)
             if g: g.Gain.Value = float(rng.uniform(0, 1.2))
@@ -212,12 +232,25 @@ def run_random_session(ctx, seed, frames=128 * 48, max_piece=128 * 9):
             if n: n.Inputs[0].SetChannelInterpretation(ChannelInterpretation(int(rng.integers(0, 2))))
         elif kind == "loop_toggle":
             s = pick(sources)
-            if s and s.Buffer is not None and s.Buffer.SampleRate == SR and s.PlaybackRate.Value == 1.0:
+            if s and s.Buffer is not None:
                 s.Loop = not s.Loop
+                detail.append((nid(s), s.Loop, s.Buffer.SampleRate, s.Buffer.Length))
+        elif kind == "rate_value":
+            s = pick(sources)
+            if s:
+                s.PlaybackRate.Value = float(rng.choice([0.5, 1.0, 1.25, 2.5]))
+                detail.append((nid(s), s.PlaybackRate.Value, s.Loop, s.Buffer.SampleRate if s.Buffer else None))
+        elif kind == "rate_sched":
+            s = pick(sources)
+            if s:
+                s.PlaybackRate.SetValueAtTime(float(rng.uniform(0.5, 2.0)), now + float(rng.uniform(0, 0.01)))
+                if rng.random() < 0.5:
+                    s.PlaybackRate.LinearRampToValueAtTime(float(rng.uniform(0.5, 2.0)), now + float(rng.uniform(0.01, 0.04)))
         return kind
 
-    global last_pieces
+    global last_pieces, details
     last_pieces = []
+    details = []
     pos = 0
     piece = 0
     while pos < frames:
@@ -230,6 +263,7 @@ def run_random_session(ctx, seed, frames=128 * 48, max_piece=128 * 9):
             try:
                 k = act(ctx.CurrentTime)
                 log.append((piece, k, None))
+                details.append((piece, k, list(detail), ctx.CurrentTime))
             except Exception as e:  # the other implementation must raise the same exception type at the same point
                 log.append((piece, "?", type(e).__name__))
     return out, log

@@ -325,3 +325,58 @@ def test_convolver_buffer_swap_back_while_queued_is_ignored():
     ref, got = outs
     assert G.rms(ref[:, 128 * 8:]) > 1e-4
     assert G.rms(ref - got) <= 2e-6 * G.rms(ref)
+
+
+_GSR_CASES = {
+    # name: (loop at start, frame at which Loop is toggled (0 = never), time of the playbackRate event (None = constant
+    #        rate), rate after the event, start offset, duration, buffer sample rate, channels)
+    "timeline": (False, 0, 0.0367, 0.99, 0.0, float("inf"), 48000, 1),
+    "timeline+loop": (True, 0, 0.0367, 0.99, 0.0, float("inf"), 48000, 2),
+    "timeline+loop toggled on": (False, 1579, 0.0367, 0.99, 0.0, float("inf"), 48000, 1),
+    "timeline+loop toggled on after the data ended": (False, 1579, 0.0367, 0.99, 0.00636, 0.088, 48000, 1),
+    "timeline, offset+duration": (False, 0, 0.0367, 0.99, 0.00636, 0.088, 48000, 1),
+    "44.1k loop": (True, 0, None, 1.0, 0.0, float("inf"), 44100, 2),
+    "44.1k loop toggled off": (True, 2000, None, 1.0, 0.0, float("inf"), 44100, 1),
+    "fast loop (rate 3.7)": (True, 0, None, 3.7, 0.0, float("inf"), 48000, 1),
+    "rate crosses exactly 1.0": (True, 0, 0.01, 1.0, 0.0, float("inf"), 44100, 1),
+}
+
+
+@pytest.mark.parametrize("case", list(_GSR_CASES))
+def test_source_general_replay_bit_exact(case):
+    """Looping + resampling, a playbackRate that moves while the source plays, Loop toggled between renders: the host
+    replays AudioBufferSourceNode.Process on indices, the device does the sample arithmetic -- bit-exact."""
+    loop0, toggle_at, t_ev, rate_after, offset, duration, sr, nch = _GSR_CASES[case]
+    rng = np.random.default_rng(3)
+    data = [(rng.standard_normal(995 if duration != float("inf") else 3089) * 0.25).astype(np.float32) for _ in range(nch)]
+    frames = 128 * 40
+    outs = []
+    for mk in (OracleContext, OfflineAudioContext):
+        ctx = mk(48000)
+        ctx.Destination.SetChannelCount(nch)
+        s = AudioBufferSourceNode(ctx)
+        s.Buffer = PlayableAudioBuffer.FromChannelArrays(data, sr)
+        s.Loop = loop0
+        if loop0:
+            s.LoopStart = 300 / sr
+            s.LoopEnd = 900 / sr
+        if t_ev is not None:
+            s.PlaybackRate.SetValueAtTime(rate_after, t_ev)
+            s.PlaybackRate.LinearRampToValueAtTime(1.0004, t_ev + 0.08)
+        else:
+            s.PlaybackRate.Value = rate_after
+        s.Connect(ctx.Destination)
+        s.Start(0.0, offset, duration)
+        out = np.zeros((nch, frames), np.float32)
+        if toggle_at:
+            ctx.Render(out, toggle_at, 0)
+            s.Loop = not s.Loop
+            s.PlaybackRate.Value = 1.25 if t_ev is None else s.PlaybackRate.Value
+            ctx.Render(out, frames - toggle_at, toggle_at)
+        else:
+            ctx.Render(out, frames)
+        outs.append(out)
+        ctx.Dispose()
+    ref, got = outs
+    assert G.rms(ref) > 1e-3
+    assert np.array_equal(ref, got)

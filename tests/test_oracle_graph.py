@@ -310,3 +310,34 @@ def test_audio_rate_param_modulation_semantics():
     m.Start()
     out = render1(ctx, 1024)[0]
     assert np.array_equal(out, np.float32(0.25) + mod[:1024])
+
+
+def test_looping_resampled_source_is_seamless_and_playback_rate_is_k_rate():
+    """Loop + resampling (AudioBufferSourceNode.cs:236-358, the 512-sample wrap buffer): a loop that holds whole
+    periods of a sine, read at rate r, is that sine at r times the frequency -- across every loop wrap."""
+    period, rate = 100, 0.5
+    x = np.sin(2 * np.pi * np.arange(800) / period)
+    ctx = mono_ctx()
+    s = src(ctx, x, connect=ctx.Destination, start=False)
+    s.Loop = True
+    s.PlaybackRate.Value = rate
+    s.Start(0.0)
+    out = render1(ctx, 128 * 40)[0].astype(np.float64)
+    # first output = in[1] (CubicResampler primes 4 samples, CubicResampler.cs:31-38): phase offset of one input sample
+    want = np.sin(2 * np.pi * (1 + rate * np.arange(out.size)) / period)
+    assert np.abs(out - want).max() < 2e-5   # Catmull-Rom error of a period-100 sine
+    # the rate is sampled once per block (k-rate, :165): a ramp on it moves the pitch in 128-frame steps
+    ctx = mono_ctx()
+    s = src(ctx, x, connect=ctx.Destination, start=False)
+    s.Loop = True
+    s.PlaybackRate.SetValueAtTime(0.5, 0.0)
+    s.PlaybackRate.LinearRampToValueAtTime(1.3, 128 * 20 / SR)   # (never exactly 1.0: that block would take the copy path)
+    s.Start(0.0)
+    out = render1(ctx, 128 * 20)[0].astype(np.float64)
+    phase = 1.0
+    want = np.zeros_like(out)
+    for b in range(20):
+        r = np.float32(0.5 + (1.3 - 0.5) * (b * 128 / SR) / (128 * 20 / SR))
+        want[b * 128:(b + 1) * 128] = np.sin(2 * np.pi * (phase + float(r) * np.arange(128)) / period)
+        phase += float(r) * 128
+    assert np.abs(out - want).max() < 2e-5

@@ -16,5 +16,5 @@ for seed in [int(x) for x in sys.argv[1:]]:
     # piece boundaries (same rng replay)
     rng = np.random.default_rng(seed ^ 0x5EED)
     print("seed", seed, res)
-    print("   log", rl)
+    print("   log", F.details)
     print("   pieces(frames end)", getattr(F, "last_pieces", None))
