@@ -215,6 +215,7 @@ int ga_set_option(ga_context* ctx, const char* key, double value) {
     else if (k == "profile") c.profile = value != 0;
     else if (k == "time_fft") c.useTimeFft = value != 0;
     else if (k == "fft64") c.fft64 = value != 0;
+    else if (k == "tconv_radix16") c.useRadix16 = value != 0;
     else if (k == "mem_budget_fraction") c.memBudgetFraction = std::min(0.95, std::max(0.05, value));
     else fail(GA_ERR_INVALID_ARGUMENT, "unknown option " + k);
   });

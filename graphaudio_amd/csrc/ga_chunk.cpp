@@ -1703,8 +1703,13 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
         const int nseg = (nn + Lc - 1) / Lc;
         size_t co = ex.plan.putv(kv.second);
         const int nc = (int)kv.second.size();
-        const float2* twc = twiddlesC(N2);
-        ex.plan.add(LK_MAC, [=](uint8_t* base) { launch_tconv(st, (const ConvSetC*)(base + co), nc, nn, hist, plb, N2, twc, nseg); });
+        static const char* r16env = getenv("GA_TCONV_RADIX16");   // A/B switch for measurements
+        const bool r16 = r16env ? atoi(r16env) != 0 : useRadix16;
+        const float2* twc = r16 ? twiddles16(N2) : twiddlesC(N2);
+        ex.plan.add(LK_MAC, [=](uint8_t* base) {
+          if (r16) launch_tconv16(st, (const ConvSetC*)(base + co), nc, nn, hist, plb, N2, twc, nseg);
+          else launch_tconv(st, (const ConvSetC*)(base + co), nc, nn, hist, plb, N2, twc, nseg);
+        });
       }
       ex.plan.add(LK_FFT, [=](uint8_t* base) {
         launch_irfft_ola_b(st, (const ConvRowIO*)(base + yo), ny, nn, plb, (const float* const*)(base + oi), (float* const*)(base + oo), tw, f64);

@@ -487,6 +487,22 @@ std::shared_ptr<IrSpectra> Context::irSpectra(int bufId, bool normalize) {
   return sp;
 }
 
+const float2* Context::twiddles16(int N2) {
+  auto it = tw16.find(N2);
+  if (it != tw16.end()) return it->second;
+  const double pi = 3.14159265358979323846264338327950288;
+  const int R3 = N2 / 256;
+  std::vector<float2> t;
+  for (int m = 1; m < 16; m++)
+    for (int kk = 0; kk < 16; kk++) t.push_back(make_float2((float)std::cos(2.0 * pi * kk * m / 256), (float)-std::sin(2.0 * pi * kk * m / 256)));
+  for (int m = 1; m < R3; m++)
+    for (int j = 0; j < 256; j++) t.push_back(make_float2((float)std::cos(2.0 * pi * j * m / N2), (float)-std::sin(2.0 * pi * j * m / N2)));
+  float2* d = (float2*)dalloc(sizeof(float2) * t.size());
+  GA_HIP(hipMemcpy(d, t.data(), sizeof(float2) * t.size(), hipMemcpyHostToDevice));
+  tw16[N2] = d;
+  return d;
+}
+
 const float2* Context::twiddlesC(int N2) {
   auto it = twC.find(N2);
   if (it != twC.end()) return it->second;

@@ -304,6 +304,9 @@ struct Context {
   ConvRowRef addGroupRow(const std::shared_ptr<IrSpectra>& ir, int ch, int depth, int nodeId);
   void ensureGroupState(ConvGroup& g);
   const float2* twiddlesC(int N2);
+  const float2* twiddles16(int N2);
+  std::map<int, float2*> tw16;
+  bool useRadix16 = true;   // option `tconv_radix16`
   void ensureTapSpectra(IrSpectra& ir);
   bool fft64 = false;            // option "fft64": double-precision 256-point transforms in the B-layout kernels (reference-like)
   bool useTimeFft = true;        // option "time_fft": formulation C for 64 < P <= 1024

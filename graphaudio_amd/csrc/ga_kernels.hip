@@ -1170,6 +1170,320 @@ void launch_tconv(hipStream_t s, const ConvSetC* sets_dev, int nsets, int nblock
   else hipLaunchKernelGGL(tconv_kernel<4096>, grid, block, lds, s, sets_dev, nsets, nseg, nblocks, hist, pl, tw);
 }
 
+// ---- packed float2 arithmetic --------------------------------------------------------------------------------------
+// A complex number lives in an aligned VGPR pair; v_pk_add/mul/fma_f32 work on both halves at the full f32 rate, and their
+// op_sel / neg modifiers give the swaps and sign flips of complex arithmetic for free: a +- (-i) b is ONE instruction, a
+// complex product two.  (The scalar form the compiler otherwise emits needs twice the issue slots, and this stage is
+// issue-bound: SQ_ACTIVE_INST_ANY x waves/SIMD ~ 100 % in the rocprof counters of round 1.)
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 add_mi(f2 a, f2 b) {   // a + (-i) b = (a.x + b.y, a.y - b.x)
+  f2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f2 sub_mi(f2 a, f2 b) {   // a - (-i) b = (a.x - b.y, a.y + b.x)
+  f2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f2 cmulp(f2 a, f2 b) {    // (a.x b.x - a.y b.y, a.x b.y + a.y b.x), second step fused
+  f2 t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+  return r;
+}
+__device__ __forceinline__ f2 cmulp_conj(f2 a, f2 b) {   // conj(a b) = (a.x b.x - a.y b.y, -(a.x b.y + a.y b.x))
+  f2 t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+  return r;
+}
+__device__ __forceinline__ f2 rot_m45(f2 a) {   // a (1 - i) = (a.x + a.y, a.y - a.x)
+  f2 r;
+  asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a));
+  return r;
+}
+__device__ __forceinline__ f2 rot_p45(f2 a) {   // a (1 + i) = (a.x - a.y, a.y + a.x)
+  f2 r;
+  asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a));
+  return r;
+}
+__device__ __forceinline__ void pdft4(f2& a0, f2& a1, f2& a2, f2& a3) {   // forward, natural order: 8 instructions
+  f2 t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = a1 - a3;
+  a0 = t0 + t2;
+  a2 = t0 - t2;
+  a1 = add_mi(t1, t3);
+  a3 = sub_mi(t1, t3);
+}
+// dft4 whose third input still has to be multiplied by -i (folded into the first butterflies)
+__device__ __forceinline__ void pdft4_a2mi(f2& a0, f2& a1, f2& a2, f2& a3) {
+  f2 t0 = add_mi(a0, a2), t1 = sub_mi(a0, a2), t2 = a1 + a3, t3 = a1 - a3;
+  a0 = t0 + t2;
+  a2 = t0 - t2;
+  a1 = add_mi(t1, t3);
+  a3 = sub_mi(t1, t3);
+}
+__device__ __forceinline__ void pdft8(f2 (&v)[8]) {   // forward 8-point DFT, natural order in / out: 26 instructions
+  const float h = 0.70710678118654752440f;
+  const f2 hh = {h, h};
+  f2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+  f2 o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+  pdft4(e0, e1, e2, e3);
+  pdft4(o0, o1, o2, o3);
+  f2 r1 = rot_m45(o1);            // o1 W8   = h * r1
+  f2 r3 = rot_p45(o3);            // o3 W8^3 = -h * r3
+  v[0] = e0 + o0; v[4] = e0 - o0;
+  v[1] = __builtin_elementwise_fma(r1, hh, e1); v[5] = __builtin_elementwise_fma(-r1, hh, e1);
+  v[2] = add_mi(e2, o2); v[6] = sub_mi(e2, o2);
+  v[3] = __builtin_elementwise_fma(-r3, hh, e3); v[7] = __builtin_elementwise_fma(r3, hh, e3);
+}
+__device__ __forceinline__ void pdft16(f2 (&v)[16]) {   // forward 16-point DFT, natural order in / out
+  const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
+  const f2 hh = {h, h}, nhh = {-h, -h};
+  f2 y[4][4];   // y[b][c] = sum_a v[4a + b] W4^(ac)
+#pragma unroll
+  for (int b = 0; b < 4; b++) {
+    f2 a0 = v[b], a1 = v[4 + b], a2 = v[8 + b], a3 = v[12 + b];
+    pdft4(a0, a1, a2, a3);
+    y[b][0] = a0; y[b][1] = a1; y[b][2] = a2; y[b][3] = a3;
+  }
+  const f2 w1 = {c1, -s1}, w3 = {s1, -c1}, w9 = {-c1, s1};
+  y[1][1] = cmulp(y[1][1], w1);
+  y[1][2] = rot_m45(y[1][2]) * hh;          // W16^2 = h (1 - i)
+  y[1][3] = cmulp(y[1][3], w3);
+  y[2][1] = rot_m45(y[2][1]) * hh;
+  // y[2][2] * W16^4 = -i y[2][2]: folded into the butterfly of column 2
+  y[2][3] = rot_p45(y[2][3]) * nhh;         // W16^6 = -h (1 + i)
+  y[3][1] = cmulp(y[3][1], w3);
+  y[3][2] = rot_p45(y[3][2]) * nhh;
+  y[3][3] = cmulp(y[3][3], w9);             // W16^9 = -W16^1
+#pragma unroll
+  for (int c = 0; c < 4; c++) {   // X[c + 4d] = sum_b z[b][c] W4^(bd)
+    f2 a0 = y[0][c], a1 = y[1][c], a2 = y[2][c], a3 = y[3][c];
+    if (c == 2) pdft4_a2mi(a0, a1, a2, a3); else pdft4(a0, a1, a2, a3);
+    v[c] = a0; v[c + 4] = a1; v[c + 8] = a2; v[c + 12] = a3;
+  }
+}
+
+// ---- radix-16 variant ------------------------------------------------------------------------------------------
+// N2 = 16 * 16 * R3 (R3 = 4, 8, 16).  A transform is owned by T = N2/16 threads (16 points each), so a 256-thread workgroup
+// runs G = 256/T transforms side by side (4, 2, 1).  Plan: radix 16 on the thread-owned points -> LDS -> radix 16 -> LDS
+// (in place) -> radix R3 back into thread-owned registers: two LDS round trips and three barriers per G transforms instead
+// of three round trips and three barriers per single transform.  One pad slot per 32 points (`i + (i >> 5)`) makes the
+// stride-16 stores of the first pass conflict-free and keeps every other access (32 consecutive, aligned points) inside one
+// row; all LDS addresses are `lane base + compile-time constant`, so they fold into the DS instruction offsets.
+// Twiddles come from two small per-pass tables whose reads are consecutive in the lane index.
+#define TC16_PADDED(n) ((n) + ((n) >> 5))
+__device__ __forceinline__ void dft16(float2 (&v)[16]) {   // forward 16-point DFT, natural order in / out
+  const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
+  float2 y[4][4];   // y[b][c] = sum_a v[4a + b] W4^(ac)
+#pragma unroll
+  for (int b = 0; b < 4; b++) {
+    float2 a0 = v[b], a1 = v[4 + b], a2 = v[8 + b], a3 = v[12 + b];
+    dft4(a0, a1, a2, a3);
+    y[b][0] = a0; y[b][1] = a1; y[b][2] = a2; y[b][3] = a3;
+  }
+  // z[b][c] = y[b][c] * W16^(bc)
+  const float2 w1 = make_float2(c1, -s1), w2 = make_float2(h, -h), w3 = make_float2(s1, -c1);
+  y[1][1] = cmul(y[1][1], w1);
+  y[1][2] = cmul(y[1][2], w2);
+  y[1][3] = cmul(y[1][3], w3);
+  y[2][1] = cmul(y[2][1], w2);
+  y[2][2] = cmul_mi(y[2][2]);                                  // W16^4 = -i
+  y[2][3] = cmul(y[2][3], make_float2(-h, -h));                // W16^6
+  y[3][1] = cmul(y[3][1], w3);
+  y[3][2] = cmul(y[3][2], make_float2(-h, -h));                // W16^6
+  y[3][3] = cmul(y[3][3], make_float2(-c1, s1));               // W16^9 = -W16^1
+#pragma unroll
+  for (int c = 0; c < 4; c++) {   // X[c + 4d] = sum_b z[b][c] W4^(bd)
+    float2 a0 = y[0][c], a1 = y[1][c], a2 = y[2][c], a3 = y[3][c];
+    dft4(a0, a1, a2, a3);
+    v[c] = a0; v[c + 4] = a1; v[c + 8] = a2; v[c + 12] = a3;
+  }
+}
+template <int N>
+struct R16Plan {
+  static constexpr int T = N / 16;          // threads per transform
+  static constexpr int G = 256 / T;         // transforms per workgroup
+  static constexpr int R3 = N / 256;        // last radix
+  static constexpr int U3 = 16 / R3;        // last-pass butterflies per thread
+  static constexpr int T2 = 15 * 16;        // table of W_256^(kk m), [m-1][kk]
+  static constexpr int T3 = (R3 - 1) * 256; // table of W_N^(j m),   [m-1][j]
+};
+// forward FFT of the 16 thread-owned points {t + T m}; `buf` is this transform's N-point LDS buffer.  Contains three
+// workgroup barriers; every thread of the workgroup must call it (threads of an idle transform pass live = false).
+template <int N>
+__device__ __forceinline__ void fft16_own(f2 (&own)[16], f2* __restrict buf, const f2* __restrict tw2,
+                                          const f2* __restrict tw3, int t) {
+  using PL = R16Plan<N>;
+  constexpr int T = PL::T;
+  pdft16(own);
+  const int b1 = 16 * t + (t >> 1);        // pad(16 t + m) = b1 + m
+  const int b2 = t + (t >> 5);             // pad(t + c)    = b2 + c + (c >> 5) for c a multiple of 32
+#pragma unroll
+  for (int m = 0; m < 16; m++) buf[b1 + m] = own[m];
+  __syncthreads();
+  {
+    const int kk = t & 15;
+#pragma unroll
+    for (int m = 0; m < 16; m++) own[m] = buf[b2 + T * m + (T / 32) * m];
+    // twiddles in groups of four with a scheduling fence in between: keeps the compiler from hoisting all 15 table
+    // reads above the products (30 more live registers cost a wave per SIMD)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+#pragma unroll
+      for (int m = 4 * q; m < 4 * q + 4; m++)
+        if (m > 0) own[m] = cmulp(own[m], tw2[(m - 1) * 16 + kk]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    pdft16(own);
+    __syncthreads();   // every read of this pass is done: write in place
+    const int b3 = (t >> 4) * 264 + kk;    // pad(256 (t / 16) + kk + 16 m) = b3 + 16 m + (m >> 1)
+#pragma unroll
+    for (int m = 0; m < 16; m++) buf[b3 + 16 * m + (m >> 1)] = own[m];
+  }
+  __syncthreads();
+  {
+    constexpr int R3 = PL::R3, U3 = PL::U3;
+#pragma unroll
+    for (int u = 0; u < U3; u++) {
+      const int j = t + T * u;   // < 256
+      f2 v[R3];
+#pragma unroll
+      for (int m = 0; m < R3; m++) v[m] = buf[b2 + (T + T / 32) * u + 264 * m];
+#pragma unroll
+      for (int q = 0; q < R3 / 4; q++) {
+#pragma unroll
+        for (int m = 4 * q; m < 4 * q + 4; m++)
+          if (m > 0) v[m] = cmulp(v[m], tw3[(m - 1) * 256 + j]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (R3 == 16) pdft16(v);
+      else if constexpr (R3 == 8) pdft8(v);
+      else pdft4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+      for (int m = 0; m < R3; m++) own[u + U3 * m] = v[m];   // position j + 256 m = t + T (u + U3 m)
+    }
+  }
+}
+
+// Persistent workgroups (one per resident slot).  The G transforms of a workgroup serve G different (set, segment) items.
+template <int N2>
+__global__ __launch_bounds__(256, 3) void tconv16_kernel(const ConvSetC* __restrict sets, int nsets, int nseg, int nblocks, int hist,
+                                                      ConvPlanesB pl, const float2* __restrict twg) {
+  using PL = R16Plan<N2>;
+  constexpr int T = PL::T, G = PL::G;
+  extern __shared__ f2 lds16[];
+  f2* lds = lds16;
+  f2* tw2 = lds;
+  f2* tw3 = lds + PL::T2;
+  const int tid = threadIdx.x;
+  // T >= 64: a wavefront belongs to ONE transform, so everything indexed by g is wave-uniform -- say so (scalar loads of
+  // the set record, SGPR base addresses for the global accesses)
+  const int g = __builtin_amdgcn_readfirstlane(tid / T), t = tid % T;
+  f2* buf = lds + PL::T2 + PL::T3 + g * TC16_PADDED(N2);
+  for (int i = tid; i < PL::T2 + PL::T3; i += 256) lds[i] = f2{twg[i].x, twg[i].y};
+  const int total = nsets * nseg;
+  const float scale = 1.0f / N2;
+  __syncthreads();
+  // work unit = (bin, step of G items); the units are dealt to the resident workgroups in contiguous, equal ranges (bin-major:
+  // a workgroup stays on one bin, whose taps spectra stay in its L2)
+  const int steps = (total + G - 1) / G;
+  const long long units = (long long)kBins * steps;
+  const long long per = (units + gridDim.x - 1) / gridDim.x;
+  const long long w0 = (long long)blockIdx.x * per, w1 = min(units, w0 + per);
+  for (long long w = w0; w < w1; w++) {
+    const int k = (int)(w / steps);
+    const int base = (int)(w % steps) * G;
+    const int item = base + g;
+    const bool live = item < total;
+    const ConvSetC* __restrict S = &sets[live ? item / nseg : 0];
+    const int seg = live ? item % nseg : 0;
+    const int P = S->P;
+    const int ncol = live ? S->ncol : 0;
+    const int L = N2 - (P - 1);
+    const int t0 = seg * L;
+    const bool work = live && t0 < nblocks;
+    int maxcol = 0;   // the same for every thread of the workgroup: barriers inside fft16_own
+#pragma unroll
+    for (int gg = 0; gg < G; gg++) {
+      const int it = base + gg;
+      if (it < total && (it % nseg) * L < nblocks) maxcol = max(maxcol, sets[it / nseg].ncol);
+    }
+    if (maxcol == 0) continue;
+    f2 xf[16];
+    const unsigned ut = (unsigned)t;
+    {
+      // window element e = t + T m is block t0 - (P - 1) + e; plane index hist + block >= 0 because hist >= P - 1
+      const int first = hist + t0 - (P - 1);
+      const int lim = work ? nblocks - (t0 - (P - 1)) : 0;   // elements at or beyond `lim` are zero padding
+      const float* __restrict xr = pl.xr + ((size_t)S->x * kBins + k) * pl.tx + first;
+      const float* __restrict xi = pl.xi + ((size_t)S->x * kBins + k) * pl.tx + first;
+#pragma unroll
+      for (int m = 0; m < 16; m++) {
+        xf[m] = f2{0.f, 0.f};
+        if ((int)(ut + T * m) < lim) xf[m] = f2{xr[ut + T * m], xi[ut + T * m]};
+      }
+    }
+    fft16_own<N2>(xf, buf, tw2, tw3, t);
+    __syncthreads();   // the last-pass reads are done before the next transform stores into the buffer
+    const int nvalid = min(L, nblocks - t0);
+    for (int j = 0; j < maxcol; j++) {
+      const bool act = work && j < ncol;
+      f2 y[16];
+      if (act) {
+        const f2* __restrict hs = reinterpret_cast<const f2*>(S->hs[j] + (size_t)k * N2);
+#pragma unroll
+        for (int m = 0; m < 16; m++) y[m] = cmulp_conj(xf[m], hs[ut + T * m]);   // conj: ifft(v) = conj(fft(conj(v))) / N
+      } else {
+#pragma unroll
+        for (int m = 0; m < 16; m++) y[m] = f2{0.f, 0.f};
+      }
+      fft16_own<N2>(y, buf, tw2, tw3, t);
+      if (act) {
+        // element e = t + T m of the result is output block t0 + e - (P - 1); valid for P - 1 <= e < P - 1 + nvalid
+        float* __restrict yr = pl.yr + ((size_t)(S->y0 + j) * kBins + k) * pl.ty + t0 - (P - 1);
+        float* __restrict yi = pl.yi + ((size_t)(S->y0 + j) * kBins + k) * pl.ty + t0 - (P - 1);
+        const int e0 = P - 1, e1 = P - 1 + nvalid;
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+          const int e = (int)(ut + T * m);
+          if (e >= e0 && e < e1) {
+            yr[ut + T * m] = y[m].x * scale;
+            yi[ut + T * m] = -y[m].y * scale;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+template <int N2>
+static void launch_tconv16_n(hipStream_t s, const ConvSetC* sets_dev, int nsets, int nblocks, int hist, ConvPlanesB pl, const float2* tw16,
+                             int nseg) {
+  using PL = R16Plan<N2>;
+  const size_t lds = (size_t)(PL::T2 + PL::T3 + PL::G * TC16_PADDED(N2)) * sizeof(float2);
+  static int groups = 0;
+  if (!groups) {
+    (void)hipFuncSetAttribute((const void*)tconv16_kernel<N2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+    int occ = 0, dev = 0, cus = 256;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, tconv16_kernel<N2>, 256, lds);
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    groups = std::max(occ, 1) * cus;   // exactly one resident round
+  }
+  const long long steps = ((long long)nsets * nseg + PL::G - 1) / PL::G;
+  dim3 grid((unsigned)std::min<long long>(steps * kBins, groups)), block(256);
+  hipLaunchKernelGGL(tconv16_kernel<N2>, grid, block, lds, s, sets_dev, nsets, nseg, nblocks, hist, pl, tw16);
+}
+void launch_tconv16(hipStream_t s, const ConvSetC* sets_dev, int nsets, int nblocks, int hist, ConvPlanesB pl, int N2, const float2* tw16,
+                    int nseg) {
+  if (nsets <= 0 || nblocks <= 0) return;
+  if (N2 == 1024) launch_tconv16_n<1024>(s, sets_dev, nsets, nblocks, hist, pl, tw16, nseg);
+  else if (N2 == 2048) launch_tconv16_n<2048>(s, sets_dev, nsets, nblocks, hist, pl, tw16, nseg);
+  else launch_tconv16_n<4096>(s, sets_dev, nsets, nblocks, hist, pl, tw16, nseg);
+}
+
 // ---- plane utilities ----------------------------------------------------------------------------------
 __global__ void plane_copy_kernel(float* __restrict dst, int dst_t, int dst_t0, const float* __restrict src, int src_t, int src_t0,
                                   int n, int rp) {
