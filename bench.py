@@ -14,7 +14,7 @@ destination bus is summed with one RCCL reduce per step (torch.distributed backe
 
 One JSON line on stdout (rank 0).  Besides the contract keys:
   roofline      -- dominant kernel.  Default path ("formulation C"): the partition sum runs as an overlap-save
-                   FFT convolution along the block axis (tconv_kernel), an HBM-bound stage.  `achieved` follows the
+                   FFT convolution along the block axis (tconv16_kernel), an HBM-bound stage.  `achieved` follows the
                    contract (SURVEY.md 8(d) per-block STREAMING bytes, 1.086 GB/block here, x blocks per launch / HIP-event
                    launch time) and therefore exceeds the 8 TB/s peak by construction; `traffic` is the HBM bytes per
                    launch measured with rocprofv3 PMC passes (profiles/), and
@@ -176,13 +176,13 @@ def main():
         ach_gbs = d["mac_bytes_total"] / mac_s / 1e9 if mac_s > 0 else 0.0
         blocks = frames // 128
         # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes of this exact workload
-        # (profiles/r01_pmc_hbm_traffic_v2_timefft.json: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per
-        # MI355X_MICROARCH.md after calibration on a known byte count); null for other shapes
+        # (profiles/r01_pmc_hbm_traffic_v3_radix16.json: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE calibrated per kernel on
+        # a known byte count as MI355X_MICROARCH.md prescribes for gfx950); null for other shapes
         traffic = None
         try:
             if world == 1 and voices_total == 1024 and args.taps == 65536 and blocks == 3750 and not args.direct:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_v2_timefft.json")))
-                traffic = pm["tconv_kernel_hbm_bytes_per_launch"]["total"]
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_v3_radix16.json")))
+                traffic = pm["tconv16_kernel_hbm_bytes_per_launch"]["total"]
             elif world == 1 and voices_total == 1024 and args.taps == 65536 and blocks == 3750:
                 pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
                 traffic = pm["spectral_mac_shared_kernel_hbm_bytes_per_launch"]["total"]
@@ -196,7 +196,7 @@ def main():
             form = ("direct partition sum, time-batched on the f32 matrix cores; dense f32 MFMA peak 157.3 TFLOP/s is the "
                     "binding roofline: see roofline_flops")
         else:
-            kernel = "tconv_kernel<2048> (overlap-save FFT convolution along the block axis, Stockham radix-8/4 in LDS)"
+            kernel = "tconv16_kernel<2048> (overlap-save FFT convolution along the block axis: radix 16-16-8 Stockham, packed f32, two LDS round trips)"
             form = ("partition sum evaluated as an FFT convolution over the block index (formulation C, DESIGN.md): ~20x "
                     "fewer flops than the direct sum, so the stage is bound by HBM traffic of the spectra planes")
         rec = {

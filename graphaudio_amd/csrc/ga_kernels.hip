@@ -519,14 +519,15 @@ constexpr int FB_KP = 130;            // staging pitch of a [block][bin] tile: 1
 // forward: workgroup = (x-row, run of 32 blocks); wave w transforms blocks w, w+4, ..., w+28 of the run, 4 in flight
 template <class T>
 __global__ __launch_bounds__(256) void rfft_fwd_b_kernel(const ConvRowIO* __restrict xrows, int nx, int nblocks, int hist,
-                                                         ConvPlanesB pl, Twiddles tw) {
+                                                         ConvPlanesB pl, Twiddles tw, int row0) {
   // staging tile [block of the run][bin], pitch FB_KP = 130 floats: a lane's bins (k0, k0 + 1) are one aligned 8-byte
   // access and the 32 lanes of a group land on distinct bank pairs (2-way at worst); same for the transposed reads below
   __shared__ __attribute__((aligned(16))) float st_r[FB_RUN * FB_KP];
   __shared__ __attribute__((aligned(16))) float st_i[FB_RUN * FB_KP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int xrow = blockIdx.x;
-  const int t0 = blockIdx.y * FB_RUN;
+  // consecutive workgroups take consecutive runs of ONE row: their 128-byte pieces of every bin line are adjacent in HBM
+  const int xrow = row0 + blockIdx.y;
+  const int t0 = blockIdx.x * FB_RUN;
   const LaneTwT<T> ltw = load_lane_tw_t<T>(tw.w128, lane);
   const int m = rev6(lane);
   const int k0 = 2 * m, k1 = 2 * m + 1;
@@ -613,9 +614,11 @@ __global__ __launch_bounds__(256) void rfft_fwd_b_kernel(const ConvRowIO* __rest
 }
 void launch_rfft_fwd_b(hipStream_t s, const ConvRowIO* xrows_dev, int nx, int nblocks, int hist, ConvPlanesB pl, Twiddles tw, bool fp64) {
   if (nx <= 0 || nblocks <= 0) return;
-  dim3 grid(nx, (nblocks + FB_RUN - 1) / FB_RUN);
-  if (fp64) hipLaunchKernelGGL(rfft_fwd_b_kernel<double>, grid, dim3(256), 0, s, xrows_dev, nx, nblocks, hist, pl, tw);
-  else hipLaunchKernelGGL(rfft_fwd_b_kernel<float>, grid, dim3(256), 0, s, xrows_dev, nx, nblocks, hist, pl, tw);
+  for (int r0 = 0; r0 < nx; r0 += 65535) {   // gridDim.y limit
+    dim3 grid((nblocks + FB_RUN - 1) / FB_RUN, std::min(65535, nx - r0));
+    if (fp64) hipLaunchKernelGGL(rfft_fwd_b_kernel<double>, grid, dim3(256), 0, s, xrows_dev, nx, nblocks, hist, pl, tw, r0);
+    else hipLaunchKernelGGL(rfft_fwd_b_kernel<float>, grid, dim3(256), 0, s, xrows_dev, nx, nblocks, hist, pl, tw, r0);
+  }
 }
 
 // MAC B: workgroup = (set, bin, 256-block time tile); wave = 64 blocks (4 M-tiles) x 16 columns; taps in segments of 256
@@ -721,7 +724,7 @@ void launch_spectral_mac_b(hipStream_t s, const ConvSetB* sets_dev, int nsets, i
 template <class T>
 __global__ __launch_bounds__(256) void irfft_ola_b_kernel(const ConvRowIO* __restrict yrows, int ny, int nblocks, ConvPlanesB pl,
                                                           const float* const* __restrict overlap_in, float* const* __restrict overlap_out,
-                                                          Twiddles tw) {
+                                                          Twiddles tw, int row0) {
   // staging tile [33 columns][bin] (pitch 130, see the forward kernel): column c <-> block ta - 1 + c ; the memory is
   // reused for the head/tail tiles afterwards
   constexpr int NC = FB_RUN + 1;
@@ -729,8 +732,8 @@ __global__ __launch_bounds__(256) void irfft_ola_b_kernel(const ConvRowIO* __res
   float* sr = smem;
   float* si = smem + NC * FB_KP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int row = blockIdx.x;
-  const int ta = blockIdx.y * FB_RUN;
+  const int row = row0 + blockIdx.y;
+  const int ta = blockIdx.x * FB_RUN;
   const int tb = min(ta + FB_RUN, nblocks);
   const int nrun = tb - ta;
   const LaneTwT<T> ltw = load_lane_tw_t<T>(tw.w128, lane);
@@ -848,9 +851,11 @@ __global__ __launch_bounds__(256) void irfft_ola_b_kernel(const ConvRowIO* __res
 void launch_irfft_ola_b(hipStream_t s, const ConvRowIO* yrows_dev, int ny, int nblocks, ConvPlanesB pl,
                         const float* const* overlap_in_dev, float* const* overlap_out_dev, Twiddles tw, bool fp64) {
   if (ny <= 0 || nblocks <= 0) return;
-  dim3 grid(ny, (nblocks + FB_RUN - 1) / FB_RUN);
-  if (fp64) hipLaunchKernelGGL(irfft_ola_b_kernel<double>, grid, dim3(256), 0, s, yrows_dev, ny, nblocks, pl, overlap_in_dev, overlap_out_dev, tw);
-  else hipLaunchKernelGGL(irfft_ola_b_kernel<float>, grid, dim3(256), 0, s, yrows_dev, ny, nblocks, pl, overlap_in_dev, overlap_out_dev, tw);
+  for (int r0 = 0; r0 < ny; r0 += 65535) {   // gridDim.y limit
+    dim3 grid((nblocks + FB_RUN - 1) / FB_RUN, std::min(65535, ny - r0));
+    if (fp64) hipLaunchKernelGGL(irfft_ola_b_kernel<double>, grid, dim3(256), 0, s, yrows_dev, ny, nblocks, pl, overlap_in_dev, overlap_out_dev, tw, r0);
+    else hipLaunchKernelGGL(irfft_ola_b_kernel<float>, grid, dim3(256), 0, s, yrows_dev, ny, nblocks, pl, overlap_in_dev, overlap_out_dev, tw, r0);
+  }
 }
 
 __global__ void hist_copy_b_kernel(const HistJobB* __restrict jobs) {
@@ -1392,6 +1397,30 @@ __global__ __launch_bounds__(256, 3) void tconv16_kernel(const ConvSetC* __restr
   const long long units = (long long)kBins * steps;
   const long long per = (units + gridDim.x - 1) / gridDim.x;
   const long long w0 = (long long)blockIdx.x * per, w1 = min(units, w0 + per);
+  const unsigned ut = (unsigned)t;
+  // window of unit w -> registers.  Called for unit w + 1 as soon as the last product of unit w has consumed the spectrum,
+  // so the HBM latency of the next window hides behind the last inverse transform.
+  auto load_window = [&](long long w, f2 (&xw)[16]) {
+    const int k = (int)(w / steps);
+    const int item = (int)(w % steps) * G + g;
+    const bool live = item < total;
+    const ConvSetC* __restrict S = &sets[live ? item / nseg : 0];
+    const int seg = live ? item % nseg : 0;
+    const int P = S->P;
+    const int t0 = seg * (N2 - (P - 1));
+    // window element e = t + T m is block t0 - (P - 1) + e; plane index hist + block >= 0 because hist >= P - 1
+    const int first = hist + t0 - (P - 1);
+    const int lim = (live && t0 < nblocks) ? nblocks - (t0 - (P - 1)) : 0;   // elements at or beyond `lim` are zero padding
+    const float* __restrict xr = pl.xr + ((size_t)S->x * kBins + k) * pl.tx + first;
+    const float* __restrict xi = pl.xi + ((size_t)S->x * kBins + k) * pl.tx + first;
+#pragma unroll
+    for (int m = 0; m < 16; m++) {
+      xw[m] = f2{0.f, 0.f};
+      if ((int)(ut + T * m) < lim) xw[m] = f2{xr[ut + T * m], xi[ut + T * m]};
+    }
+  };
+  f2 xf[16];
+  if (w0 < w1) load_window(w0, xf);
   for (long long w = w0; w < w1; w++) {
     const int k = (int)(w / steps);
     const int base = (int)(w % steps) * G;
@@ -1410,20 +1439,9 @@ __global__ __launch_bounds__(256, 3) void tconv16_kernel(const ConvSetC* __restr
       const int it = base + gg;
       if (it < total && (it % nseg) * L < nblocks) maxcol = max(maxcol, sets[it / nseg].ncol);
     }
-    if (maxcol == 0) continue;
-    f2 xf[16];
-    const unsigned ut = (unsigned)t;
-    {
-      // window element e = t + T m is block t0 - (P - 1) + e; plane index hist + block >= 0 because hist >= P - 1
-      const int first = hist + t0 - (P - 1);
-      const int lim = work ? nblocks - (t0 - (P - 1)) : 0;   // elements at or beyond `lim` are zero padding
-      const float* __restrict xr = pl.xr + ((size_t)S->x * kBins + k) * pl.tx + first;
-      const float* __restrict xi = pl.xi + ((size_t)S->x * kBins + k) * pl.tx + first;
-#pragma unroll
-      for (int m = 0; m < 16; m++) {
-        xf[m] = f2{0.f, 0.f};
-        if ((int)(ut + T * m) < lim) xf[m] = f2{xr[ut + T * m], xi[ut + T * m]};
-      }
+    if (maxcol == 0) {
+      if (w + 1 < w1) load_window(w + 1, xf);
+      continue;
     }
     fft16_own<N2>(xf, buf, tw2, tw3, t);
     __syncthreads();   // the last-pass reads are done before the next transform stores into the buffer
@@ -1439,6 +1457,7 @@ __global__ __launch_bounds__(256, 3) void tconv16_kernel(const ConvSetC* __restr
 #pragma unroll
         for (int m = 0; m < 16; m++) y[m] = f2{0.f, 0.f};
       }
+      if (j == maxcol - 1 && w + 1 < w1) load_window(w + 1, xf);
       fft16_own<N2>(y, buf, tw2, tw3, t);
       if (act) {
         // element e = t + T m of the result is output block t0 + e - (P - 1); valid for P - 1 <= e < P - 1 + nvalid
