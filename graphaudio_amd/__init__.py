@@ -8,7 +8,8 @@ from ._capi import (ArgumentException, ArgumentOutOfRangeException, DeviceExcept
                     product_api)
 from .core import (AudioBufferSourceNode, AudioContextBase, AudioDestinationNode, AudioNode, AudioNodeInput,
                    AudioParam, AutomationRate, BiQuadFilterNode, ChannelCountMode, ChannelInterpretation,
-                   ConvolverNode, FilterType, FramesPerBlock, GainNode, HipOfflineAudioContext,
-                   OfflineAudioContext, PlayableAudioBuffer)
+                   ChannelMergerNode, ChannelSplitterNode, ConstantSourceNode, ConvolverNode, DelayNode, FilterType,
+                   FramesPerBlock, GainNode, HipOfflineAudioContext, OfflineAudioContext, OscillatorNode,
+                   OscillatorType, PlayableAudioBuffer, StereoPannerNode)
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -99,6 +99,7 @@ SIGNATURES = {
     "buffer_create": (_i, [_vp, _pp, _i, _i64, _i, C.POINTER(_i)]),
     "buffer_release": (_i, [_vp, _i]),
     "node_create": (_i, [_vp, _i, C.POINTER(_i)]),
+    "node_create_ex": (_i, [_vp, _i, _d, C.POINTER(_i)]),
     "node_dispose": (_i, [_vp, _i]),
     "node_connect": (_i, [_vp, _i, _i, _i, _i]),
     "node_disconnect": (_i, [_vp, _i, _i, _i, _i]),
@@ -122,6 +123,7 @@ SIGNATURES = {
     "source_set_loop": (_i, [_vp, _i, _i, _d, _d]),
     "source_start": (_i, [_vp, _i, _d, _d, _d]),
     "source_stop": (_i, [_vp, _i, _d]),
+    "oscillator_set_type": (_i, [_vp, _i, _i]),
     "biquad_set_type": (_i, [_vp, _i, _i]),
     "convolver_set_normalize": (_i, [_vp, _i, _i]),
     "convolver_set_enable_true_stereo": (_i, [_vp, _i, _i]),

@@ -171,13 +171,17 @@ class AudioNode:
     _node_type: int = -1
     _input_count = 1
     _output_count = 1
+    _ctor_arg = None   # constructor argument of nodes that take one (node_create_ex)
 
     def __init__(self, context: "AudioContextBase", name: Optional[str] = None, _id: Optional[int] = None):
         self.Context = context
         self.Name = name or type(self).__name__
         if _id is None:
             out = C.c_int(-1)
-            context._call("node_create", self._node_type, C.byref(out))
+            if self._ctor_arg is None:
+                context._call("node_create", self._node_type, C.byref(out))
+            else:
+                context._call("node_create_ex", self._node_type, float(self._ctor_arg), C.byref(out))
             _id = out.value
         self._id = _id
         self.NodeId = _id
@@ -332,6 +336,88 @@ class AudioBufferSourceNode(AudioNode):  # Nodes/AudioBufferSourceNode.cs:13-415
 
     def Stop(self, when: float = 0.0):  # :116-129
         self.Context._call("source_stop", self._id, float(when))
+
+
+class OscillatorType(enum.IntEnum):  # OscillatorNode.cs:207-213
+    Sine = 0
+    Square = 1
+    Sawtooth = 2
+    Triangle = 3
+
+
+class ChannelSplitterNode(AudioNode):  # Nodes/ChannelSplitterNode.cs:9-71
+    _node_type = 5
+
+    def __init__(self, context, numberOfOutputs: int = 2):
+        self._ctor_arg = int(numberOfOutputs)
+        self._output_count = int(numberOfOutputs)
+        super().__init__(context, "ChannelSplitter")
+
+
+class ChannelMergerNode(AudioNode):  # Nodes/ChannelMergerNode.cs:9-65
+    _node_type = 6
+
+    def __init__(self, context, numberOfInputs: int = 2):
+        self._ctor_arg = int(numberOfInputs)
+        self._input_count = max(int(numberOfInputs), 0)
+        super().__init__(context, "ChannelMerger")
+
+
+class _ScheduledSource(AudioNode):
+    """IAudioScheduledSourceNode members shared by ConstantSourceNode and OscillatorNode."""
+    _input_count = 0
+
+    def Start(self, when: float = 0.0, offset: float = 0.0, duration: float = math.nan):
+        self.Context._call("source_start", self._id, float(when), float(offset), float(duration))
+
+    def Stop(self, when: float = 0.0):
+        self.Context._call("source_stop", self._id, float(when))
+
+
+class ConstantSourceNode(_ScheduledSource):  # Nodes/ConstantSourceNode.cs:15-163
+    _node_type = 7
+
+    def __init__(self, context):
+        super().__init__(context, "ConstantSource")
+        fmax = float(np.finfo(np.float32).max)
+        self.Offset = self._param("offset", 1.0, -fmax, fmax, AutomationRate.ARate)
+        self.Ended = []
+
+
+class StereoPannerNode(AudioNode):  # Nodes/StereoPannerNode.cs:9-163
+    _node_type = 8
+
+    def __init__(self, context):
+        super().__init__(context, "StereoPanner")
+        self.Pan = self._param("pan", 0.0, -1.0, 1.0, AutomationRate.ARate)
+
+
+class OscillatorNode(_ScheduledSource):  # Nodes/OscillatorNode.cs:12-214
+    _node_type = 9
+
+    def __init__(self, context):
+        super().__init__(context, "Oscillator")
+        self.Frequency = self._param("frequency", 440.0, 0.0, context.SampleRate / 2.0, AutomationRate.ARate)
+        self._type = OscillatorType.Sine
+        self.Ended = []
+
+    @property
+    def Type(self) -> OscillatorType:
+        return self._type
+
+    @Type.setter
+    def Type(self, value: OscillatorType):  # :33-42
+        self.Context._call("oscillator_set_type", self._id, int(value))
+        self._type = OscillatorType(int(value))
+
+
+class DelayNode(AudioNode):  # Nodes/DelayNode.cs:9-150
+    _node_type = 10
+
+    def __init__(self, context, maxDelayTime: float = 1.0):
+        self._ctor_arg = float(maxDelayTime)
+        super().__init__(context, "Delay")
+        self.DelayTime = self._param("delayTime", 0.0, 0.0, float(maxDelayTime), AutomationRate.ARate)
 
 
 class AudioContextBase:

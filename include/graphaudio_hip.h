@@ -55,10 +55,18 @@ enum { /* node types creatable through ga_node_create; the destination is always
   GA_NODE_BUFFER_SOURCE = 1, /* Nodes/AudioBufferSourceNode.cs:13 ; params: 0 = playbackRate (k-rate) */
   GA_NODE_GAIN = 2,          /* Nodes/GainNode.cs:9            ; params: 0 = gain (a-rate) */
   GA_NODE_BIQUAD = 3,        /* Nodes/BiQuadFilterNode.cs:10   ; params: 0 = frequency (a), 1 = Q (a), 2 = gain dB (k) */
-  GA_NODE_CONVOLVER = 4      /* Nodes/ConvolverNode.cs:10      ; no params */
+  GA_NODE_CONVOLVER = 4,     /* Nodes/ConvolverNode.cs:10      ; no params */
+  /* the remaining pure-Core nodes */
+  GA_NODE_CHANNEL_SPLITTER = 5, /* Nodes/ChannelSplitterNode.cs:9  ; N mono outputs (create_ex arg = numberOfOutputs) */
+  GA_NODE_CHANNEL_MERGER = 6,   /* Nodes/ChannelMergerNode.cs:9    ; N inputs (create_ex arg = numberOfInputs) */
+  GA_NODE_CONSTANT_SOURCE = 7,  /* Nodes/ConstantSourceNode.cs:15  ; params: 0 = offset (a-rate) ; scheduled source */
+  GA_NODE_STEREO_PANNER = 8,    /* Nodes/StereoPannerNode.cs:9     ; params: 0 = pan (a-rate) */
+  GA_NODE_OSCILLATOR = 9,       /* Nodes/OscillatorNode.cs:12      ; params: 0 = frequency (a-rate) ; scheduled source */
+  GA_NODE_DELAY = 10            /* Nodes/DelayNode.cs:9            ; params: 0 = delayTime (a-rate) ; create_ex arg = maxDelayTime */
 };
 enum { GA_FILTER_LOWPASS = 0, GA_FILTER_HIGHPASS, GA_FILTER_BANDPASS, GA_FILTER_NOTCH, GA_FILTER_ALLPASS,
        GA_FILTER_PEAKING, GA_FILTER_LOWSHELF, GA_FILTER_HIGHSHELF }; /* BiQuadFilterNode.cs:288-298 */
+enum { GA_OSC_SINE = 0, GA_OSC_SQUARE, GA_OSC_SAWTOOTH, GA_OSC_TRIANGLE };   /* OscillatorNode.cs:207-213 */
 enum { GA_COUNT_MODE_MAX = 0, GA_COUNT_MODE_CLAMPED_MAX = 1, GA_COUNT_MODE_EXPLICIT = 2 }; /* AudioNodeInput.cs:258-272 */
 enum { GA_INTERP_SPEAKERS = 0, GA_INTERP_DISCRETE = 1 };                                    /* AudioNodeInput.cs:246-256 */
 
@@ -104,6 +112,9 @@ GA_EXPORT int GA_FN(buffer_release)(ga_context* ctx, int buffer_id);
 
 /* ---- nodes: constructors of GainNode / BiQuadFilterNode / ConvolverNode / AudioBufferSourceNode ---- */
 GA_EXPORT int GA_FN(node_create)(ga_context* ctx, int node_type, int* out_node_id);
+/* constructors with an argument: ChannelSplitterNode(numberOfOutputs) ChannelSplitterNode.cs:14, ChannelMergerNode(numberOfInputs)
+   ChannelMergerNode.cs:14, DelayNode(maxDelayTime seconds) DelayNode.cs:22 ; other node types ignore `arg` */
+GA_EXPORT int GA_FN(node_create_ex)(ga_context* ctx, int node_type, double arg, int* out_node_id);
 GA_EXPORT int GA_FN(node_dispose)(ga_context* ctx, int node);  /* AudioNode.Dispose, Nodes/AudioNode.cs:207-238 */
 /* AudioNode.Connect(destination, outputIndex, inputIndex), Nodes/AudioNode.cs:68-73,109-123 */
 GA_EXPORT int GA_FN(node_connect)(ga_context* ctx, int src, int dst, int output_index, int input_index);
@@ -141,8 +152,13 @@ GA_EXPORT int GA_FN(param_cancel_scheduled_values)(ga_context* ctx, int node, in
 /* ---- AudioBufferSourceNode (Nodes/AudioBufferSourceNode.cs:39-129) ---- */
 GA_EXPORT int GA_FN(source_set_buffer)(ga_context* ctx, int node, int buffer_id); /* buffer_id < 0 = null */
 GA_EXPORT int GA_FN(source_set_loop)(ga_context* ctx, int node, int loop, double loop_start, double loop_end);
+/* Start / Stop of every IAudioScheduledSourceNode: AudioBufferSourceNode (duration default +inf, :79-129), ConstantSourceNode
+   (ConstantSourceNode.cs:44-74) and OscillatorNode (OscillatorNode.cs:54-88) -- for those two pass NaN for "no duration" */
 GA_EXPORT int GA_FN(source_start)(ga_context* ctx, int node, double when, double offset, double duration);
 GA_EXPORT int GA_FN(source_stop)(ga_context* ctx, int node, double when);
+
+/* ---- OscillatorNode.Type (Nodes/OscillatorNode.cs:33-42) ---- */
+GA_EXPORT int GA_FN(oscillator_set_type)(ga_context* ctx, int node, int oscillator_type);
 
 /* ---- BiQuadFilterNode.Type (Nodes/BiQuadFilterNode.cs:21-37) ---- */
 GA_EXPORT int GA_FN(biquad_set_type)(ga_context* ctx, int node, int filter_type);

@@ -587,6 +587,7 @@ struct Node {
   int lastProcessedBlock = -1;
   bool isProcessing = false;
   bool disposed = false;
+  bool endedRaised = false, endedReported = false;  // scheduled sources (Ended event)
 
   Node(Context* c, int id_, int type_, int nIn, int nOut) : ctx(c), id(id_), type(type_) {
     for (int i = 0; i < nIn; i++) inputs.push_back(std::make_unique<Input>(this, i));
@@ -1050,7 +1051,7 @@ struct ConvolverNode : Node {
 // ---- AudioBufferSourceNode (Nodes/AudioBufferSourceNode.cs:13-415) ----
 struct SourceNode : Node {
   PlayableBuffer* buffer = nullptr;
-  bool hasStarted = false, hasStopped = false, endedRaised = false, endedReported = false;
+  bool hasStarted = false, hasStopped = false;
   double startTime = std::nan(""), stopTime = std::nan("");
   double offset = 0, duration = std::numeric_limits<double>::infinity();
   int64_t playbackPosition = 0;
@@ -1251,6 +1252,310 @@ struct SourceNode : Node {
   }
 };
 
+// ---- ChannelSplitterNode (Nodes/ChannelSplitterNode.cs:9-71) ----
+struct SplitterNode : Node {
+  std::vector<BufPtr> outs;
+  SplitterNode(Context* c, int id, int nOut) : Node(c, id, GA_NODE_CHANNEL_SPLITTER, 1, nOut), outs(nOut) {}
+  void process() override {  // :24-59
+    AudioBuffer* in = inputs[0]->buffer.get();
+    const int n = (int)outs.size();
+    if (!in || in->silent) {
+      for (int i = 0; i < n; i++) {
+        if (!outs[i]) outs[i] = rent(1);
+        outs[i]->clear();
+        outputs[i]->buffer = outs[i];
+      }
+      return;
+    }
+    for (int i = 0; i < n; i++) {
+      if (!outs[i]) outs[i] = rent(1);
+      if (i < in->channelCount) {
+        std::memcpy(outs[i]->span(0), in->span(i), sizeof(float) * kBlock);  // CopyChannelFrom marks non-silent (AudioBuffer.cs:110-121)
+        outs[i]->silent = false;
+      } else {
+        outs[i]->clear();
+      }
+      outputs[i]->buffer = outs[i];
+    }
+  }
+  void onDispose() override { for (auto& o : outs) o.reset(); }
+};
+
+// ---- ChannelMergerNode (Nodes/ChannelMergerNode.cs:9-65) ----
+struct MergerNode : Node {
+  BufPtr out;
+  int nIn;
+  MergerNode(Context* c, int id, int nIn_) : Node(c, id, GA_NODE_CHANNEL_MERGER, nIn_, 1), nIn(nIn_) {}
+  void process() override {  // :23-55
+    if (!out || out->channelCount != nIn) out = rent(nIn);
+    out->clear();
+    bool hasAudio = false;
+    for (int i = 0; i < nIn; i++) {
+      AudioBuffer* in = inputs[i]->buffer.get();
+      if (in && !in->silent) {
+        std::memcpy(out->span(i), in->span(0), sizeof(float) * kBlock);  // source channel 0 only (:38-43)
+        out->silent = false;
+        hasAudio = true;
+      }
+    }
+    if (hasAudio) out->markNonSilent();
+    outputs[0]->buffer = out;
+  }
+  void onDispose() override { out.reset(); }
+};
+
+// scheduling shared by ConstantSourceNode and OscillatorNode (ConstantSourceNode.cs:44-74,83-110; OscillatorNode.cs:54-88,97-118)
+struct ScheduledNode : Node {
+  bool hasStarted = false, hasStopped = false;
+  double startTime = std::nan(""), stopTime = std::nan("");
+  BufPtr out;
+  using Node::Node;
+  void stop(double when) {
+    ctx->executeOrPost([this, when]() {
+      if (hasStopped) return;
+      double at = std::max(0.0, when);
+      stopTime = std::isnan(stopTime) ? at : std::min(stopTime, at);
+      hasStopped = true;
+    });
+  }
+  // returns shouldPlay and the frame window of this block
+  bool window(double t0, double t1, int& startFrame, int& endFrame) {
+    startFrame = 0;
+    endFrame = kBlock;
+    if (!hasStarted) return false;
+    if (!(t1 > startTime && (std::isnan(stopTime) || t0 < stopTime))) return false;
+    if (t0 < startTime && startTime < t1)
+      startFrame = (int)std::clamp(std::ceil((startTime - t0) * ctx->sampleRate), 0.0, (double)kBlock);
+    if (!std::isnan(stopTime) && t0 < stopTime && stopTime < t1)
+      endFrame = (int)std::clamp(std::floor((stopTime - t0) * ctx->sampleRate), 0.0, (double)kBlock);
+    return true;
+  }
+  void tryRaiseEnded(double blockEndTime) {  // ConstantSourceNode.cs:143-152, OscillatorNode.cs:160-169
+    if (hasStarted && hasStopped && !endedRaised && !std::isnan(stopTime) && blockEndTime >= stopTime) {
+      endedRaised = true;
+      ctx->executeOrPost([this]() { doDispose(); });
+    }
+  }
+  void onDispose() override { out.reset(); }
+};
+
+// ---- ConstantSourceNode (Nodes/ConstantSourceNode.cs:15-163) ----
+struct ConstantSourceNode : ScheduledNode {
+  ConstantSourceNode(Context* c, int id) : ScheduledNode(c, id, GA_NODE_CONSTANT_SOURCE, 0, 1) {
+    createParam(1.f, std::numeric_limits<float>::lowest(), std::numeric_limits<float>::max(), true);  // offset (:32-37)
+  }
+  void start(double when, double, double duration) {  // :44-63: a second Start is ignored
+    ctx->executeOrPost([this, when, duration]() {
+      if (hasStarted) return;
+      hasStarted = true;
+      startTime = std::max(0.0, when);
+      if (!std::isnan(duration) && duration >= 0) {
+        stopTime = startTime + duration;
+        hasStopped = true;
+      }
+    });
+  }
+  void process() override {  // :76-141
+    if (!out) out = rent(1);
+    double t0 = ctx->currentTime;
+    double t1 = t0 + (double)kBlock / ctx->sampleRate;
+    int startFrame, endFrame;
+    if (!window(t0, t1, startFrame, endFrame)) {
+      out->clear();
+      outputs[0]->buffer = out;
+      tryRaiseEnded(t1);
+      return;
+    }
+    float* o = out->span(0);
+    const float* v = params[0]->computed;
+    for (int i = 0; i < startFrame; i++) o[i] = 0.f;
+    for (int i = startFrame; i < endFrame; i++) o[i] = v[i];
+    for (int i = std::max(endFrame, 0); i < kBlock; i++) o[i] = 0.f;
+    out->markNonSilent();
+    outputs[0]->buffer = out;
+    tryRaiseEnded(t1);
+  }
+};
+
+// ---- OscillatorNode (Nodes/OscillatorNode.cs:12-214) ----
+struct OscillatorNode : ScheduledNode {
+  int oscType = 0;  // Sine, Square, Sawtooth, Triangle (:207-213)
+  double phase = 0.0;
+  OscillatorNode(Context* c, int id) : ScheduledNode(c, id, GA_NODE_OSCILLATOR, 0, 1) {
+    createParam(440.f, 0.f, c->sampleRate / 2.f, true);  // frequency (:46-51)
+  }
+  void start(double when, double, double duration) {  // :54-73
+    ctx->executeOrPost([this, when, duration]() {
+      if (hasStarted) fail(GA_ERR_INVALID_OPERATION, "OscillatorNode can only be started once.");
+      hasStarted = true;
+      phase = 0.0;
+      startTime = std::max(0.0, when);
+      if (!std::isnan(duration) && duration >= 0) {
+        stopTime = startTime + duration;
+        hasStopped = true;
+      }
+    });
+  }
+  static float generate(double ph, int type) {  // :171-195
+    const double PI = 3.14159265358979323846;
+    switch (type) {
+      case 0: return (float)std::sin(ph);
+      case 1: return ph < PI ? 1.0f : -1.0f;
+      case 2: return (float)(2.0 * (ph / (2.0 * PI)) - 1.0);
+      case 3: {
+        double t = ph / (2.0 * PI);
+        return (float)(4.0 * std::fabs(t - std::floor(t + 0.5)) - 1.0);
+      }
+      default: return 0.f;
+    }
+  }
+  void process() override {  // :91-158
+    const double PI = 3.14159265358979323846;
+    if (!out) out = rent(1);
+    double t0 = ctx->currentTime;
+    double t1 = t0 + (double)kBlock / ctx->sampleRate;
+    int startFrame, endFrame;
+    if (!window(t0, t1, startFrame, endFrame)) {
+      out->clear();
+      outputs[0]->buffer = out;
+      tryRaiseEnded(t1);
+      return;
+    }
+    float* o = out->span(0);
+    const float* f = params[0]->computed;
+    for (int i = 0; i < startFrame; i++) o[i] = 0.f;
+    for (int i = startFrame; i < endFrame; i++) {
+      o[i] = generate(phase, oscType);
+      double phaseIncrement = (2.0 * PI * f[i]) / ctx->sampleRate;
+      phase += phaseIncrement;
+      if (phase >= 2.0 * PI) phase -= 2.0 * PI;
+    }
+    for (int i = std::max(endFrame, 0); i < kBlock; i++) o[i] = 0.f;
+    out->markNonSilent();
+    outputs[0]->buffer = out;
+    tryRaiseEnded(t1);
+  }
+};
+
+// ---- StereoPannerNode (Nodes/StereoPannerNode.cs:9-163) ----
+struct StereoPannerNode : Node {
+  BufPtr out;
+  float lastPan = std::nanf(""), lastGainL = 0.5f, lastGainR = 0.5f;
+  StereoPannerNode(Context* c, int id) : Node(c, id, GA_NODE_STEREO_PANNER, 1, 1) {
+    inputs[0]->setChannelCount(2);                      // :24-26
+    inputs[0]->mode = GA_COUNT_MODE_CLAMPED_MAX;
+    inputs[0]->interpretation = GA_INTERP_SPEAKERS;
+    createParam(0.f, -1.f, 1.f, true);                  // pan (:28-33)
+  }
+  void process() override {  // :36-74
+    AudioBuffer* in = inputs[0]->buffer.get();
+    int inputChannels = in->channelCount;
+    if (!out || out->channelCount != 2) out = rent(2);
+    if (in->silent) {
+      out->clear();
+      outputs[0]->buffer = out;
+      return;
+    }
+    const float PIf = 3.14159265358979323846f;  // MathF.PI
+    const float* pv = params[0]->computed;
+    float* oL = out->span(0);
+    float* oR = out->span(1);
+    float gainL = lastGainL, gainR = lastGainR, lp = lastPan;
+    if (inputChannels == 1) {  // ProcessMono, :76-109
+      const float* x = in->span(0);
+      for (int i = 0; i < kBlock; i++) {
+        float pan = std::min(std::max(pv[i], -1.0f), 1.0f);
+        if (pan != lp) {
+          float xx = (pan + 1.0f) * 0.5f;
+          gainL = std::cos(xx * PIf / 2.0f);
+          gainR = std::sin(xx * PIf / 2.0f);
+          lp = pan;
+        }
+        float sm = x[i];
+        oL[i] = sm * gainL;
+        oR[i] = sm * gainR;
+      }
+      lastPan = lp; lastGainL = gainL; lastGainR = gainR;
+    } else if (inputChannels >= 2) {  // ProcessStereo, :111-153
+      const float* xl = in->span(0);
+      const float* xr = in->span(1);
+      for (int i = 0; i < kBlock; i++) {
+        float pan = std::min(std::max(pv[i], -1.0f), 1.0f);
+        if (pan != lp) {
+          float xx = pan <= 0.0f ? pan + 1.0f : pan;
+          gainL = std::cos(xx * PIf / 2.0f);
+          gainR = std::sin(xx * PIf / 2.0f);
+          lp = pan;
+        }
+        float inL = xl[i], inR = xr[i];
+        if (pan <= 0.0f) {
+          oL[i] = inL + inR * gainL;
+          oR[i] = inR * gainR;
+        } else {
+          oL[i] = inL * gainL;
+          oR[i] = inR + inL * gainR;
+        }
+      }
+      lastPan = lp; lastGainL = gainL; lastGainR = gainR;
+    }
+    out->markNonSilent();
+    outputs[0]->buffer = out;
+  }
+  void onDispose() override { out.reset(); }
+};
+
+// ---- DelayNode (Nodes/DelayNode.cs:9-150) ----
+struct DelayNode : Node {
+  struct Ring {  // CircularBuffer, :125-149
+    std::vector<float> buf;
+    int writePos = 0;
+    explicit Ring(int size) : buf((size_t)size, 0.f) {}
+    void write(float v) {
+      buf[writePos] = v;
+      writePos = (writePos + 1) % (int)buf.size();
+    }
+    float read(int d) const {
+      if (d <= 0 || d > (int)buf.size()) return 0.f;
+      int rp = (writePos - d + (int)buf.size()) % (int)buf.size();
+      return buf[rp];
+    }
+  };
+  std::vector<Ring> rings;
+  BufPtr out;
+  int maxDelaySamples;
+  DelayNode(Context* c, int id, double maxDelayTime) : Node(c, id, GA_NODE_DELAY, 1, 1) {
+    if (maxDelayTime <= 0 || maxDelayTime > 10) fail(GA_ERR_OUT_OF_RANGE, "maxDelayTime");  // :25-26
+    maxDelaySamples = (int)(maxDelayTime * c->sampleRate);
+    if (maxDelaySamples < 1) fail(GA_ERR_OUT_OF_RANGE, "maxDelayTime");  // (new float[0] + modulo by zero in the reference)
+    for (int i = 0; i < 2; i++) rings.emplace_back(maxDelaySamples);
+    createParam(0.f, 0.f, (float)maxDelayTime, true);  // delayTime (:35-40)
+  }
+  void process() override {  // :43-100
+    AudioBuffer* in = inputs[0]->buffer.get();
+    int ch = in ? in->channelCount : 2;
+    while ((int)rings.size() < ch) rings.emplace_back(maxDelaySamples);
+    if (!out || out->channelCount != ch) out = rent(ch);
+    bool hasAudio = false;
+    const float* dt = params[0]->computed;
+    const bool silentIn = !in || in->silent;
+    for (int c = 0; c < ch; c++) {
+      const float* x = silentIn ? nullptr : in->span(c);
+      float* o = out->span(c);
+      for (int i = 0; i < kBlock; i++) {
+        int d = (int)(dt[i] * ctx->sampleRate);   // float * int -> float, truncated (:68,:88)
+        d = std::min(std::max(d, 0), maxDelaySamples);
+        o[i] = rings[c].read(d);
+        rings[c].write(x ? x[i] : 0.f);
+        if (o[i] != 0.f) hasAudio = true;
+      }
+    }
+    // the rented buffer keeps its silent flag from the previous block unless audio appears (:96-97): it is never re-cleared
+    if (hasAudio) out->markNonSilent();
+    outputs[0]->buffer = out;
+  }
+  void onDispose() override { out.reset(); }
+};
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -1365,7 +1670,7 @@ int gao_buffer_create(ga_context* ctx, const float* const* planar, int channels,
 }
 int gao_buffer_release(ga_context* ctx, int) { return ctx ? GA_OK : GA_ERR_INVALID_ARGUMENT; }  // kept alive: nodes hold raw pointers
 
-int gao_node_create(ga_context* ctx, int node_type, int* out_id) {
+int gao_node_create_ex(ga_context* ctx, int node_type, double arg, int* out_id) {
   return guard(ctx, [&](Context& c) {
     if (!out_id) fail(GA_ERR_INVALID_ARGUMENT, "null pointer");
     int id = (int)c.nodes.size();
@@ -1374,10 +1679,26 @@ int gao_node_create(ga_context* ctx, int node_type, int* out_id) {
       case GA_NODE_GAIN: c.nodes.push_back(std::make_unique<GainNode>(&c, id)); break;
       case GA_NODE_BIQUAD: c.nodes.push_back(std::make_unique<BiquadNode>(&c, id)); break;
       case GA_NODE_CONVOLVER: c.nodes.push_back(std::make_unique<ConvolverNode>(&c, id)); break;
+      case GA_NODE_CHANNEL_SPLITTER:
+      case GA_NODE_CHANNEL_MERGER: {
+        int n = (int)arg;
+        if (n < 1 || n > 32) fail(GA_ERR_OUT_OF_RANGE, node_type == GA_NODE_CHANNEL_SPLITTER ? "numberOfOutputs" : "numberOfInputs");
+        if (node_type == GA_NODE_CHANNEL_SPLITTER) c.nodes.push_back(std::make_unique<SplitterNode>(&c, id, n));
+        else c.nodes.push_back(std::make_unique<MergerNode>(&c, id, n));
+        break;
+      }
+      case GA_NODE_CONSTANT_SOURCE: c.nodes.push_back(std::make_unique<ConstantSourceNode>(&c, id)); break;
+      case GA_NODE_STEREO_PANNER: c.nodes.push_back(std::make_unique<StereoPannerNode>(&c, id)); break;
+      case GA_NODE_OSCILLATOR: c.nodes.push_back(std::make_unique<OscillatorNode>(&c, id)); break;
+      case GA_NODE_DELAY: c.nodes.push_back(std::make_unique<DelayNode>(&c, id, arg)); break;
       default: fail(GA_ERR_INVALID_ARGUMENT, "unknown node type");
     }
     *out_id = id;
   });
+}
+int gao_node_create(ga_context* ctx, int node_type, int* out_id) {  // constructor defaults: 2 outputs / 2 inputs / 1.0 s
+  double arg = node_type == GA_NODE_DELAY ? 1.0 : 2.0;
+  return gao_node_create_ex(ctx, node_type, arg, out_id);
 }
 int gao_node_dispose(ga_context* ctx, int node) {
   return guard(ctx, [&](Context& c) {
@@ -1434,7 +1755,7 @@ int gao_node_has_ended(ga_context* ctx, int node) {
   int r = 0;
   int rc = guard(ctx, [&](Context& c) {
     Node* n = getNode(c, node);
-    if (n->type == GA_NODE_BUFFER_SOURCE) r = static_cast<SourceNode*>(n)->endedRaised ? 1 : 0;
+    r = n->endedRaised ? 1 : 0;
   });
   return rc < 0 ? rc : r;
 }
@@ -1445,8 +1766,7 @@ int gao_poll_ended(ga_context* ctx, int* out_ids, int capacity) {
     if (!out_ids || capacity < 0) fail(GA_ERR_INVALID_ARGUMENT, "bad buffer");
     for (auto& np : c.nodes) {
       if (n >= capacity) break;
-      if (np->type != GA_NODE_BUFFER_SOURCE) continue;
-      auto* s = static_cast<SourceNode*>(np.get());
+      Node* s = np.get();
       if (s->endedRaised && !s->endedReported) {
         s->endedReported = true;
         out_ids[n++] = np->id;
@@ -1530,10 +1850,26 @@ int gao_source_set_loop(ga_context* ctx, int node, int loop, double loop_start, 
   });
 }
 int gao_source_start(ga_context* ctx, int node, double when, double offset, double duration) {
-  return guard(ctx, [&](Context& c) { as<SourceNode>(getNode(c, node), GA_NODE_BUFFER_SOURCE)->start(when, offset, duration); });
+  return guard(ctx, [&](Context& c) {
+    Node* n = getNode(c, node);
+    if (n->type == GA_NODE_CONSTANT_SOURCE) static_cast<ConstantSourceNode*>(n)->start(when, offset, duration);
+    else if (n->type == GA_NODE_OSCILLATOR) static_cast<OscillatorNode*>(n)->start(when, offset, duration);
+    else as<SourceNode>(n, GA_NODE_BUFFER_SOURCE)->start(when, offset, duration);
+  });
 }
 int gao_source_stop(ga_context* ctx, int node, double when) {
-  return guard(ctx, [&](Context& c) { as<SourceNode>(getNode(c, node), GA_NODE_BUFFER_SOURCE)->stop(when); });
+  return guard(ctx, [&](Context& c) {
+    Node* n = getNode(c, node);
+    if (n->type == GA_NODE_CONSTANT_SOURCE || n->type == GA_NODE_OSCILLATOR) static_cast<ScheduledNode*>(n)->stop(when);
+    else as<SourceNode>(n, GA_NODE_BUFFER_SOURCE)->stop(when);
+  });
+}
+int gao_oscillator_set_type(ga_context* ctx, int node, int oscillator_type) {
+  return guard(ctx, [&](Context& c) {
+    auto* o = as<OscillatorNode>(getNode(c, node), GA_NODE_OSCILLATOR);
+    if (oscillator_type < 0 || oscillator_type > 3) fail(GA_ERR_INVALID_ARGUMENT, "oscillator type");
+    c.executeOrPost([o, oscillator_type]() { o->oscType = oscillator_type; });  // OscillatorNode.cs:33-42
+  });
 }
 int gao_biquad_set_type(ga_context* ctx, int node, int filter_type) {
   return guard(ctx, [&](Context& c) {
