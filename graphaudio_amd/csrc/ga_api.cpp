@@ -271,7 +271,10 @@ int ga_buffer_release(ga_context* ctx, int buffer_id) {
   return guard(ctx, [&](Context& c) { (void)c.buffer(buffer_id); });  // storage lives until the context is destroyed
 }
 
-int ga_node_create(ga_context* ctx, int node_type, int* out_id) {
+int ga_node_create(ga_context* ctx, int node_type, int* out_id) {  // constructor defaults: 2 outputs / 2 inputs / 1.0 s
+  return ga_node_create_ex(ctx, node_type, node_type == GA_NODE_DELAY ? 1.0 : 2.0, out_id);
+}
+int ga_node_create_ex(ga_context* ctx, int node_type, double arg, int* out_id) {
   return guard(ctx, [&](Context& c) {
     if (!out_id) fail(GA_ERR_INVALID_ARGUMENT, "null pointer");
     auto n = std::make_unique<NodeS>();
@@ -301,6 +304,40 @@ int ga_node_create(ga_context* ctx, int node_type, int* out_id) {
         n->inputs.resize(1);
         n->outputs.resize(1);
         break;
+      case GA_NODE_CHANNEL_SPLITTER:   // ChannelSplitterNode.cs:14-22
+      case GA_NODE_CHANNEL_MERGER: {   // ChannelMergerNode.cs:14-21
+        int cnt = (int)arg;
+        if (cnt < 1 || cnt > 32) fail(GA_ERR_OUT_OF_RANGE, node_type == GA_NODE_CHANNEL_SPLITTER ? "numberOfOutputs" : "numberOfInputs");
+        n->inputs.resize(node_type == GA_NODE_CHANNEL_SPLITTER ? 1 : cnt);
+        n->outputs.resize(node_type == GA_NODE_CHANNEL_SPLITTER ? cnt : 1);
+        break;
+      }
+      case GA_NODE_CONSTANT_SOURCE:    // ConstantSourceNode.cs:29-38
+        n->outputs.resize(1);
+        n->params.push_back(makeParam(1.f, -FMAX, FMAX, true));
+        break;
+      case GA_NODE_STEREO_PANNER:      // StereoPannerNode.cs:21-34
+        n->inputs.resize(1);
+        n->outputs.resize(1);
+        n->inputs[0].channelCount = 2;
+        n->inputs[0].mode = GA_COUNT_MODE_CLAMPED_MAX;
+        n->inputs[0].interp = GA_INTERP_SPEAKERS;
+        n->params.push_back(makeParam(0.f, -1.f, 1.f, true));
+        break;
+      case GA_NODE_OSCILLATOR:         // OscillatorNode.cs:43-52
+        n->outputs.resize(1);
+        n->params.push_back(makeParam(440.f, 0.f, c.sampleRate / 2.f, true));
+        break;
+      case GA_NODE_DELAY: {            // DelayNode.cs:22-41
+        if (!(arg > 0) || arg > 10) fail(GA_ERR_OUT_OF_RANGE, "maxDelayTime");
+        n->maxDelaySamples = (int)(arg * c.sampleRate);
+        if (n->maxDelaySamples < 1) fail(GA_ERR_OUT_OF_RANGE, "maxDelayTime");
+        n->delayRings = 2;
+        n->inputs.resize(1);
+        n->outputs.resize(1);
+        n->params.push_back(makeParam(0.f, 0.f, (float)arg, true));
+        break;
+      }
       default: fail(GA_ERR_INVALID_ARGUMENT, "unknown node type");
     }
     *out_id = n->id;
@@ -369,7 +406,7 @@ int ga_node_has_ended(ga_context* ctx, int node) {
   int r = 0;
   int rc = guard(ctx, [&](Context& c) {
     NodeS* n = c.node(node);
-    r = (n->type == GA_NODE_BUFFER_SOURCE && n->endedRaised) ? 1 : 0;
+    r = n->endedRaised ? 1 : 0;
   });
   return rc < 0 ? rc : r;
 }
@@ -509,8 +546,26 @@ int ga_source_set_loop(ga_context* ctx, int node, int loop, double loop_start, d
 }
 int ga_source_start(ga_context* ctx, int node, double when, double offset, double duration) {
   return guard(ctx, [&](Context& c) {
-    typed(c, node, GA_NODE_BUFFER_SOURCE);
     Context* cp = &c;
+    const int ty = c.node(node)->type;
+    if (ty == GA_NODE_CONSTANT_SOURCE || ty == GA_NODE_OSCILLATOR) {
+      c.executeOrPost([cp, node, when, duration, ty]() {  // ConstantSourceNode.cs:44-63, OscillatorNode.cs:54-73
+        NodeS& s = *cp->nodes[node];
+        if (s.hasStarted) {
+          if (ty == GA_NODE_OSCILLATOR) fail(GA_ERR_INVALID_OPERATION, "OscillatorNode can only be started once.");
+          return;   // a second ConstantSourceNode.Start is ignored
+        }
+        s.hasStarted = true;
+        s.oscPhaseReset = true;
+        s.startTime = std::max(0.0, when);
+        if (!std::isnan(duration) && duration >= 0) {
+          s.stopTime = s.startTime + duration;
+          s.hasStopped = true;
+        }
+      });
+      return;
+    }
+    typed(c, node, GA_NODE_BUFFER_SOURCE);
     c.executeOrPost([cp, node, when, offset, duration]() {  // AudioBufferSourceNode.cs:81-111
       NodeS& s = *cp->nodes[node];
       if (s.hasStarted) fail(GA_ERR_INVALID_OPERATION, "AudioBufferSourceNode can only be started once.");
@@ -530,7 +585,8 @@ int ga_source_start(ga_context* ctx, int node, double when, double offset, doubl
 }
 int ga_source_stop(ga_context* ctx, int node, double when) {
   return guard(ctx, [&](Context& c) {
-    typed(c, node, GA_NODE_BUFFER_SOURCE);
+    const int ty = c.node(node)->type;
+    if (ty != GA_NODE_CONSTANT_SOURCE && ty != GA_NODE_OSCILLATOR) typed(c, node, GA_NODE_BUFFER_SOURCE);
     Context* cp = &c;
     c.executeOrPost([cp, node, when]() {  // AudioBufferSourceNode.cs:118-126
       NodeS& s = *cp->nodes[node];
@@ -539,6 +595,14 @@ int ga_source_stop(ga_context* ctx, int node, double when) {
       s.stopTime = std::isnan(s.stopTime) ? at : std::min(s.stopTime, at);
       s.hasStopped = true;
     });
+  });
+}
+int ga_oscillator_set_type(ga_context* ctx, int node, int oscillator_type) {
+  return guard(ctx, [&](Context& c) {  // OscillatorNode.cs:33-42
+    typed(c, node, GA_NODE_OSCILLATOR);
+    if (oscillator_type < 0 || oscillator_type > 3) fail(GA_ERR_INVALID_ARGUMENT, "oscillator type");
+    Context* cp = &c;
+    c.executeOrPost([cp, node, oscillator_type]() { cp->nodes[node]->oscType = oscillator_type; });
   });
 }
 int ga_biquad_set_type(ga_context* ctx, int node, int filter_type) {

@@ -473,6 +473,48 @@ static SrcPlanOut planSource(Context& c, NodeS& s, int64_t n, const std::vector<
   return po;
 }
 
+// ConstantSourceNode / OscillatorNode scheduling (ConstantSourceNode.cs:83-110,143-152; OscillatorNode.cs:97-118,160-169):
+// sample-accurate start and stop inside a block, Ended + queued Dispose after the first block whose end reaches stopTime
+static SrcPlanOut planScheduled(Context& c, NodeS& s, int64_t n, const std::vector<double>& bt) {
+  SrcPlanOut po;
+  s.spans.clear();
+  s.schedLo = s.schedHi = 0;
+  const int64_t INF = std::numeric_limits<int64_t>::max() / 4;
+  // kEnd: first block with t1 >= stopTime (TryRaiseEnded runs in every processed block, playing or not)
+  int64_t kEnd = INF;
+  if (s.hasStarted && s.hasStopped && !s.endedRaised && !std::isnan(s.stopTime))
+    kEnd = std::lower_bound(bt.begin() + 1, bt.begin() + 1 + n, s.stopTime) - (bt.begin() + 1);   // may be n: not in this chunk
+  s.spans.push_back(SrcSpan{0, SRC_IDLE, 0, 0});
+  if (s.hasStarted && !s.disposed) {
+    // first block with t1 > startTime, last block with t0 < stopTime
+    int64_t bs = std::upper_bound(bt.begin() + 1, bt.begin() + 1 + n, s.startTime) - (bt.begin() + 1);
+    int64_t be = n - 1;
+    if (!std::isnan(s.stopTime)) be = (std::lower_bound(bt.begin(), bt.begin() + n, s.stopTime) - bt.begin()) - 1;   // t0 < stop
+    be = std::min(be, std::min<int64_t>(n - 1, kEnd));
+    if (bs < n && bs <= be) {
+      int startFrame = 0, endFrame = kBlock;
+      if (bt[bs] < s.startTime && s.startTime < bt[bs + 1])
+        startFrame = (int)std::min(std::max(std::ceil((s.startTime - bt[bs]) * c.sampleRate), 0.0), (double)kBlock);
+      if (!std::isnan(s.stopTime) && bt[be] < s.stopTime && s.stopTime < bt[be + 1])
+        endFrame = (int)std::min(std::max(std::floor((s.stopTime - bt[be]) * c.sampleRate), 0.0), (double)kBlock);
+      s.schedLo = bs * kBlock + startFrame;
+      s.schedHi = be * kBlock + endFrame;
+      if (bs == be && endFrame < startFrame) s.schedHi = s.schedLo;   // `if (endFrame > startFrame)` (:126): nothing copied
+      if (bs > 0) s.spans.push_back(SrcSpan{bs, SRC_PLAY, 0, 0}); else s.spans[0].phase = SRC_PLAY;
+      if (be + 1 < n) s.spans.push_back(SrcSpan{be + 1, SRC_IDLE, 0, 0});
+    }
+  }
+  if (kEnd < n) {
+    po.gone = true;
+    po.goneAt = kEnd + 1;
+    if (po.goneAt < n) {
+      while (!s.spans.empty() && s.spans.back().b0 >= po.goneAt) s.spans.pop_back();
+      s.spans.push_back(SrcSpan{po.goneAt, SRC_GONE, 0, 0});
+    }
+  }
+  return po;
+}
+
 static const SrcSpan& spanAt(const NodeS& s, int64_t b) {
   size_t i = s.spans.size() - 1;
   while (i > 0 && s.spans[i].b0 > b) i--;
@@ -631,6 +673,56 @@ struct Sim {
         }
         break;
       }
+      case GA_NODE_CHANNEL_SPLITTER: {  // ChannelSplitterNode.cs:24-59: N mono outputs
+        const InSeg& in = ns.ins[0];
+        for (int o = 0; o < (int)n_.outputs.size(); o++) {
+          const bool audio = !in.silent && o < in.bufCh;
+          n_.outputs[o].bufCh = 1;
+          n_.outputs[o].silent = !audio;
+          if (audio) ns.outMask |= 1u << o;
+        }
+        break;
+      }
+      case GA_NODE_CHANNEL_MERGER: {  // ChannelMergerNode.cs:23-55: channel i = channel 0 of input i
+        bool any = false;
+        for (int i = 0; i < (int)ns.ins.size(); i++)
+          if (!ns.ins[i].silent) {
+            any = true;
+            ns.outMask |= 1u << i;
+          }
+        n_.outputs[0].bufCh = (int)ns.ins.size();
+        n_.outputs[0].silent = !any;
+        break;
+      }
+      case GA_NODE_CONSTANT_SOURCE:
+      case GA_NODE_OSCILLATOR: {  // always a 1-channel buffer; non-silent in every block that plays (:136, :151)
+        const SrcSpan& sp = spanAt(n_, brel);
+        ns.srcPhase = sp.phase;
+        n_.outputs[0].bufCh = 1;
+        n_.outputs[0].silent = sp.phase != SRC_PLAY;
+        break;
+      }
+      case GA_NODE_STEREO_PANNER: {  // StereoPannerNode.cs:36-74
+        n_.outputs[0].bufCh = 2;
+        n_.outputs[0].silent = ns.ins[0].silent;
+        if (!ns.ins[0].silent) {
+          if (!n_.params[0].events.empty())
+            fail(GA_ERR_UNSUPPORTED, "automation of StereoPannerNode.pan is not on the device path yet");
+          float pan = std::min(std::max(n_.params[0].value, -1.0f), 1.0f);
+          ns.panMode = ns.ins[0].bufCh == 1 ? 1 : 2;
+          if (pan != n_.panLast) {  // the gains follow the law of the path that sees the change (:92-99, :127-134)
+            const float PIf = 3.14159265358979323846f;
+            float x = ns.panMode == 1 ? (pan + 1.0f) * 0.5f : (pan <= 0.0f ? pan + 1.0f : pan);
+            n_.panGL = std::cos(x * PIf / 2.0f);
+            n_.panGR = std::sin(x * PIf / 2.0f);
+            n_.panLast = pan;
+          }
+          ns.pan = pan;
+          ns.panGL = n_.panGL;
+          ns.panGR = n_.panGR;
+        }
+        break;
+      }
       default: fail(GA_ERR_UNSUPPORTED, "node type not supported on the device path");
     }
     if (!n_.outputs.empty()) {
@@ -643,7 +735,8 @@ struct Sim {
     uint64_t h = 1469598103934665603ull;
     for (const NodeSeg& ns : s.nodes) {
       h = hmix(h, (uint64_t)ns.id);
-      h = hmix(h, ((uint64_t)ns.outCh << 8) | (ns.outSilent ? 1 : 0) | ((uint64_t)ns.srcPhase << 4) | (ns.bqActive ? 2 : 0));
+      h = hmix(h, ((uint64_t)ns.outCh << 8) | (ns.outSilent ? 1 : 0) | ((uint64_t)ns.srcPhase << 4) | (ns.bqActive ? 2 : 0) |
+                      ((uint64_t)ns.outMask << 16) | ((uint64_t)ns.panMode << 48));
       for (const InSeg& is : ns.ins) {
         h = hmix(h, ((uint64_t)is.bufCh << 1) | (is.silent ? 1 : 0));
         for (const TermS& t : is.terms) h = hmix(h, ((uint64_t)t.node << 16) | ((uint64_t)t.out << 8) | (uint64_t)t.ch);
@@ -676,6 +769,9 @@ struct Exec {
   std::vector<LoopJob> loopJobs;
   std::vector<ResampleJob> rsJobs;
   std::vector<GsrJob> gsrJobs;
+  std::vector<ConstJob> constJobs;
+  std::vector<OscJob> oscJobs;
+  std::vector<PanJob> panJobs;
   std::vector<ResampleBlock> traj;  // per-chunk trajectory table (all rates + custom tail blocks)
   bool mixAligned = true;
   // conv inputs: node -> slot -> per segment view
@@ -708,7 +804,11 @@ struct Exec {
     const int64_t f0 = sg.b0 * kBlock, nf = (sg.b1 - sg.b0) * kBlock;
     std::vector<std::vector<const float*>> lists(dstCh);
     for (const TermS& t : is.terms) {
-      const auto& uv = outViews[si][t.node];
+      const auto& uvAll = outViews[si][t.node];
+      // a ChannelSplitterNode keeps one mono view per OUTPUT; every other node has one output with t.ch channels
+      std::vector<const float*> uvOne;
+      if (c.nodes[t.node]->type == GA_NODE_CHANNEL_SPLITTER) uvOne.assign(1, t.out < (int)uvAll.size() ? uvAll[t.out] : nullptr);
+      const auto& uv = c.nodes[t.node]->type == GA_NODE_CHANNEL_SPLITTER ? uvOne : uvAll;
       const int srcCh = t.ch;
       if (srcCh == dstCh) {
         for (int ch = 0; ch < dstCh; ch++)
@@ -815,6 +915,28 @@ struct Exec {
       hipStream_t st = c.stream;
       plan.add(LK_OTHER, [=](uint8_t* base) { launch_gsr(st, (const GsrJob*)(base + off), nj, base, mx); });
     }
+    if (!constJobs.empty()) {
+      size_t off = plan.putv(constJobs);
+      int nj = (int)constJobs.size();
+      int64_t mx = 0;
+      for (auto& j : constJobs) mx = std::max(mx, j.n);
+      hipStream_t st = c.stream;
+      plan.add(LK_OTHER, [=](uint8_t* base) { launch_const_source(st, (const ConstJob*)(base + off), nj, mx); });
+    }
+    if (!oscJobs.empty()) {
+      size_t off = plan.putv(oscJobs);
+      int nj = (int)oscJobs.size();
+      hipStream_t st = c.stream;
+      plan.add(LK_OTHER, [=](uint8_t* base) { launch_oscillator(st, (const OscJob*)(base + off), nj); });
+    }
+    if (!panJobs.empty()) {
+      size_t off = plan.putv(panJobs);
+      int nj = (int)panJobs.size();
+      int64_t mx = 0;
+      for (auto& j : panJobs) mx = std::max(mx, j.n);
+      hipStream_t st = c.stream;
+      plan.add(LK_OTHER, [=](uint8_t* base) { launch_stereo_panner(st, (const PanJob*)(base + off), nj, mx); });
+    }
     if (!gainJobs.empty()) {
       size_t off = plan.putv(gainJobs);
       int nj = (int)gainJobs.size();
@@ -855,6 +977,9 @@ struct Exec {
     loopJobs.clear();
     rsJobs.clear();
     gsrJobs.clear();
+    constJobs.clear();
+    oscJobs.clear();
+    panJobs.clear();
     mixAligned = true;
   }
   struct RsLaunch {
@@ -998,9 +1123,10 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
   std::vector<int64_t> breaks;
   for (int id : topo) {
     NodeS& nd = *nodes[id];
-    if (nd.type != GA_NODE_BUFFER_SOURCE) continue;
+    const bool scheduled = nd.type == GA_NODE_CONSTANT_SOURCE || nd.type == GA_NODE_OSCILLATOR;
+    if (nd.type != GA_NODE_BUFFER_SOURCE && !scheduled) continue;
     srcIds.push_back(id);
-    srcPlans.push_back(planSource(*this, nd, n, bt));
+    srcPlans.push_back(scheduled ? planScheduled(*this, nd, n, bt) : planSource(*this, nd, n, bt));
     for (const SrcSpan& sp : nd.spans)
       if (sp.b0 > 0 && sp.b0 < n) breaks.push_back(sp.b0);
     if (srcPlans.back().partialBlock >= 0) {
@@ -1099,7 +1225,9 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
     for (int id : topo) {
       NodeS& nd = *nodes[id];
       for (auto& p : nd.params) p.curve = nullptr;
-      if (nd.type != GA_NODE_GAIN && nd.type != GA_NODE_BIQUAD) continue;
+      if (nd.type != GA_NODE_GAIN && nd.type != GA_NODE_BIQUAD && nd.type != GA_NODE_CONSTANT_SOURCE && nd.type != GA_NODE_OSCILLATOR &&
+          nd.type != GA_NODE_DELAY)
+        continue;
       for (ParamS& p : nd.params) {
         if (p.events.empty()) continue;
         p.curve = getSlab(*this);
@@ -1168,6 +1296,12 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
     }
   }
 
+  for (int id : topo) {  // OscillatorNode._phase lives on the device (one double, zero at Start)
+    NodeS& nd = *nodes[id];
+    if (nd.type != GA_NODE_OSCILLATOR || nd.oscPhase) continue;
+    nd.oscPhase = (double*)dalloc(64);
+    GA_HIP(hipMemsetAsync(nd.oscPhase, 0, 64, stream));
+  }
   auto ensureBiquadState = [&](NodeS& bn) {
     if (bn.bqDyn) return;
     const size_t per = (sizeof(BiquadDynState) + 31) & ~(size_t)31;
@@ -1224,8 +1358,75 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
           curLevel = nd.level;
         }
         auto& ov = ex.outViews[si][ns.id];
-        ov.assign(std::max(ns.outCh, 1), nullptr);
+        ov.assign(nd.type == GA_NODE_CHANNEL_SPLITTER ? (int)nd.outputs.size() : std::max(ns.outCh, 1), nullptr);
         switch (nd.type) {
+          case GA_NODE_CHANNEL_SPLITTER: {   // zero-copy: output o IS channel o of the mixed input
+            if (!ns.outMask) break;
+            auto iv = ex.resolveInput((int)si, ns, 0, false, nullptr);
+            for (int o = 0; o < (int)nd.outputs.size(); o++)
+              if ((ns.outMask >> o) & 1) ov[o] = iv[o];
+            break;
+          }
+          case GA_NODE_CHANNEL_MERGER: {     // zero-copy: channel i IS channel 0 of input i
+            for (int i = 0; i < (int)ns.ins.size(); i++) {
+              if (!((ns.outMask >> i) & 1)) continue;
+              auto iv = ex.resolveInput((int)si, ns, i, false, nullptr);
+              ov[i] = iv.empty() ? nullptr : iv[0];
+            }
+            break;
+          }
+          case GA_NODE_CONSTANT_SOURCE: {
+            if (ns.srcPhase != SRC_PLAY) break;
+            ConstJob cj;
+            cj.curve = nd.params[0].curve;
+            cj.out = ex.nodeOut(ns.id, 0);
+            cj.value = nd.params[0].value;
+            cj.pad_ = 0;
+            cj.f0 = f0;
+            cj.n = nf;
+            cj.lo = nd.schedLo;
+            cj.hi = nd.schedHi;
+            ex.constJobs.push_back(cj);
+            ov[0] = cj.out;
+            break;
+          }
+          case GA_NODE_OSCILLATOR: {
+            if (ns.srcPhase != SRC_PLAY) break;
+            OscJob oj;
+            oj.curve = nd.params[0].curve;
+            oj.out = ex.nodeOut(ns.id, 0);
+            oj.phase = nd.oscPhase;
+            oj.value = nd.params[0].value;
+            oj.type = nd.oscType;
+            oj.sample_rate = sampleRate;
+            oj.pad_ = 0;
+            oj.f0 = f0;
+            oj.n = nf;
+            oj.lo = nd.schedLo;
+            oj.hi = nd.schedHi;
+            ex.oscJobs.push_back(oj);
+            ov[0] = oj.out;
+            break;
+          }
+          case GA_NODE_STEREO_PANNER: {
+            if (ns.ins[0].silent) break;   // cleared 2-channel output (:49-54)
+            auto iv = ex.resolveInput((int)si, ns, 0, false, nullptr);
+            PanJob pj;
+            pj.in_l = iv[0] ? iv[0] : zeros;
+            pj.in_r = ns.panMode == 2 ? (iv[1] ? iv[1] : zeros) : nullptr;
+            pj.out_l = ex.nodeOut(ns.id, 0);
+            pj.out_r = ex.nodeOut(ns.id, 1);
+            pj.gain_l = ns.panGL;
+            pj.gain_r = ns.panGR;
+            pj.pan = ns.pan;
+            pj.stereo = ns.panMode == 2 ? 1 : 0;
+            pj.f0 = f0;
+            pj.n = nf;
+            ex.panJobs.push_back(pj);
+            ov[0] = pj.out_l;
+            ov[1] = pj.out_r;
+            break;
+          }
           case GA_NODE_BUFFER_SOURCE: {
             if (ns.srcPhase != SRC_PLAY) break;  // silent: ZERO views
             PlayBuf& pb = *buffers[ns.srcBuf];
@@ -1811,6 +2012,14 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
   for (size_t i = 0; i < srcIds.size(); i++) {
     NodeS& s = *nodes[srcIds[i]];
     SrcPlanOut& po = srcPlans[i];
+    if (s.type != GA_NODE_BUFFER_SOURCE) {  // ConstantSourceNode / OscillatorNode: only the Ended + Dispose bookkeeping
+      if (po.gone && po.goneAt <= n) {
+        if (!s.endedRaised) endedQueue.push_back(srcIds[i]);
+        s.endedRaised = true;
+        if (po.goneAt == n) pending.push_back([this, id = srcIds[i]]() { doDispose(id); });
+      }
+      continue;
+    }
     // recompute progress against the (possibly shortened) chunk
     if (s.spans.empty()) continue;
     int64_t firstPlay = -1;

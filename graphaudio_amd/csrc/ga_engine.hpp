@@ -147,6 +147,21 @@ struct NodeS {
   std::vector<GsrBlock> gsrBlocks;  // per chunk: one per processed block from the first played block, + the end state
   uint64_t gsrDevOff = 0;
   bool gsrUploaded = false;
+  // ConstantSourceNode / OscillatorNode share hasStarted/hasStopped/startTime/stopTime/endedRaised with the buffer source
+  int oscType = 0;                 // OscillatorNode._type
+  double* oscPhase = nullptr;      // device: OscillatorNode._phase (one double)
+  bool oscPhaseReset = false;      // Start() sets _phase = 0 (OscillatorNode.cs:62)
+  int64_t schedLo = 0, schedHi = 0;  // per chunk: frames [lo, hi) of the chunk in which the scheduled source plays
+  // StereoPannerNode (StereoPannerNode.cs:12-14)
+  float panLast = std::nanf(""), panGL = 0.5f, panGR = 0.5f;
+  // DelayNode (DelayNode.cs:13-15)
+  int maxDelaySamples = 0;
+  int delayCh = 0;                 // channels of `_outputBuffer` (re-rented, i.e. silent again, when the count changes)
+  int delayRings = 0;              // CircularBuffers allocated so far (2 at construction, grown on demand)
+  bool delayAudible = false;       // the output buffer's non-silent flag (sticky, :96-97)
+  float* delayLine = nullptr;      // device [rings][maxDelaySamples + delayCap]: history followed by the chunk's input
+  int64_t delayCap = 0;
+  std::vector<uint8_t> delayInFlags;  // host: non-silent flags of the input blocks still inside the delay window (newest last)
   // BiQuadFilterNode (BiQuadFilterNode.cs:12-19)
   int filterType = GA_FILTER_LOWPASS;
   float b0 = 0, b1 = 0, b2 = 0, a1 = 0, a2 = 0;
@@ -193,6 +208,10 @@ struct NodeSeg {
   int srcBuf = -1;  // buffer id at evaluation time (a later Dispose clears the node's reference)
   bool bqActive = false;
   float b0 = 0, b1 = 0, b2 = 0, a1 = 0, a2 = 0;
+  uint32_t outMask = 0;     // ChannelSplitterNode: outputs that carry audio
+  float panGL = 0, panGR = 0, pan = 0;   // StereoPannerNode: gains in force in this segment
+  int panMode = 0;          // 1 = mono law, 2 = stereo law
+  bool delayAudible = false;
 };
 struct Segment {
   int64_t b0 = 0, b1 = 0;  // chunk-relative block range

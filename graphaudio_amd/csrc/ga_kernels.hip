@@ -2033,4 +2033,124 @@ void launch_gsr(hipStream_t s, const GsrJob* jobs_dev, int njobs, const uint8_t*
   hipLaunchKernelGGL(gsr_kernel, dim3(gx, njobs), dim3(64), 0, s, jobs_dev, plan_base_dev);
 }
 
+
+// =====================================================================================================
+//  ConstantSourceNode / OscillatorNode / StereoPannerNode (see ga_kernels.hpp)
+// =====================================================================================================
+__global__ __launch_bounds__(256) void const_source_kernel(const ConstJob* __restrict jobs) {
+  const ConstJob job = jobs[blockIdx.y];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < job.n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t f = job.f0 + i;
+    float v = 0.f;
+    if (f >= job.lo && f < job.hi) v = job.curve ? job.curve[f] : job.value;
+    job.out[f] = v;
+  }
+}
+void launch_const_source(hipStream_t s, const ConstJob* jobs_dev, int njobs, int64_t max_n) {
+  if (njobs <= 0 || max_n <= 0) return;
+  int gx = (int)std::min<int64_t>((max_n + 255) / 256, 1024);
+  hipLaunchKernelGGL(const_source_kernel, dim3(gx, njobs), dim3(256), 0, s, jobs_dev);
+}
+
+__device__ __forceinline__ float osc_sample(double ph, int type) {   // GenerateSample, OscillatorNode.cs:171-195
+  const double PI = 3.14159265358979323846;
+  switch (type) {
+    case 0: return (float)sin(ph);
+    case 1: return ph < PI ? 1.0f : -1.0f;
+    case 2: return (float)(2.0 * (ph / (2.0 * PI)) - 1.0);
+    case 3: {
+      double t = ph / (2.0 * PI);
+      return (float)(4.0 * fabs(t - floor(t + 0.5)) - 1.0);
+    }
+    default: return 0.f;
+  }
+}
+__global__ __launch_bounds__(64) void oscillator_kernel(const OscJob* __restrict jobs) {
+  __shared__ float tile[64][kBlock + 1];   // frequency values in, samples out
+  __shared__ double start_ph[64];
+  const OscJob job = jobs[blockIdx.x];
+  const int lane = threadIdx.x;
+  const double PI2 = 2.0 * 3.14159265358979323846;
+  const double sr = (double)job.sample_rate;
+  double ph = *job.phase;
+  const int64_t nblk = job.n / kBlock;
+  for (int64_t g0 = 0; g0 < nblk; g0 += 64) {
+    const int nb = (int)min<int64_t>(64, nblk - g0);
+    const int64_t fg = job.f0 + g0 * kBlock;   // first frame of this group of blocks
+    // frequency of every frame of the group -> LDS (coalesced)
+    for (int r = 0; r < nb; r++) {
+      const int64_t f = fg + (int64_t)r * kBlock;
+      tile[r][lane] = job.curve ? job.curve[f + lane] : job.value;
+      tile[r][64 + lane] = job.curve ? job.curve[f + 64 + lane] : job.value;
+    }
+    __syncthreads();
+    if (lane == 0) {   // the serial recurrence (:139-143), only the phase: `_phase += 2 pi f / sr; if (_phase >= 2 pi) _phase -= 2 pi`
+      for (int r = 0; r < nb; r++) {
+        start_ph[r] = ph;
+        const int64_t f = fg + (int64_t)r * kBlock;
+        if (f + kBlock <= job.lo || f >= job.hi) continue;
+        for (int i = 0; i < kBlock; i++) {
+          if (f + i >= job.lo && f + i < job.hi) {
+            ph += (PI2 * (double)tile[r][i]) / sr;
+            if (ph >= PI2) ph -= PI2;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (lane < nb) {
+      double p = start_ph[lane];
+      const int64_t f = fg + (int64_t)lane * kBlock;
+      for (int i = 0; i < kBlock; i++) {
+        float v = 0.f;
+        if (f + i >= job.lo && f + i < job.hi) {
+          v = osc_sample(p, job.type);
+          p += (PI2 * (double)tile[lane][i]) / sr;
+          if (p >= PI2) p -= PI2;
+        }
+        tile[lane][i] = v;   // the frequency at [lane][i] is not needed again
+      }
+    }
+    __syncthreads();
+    for (int r = 0; r < nb; r++) {
+      float* o = job.out + fg + (int64_t)r * kBlock;
+      o[lane] = tile[r][lane];
+      o[64 + lane] = tile[r][64 + lane];
+    }
+    __syncthreads();
+    ph = __shfl(ph, 0);   // every lane carries the running phase (only lane 0 advanced it)
+  }
+  if (lane == 0) *job.phase = ph;
+}
+void launch_oscillator(hipStream_t s, const OscJob* jobs_dev, int njobs) {
+  if (njobs <= 0) return;
+  hipLaunchKernelGGL(oscillator_kernel, dim3(njobs), dim3(64), 0, s, jobs_dev);
+}
+
+__global__ __launch_bounds__(256) void stereo_panner_kernel(const PanJob* __restrict jobs) {
+  const PanJob job = jobs[blockIdx.y];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < job.n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t f = job.f0 + i;
+    if (!job.stereo) {   // ProcessMono, :103-105
+      const float x = job.in_l[f];
+      job.out_l[f] = x * job.gain_l;
+      job.out_r[f] = x * job.gain_r;
+    } else {             // ProcessStereo, :135-145
+      const float inl = job.in_l[f], inr = job.in_r[f];
+      if (job.pan <= 0.0f) {
+        job.out_l[f] = inl + inr * job.gain_l;
+        job.out_r[f] = inr * job.gain_r;
+      } else {
+        job.out_l[f] = inl * job.gain_l;
+        job.out_r[f] = inr + inl * job.gain_r;
+      }
+    }
+  }
+}
+void launch_stereo_panner(hipStream_t s, const PanJob* jobs_dev, int njobs, int64_t max_n) {
+  if (njobs <= 0 || max_n <= 0) return;
+  int gx = (int)std::min<int64_t>((max_n + 255) / 256, 1024);
+  hipLaunchKernelGGL(stereo_panner_kernel, dim3(gx, njobs), dim3(256), 0, s, jobs_dev);
+}
+
 }  // namespace ga

@@ -303,4 +303,47 @@ struct GsrJob {
 };
 void launch_gsr(hipStream_t s, const GsrJob* jobs_dev, int njobs, const uint8_t* plan_base_dev, int64_t max_blocks);
 
+
+// ---- remaining pure-Core nodes ------------------------------------------------
+// ConstantSourceNode.Process (ConstantSourceNode.cs:76-141): out[f] = offset[f] for frames inside [lo, hi) of the chunk,
+// 0 outside (sample-accurate start / stop)
+struct ConstJob {
+  const float* curve;   // a-rate offset curve (chunk-frame indexed) or null -> `value`
+  float* out;
+  float value;
+  int pad_;
+  int64_t f0, n;        // frames of this job
+  int64_t lo, hi;       // playing window in chunk frames
+};
+void launch_const_source(hipStream_t s, const ConstJob* jobs_dev, int njobs, int64_t max_n);
+
+// OscillatorNode.Process (OscillatorNode.cs:91-158): phase accumulated in double with a conditional 2 pi wrap -- a serial
+// recurrence.  One wavefront per oscillator: lane 0 walks the phase over 64 blocks at a time and leaves the phase at every
+// block start in LDS, then 64 lanes generate one block each (the sin / saw / triangle evaluation runs 64-wide).
+struct OscJob {
+  const float* curve;   // a-rate frequency curve or null -> `value`
+  float* out;
+  double* phase;        // device: OscillatorNode._phase, read at the start and written back at the end
+  float value;
+  int type;             // 0 sine, 1 square, 2 sawtooth, 3 triangle (GA_OSC_*)
+  int sample_rate;
+  int pad_;
+  int64_t f0, n;        // frames of this job (multiples of 128)
+  int64_t lo, hi;       // playing window in chunk frames
+};
+void launch_oscillator(hipStream_t s, const OscJob* jobs_dev, int njobs);
+
+// StereoPannerNode.Process with a constant pan (StereoPannerNode.cs:76-153): the gains in force are tracked on the host
+// (they only change when pan changes, :92/:127), the device applies the mono or the stereo law
+struct PanJob {
+  const float* in_l;
+  const float* in_r;    // null on the mono path
+  float* out_l;
+  float* out_r;
+  float gain_l, gain_r, pan;
+  int stereo;           // 0: mono law (:103-105) ; 1: stereo law (:135-145)
+  int64_t f0, n;
+};
+void launch_stereo_panner(hipStream_t s, const PanJob* jobs_dev, int njobs, int64_t max_n);
+
 }  // namespace ga

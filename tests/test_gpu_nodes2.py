@@ -1,0 +1,191 @@
+"""GPU parity for the remaining pure-Core nodes: HIP path vs the CPU oracle, through the C ABI."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from graphaudio_amd import (AudioBufferSourceNode, BiQuadFilterNode, ChannelMergerNode, ChannelSplitterNode, ConstantSourceNode,
+                            GainNode, NotSupportedException, OfflineAudioContext, OscillatorNode, OscillatorType,
+                            PlayableAudioBuffer, StereoPannerNode)
+from tests import _graphs as G
+from tests._oracle import OracleContext
+
+SR = 48000
+
+
+def pair(build, ch, frames, pieces=None, chunk=0):
+    outs = []
+    for mk in (OracleContext, OfflineAudioContext):
+        ctx = mk(SR)
+        if chunk and mk is OfflineAudioContext:
+            ctx.SetOption("max_chunk_blocks", chunk)
+        ctx.Destination.SetChannelCount(ch)
+        hold = build(ctx)
+        out = np.zeros((ch, frames), np.float32)
+        pos = 0
+        for p in (pieces or [frames]):
+            k = min(p, frames - pos)
+            if k <= 0:
+                break
+            ctx.Render(out, k, pos)
+            pos += k
+        if pos < frames:
+            ctx.Render(out, frames - pos, pos)
+        outs.append(out)
+        del hold
+        ctx.Dispose()
+    return outs
+
+
+def _stereo(ctx, n, seed):
+    rng = np.random.default_rng(seed)
+    s = AudioBufferSourceNode(ctx)
+    s.Buffer = PlayableAudioBuffer.FromStereoArrays((rng.standard_normal(n) * 0.25).astype(np.float32),
+                                                   (rng.standard_normal(n) * 0.25).astype(np.float32), SR)
+    return s
+
+
+def test_splitter_merger_swap_and_processing_between():
+    def build(ctx):
+        s = _stereo(ctx, 128 * 30, 1)
+        sp = ChannelSplitterNode(ctx, 3)
+        mg = ChannelMergerNode(ctx, 3)
+        g = GainNode(ctx)
+        g.Gain.Value = 0.5
+        g.Inputs[0].SetChannelCount(1)
+        bq = BiQuadFilterNode(ctx)
+        bq.Inputs[0].SetChannelCount(1)
+        s.Connect(sp)
+        sp.Connect(g, 0, 0)
+        g.Connect(mg, 0, 1)      # L * 0.5 -> channel 1
+        sp.Connect(bq, 1, 0)
+        bq.Connect(mg, 0, 0)     # lowpass(R) -> channel 0
+        sp.Connect(mg, 2, 2)     # the source has no third channel: silent
+        mg.Connect(ctx.Destination)
+        s.Start(0.01)
+        return (s, sp, mg, g, bq)
+    ref, got = pair(build, 3, 128 * 36, pieces=[700, 1300], chunk=9)
+    assert G.rms(ref) > 1e-3 and np.abs(ref[2]).max() == 0.0
+    assert np.array_equal(ref, got)
+
+
+def test_constant_source_window_and_automation():
+    def build(ctx):
+        ctx.Destination.Inputs[0].SetChannelCount(1)
+        cs = ConstantSourceNode(ctx)
+        cs.Offset.SetValueAtTime(0.1, 0.0)
+        cs.Offset.LinearRampToValueAtTime(0.9, 0.05)
+        cs.Offset.SetTargetAtTime(0.2, 0.06, 0.01)
+        cs.Connect(ctx.Destination)
+        cs.Start(1234.5 / SR)
+        cs.Stop(4000.25 / SR)
+        c2 = ConstantSourceNode(ctx)       # constant value, stopped through the Start duration
+        c2.Offset.Value = -0.25
+        c2.Connect(ctx.Destination)
+        c2.Start(0.0, 0.0, 2000.7 / SR)
+        return (cs, c2)
+    ref, got = pair(build, 1, 128 * 40, pieces=[1000, 300, 2900], chunk=7)
+    assert np.count_nonzero(ref) > 3000
+    assert np.abs(ref - got).max() <= 1e-6          # ramps: device pow/exp vs glibc
+
+
+@pytest.mark.parametrize("typ", list(OscillatorType))
+def test_oscillator_types_bit_exact(typ):
+    def build(ctx):
+        ctx.Destination.Inputs[0].SetChannelCount(1)
+        o = OscillatorNode(ctx)
+        o.Type = typ
+        o.Frequency.Value = 997.0
+        o.Connect(ctx.Destination)
+        o.Start(300.2 / SR)
+        o.Stop(128 * 70 + 17.5 / SR)
+        o2 = OscillatorNode(ctx)
+        o2.Type = typ
+        o2.Frequency.Value = 31.0
+        g = GainNode(ctx)
+        g.Gain.Value = 0.25
+        g.Inputs[0].SetChannelCount(1)
+        o2.Connect(g)
+        g.Connect(ctx.Destination)
+        o2.Start(0.0)
+        o2.Stop(5000.9 / SR)
+        return (o, o2, g)
+    ref, got = pair(build, 1, 128 * 80, pieces=[3000, 5000], chunk=11)
+    assert G.rms(ref) > 0.1
+    # sin(double) of the device math library vs glibc differ in the last bit of the DOUBLE result: after the cast to float
+    # a sample can differ by one float ulp in rare cases
+    assert np.abs(ref - got).max() <= 1.2e-7
+    assert np.mean(ref != got) < 1e-3
+
+
+def test_oscillator_frequency_automation():
+    def build(ctx):
+        ctx.Destination.Inputs[0].SetChannelCount(1)
+        o = OscillatorNode(ctx)
+        o.Frequency.SetValueAtTime(200.0, 0.0)
+        o.Frequency.ExponentialRampToValueAtTime(4000.0, 0.1)
+        o.Connect(ctx.Destination)
+        o.Start(0.0)
+        return (o,)
+    ref, got = pair(build, 1, 128 * 50, chunk=13)
+    # the frequency curve comes from device pow(): a 1-ulp float difference in f shifts the phase by ~1e-9 per sample
+    assert G.rms(ref - got) <= 1e-5
+
+
+@pytest.mark.parametrize("pan", [-1.0, -0.4, 0.0, 0.3, 1.0])
+def test_stereo_panner_static_bit_exact(pan):
+    def build(ctx):
+        rng = np.random.default_rng(3)
+        m = AudioBufferSourceNode(ctx)
+        m.Buffer = PlayableAudioBuffer.FromMonoArray((rng.standard_normal(128 * 30) * 0.25).astype(np.float32), SR)
+        p1 = StereoPannerNode(ctx)      # default input: block 0 stereo law on the up-mixed mono, then mono path with stale gains
+        p1.Pan.Value = pan
+        m.Connect(p1)
+        p1.Connect(ctx.Destination)
+        s = _stereo(ctx, 128 * 30, 5)
+        p2 = StereoPannerNode(ctx)
+        p2.Pan.Value = -pan
+        s.Connect(p2)
+        p2.Connect(ctx.Destination)
+        m2 = AudioBufferSourceNode(ctx)
+        m2.Buffer = PlayableAudioBuffer.FromMonoArray((rng.standard_normal(128 * 30) * 0.25).astype(np.float32), SR)
+        p3 = StereoPannerNode(ctx)      # mono law from the first block
+        p3.Inputs[0].SetChannelCount(1)
+        p3.Pan.Value = pan
+        m2.Connect(p3)
+        p3.Connect(ctx.Destination)
+        m.Start(0.0)
+        s.Start(0.004)
+        m2.Start(0.0)
+        return (m, p1, s, p2, m2, p3)
+    ref, got = pair(build, 2, 128 * 32, pieces=[1000], chunk=9)
+    assert G.rms(ref) > 1e-2
+    # the three panner outputs are summed on the bus in connection order: bit-exact
+    assert np.array_equal(ref, got)
+
+
+def test_stereo_panner_value_change_between_renders_and_automation_unsupported():
+    outs = []
+    for mk in (OracleContext, OfflineAudioContext):
+        ctx = mk(SR)
+        s = _stereo(ctx, 128 * 30, 9)
+        p = StereoPannerNode(ctx)
+        p.Pan.Value = 0.25
+        s.Connect(p)
+        p.Connect(ctx.Destination)
+        s.Start()
+        out = np.zeros((2, 128 * 20), np.float32)
+        ctx.Render(out, 128 * 8, 0)
+        p.Pan.Value = -0.75
+        ctx.Render(out, 128 * 12, 128 * 8)
+        outs.append(out)
+    assert np.array_equal(outs[0], outs[1])
+    ctx = OfflineAudioContext(SR)
+    s = _stereo(ctx, 128 * 30, 9)
+    p = StereoPannerNode(ctx)
+    p.Pan.LinearRampToValueAtTime(1.0, 0.1)
+    s.Connect(p)
+    p.Connect(ctx.Destination)
+    s.Start()
+    with pytest.raises(NotSupportedException):
+        ctx.Render(np.zeros((2, 256), np.float32), 256)
