@@ -530,6 +530,7 @@ struct Sim {
   int64_t blockNumber = 0;
   Segment* cur = nullptr;
   int64_t brel = 0;
+  std::vector<int64_t>* extraBreaks = nullptr;   // chunk-relative blocks at which a node asks to be evaluated again
 
   int computeOutputChannelCount(InputS& in) {  // AudioNodeInput.cs:140-168
     switch (in.mode) {
@@ -705,11 +706,11 @@ struct Sim {
       case GA_NODE_STEREO_PANNER: {  // StereoPannerNode.cs:36-74
         n_.outputs[0].bufCh = 2;
         n_.outputs[0].silent = ns.ins[0].silent;
-        if (!ns.ins[0].silent) {
-          if (!n_.params[0].events.empty())
-            fail(GA_ERR_UNSUPPORTED, "automation of StereoPannerNode.pan is not on the device path yet");
+        ns.panMode = ns.ins[0].bufCh == 1 ? 1 : 2;
+        if (!ns.ins[0].silent && !n_.params[0].events.empty()) {
+          ns.panDyn = true;   // gains follow the a-rate curve on the device (stereo_panner_dynamic_kernel)
+        } else if (!ns.ins[0].silent) {
           float pan = std::min(std::max(n_.params[0].value, -1.0f), 1.0f);
-          ns.panMode = ns.ins[0].bufCh == 1 ? 1 : 2;
           if (pan != n_.panLast) {  // the gains follow the law of the path that sees the change (:92-99, :127-134)
             const float PIf = 3.14159265358979323846f;
             float x = ns.panMode == 1 ? (pan + 1.0f) * 0.5f : (pan <= 0.0f ? pan + 1.0f : pan);
@@ -721,6 +722,53 @@ struct Sim {
           ns.panGL = n_.panGL;
           ns.panGR = n_.panGR;
         }
+        break;
+      }
+      case GA_NODE_DELAY: {  // DelayNode.cs:43-100
+        const InSeg& in = ns.ins[0];
+        const int ch = in.bufCh;
+        if (ch != n_.delayCh) {   // `_outputBuffer` re-rented: a cleared buffer is silent again (:49-55)
+          n_.delayAudible = false;
+          n_.delayCh = ch;
+        }
+        const int64_t B = c.currentBlock + brel;   // the node's time line, in blocks
+        const int64_t OPEN = std::numeric_limits<int64_t>::max();
+        auto& runs = n_.delayRuns;
+        if (!in.silent) {
+          if (runs.empty() || runs.back().second != OPEN) runs.push_back({B, OPEN});
+        } else if (!runs.empty() && runs.back().second == OPEN) {
+          runs.back().second = B;
+        }
+        const int maxD = n_.maxDelaySamples;
+        while (runs.size() > 1 && runs.front().second != OPEN && (runs.front().second + 2) * kBlock + maxD < B * kBlock) runs.erase(runs.begin());
+        // The output buffer's non-silent flag is set by the first non-zero output SAMPLE and never cleared (:72,:92,:96-97).
+        // Data is not visible to the control plane: a non-silent input block is taken to arrive as non-zero samples.
+        int dmin = 1, dmax = maxD;
+        if (n_.params[0].events.empty()) {
+          int d = (int)(n_.params[0].value * (float)c.sampleRate);
+          d = std::min(std::max(d, 0), maxD);
+          dmin = dmax = d;
+        }
+        if (!n_.delayAudible && dmax > 0) {
+          dmin = std::max(dmin, 1);
+          const int64_t lo = B * kBlock - dmax, hi = B * kBlock + (kBlock - 1) - dmin;   // input frames this block can read
+          int64_t nextFlip = OPEN;
+          for (auto& r : runs) {
+            const int64_t rs = r.first * kBlock, re = r.second == OPEN ? OPEN : r.second * kBlock - 1;
+            if (rs <= hi && re >= lo) {
+              n_.delayAudible = true;
+              break;
+            }
+            if (rs > hi) {   // arrives later: block k with k * 128 + 127 - dmin >= rs
+              int64_t k = (rs + dmin - (kBlock - 1) + kBlock - 1) / kBlock;
+              nextFlip = std::min(nextFlip, std::max(k, B + 1));
+            }
+          }
+          if (!n_.delayAudible && nextFlip != OPEN && extraBreaks) extraBreaks->push_back(nextFlip - c.currentBlock);
+        }
+        ns.delayAudible = n_.delayAudible;
+        n_.outputs[0].bufCh = ch;
+        n_.outputs[0].silent = !n_.delayAudible;
         break;
       }
       default: fail(GA_ERR_UNSUPPORTED, "node type not supported on the device path");
@@ -736,7 +784,7 @@ struct Sim {
     for (const NodeSeg& ns : s.nodes) {
       h = hmix(h, (uint64_t)ns.id);
       h = hmix(h, ((uint64_t)ns.outCh << 8) | (ns.outSilent ? 1 : 0) | ((uint64_t)ns.srcPhase << 4) | (ns.bqActive ? 2 : 0) |
-                      ((uint64_t)ns.outMask << 16) | ((uint64_t)ns.panMode << 48));
+                      ((uint64_t)ns.outMask << 16) | ((uint64_t)ns.panMode << 48) | ((uint64_t)(ns.panDyn ? 1 : 0) << 52));
       for (const InSeg& is : ns.ins) {
         h = hmix(h, ((uint64_t)is.bufCh << 1) | (is.silent ? 1 : 0));
         for (const TermS& t : is.terms) h = hmix(h, ((uint64_t)t.node << 16) | ((uint64_t)t.out << 8) | (uint64_t)t.ch);
@@ -772,6 +820,8 @@ struct Exec {
   std::vector<ConstJob> constJobs;
   std::vector<OscJob> oscJobs;
   std::vector<PanJob> panJobs;
+  std::vector<DelayJob> delayJobs;
+  std::vector<PanDynJob> panDynJobs;
   std::vector<ResampleBlock> traj;  // per-chunk trajectory table (all rates + custom tail blocks)
   bool mixAligned = true;
   // conv inputs: node -> slot -> per segment view
@@ -937,6 +987,20 @@ struct Exec {
       hipStream_t st = c.stream;
       plan.add(LK_OTHER, [=](uint8_t* base) { launch_stereo_panner(st, (const PanJob*)(base + off), nj, mx); });
     }
+    if (!panDynJobs.empty()) {
+      size_t off = plan.putv(panDynJobs);
+      int nj = (int)panDynJobs.size();
+      hipStream_t st = c.stream;
+      plan.add(LK_OTHER, [=](uint8_t* base) { launch_stereo_panner_dynamic(st, (const PanDynJob*)(base + off), nj); });
+    }
+    if (!delayJobs.empty()) {   // after the mix jobs of this level, which append the input to the delay lines
+      size_t off = plan.putv(delayJobs);
+      int nj = (int)delayJobs.size();
+      int64_t mx = 0;
+      for (auto& j : delayJobs) mx = std::max(mx, j.n);
+      hipStream_t st = c.stream;
+      plan.add(LK_OTHER, [=](uint8_t* base) { launch_delay(st, (const DelayJob*)(base + off), nj, mx); });
+    }
     if (!gainJobs.empty()) {
       size_t off = plan.putv(gainJobs);
       int nj = (int)gainJobs.size();
@@ -980,6 +1044,8 @@ struct Exec {
     constJobs.clear();
     oscJobs.clear();
     panJobs.clear();
+    delayJobs.clear();
+    panDynJobs.clear();
     mixAligned = true;
   }
   struct RsLaunch {
@@ -1097,6 +1163,15 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
     maxDepth = std::max(maxDepth, nodes[id]->depth);
     maxLevel = std::max(maxLevel, nodes[id]->level);
     NodeS& nd = *nodes[id];
+    if (nd.type == GA_NODE_STEREO_PANNER && nd.panOnDevice && nd.params[0].events.empty()) {
+      PanState tmp;   // back to a constant pan: the gains the automated run left on the device are the node's state
+      GA_HIP(hipStreamSynchronize(stream));
+      GA_HIP(hipMemcpy(&tmp, nd.panDev, sizeof(PanState), hipMemcpyDeviceToHost));
+      nd.panLast = tmp.last_pan;
+      nd.panGL = tmp.gain_l;
+      nd.panGR = tmp.gain_r;
+      nd.panOnDevice = false;
+    }
     if (nd.type == GA_NODE_BIQUAD && nd.coefOnDevice && nd.bqDyn) {
       bool automated = false;
       for (auto& p : nd.params) automated = automated || !p.events.empty();
@@ -1143,6 +1218,8 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
   // ---- simulate ----
   std::vector<Segment> segs;
   Sim sim{*this, n};
+  std::vector<int64_t> extraBreaks;
+  sim.extraBreaks = &extraBreaks;
   int minDestCh = 32;
   {
     int64_t b = 0;
@@ -1169,6 +1246,12 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
         throw;
       }
       inRender = false;
+      for (int64_t x : extraBreaks)   // e.g. the block in which delayed audio reaches a DelayNode's output
+        if (x > b && x < n) {
+          auto it = std::lower_bound(breaks.begin(), breaks.end(), x);
+          if (it == breaks.end() || *it != x) breaks.insert(it, x);
+        }
+      extraBreaks.clear();
       sg.hash = sim.hashSeg(sg);
       int64_t nb;
       if (sg.hash != prevHash) {
@@ -1189,6 +1272,41 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
   chunkMinDestCh = minDestCh;
   const int64_t frames = n * kBlock;
   tmSim = nowMs();
+
+  // ---- DelayNode state: history [rings][maxDelay] (persistent) and the chunk's line [rings][maxDelay + frames] ----
+  for (int id : topo) {
+    NodeS& nd = *nodes[id];
+    if (nd.type != GA_NODE_DELAY) continue;
+    nd.delayLoaded = false;
+    int rings = std::max(nd.delayRings, 2);
+    for (const Segment& sg : segs)
+      for (const NodeSeg& ns : sg.nodes)
+        if (ns.id == id) rings = std::max(rings, ns.ins[0].bufCh);   // EnsureChannelCount (:102-113): new rings start empty
+    nd.delayRings = rings;
+    const size_t maxD = (size_t)nd.maxDelaySamples;
+    if (nd.delayHistRings < rings) {
+      float* nh = (float*)dalloc(maxD * rings * sizeof(float));
+      GA_HIP(hipMemsetAsync(nh, 0, maxD * rings * sizeof(float), stream));
+      if (nd.delayHist) {
+        GA_HIP(hipMemcpyAsync(nh, nd.delayHist, maxD * nd.delayHistRings * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        GA_HIP(hipStreamSynchronize(stream));
+        dfree(nd.delayHist, maxD * nd.delayHistRings * sizeof(float));
+      }
+      nd.delayHist = nh;
+      nd.delayHistRings = rings;
+    }
+    const int64_t cap = roundup(frames, 4096);
+    if (nd.delayCap < cap || nd.delayLineRings < rings) {
+      if (nd.delayLine) {
+        GA_HIP(hipStreamSynchronize(stream));
+        dfree(nd.delayLine, (maxD + (size_t)nd.delayCap) * nd.delayLineRings * sizeof(float));
+      }
+      nd.delayCap = std::max(nd.delayCap, cap);
+      nd.delayLineRings = rings;
+      nd.delayLine = (float*)dalloc((maxD + (size_t)nd.delayCap) * rings * sizeof(float));
+    }
+    nd.delayW.assign(rings, 0);
+  }
 
   // ---- device resources for this chunk ----
   resetSlabs(*this, frames);
@@ -1226,7 +1344,7 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
       NodeS& nd = *nodes[id];
       for (auto& p : nd.params) p.curve = nullptr;
       if (nd.type != GA_NODE_GAIN && nd.type != GA_NODE_BIQUAD && nd.type != GA_NODE_CONSTANT_SOURCE && nd.type != GA_NODE_OSCILLATOR &&
-          nd.type != GA_NODE_DELAY)
+          nd.type != GA_NODE_DELAY && nd.type != GA_NODE_STEREO_PANNER)
         continue;
       for (ParamS& p : nd.params) {
         if (p.events.empty()) continue;
@@ -1408,9 +1526,79 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
             ov[0] = oj.out;
             break;
           }
+          case GA_NODE_DELAY: {
+            const int ch = ns.ins[0].bufCh;
+            const int maxD = nd.maxDelaySamples;
+            const size_t pitch = (size_t)maxD + (size_t)nd.delayCap;
+            if (!nd.delayLoaded) {   // history of the previous chunks in front of every ring's line
+              nd.delayLoaded = true;
+              std::fill(nd.delayW.begin(), nd.delayW.end(), 0);
+              float* line = nd.delayLine;
+              float* hist = nd.delayHist;
+              const int rings = nd.delayHistRings;
+              hipStream_t st = stream;
+              ex.plan.add(LK_OTHER, [=](uint8_t*) {
+                GA_HIP(hipMemcpy2DAsync(line, pitch * 4, hist, (size_t)maxD * 4, (size_t)maxD * 4, rings, hipMemcpyDeviceToDevice, st));
+              });
+            }
+            // append this segment's input to the rings that are processed (a ring beyond the input's channel count does not
+            // move, DelayNode.cs:62-94), then gather
+            std::vector<const float*> iv;
+            if (!ns.ins[0].silent) iv = ex.resolveInput((int)si, ns, 0, false, nullptr);
+            for (int cch = 0; cch < ch; cch++) {
+              float* base = nd.delayLine + (size_t)cch * pitch + maxD + nd.delayW[cch] - f0;   // base[f] = input sample of frame f
+              MixJob mj;
+              mj.out = base;
+              mj.term0 = (int)ex.terms.size();
+              const float* v = (!ns.ins[0].silent && cch < (int)iv.size()) ? iv[cch] : nullptr;
+              mj.nterms = v ? 1 : 0;
+              mj.f0 = f0;
+              mj.n = nf;
+              if (v) {
+                ex.terms.push_back(v);
+                ex.noteAlign(v, f0);
+              }
+              ex.noteAlign(base, f0);
+              ex.mixJobs.push_back(mj);
+              DelayJob dj;
+              dj.line = base;
+              dj.curve = nd.params[0].curve;
+              dj.out = ex.nodeOut(ns.id, cch);
+              dj.value = nd.params[0].value;
+              dj.sample_rate = sampleRate;
+              dj.max_delay = maxD;
+              dj.pad_ = 0;
+              dj.f0 = f0;
+              dj.n = nf;
+              ex.delayJobs.push_back(dj);
+              nd.delayW[cch] += nf;
+              if (ns.delayAudible) ov[cch] = dj.out;   // a buffer still flagged silent is skipped by every consumer
+            }
+            break;
+          }
           case GA_NODE_STEREO_PANNER: {
             if (ns.ins[0].silent) break;   // cleared 2-channel output (:49-54)
             auto iv = ex.resolveInput((int)si, ns, 0, false, nullptr);
+            if (ns.panDyn) {
+              if (!nd.panDev) nd.panDev = (PanState*)dalloc(64);
+              PanDynJob dj;
+              dj.in_l = iv[0] ? iv[0] : zeros;
+              dj.in_r = ns.panMode == 2 ? (iv[1] ? iv[1] : zeros) : nullptr;
+              dj.out_l = ex.nodeOut(ns.id, 0);
+              dj.out_r = ex.nodeOut(ns.id, 1);
+              dj.curve = nd.params[0].curve;
+              dj.state = nd.panDev;
+              dj.init_state = PanState{nd.panLast, nd.panGL, nd.panGR, 0.f};
+              dj.init = nd.panOnDevice ? 0 : 1;   // the host-tracked state is handed over once
+              nd.panOnDevice = true;
+              dj.stereo = ns.panMode == 2 ? 1 : 0;
+              dj.f0 = f0;
+              dj.n = nf;
+              ex.panDynJobs.push_back(dj);
+              ov[0] = dj.out_l;
+              ov[1] = dj.out_r;
+              break;
+            }
             PanJob pj;
             pj.in_l = iv[0] ? iv[0] : zeros;
             pj.in_r = ns.panMode == 2 ? (iv[1] ? iv[1] : zeros) : nullptr;
@@ -1942,6 +2130,20 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
         float *a = kv.second[o], *b2 = kv.second[o + 2];
         if (a && b2) ex.plan.add(LK_OTHER, [=](uint8_t*) { launch_pair_sum(st, out, a, b2, fr); });
       }
+    }
+  }
+
+  // DelayNode: the last maxDelay samples every ring has seen become the history of the next chunk
+  for (int id : topo) {
+    NodeS& nd = *nodes[id];
+    if (nd.type != GA_NODE_DELAY || !nd.delayLoaded) continue;
+    const size_t maxD = (size_t)nd.maxDelaySamples, pitch = maxD + (size_t)nd.delayCap;
+    for (int r = 0; r < nd.delayHistRings; r++) {
+      if (nd.delayW[r] == 0) continue;
+      float* dst = nd.delayHist + (size_t)r * maxD;
+      const float* src = nd.delayLine + (size_t)r * pitch + nd.delayW[r];
+      hipStream_t st = stream;
+      ex.plan.add(LK_OTHER, [=](uint8_t*) { GA_HIP(hipMemcpyAsync(dst, src, maxD * sizeof(float), hipMemcpyDeviceToDevice, st)); });
     }
   }
 

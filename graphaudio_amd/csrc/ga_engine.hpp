@@ -154,14 +154,21 @@ struct NodeS {
   int64_t schedLo = 0, schedHi = 0;  // per chunk: frames [lo, hi) of the chunk in which the scheduled source plays
   // StereoPannerNode (StereoPannerNode.cs:12-14)
   float panLast = std::nanf(""), panGL = 0.5f, panGR = 0.5f;
+  PanState* panDev = nullptr;      // device copy of the three, authoritative while pan is automated (panOnDevice)
+  bool panOnDevice = false;
   // DelayNode (DelayNode.cs:13-15)
   int maxDelaySamples = 0;
   int delayCh = 0;                 // channels of `_outputBuffer` (re-rented, i.e. silent again, when the count changes)
   int delayRings = 0;              // CircularBuffers allocated so far (2 at construction, grown on demand)
   bool delayAudible = false;       // the output buffer's non-silent flag (sticky, :96-97)
-  float* delayLine = nullptr;      // device [rings][maxDelaySamples + delayCap]: history followed by the chunk's input
+  float* delayHist = nullptr;      // device [rings][maxDelaySamples]: the samples written just before the current chunk
+  int delayHistRings = 0;
+  float* delayLine = nullptr;      // device scratch [rings][maxDelaySamples + delayCap]: history followed by the chunk's input
   int64_t delayCap = 0;
-  std::vector<uint8_t> delayInFlags;  // host: non-silent flags of the input blocks still inside the delay window (newest last)
+  int delayLineRings = 0;
+  std::vector<int64_t> delayW;     // per ring: frames appended in the current chunk (a ring only advances while it is processed)
+  bool delayLoaded = false;        // per chunk: history copied in front of the line
+  std::vector<std::pair<int64_t, int64_t>> delayRuns;  // absolute block ranges [from, to) in which the input was non-silent
   // BiQuadFilterNode (BiQuadFilterNode.cs:12-19)
   int filterType = GA_FILTER_LOWPASS;
   float b0 = 0, b1 = 0, b2 = 0, a1 = 0, a2 = 0;
@@ -211,6 +218,7 @@ struct NodeSeg {
   uint32_t outMask = 0;     // ChannelSplitterNode: outputs that carry audio
   float panGL = 0, panGR = 0, pan = 0;   // StereoPannerNode: gains in force in this segment
   int panMode = 0;          // 1 = mono law, 2 = stereo law
+  bool panDyn = false;      // automated pan: per-sample gains on the device
   bool delayAudible = false;
 };
 struct Segment {

@@ -2153,4 +2153,104 @@ void launch_stereo_panner(hipStream_t s, const PanJob* jobs_dev, int njobs, int6
   hipLaunchKernelGGL(stereo_panner_kernel, dim3(gx, njobs), dim3(256), 0, s, jobs_dev);
 }
 
+
+__global__ __launch_bounds__(256) void delay_kernel(const DelayJob* __restrict jobs) {
+  const DelayJob job = jobs[blockIdx.y];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < job.n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t f = job.f0 + i;
+    const float dt = job.curve ? job.curve[f] : job.value;
+    int d = (int)(dt * (float)job.sample_rate);   // float * int -> float, truncated (:68, :88)
+    d = min(max(d, 0), job.max_delay);
+    job.out[f] = d > 0 ? job.line[f - d] : 0.f;
+  }
+}
+void launch_delay(hipStream_t s, const DelayJob* jobs_dev, int njobs, int64_t max_n) {
+  if (njobs <= 0 || max_n <= 0) return;
+  int gx = (int)std::min<int64_t>((max_n + 255) / 256, 1024);
+  hipLaunchKernelGGL(delay_kernel, dim3(gx, njobs), dim3(256), 0, s, jobs_dev);
+}
+
+
+__device__ __forceinline__ void pan_gains(float pan, int stereo, float& gl, float& gr) {   // :94-98 / :129-133
+  const float PIf = 3.14159265358979323846f;
+  const float x = stereo ? (pan <= 0.0f ? pan + 1.0f : pan) : (pan + 1.0f) * 0.5f;
+  gl = cosf(x * PIf / 2.0f);
+  gr = sinf(x * PIf / 2.0f);
+}
+__global__ __launch_bounds__(64) void stereo_panner_dynamic_kernel(const PanDynJob* __restrict jobs) {
+  __shared__ float chg_pan[64];
+  __shared__ int chg_has[64];
+  __shared__ PanState carry[65];
+  const PanDynJob job = jobs[blockIdx.x];
+  const int lane = threadIdx.x;
+  PanState st = job.init ? job.init_state : *job.state;
+  const int64_t nblk = job.n / kBlock;
+  auto panAt = [&](int64_t f) { return fminf(fmaxf(job.curve[f], -1.0f), 1.0f); };   // Math.Clamp(panValues[i], -1, 1)
+  for (int64_t g0 = 0; g0 < nblk; g0 += 64) {
+    const int nb = (int)min<int64_t>(64, nblk - g0);
+    const int64_t fb = job.f0 + (g0 + lane) * kBlock;
+    // last index of this block at which pan differs from the previous sample's pan (the previous sample of the block's first
+    // frame is the last frame of the block before; for the job's very first frame it is the carried _lastPan)
+    int has = 0;
+    float cp = 0.f;
+    if (lane < nb) {
+      float prev = (g0 + lane == 0) ? st.last_pan : panAt(fb - 1);
+      for (int i = 0; i < kBlock; i++) {
+        const float p = panAt(fb + i);
+        if (p != prev) { has = 1; cp = p; }   // NaN != NaN: a NaN _lastPan (initial state) forces the first computation
+        prev = p;
+      }
+    }
+    chg_has[lane] = has;
+    chg_pan[lane] = cp;
+    __syncthreads();
+    if (lane == 0) {   // state at the start of every block of the group
+      PanState cur = st;
+      for (int r = 0; r < nb; r++) {
+        carry[r] = cur;
+        if (chg_has[r]) {
+          cur.last_pan = chg_pan[r];
+          pan_gains(cur.last_pan, job.stereo, cur.gain_l, cur.gain_r);
+        }   // no change in the block: every pan of the block equals the carried _lastPan
+      }
+      carry[nb] = cur;
+    }
+    __syncthreads();
+    if (lane < nb) {
+      PanState s0 = carry[lane];
+      float gl = s0.gain_l, gr = s0.gain_r, lp = s0.last_pan;
+      for (int i = 0; i < kBlock; i++) {
+        const int64_t f = fb + i;
+        const float pan = panAt(f);
+        if (pan != lp) {
+          pan_gains(pan, job.stereo, gl, gr);
+          lp = pan;
+        }
+        if (!job.stereo) {
+          const float x = job.in_l[f];
+          job.out_l[f] = x * gl;
+          job.out_r[f] = x * gr;
+        } else {
+          const float inl = job.in_l[f], inr = job.in_r[f];
+          if (pan <= 0.0f) {
+            job.out_l[f] = inl + inr * gl;
+            job.out_r[f] = inr * gr;
+          } else {
+            job.out_l[f] = inl * gl;
+            job.out_r[f] = inr + inl * gr;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    st = carry[nb];
+    __syncthreads();
+  }
+  if (lane == 0) *job.state = st;
+}
+void launch_stereo_panner_dynamic(hipStream_t s, const PanDynJob* jobs_dev, int njobs) {
+  if (njobs <= 0) return;
+  hipLaunchKernelGGL(stereo_panner_dynamic_kernel, dim3(njobs), dim3(64), 0, s, jobs_dev);
+}
+
 }  // namespace ga

@@ -346,4 +346,40 @@ struct PanJob {
 };
 void launch_stereo_panner(hipStream_t s, const PanJob* jobs_dev, int njobs, int64_t max_n);
 
+// StereoPannerNode with an automated pan: the gains are recomputed whenever pan differs from the previous SAMPLE's pan
+// (`if (pan != lastPan)`, :92/:127) with the law of the path in force at that moment, and persist across blocks and paths.
+// One wavefront per job: every lane finds the last change inside its block, the carried gains are resolved across the 64
+// blocks of a group, then every lane walks its block.
+struct PanState {
+  float last_pan, gain_l, gain_r, pad_;
+};
+struct PanDynJob {
+  const float* in_l;
+  const float* in_r;     // null on the mono path
+  float* out_l;
+  float* out_r;
+  const float* curve;    // a-rate pan curve (chunk-frame indexed)
+  PanState* state;       // device-resident (_lastPan, _lastGainL, _lastGainR); read at the start unless `init`, written at the end
+  PanState init_state;   // host-tracked state handed over when the node turns dynamic
+  int init;
+  int stereo;
+  int64_t f0, n;         // multiples of 128
+};
+void launch_stereo_panner_dynamic(hipStream_t s, const PanDynJob* jobs_dev, int njobs);
+
+// DelayNode.Process (DelayNode.cs:43-100): out[f] = line[f - d(f)], d(f) = clamp((int)(delayTime[f] * sampleRate), 0, max);
+// d = 0 reads 0 (CircularBuffer.Read, :136-144).  `line` is indexed like the chunk (line[f] = input sample of frame f) and
+// preceded by the history of the previous chunks, so every read is a plain gather.
+struct DelayJob {
+  const float* line;    // line[f0 - max_delay .. f0 + n) must be readable
+  const float* curve;   // a-rate delayTime curve or null -> `value`
+  float* out;
+  float value;
+  int sample_rate;
+  int max_delay;
+  int pad_;
+  int64_t f0, n;
+};
+void launch_delay(hipStream_t s, const DelayJob* jobs_dev, int njobs, int64_t max_n);
+
 }  // namespace ga

@@ -164,7 +164,7 @@ def test_stereo_panner_static_bit_exact(pan):
     assert np.array_equal(ref, got)
 
 
-def test_stereo_panner_value_change_between_renders_and_automation_unsupported():
+def test_stereo_panner_value_change_between_renders():
     outs = []
     for mk in (OracleContext, OfflineAudioContext):
         ctx = mk(SR)
@@ -180,12 +180,93 @@ def test_stereo_panner_value_change_between_renders_and_automation_unsupported()
         ctx.Render(out, 128 * 12, 128 * 8)
         outs.append(out)
     assert np.array_equal(outs[0], outs[1])
-    ctx = OfflineAudioContext(SR)
-    s = _stereo(ctx, 128 * 30, 9)
-    p = StereoPannerNode(ctx)
-    p.Pan.LinearRampToValueAtTime(1.0, 0.1)
-    s.Connect(p)
-    p.Connect(ctx.Destination)
-    s.Start()
-    with pytest.raises(NotSupportedException):
-        ctx.Render(np.zeros((2, 256), np.float32), 256)
+
+
+def test_stereo_panner_automation_then_constant_again():
+    outs = []
+    for mk in (OracleContext, OfflineAudioContext):
+        ctx = mk(SR)
+        if mk is OfflineAudioContext:
+            ctx.SetOption("max_chunk_blocks", 9)
+        rng = np.random.default_rng(21)
+        s = _stereo(ctx, 128 * 70, 9)
+        p = StereoPannerNode(ctx)
+        p.Pan.SetValueAtTime(-0.8, 0.0)
+        p.Pan.LinearRampToValueAtTime(0.9, 0.04)          # sweeps through the pan <= 0 / pan > 0 laws, then holds
+        s.Connect(p)
+        p.Connect(ctx.Destination)
+        m = AudioBufferSourceNode(ctx)
+        m.Buffer = PlayableAudioBuffer.FromMonoArray((rng.standard_normal(128 * 70) * 0.25).astype(np.float32), SR)
+        p2 = StereoPannerNode(ctx)                         # mono path (after block 0), exponential-style curve via SetTarget
+        p2.Pan.SetValueAtTime(0.7, 0.0)
+        p2.Pan.SetTargetAtTime(-0.6, 0.01, 0.015)
+        m.Connect(p2)
+        p2.Connect(ctx.Destination)
+        s.Start()
+        m.Start(0.003)
+        out = np.zeros((2, 128 * 64), np.float32)
+        ctx.Render(out, 128 * 40 + 50, 0)
+        p.Pan.Value = 0.9      # same value as the held ramp end: no recomputation, the gains of the automated run stay
+        p2.Pan.Value = 0.1
+        ctx.Render(out, 128 * 24 - 50, 128 * 40 + 50)
+        outs.append(out)
+    ref, got = outs
+    assert G.rms(ref) > 1e-2
+    # device cosf/sinf (gains) and exp (SetTarget curve) differ from glibc by an ulp
+    assert G.rms(ref - got) <= 2e-7 and np.abs(ref - got).max() <= 2e-6
+
+
+def test_delay_constant_and_tail_bit_exact():
+    from graphaudio_amd import DelayNode
+
+    def build(ctx):
+        rng = np.random.default_rng(11)
+        s = _stereo(ctx, 128 * 20, 4)                 # ends after 19 blocks: the delay tail outlives it
+        d = DelayNode(ctx, 0.05)
+        d.DelayTime.Value = 777.3 / SR
+        s.Connect(d)
+        d.Connect(ctx.Destination)
+        m = AudioBufferSourceNode(ctx)
+        m.Buffer = PlayableAudioBuffer.FromMonoArray((rng.standard_normal(128 * 40) * 0.25).astype(np.float32), SR)
+        d2 = DelayNode(ctx, 1.0)                      # long line, short delay, mono input limited to one channel
+        d2.Inputs[0].SetChannelCount(1)
+        d2.DelayTime.Value = 0.011
+        bq = BiQuadFilterNode(ctx)                    # a state-freezing node behind the delay: silent until the audio arrives
+        m.Connect(d2)
+        d2.Connect(bq)
+        bq.Connect(ctx.Destination)
+        s.Start(0.0)
+        m.Start(0.013)
+        return (s, d, m, d2, bq)
+    ref, got = pair(build, 2, 128 * 48, pieces=[900, 2000, 128 * 20], chunk=7)
+    assert G.rms(ref) > 1e-2
+    assert np.array_equal(ref, got)
+
+
+def test_delay_time_automation_and_value_change():
+    from graphaudio_amd import DelayNode
+    outs = []
+    for mk in (OracleContext, OfflineAudioContext):
+        ctx = mk(SR)
+        ctx.Destination.SetChannelCount(1)
+        ctx.Destination.Inputs[0].SetChannelCount(1)
+        rng = np.random.default_rng(12)
+        m = AudioBufferSourceNode(ctx)
+        m.Buffer = PlayableAudioBuffer.FromMonoArray((rng.standard_normal(128 * 60) * 0.25).astype(np.float32), SR)
+        d = DelayNode(ctx, 0.02)
+        d.Inputs[0].SetChannelCount(1)
+        d.DelayTime.SetValueAtTime(0.001, 0.0)
+        d.DelayTime.LinearRampToValueAtTime(0.019, 0.05)     # a-rate: the read position sweeps (:68)
+        m.Connect(d)
+        d.Connect(ctx.Destination)
+        m.Start()
+        out = np.zeros((1, 128 * 50), np.float32)
+        ctx.Render(out, 128 * 30, 0)
+        d.DelayTime.Value = 0.0033                             # cancels the timeline
+        ctx.Render(out, 128 * 20, 128 * 30)
+        outs.append(out)
+    ref, got = outs
+    assert G.rms(ref) > 1e-2
+    # the delay in samples is (int)(float curve * sr): a 1-ulp difference of the device-made curve can move a read by one
+    # sample at the instants where the product crosses an integer
+    assert np.mean(ref != got) < 2e-3
