@@ -731,18 +731,30 @@ struct Sim {
           n_.delayAudible = false;
           n_.delayCh = ch;
         }
-        const int64_t B = c.currentBlock + brel;   // the node's time line, in blocks
+        const int64_t B = c.currentBlock + brel;   // absolute block of this evaluation
         const int64_t OPEN = std::numeric_limits<int64_t>::max();
-        auto& runs = n_.delayRuns;
-        if (!in.silent) {
-          if (runs.empty() || runs.back().second != OPEN) runs.push_back({B, OPEN});
-        } else if (!runs.empty() && runs.back().second == OPEN) {
-          runs.back().second = B;
-        }
         const int maxD = n_.maxDelaySamples;
-        while (runs.size() > 1 && runs.front().second != OPEN && (runs.front().second + 2) * kBlock + maxD < B * kBlock) runs.erase(runs.begin());
+        auto& model = n_.delayModel;
+        // rings that were written since the previous evaluation advanced by the blocks in between
+        if (n_.delayPrevEval >= 0)
+          for (int r = 0; r < std::min((int)model.size(), n_.delayPrevCh); r++) model[r].pos += (B - n_.delayPrevEval) * kBlock;
+        n_.delayPrevEval = B;
+        n_.delayPrevCh = ch;
+        if ((int)model.size() < std::max(ch, 2)) model.resize(std::max(ch, 2));   // EnsureChannelCount (:102-113)
+        for (int r = 0; r < (int)model.size(); r++) {
+          auto& m = model[r];
+          const bool writesAudio = r < ch && !in.silent;
+          if (writesAudio && !m.open) {
+            m.runs.push_back({m.pos, OPEN});
+            m.open = true;
+          } else if (!writesAudio && m.open) {
+            m.runs.back().second = m.pos;
+            m.open = false;
+          }
+          while (m.runs.size() > 1 && m.runs.front().second != OPEN && m.runs.front().second + maxD + 2 * kBlock < m.pos) m.runs.erase(m.runs.begin());
+        }
         // The output buffer's non-silent flag is set by the first non-zero output SAMPLE and never cleared (:72,:92,:96-97).
-        // Data is not visible to the control plane: a non-silent input block is taken to arrive as non-zero samples.
+        // Data is not visible to the control plane: samples that came from a non-silent input block are taken to be non-zero.
         int dmin = 1, dmax = maxD;
         if (n_.params[0].events.empty()) {
           int d = (int)(n_.params[0].value * (float)c.sampleRate);
@@ -751,17 +763,20 @@ struct Sim {
         }
         if (!n_.delayAudible && dmax > 0) {
           dmin = std::max(dmin, 1);
-          const int64_t lo = B * kBlock - dmax, hi = B * kBlock + (kBlock - 1) - dmin;   // input frames this block can read
           int64_t nextFlip = OPEN;
-          for (auto& r : runs) {
-            const int64_t rs = r.first * kBlock, re = r.second == OPEN ? OPEN : r.second * kBlock - 1;
-            if (rs <= hi && re >= lo) {
-              n_.delayAudible = true;
-              break;
-            }
-            if (rs > hi) {   // arrives later: block k with k * 128 + 127 - dmin >= rs
-              int64_t k = (rs + dmin - (kBlock - 1) + kBlock - 1) / kBlock;
-              nextFlip = std::min(nextFlip, std::max(k, B + 1));
+          for (int r = 0; r < ch && !n_.delayAudible; r++) {
+            auto& m = model[r];
+            const int64_t lo = m.pos - dmax, hi = m.pos + (kBlock - 1) - dmin;   // ring frames this block can read
+            for (auto& run : m.runs) {
+              const int64_t rs = run.first, re = run.second == OPEN ? OPEN : run.second - 1;
+              if (rs <= hi && re >= lo) {
+                n_.delayAudible = true;
+                break;
+              }
+              if (rs > hi) {   // arrives k blocks from now: pos + 128 k + 127 - dmin >= rs
+                int64_t k = (rs + dmin - (kBlock - 1) - m.pos + kBlock - 1) / kBlock;
+                nextFlip = std::min(nextFlip, B + std::max<int64_t>(k, 1));
+              }
             }
           }
           if (!n_.delayAudible && nextFlip != OPEN && extraBreaks) extraBreaks->push_back(nextFlip - c.currentBlock);

@@ -168,7 +168,16 @@ struct NodeS {
   int delayLineRings = 0;
   std::vector<int64_t> delayW;     // per ring: frames appended in the current chunk (a ring only advances while it is processed)
   bool delayLoaded = false;        // per chunk: history copied in front of the line
-  std::vector<std::pair<int64_t, int64_t>> delayRuns;  // absolute block ranges [from, to) in which the input was non-silent
+  // control-plane model of what the rings hold, each ring on its OWN time line (a ring beyond the input's channel count is not
+  // written and keeps its content and position until the channel count grows again, DelayNode.cs:62-94)
+  struct DelayRingModel {
+    int64_t pos = 0;                                      // frames appended so far
+    bool open = false;                                    // the last run is still growing
+    std::vector<std::pair<int64_t, int64_t>> runs;        // [from, to) frame ranges that came from non-silent input blocks
+  };
+  std::vector<DelayRingModel> delayModel;
+  int64_t delayPrevEval = -1;                             // absolute block of the previous evaluation
+  int delayPrevCh = 0;
   // BiQuadFilterNode (BiQuadFilterNode.cs:12-19)
   int filterType = GA_FILTER_LOWPASS;
   float b0 = 0, b1 = 0, b2 = 0, a1 = 0, a2 = 0;

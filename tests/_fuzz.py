@@ -1,8 +1,9 @@
 """Random graph generator shared by the fuzz tests: builds the SAME random graph on any context."""
 import numpy as np
 
-from graphaudio_amd import (AudioBufferSourceNode, BiQuadFilterNode, ChannelCountMode, ChannelInterpretation, ConvolverNode,
-                            FilterType, GainNode, PlayableAudioBuffer)
+from graphaudio_amd import (AudioBufferSourceNode, BiQuadFilterNode, ChannelCountMode, ChannelInterpretation, ChannelMergerNode,
+                            ChannelSplitterNode, ConstantSourceNode, ConvolverNode, DelayNode, FilterType, GainNode, OscillatorNode,
+                            OscillatorType, PlayableAudioBuffer, StereoPannerNode)
 
 SR = 48000
 
@@ -94,6 +95,38 @@ def build_random_graph(ctx, seed, frames, keep=None, handles=None):
             node = n
             if handles is not None:
                 handles.setdefault(type(n).__name__, []).append(n)
+        # the remaining pure-Core nodes (drawn from rng2: the graphs of old seeds keep their shape and gain a tail)
+        extra = float(rng2.random())
+        if extra < 0.12:
+            n = StereoPannerNode(ctx)
+            if rng2.random() < 0.5:
+                n.Pan.Value = float(rng2.uniform(-1, 1))
+            else:
+                n.Pan.SetValueAtTime(float(rng2.uniform(-1, 1)), 0.0)
+                n.Pan.LinearRampToValueAtTime(float(rng2.uniform(-1, 1)), float(rng2.uniform(0.01, frames / SR)))
+            node.Connect(n)
+            node = n
+            if handles is not None:
+                handles.setdefault("StereoPannerNode", []).append(n)
+        elif extra < 0.22:
+            n = DelayNode(ctx, float(rng2.choice([0.01, 0.05, 1.0])))
+            if rng2.random() < 0.7:
+                n.DelayTime.Value = float(rng2.uniform(0, 0.01))
+            else:
+                n.DelayTime.SetValueAtTime(float(rng2.uniform(0, 0.01)), 0.0)
+                n.DelayTime.LinearRampToValueAtTime(float(rng2.uniform(0, 0.01)), float(rng2.uniform(0.01, frames / SR)))
+            node.Connect(n)
+            node = n
+            if handles is not None:
+                handles.setdefault("DelayNode", []).append(n)
+        elif extra < 0.30:
+            sp = ChannelSplitterNode(ctx, int(rng2.integers(1, 4)))
+            mg = ChannelMergerNode(ctx, int(rng2.integers(1, 4)))
+            node.Connect(sp)
+            for o in range(sp._output_count):
+                if rng2.random() < 0.8:
+                    sp.Connect(mg, o, int(rng2.integers(0, mg._input_count)))
+            node = mg
         target = buses[int(rng.integers(0, len(buses)))] if buses and rng.random() < 0.6 else ctx.Destination
         live = keep is None or v in keep  # (minimiser hook: unconnected voices are never pulled)
         if live:
@@ -107,6 +140,35 @@ def build_random_graph(ctx, seed, frames, keep=None, handles=None):
             s.Start(when)
         if rng.random() < 0.2:
             s.Stop(float(rng.uniform(when, frames / SR)))
+    # oscillator / constant-source voices (scheduled sources with sample-accurate start and stop)
+    for _ in range(int(rng2.integers(0, 3))):
+        if rng2.random() < 0.6:
+            o = OscillatorNode(ctx)
+            o.Type = OscillatorType(int(rng2.integers(0, 4)))
+            if rng2.random() < 0.6:
+                o.Frequency.Value = float(rng2.uniform(20, 8000))
+            else:
+                o.Frequency.SetValueAtTime(float(rng2.uniform(50, 2000)), 0.0)
+                o.Frequency.LinearRampToValueAtTime(float(rng2.uniform(50, 4000)), float(rng2.uniform(0.01, frames / SR)))
+        else:
+            o = ConstantSourceNode(ctx)
+            o.Offset.Value = float(rng2.uniform(-0.5, 0.5))
+            if rng2.random() < 0.5:
+                o.Offset.LinearRampToValueAtTime(float(rng2.uniform(-0.5, 0.5)), float(rng2.uniform(0.01, frames / SR)))
+        g = GainNode(ctx)
+        g.Gain.Value = float(rng2.uniform(0.05, 0.3))
+        o.Connect(g)
+        g.Connect(buses[0] if buses and rng2.random() < 0.5 else ctx.Destination)
+        when = float(rng2.uniform(0, frames / SR * 0.5))
+        if rng2.random() < 0.4:
+            o.Start(when, 0.0, float(rng2.uniform(0.001, frames / SR * 0.6)))
+        else:
+            o.Start(when)
+            if rng2.random() < 0.5:
+                o.Stop(float(rng2.uniform(when, frames / SR)))
+        if handles is not None:
+            handles.setdefault("scheduled", []).append(o)
+            handles.setdefault("GainNode", []).append(g)
     if handles is not None:
         handles.update(buses=buses, shared_ir=shared_ir)
     return dest_ch
@@ -125,7 +187,7 @@ def run_random_session(ctx, seed, frames=128 * 48, max_piece=128 * 9, keep=None)
     biquads = h.get("BiQuadFilterNode", [])
     convs = h.get("ConvolverNode", [])
     sources = h.get("sources", [])
-    everything = lambda: gains + biquads + convs + sources
+    everything = lambda: gains + biquads + convs + sources + h.get("StereoPannerNode", []) + h.get("DelayNode", []) + h.get("scheduled", [])
     dead = set()
 
     def pick(lst):
@@ -160,7 +222,7 @@ def run_random_session(ctx, seed, frames=128 * 48, max_piece=128 * 9, keep=None)
         detail.clear()
         kind = str(rng.choice(["gain_value", "gain_sched", "gain_cancel", "bq_value", "bq_type", "bq_ramp", "stop", "voice",
                                "dispose", "rewire", "ir_swap", "modulate", "dest_ch", "interp", "loop_toggle", "rate_value",
-                               "rate_sched"]))
+                               "rate_sched", "pan", "delay", "osc"]))
         if kind == "gain_value":
             g = pick(gains)
             if g: g.Gain.Value = float(rng.uniform(0, 1.2))
@@ -235,6 +297,24 @@ def run_random_session(ctx, seed, frames=128 * 48, max_piece=128 * 9, keep=None)
             if s and s.Buffer is not None:
                 s.Loop = not s.Loop
                 detail.append((nid(s), s.Loop, s.Buffer.SampleRate, s.Buffer.Length))
+        elif kind == "pan":
+            pn = pick(h.get("StereoPannerNode", []))
+            if pn:
+                if rng.random() < 0.5:
+                    pn.Pan.Value = float(rng.uniform(-1, 1))
+                else:
+                    pn.Pan.SetValueAtTime(float(rng.uniform(-1, 1)), now)
+                    pn.Pan.LinearRampToValueAtTime(float(rng.uniform(-1, 1)), now + float(rng.uniform(0.005, 0.03)))
+        elif kind == "delay":
+            dn = pick(h.get("DelayNode", []))
+            if dn: dn.DelayTime.Value = float(rng.uniform(0, 0.01))
+        elif kind == "osc":
+            o = pick(h.get("scheduled", []))
+            if o is not None:
+                if isinstance(o, OscillatorNode):
+                    if rng.random() < 0.5: o.Type = OscillatorType(int(rng.integers(0, 4)))
+                    else: o.Frequency.Value = float(rng.uniform(20, 8000))
+                if rng.random() < 0.3: o.Stop(now + float(rng.uniform(0, 0.02)))
         elif kind == "rate_value":
             s = pick(sources)
             if s:

@@ -270,3 +270,29 @@ def test_delay_time_automation_and_value_change():
     # the delay in samples is (int)(float curve * sr): a 1-ulp difference of the device-made curve can move a read by one
     # sample at the instants where the product crosses an integer
     assert np.mean(ref != got) < 2e-3
+
+
+def test_delay_ring_beyond_the_channel_count_stalls_and_resumes():
+    """DelayNode.cs:62-94 writes only the rings of the input's current channels.  Block 1 sees a 3-channel input (lagged channel
+    counts), so ring 2 takes 128 samples and then stalls; when the source is disposed the input has 3 channels again and ring 2
+    plays those 128 samples back -- 14 blocks late."""
+    from graphaudio_amd import ChannelCountMode, DelayNode
+
+    def build(ctx):
+        rng = np.random.default_rng(0)
+        s = AudioBufferSourceNode(ctx)
+        s.Buffer = PlayableAudioBuffer.FromMonoArray((rng.standard_normal(1540) * 0.25).astype(np.float32), SR)
+        g = GainNode(ctx)
+        g.Gain.Value = 0.82
+        g.Inputs[0].SetChannelCount(3)
+        g.Inputs[0].SetChannelCountMode(ChannelCountMode.ClampedMax)
+        d = DelayNode(ctx, 0.01)
+        d.DelayTime.Value = 0.004412005290681458
+        s.Connect(g)
+        g.Connect(d)
+        d.Connect(ctx.Destination)
+        s.Start(0.00402)
+        return (s, g, d)
+    ref, got = pair(build, 4, 128 * 20, pieces=[174, 777, 479, 286, 81], chunk=11)
+    assert np.count_nonzero(ref[2]) == 128
+    assert np.array_equal(ref, got)
