@@ -18,6 +18,8 @@ internal static unsafe partial class GraphAudioHip
                      GA_ERR_DISPOSED = -4, GA_ERR_CYCLE = -5, GA_ERR_UNSUPPORTED = -6, GA_ERR_DEVICE = -7,
                      GA_ERR_OUT_OF_MEMORY = -8, GA_ERR_NO_DEVICE = -9;
     public const int NodeBufferSource = 1, NodeGain = 2, NodeBiquad = 3, NodeConvolver = 4;
+    public const int NodeChannelSplitter = 5, NodeChannelMerger = 6, NodeConstantSource = 7, NodeStereoPanner = 8,
+                     NodeOscillator = 9, NodeDelay = 10;
 
     [StructLayout(LayoutKind.Sequential)]
     public struct Stats
@@ -55,6 +57,10 @@ internal static unsafe partial class GraphAudioHip
 
     [LibraryImport(Lib, EntryPoint = "ga_node_create")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]
     public static partial int ga_node_create(IntPtr ctx, int nodeType, out int nodeId);
+    [LibraryImport(Lib, EntryPoint = "ga_node_create_ex")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]
+    public static partial int ga_node_create_ex(IntPtr ctx, int nodeType, double ctorArg, out int nodeId);
+    [LibraryImport(Lib, EntryPoint = "ga_oscillator_set_type")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]
+    public static partial int ga_oscillator_set_type(IntPtr ctx, int node, int oscillatorType);
     [LibraryImport(Lib, EntryPoint = "ga_node_dispose")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]
     public static partial int ga_node_dispose(IntPtr ctx, int node);
     [LibraryImport(Lib, EntryPoint = "ga_node_connect")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]

@@ -12,7 +12,8 @@
 // command queue exactly like AudioContextBase.ProcessBlock does (AudioContextBase.cs:57), (2) walks the graph from
 // Destination (same traversal as GetAllNodes, AudioContextBase.cs:191-218), (3) replays what changed since the last
 // call through the flat C ABI -- O(graph delta) calls -- and (4) makes ONE ga_render call for the whole frame range.
-// Unsupported node types (anything but AudioBufferSourceNode, GainNode, BiQuadFilterNode, ConvolverNode and the
+// Unsupported node types (anything but AudioBufferSourceNode, GainNode, BiQuadFilterNode, ConvolverNode, ChannelSplitterNode,
+// ChannelMergerNode, ConstantSourceNode, StereoPannerNode, OscillatorNode, DelayNode and the
 // destination) make EnsureSynced throw NotSupportedException; callers fall back to the stock CPU context.
 // NOTE: not compiled in this repository's build image (no .NET); reviewed by reading.  The Python host in
 // graphaudio_amd/core.py drives the very same C ABI calls in the same order and IS tested.
@@ -98,15 +99,23 @@ public sealed unsafe class HipOfflineAudioContext : AudioContextBase
 
     private int CreateNative(AudioNode node)
     {
-        int type = node switch
+        // (node type, constructor argument): the argument is the output / input count of a splitter / merger
+        // (ChannelSplitterNode.cs:14, ChannelMergerNode.cs:14) or DelayNode's maxDelayTime (DelayNode.cs:22, internal accessor)
+        (int type, double arg) = node switch
         {
-            AudioBufferSourceNode => GraphAudioHip.NodeBufferSource,
-            GainNode => GraphAudioHip.NodeGain,
-            BiQuadFilterNode => GraphAudioHip.NodeBiquad,
-            ConvolverNode => GraphAudioHip.NodeConvolver,
+            AudioBufferSourceNode => (GraphAudioHip.NodeBufferSource, 0.0),
+            GainNode => (GraphAudioHip.NodeGain, 0.0),
+            BiQuadFilterNode => (GraphAudioHip.NodeBiquad, 0.0),
+            ConvolverNode => (GraphAudioHip.NodeConvolver, 0.0),
+            ChannelSplitterNode sp => (GraphAudioHip.NodeChannelSplitter, (double)sp.Outputs.Count),
+            ChannelMergerNode mg => (GraphAudioHip.NodeChannelMerger, (double)mg.Inputs.Count),
+            ConstantSourceNode => (GraphAudioHip.NodeConstantSource, 0.0),
+            StereoPannerNode => (GraphAudioHip.NodeStereoPanner, 0.0),
+            OscillatorNode => (GraphAudioHip.NodeOscillator, 0.0),
+            DelayNode d => (GraphAudioHip.NodeDelay, d.MaxDelayTimeInternal),
             _ => throw new NotSupportedException($"{node.GetType().Name} is not on the HIP render path; use OfflineAudioContext"),
         };
-        GraphAudioHip.Check(_native, GraphAudioHip.ga_node_create(_native, type, out int id));
+        GraphAudioHip.Check(_native, GraphAudioHip.ga_node_create_ex(_native, type, arg, out int id));
         _nodeIds[node] = id;
         _shadow[node] = new NodeShadow();
         return id;
@@ -174,6 +183,13 @@ public sealed unsafe class HipOfflineAudioContext : AudioContextBase
                 GraphAudioHip.Check(_native, GraphAudioHip.ga_convolver_set_buffer(_native, id, cv.Buffer is null ? -1 : BufferId(cv.Buffer)));
                 sh.Buffer = cv.Buffer;
                 break;
+            case OscillatorNode osc:
+                GraphAudioHip.Check(_native, GraphAudioHip.ga_oscillator_set_type(_native, id, (int)osc.Type));
+                SyncScheduled(osc, id, sh);
+                break;
+            case ConstantSourceNode cs:
+                SyncScheduled(cs, id, sh);
+                break;
             case AudioBufferSourceNode src:
                 if (!ReferenceEquals(sh.Buffer, src.Buffer))
                 {
@@ -190,6 +206,18 @@ public sealed unsafe class HipOfflineAudioContext : AudioContextBase
                     GraphAudioHip.Check(_native, GraphAudioHip.ga_source_stop(_native, id, src.StopTimeInternal));
                 break;
         }
+    }
+
+    // Start / Stop of ConstantSourceNode and OscillatorNode (IAudioScheduledSourceNode): NaN duration = none
+    private void SyncScheduled(IAudioScheduledSourceNode src, int id, NodeShadow sh)
+    {
+        if (src.HasStartedInternal && !sh.Started)
+        {
+            GraphAudioHip.Check(_native, GraphAudioHip.ga_source_start(_native, id, src.StartTimeInternal, 0.0, double.NaN));
+            sh.Started = true;
+        }
+        if (!double.IsNaN(src.StopTimeInternal))
+            GraphAudioHip.Check(_native, GraphAudioHip.ga_source_stop(_native, id, src.StopTimeInternal));
     }
 
     private void SyncConnections(AudioNode node, int id)
