@@ -72,6 +72,11 @@ internal static unsafe partial class GraphAudioHip
     [LibraryImport(Lib, EntryPoint = "ga_node_has_ended")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]
     public static partial int ga_node_has_ended(IntPtr ctx, int node);
 
+    [LibraryImport(Lib, EntryPoint = "ga_process_blocks")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]
+    public static partial int ga_process_blocks(IntPtr ctx, float** outPlanar, int outChannels, long blockCount, int outOnDevice);
+    [LibraryImport(Lib, EntryPoint = "ga_process_blocks_interleaved")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]
+    public static partial int ga_process_blocks_interleaved(IntPtr ctx, float* interleaved, int channels, long blockCount, int outOnDevice);
+
     [LibraryImport(Lib, EntryPoint = "ga_poll_ended")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]
     public static partial int ga_poll_ended(IntPtr ctx, int* outNodeIds, int capacity);
 

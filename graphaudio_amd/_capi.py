@@ -130,6 +130,8 @@ SIGNATURES = {
     "convolver_set_buffer": (_i, [_vp, _i, _i]),
     "render": (_i, [_vp, _pp, _i, _i64, _i64]),
     "render_device": (_i, [_vp, _pp, _i, _i64, _i64]),
+    "process_blocks": (_i, [_vp, _pp, _i, _i64, _i]),
+    "process_blocks_interleaved": (_i, [_vp, C.POINTER(C.c_float), _i, _i64, _i]),
     "context_set_stream": (_i, [_vp, _vp]),
 }
 

@@ -447,6 +447,41 @@ class AudioContextBase:
     def CurrentBlock(self) -> int:  # :223
         return self._api.current_block(self._h)
 
+    def ProcessBlocks(self, outputBuffers, blockCount: int):  # AudioContextBase.cs:163-186
+        """Render `blockCount` whole blocks into planar float32 arrays (list of 1-D arrays or one 2-D array); per block only the
+        channels the destination buffer has are written, `None` entries are skipped."""
+        if blockCount < 0:
+            raise ArgumentOutOfRangeException("blockCount")
+        chans = list(outputBuffers)
+        ptrs = (C.c_void_p * max(len(chans), 1))()
+        for i, a in enumerate(chans):
+            if a is None:
+                ptrs[i] = None
+                continue
+            if a.dtype != np.float32 or not a.flags["C_CONTIGUOUS"] or a.ndim != 1:
+                raise ArgumentException("outputBuffers must hold contiguous 1-D float32 arrays")
+            if a.shape[0] < blockCount * FramesPerBlock:
+                raise ArgumentException("Destination is too short.")   # Span.CopyTo
+            ptrs[i] = a.ctypes.data
+        self._call("process_blocks", ptrs, len(chans), int(blockCount), 0)
+        self._raise_ended()
+
+    def ProcessBlockInterleaved(self, interleavedBuffer: np.ndarray, channels: int):  # AudioContextBase.cs:88-157
+        """One block, frame-major interleaved: interleavedBuffer[frame * channels + ch]."""
+        self.ProcessBlocksInterleaved(interleavedBuffer, channels, 1)
+
+    def ProcessBlocksInterleaved(self, interleavedBuffer: np.ndarray, channels: int, blockCount: int):
+        """`blockCount` consecutive ProcessBlockInterleaved calls in one native call (device-side interleave)."""
+        if channels < 1 or channels > 32:
+            raise ArgumentOutOfRangeException("channels")
+        a = interleavedBuffer
+        if a.dtype != np.float32 or not a.flags["C_CONTIGUOUS"]:
+            raise ArgumentException("interleavedBuffer must be a contiguous float32 array")
+        if a.size < FramesPerBlock * channels * blockCount:
+            raise ArgumentException("Buffer too small for interleaved output.")
+        self._call("process_blocks_interleaved", a.ctypes.data_as(C.POINTER(C.c_float)), int(channels), int(blockCount), 0)
+        self._raise_ended()
+
     def FramesToSeconds(self, frames: int) -> float:  # :228-231
         return frames / float(self.SampleRate)
 

@@ -85,6 +85,87 @@ ParamS makeParam(float def, float mn, float mx, bool arate) {
 // ------------------------------------------------------------------------------------------------------
 // OfflineAudioContext.Render (OfflineAudioContext.cs:30-102) on top of runChunk
 // ------------------------------------------------------------------------------------------------------
+// chunk size: bounded by the option and by device memory (slabs + convolver planes scale with the block count)
+int64_t Context::chunkLimit(int64_t) {
+    int64_t limit = maxChunkBlocks;
+    {
+      size_t freeB = 0, totalB = 0;
+      if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
+        double perBlock = 0;
+        int convRowsMax = 0;
+        for (auto& g : groups) convRowsMax = std::max(convRowsMax, (int)((g->rows.size() + 127) / 128 * 128));
+        perBlock += (double)convRowsMax * kBins * 4.0 * 4.0;
+        for (auto& np : nodes)   // private-IR convolvers (formulation B): x rows + y rows
+          if (np->type == GA_NODE_CONVOLVER && np->ir && np->convPath != 1)
+            perBlock += (double)(np->ir->nch + (np->isTrueStereo ? 2 : np->ir->nch)) * kBins * 8.0;
+        perBlock += ((double)nodes.size() * 2.0 + 64.0) * kBlock * 4.0;
+        double budget = ((double)freeB + (double)slabBlocks.size() * (double)((size_t)1 << 30) * 0.0) * memBudgetFraction;
+        // memory already held by slabs / planes is reused, so add it back to the budget
+        budget += (double)(planes[0].bytes + planes[1].bytes + planes[2].bytes + planes[3].bytes);
+        budget += (double)slabAll.size() * (double)slabFrames * 4.0;
+        int64_t byMem = (int64_t)(budget / std::max(perBlock, 1.0));
+        limit = std::max<int64_t>(1, std::min<int64_t>(limit, byMem));
+      }
+    }
+  return limit;
+}
+
+// AudioContextBase.ProcessBlocks (AudioContextBase.cs:163-186) / ProcessBlockInterleaved (:88-157) over whole chunks
+void Context::processBlocks(float* const* outPlanar, float* outInterleaved, int channels, int64_t blockCount, bool deviceOut) {
+  if (blockCount < 0) fail(GA_ERR_OUT_OF_RANGE, "blockCount");
+  if (disposed) fail(GA_ERR_DISPOSED, "context disposed");
+  if (outInterleaved || outPlanar == nullptr) {
+    if (channels < 1 || channels > 32) fail(GA_ERR_OUT_OF_RANGE, "channels");
+    if (!outInterleaved) fail(GA_ERR_INVALID_ARGUMENT, "Buffer too small for interleaved output.");
+  } else if (channels < 0 || channels > 32) {
+    fail(GA_ERR_OUT_OF_RANGE, "channels");
+  }
+  GA_HIP(hipSetDevice(device));
+  const hipMemcpyKind kind = deviceOut ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  int64_t doneBlocks = 0;
+  while (doneBlocks < blockCount) {
+    int64_t nblk = std::min(blockCount - doneBlocks, chunkLimit(blockCount - doneBlocks));
+    runChunk(nblk, nullptr);
+    const int64_t done = chunkBlocksDone;
+    if (done <= 0) fail(GA_ERR_INVALID_OPERATION, "render made no progress");
+    const int64_t base = doneBlocks * kBlock;
+    if (outInterleaved) {
+      float* stage = outInterleaved + base * channels;
+      if (!deviceOut) {
+        size_t need = (size_t)done * kBlock * channels * sizeof(float);
+        if (ilvBytes < need) {
+          if (ilvDev) {
+            GA_HIP(hipStreamSynchronize(stream));
+            dfree(ilvDev, ilvBytes);
+          }
+          ilvBytes = need + need / 4;
+          ilvDev = (float*)dalloc(ilvBytes);
+        }
+        stage = ilvDev;
+      }
+      for (const SegCh& sg : chunkSegCh) {
+        InterleaveSrc src{};
+        const int used = std::min(channels, sg.ch);
+        for (int ch = 0; ch < used; ch++) src.ch[ch] = busSlabs[ch];
+        launch_interleave(stream, stage, src, channels, used, sg.b0 * kBlock, (sg.b1 - sg.b0) * kBlock);
+      }
+      if (!deviceOut)
+        GA_HIP(hipMemcpyAsync(outInterleaved + base * channels, ilvDev, (size_t)done * kBlock * channels * sizeof(float), kind, stream));
+    } else {
+      for (const SegCh& sg : chunkSegCh) {   // `channels = Math.Min(outputBuffers.Length, buffer.ChannelCount)` per block (:173)
+        const int used = std::min(channels, sg.ch);
+        for (int ch = 0; ch < used; ch++)
+          if (outPlanar[ch])
+            GA_HIP(hipMemcpyAsync(outPlanar[ch] + base + sg.b0 * kBlock, busSlabs[ch] + sg.b0 * kBlock,
+                                  sizeof(float) * (size_t)(sg.b1 - sg.b0) * kBlock, kind, stream));
+      }
+    }
+    GA_HIP(hipStreamSynchronize(stream));
+    doneBlocks += done;
+  }
+  stats.device_bytes_in_use = devBytes;
+}
+
 void Context::render(float* const* out, int channels, int64_t frameCount, int64_t startIndex, bool deviceOut) {
   if (channels == 0 || !out) fail(GA_ERR_INVALID_ARGUMENT, "Output buffer must have at least one channel.");
   if (frameCount <= 0) fail(GA_ERR_OUT_OF_RANGE, "Frame count must be positive.");
@@ -109,27 +190,7 @@ void Context::render(float* const* out, int channels, int64_t frameCount, int64_
   while (written < frameCount) {
     int64_t need = frameCount - written;
     int64_t nblk = (need + kBlock - 1) / kBlock;
-    // chunk size: bounded by the option and by device memory (slabs + convolver planes scale with the block count)
-    int64_t limit = maxChunkBlocks;
-    {
-      size_t freeB = 0, totalB = 0;
-      if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
-        double perBlock = 0;
-        int convRowsMax = 0;
-        for (auto& g : groups) convRowsMax = std::max(convRowsMax, (int)((g->rows.size() + 127) / 128 * 128));
-        perBlock += (double)convRowsMax * kBins * 4.0 * 4.0;
-        for (auto& np : nodes)   // private-IR convolvers (formulation B): x rows + y rows
-          if (np->type == GA_NODE_CONVOLVER && np->ir && np->convPath != 1)
-            perBlock += (double)(np->ir->nch + (np->isTrueStereo ? 2 : np->ir->nch)) * kBins * 8.0;
-        perBlock += ((double)nodes.size() * 2.0 + 64.0) * kBlock * 4.0;
-        double budget = ((double)freeB + (double)slabBlocks.size() * (double)((size_t)1 << 30) * 0.0) * memBudgetFraction;
-        // memory already held by slabs / planes is reused, so add it back to the budget
-        budget += (double)(planes[0].bytes + planes[1].bytes + planes[2].bytes + planes[3].bytes);
-        budget += (double)slabAll.size() * (double)slabFrames * 4.0;
-        int64_t byMem = (int64_t)(budget / std::max(perBlock, 1.0));
-        limit = std::max<int64_t>(1, std::min<int64_t>(limit, byMem));
-      }
-    }
+    const int64_t limit = chunkLimit(nblk);
     nblk = std::min(nblk, limit);
     runChunk(nblk, nullptr);
     const int64_t done = chunkBlocksDone;
@@ -671,6 +732,16 @@ int ga_convolver_set_buffer(ga_context* ctx, int node, int buffer_id) {
 
 int ga_render(ga_context* ctx, float* const* out_planar, int out_channels, int64_t frame_count, int64_t start_index) {
   return guard(ctx, [&](Context& c) { c.render(out_planar, out_channels, frame_count, start_index, false); });
+}
+int ga_process_blocks(ga_context* ctx, float* const* out_planar, int out_channels, int64_t block_count, int out_on_device) {
+  return guard(ctx, [&](Context& c) {
+    if (out_channels > 0 && !out_planar) fail(GA_ERR_INVALID_ARGUMENT, "outputBuffers");
+    static float* const none[1] = {nullptr};
+    c.processBlocks(out_planar ? out_planar : none, nullptr, out_channels, block_count, out_on_device != 0);
+  });
+}
+int ga_process_blocks_interleaved(ga_context* ctx, float* interleaved, int channels, int64_t block_count, int out_on_device) {
+  return guard(ctx, [&](Context& c) { c.processBlocks(nullptr, interleaved, channels, block_count, out_on_device != 0); });
 }
 int ga_render_device(ga_context* ctx, float* const* out_planar_dev, int out_channels, int64_t frame_count, int64_t start_index) {
   return guard(ctx, [&](Context& c) { c.render(out_planar_dev, out_channels, frame_count, start_index, true); });

@@ -2284,6 +2284,8 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
   stats.chunks++;
   stats.segments += (int64_t)segs.size();
   chunkBlocksDone = n;
+  chunkSegCh.clear();
+  for (const Segment& sg : segs) chunkSegCh.push_back(SegCh{sg.b0, sg.b1, sg.nodes.back().outCh});
 }
 
 }  // namespace ga

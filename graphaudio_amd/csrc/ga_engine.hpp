@@ -353,6 +353,12 @@ struct Context {
 
   int64_t busCapFrames = 0;
   std::vector<float*> busSlabs;
+  struct SegCh { int64_t b0, b1; int ch; };
+  std::vector<SegCh> chunkSegCh;   // destination buffer channel count of every segment of the last chunk
+  float* ilvDev = nullptr;         // device staging for interleaved output
+  size_t ilvBytes = 0;
+  void processBlocks(float* const* outPlanar, float* outInterleaved, int channels, int64_t blockCount, bool deviceOut);
+  int64_t chunkLimit(int64_t nblk);
   std::deque<int> endedQueue;  // sources whose Ended was raised and not yet reported through ga_poll_ended
   uint64_t lastHash = 0;       // control-state hash of the last block of the previous chunk
   int chunkMinDestCh = 0;      // smallest destination channel count over the blocks of the last chunk

@@ -2253,4 +2253,21 @@ void launch_stereo_panner_dynamic(hipStream_t s, const PanDynJob* jobs_dev, int 
   hipLaunchKernelGGL(stereo_panner_dynamic_kernel, dim3(njobs), dim3(64), 0, s, jobs_dev);
 }
 
+
+__global__ __launch_bounds__(256) void interleave_kernel(float* __restrict dst, InterleaveSrc src, int channels, int used, int64_t f0, int64_t n) {
+  // one thread per output element: consecutive threads write consecutive floats (coalesced); the reads of one channel are
+  // strided by `channels` across the wave and served from L2
+  const int64_t total = n * channels;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t f = i / channels;
+    const int ch = (int)(i - f * channels);
+    dst[(f0 + f) * channels + ch] = ch < used ? src.ch[ch][f0 + f] : 0.f;
+  }
+}
+void launch_interleave(hipStream_t s, float* dst, InterleaveSrc src, int channels, int used, int64_t f0, int64_t n) {
+  if (n <= 0 || channels <= 0) return;
+  int gx = (int)std::min<int64_t>((n * channels + 255) / 256, 4096);
+  hipLaunchKernelGGL(interleave_kernel, dim3(gx), dim3(256), 0, s, dst, src, channels, used, f0, n);
+}
+
 }  // namespace ga

@@ -382,4 +382,10 @@ struct DelayJob {
 };
 void launch_delay(hipStream_t s, const DelayJob* jobs_dev, int njobs, int64_t max_n);
 
+// ProcessBlockInterleaved (AudioContextBase.cs:125-155): dst[(f0 + i) * channels + ch] = ch < used ? src[ch][f0 + i] : 0
+struct InterleaveSrc {
+  const float* ch[32];
+};
+void launch_interleave(hipStream_t s, float* dst, InterleaveSrc src, int channels, int used, int64_t f0, int64_t n);
+
 }  // namespace ga

@@ -177,6 +177,20 @@ GA_EXPORT int GA_FN(render)(ga_context* ctx, float* const* out_planar, int out_c
  * can be summed across GPUs with RCCL without a host round trip).  The oracle build returns GA_ERR_UNSUPPORTED. */
 GA_EXPORT int GA_FN(render_device)(ga_context* ctx, float* const* out_planar_dev, int out_channels, int64_t frame_count,
                                    int64_t start_index);
+/* AudioContextBase.ProcessBlocks(float[][] outputBuffers, int blockCount), AudioContextBase.cs:163-186: block_count whole
+   blocks; for every block the first min(out_channels, channels of the destination buffer) channels are written at
+   block * 128, further channels are left untouched, null channel pointers are skipped.  (Frames cached by a previous
+   partial Render are not consumed, as in the reference.)  out_on_device != 0: the pointers are device memory. */
+GA_EXPORT int GA_FN(process_blocks)(ga_context* ctx, float* const* out_planar, int out_channels, int64_t block_count,
+                                    int out_on_device);
+/* AudioContextBase.ProcessBlockInterleaved(float[] interleavedBuffer, int channels), AudioContextBase.cs:88-157, for
+   block_count consecutive blocks (the reference call is block_count = 1): frame-major interleaved samples,
+   interleaved[(block * 128 + frame) * channels + ch]; channels beyond the destination buffer's are zero-filled.  The
+   interleave runs on the device; this is the format RealtimeAudioContext.RenderLoop hands to the audio device
+   (GraphAudio.Realtime/RealtimeAudioContext.cs:143-165). */
+GA_EXPORT int GA_FN(process_blocks_interleaved)(ga_context* ctx, float* interleaved, int channels, int64_t block_count,
+                                                int out_on_device);
+
 /* Run the render on this HIP stream (a hipStream_t passed as void*) instead of the context's own stream. */
 GA_EXPORT int GA_FN(context_set_stream)(ga_context* ctx, void* hip_stream);
 

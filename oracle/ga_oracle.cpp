@@ -1932,6 +1932,41 @@ int gao_render(ga_context* ctx, float* const* output, int channels, int64_t fram
 }
 int gao_render_device(ga_context*, float* const*, int, int64_t, int64_t) { return GA_ERR_UNSUPPORTED; }
 
+// AudioContextBase.ProcessBlocks, AudioContextBase.cs:163-186
+int gao_process_blocks(ga_context* ctx, float* const* outputBuffers, int nOut, int64_t blockCount, int onDevice) {
+  return guard(ctx, [&](Context& c) {
+    if (onDevice) fail(GA_ERR_UNSUPPORTED, "the oracle has no device memory");
+    if (blockCount < 0) fail(GA_ERR_OUT_OF_RANGE, "blockCount");
+    if (nOut < 0 || (nOut > 0 && !outputBuffers)) fail(GA_ERR_INVALID_ARGUMENT, "outputBuffers");
+    for (int64_t block = 0; block < blockCount; block++) {
+      AudioBuffer* buffer = c.processBlock();
+      int channels = std::min(nOut, buffer->channelCount);
+      for (int ch = 0; ch < channels; ch++)
+        if (outputBuffers[ch]) std::memcpy(outputBuffers[ch] + block * kBlock, buffer->span(ch), sizeof(float) * kBlock);
+    }
+  });
+}
+// AudioContextBase.ProcessBlockInterleaved, AudioContextBase.cs:88-157, repeated blockCount times
+int gao_process_blocks_interleaved(ga_context* ctx, float* interleaved, int channels, int64_t blockCount, int onDevice) {
+  return guard(ctx, [&](Context& c) {
+    if (onDevice) fail(GA_ERR_UNSUPPORTED, "the oracle has no device memory");
+    if (channels < 1 || channels > 32) fail(GA_ERR_OUT_OF_RANGE, "channels");
+    if (!interleaved) fail(GA_ERR_INVALID_ARGUMENT, "Buffer too small for interleaved output.");
+    if (blockCount < 0) fail(GA_ERR_OUT_OF_RANGE, "blockCount");
+    for (int64_t block = 0; block < blockCount; block++) {
+      AudioBuffer* buffer = c.processBlock();
+      float* out = interleaved + block * kBlock * channels;
+      int used = std::min(channels, buffer->channelCount);
+      for (int ch = 0; ch < used; ch++) {
+        const float* src = buffer->span(ch);
+        for (int f = 0; f < kBlock; f++) out[(size_t)f * channels + ch] = src[f];
+      }
+      for (int ch = used; ch < channels; ch++)
+        for (int f = 0; f < kBlock; f++) out[(size_t)f * channels + ch] = 0.f;
+    }
+  });
+}
+
 // ---- test-only extras (not part of the product ABI): direct access to the DSP primitives so that
 // tests/ can pin them against numpy/scipy without building a graph ----
 int gao_test_rfft256(const double* x, double* re, double* im) {
