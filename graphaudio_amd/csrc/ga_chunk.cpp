@@ -992,7 +992,9 @@ struct Exec {
       size_t off = plan.putv(oscJobs);
       int nj = (int)oscJobs.size();
       hipStream_t st = c.stream;
-      plan.add(LK_OTHER, [=](uint8_t* base) { launch_oscillator(st, (const OscJob*)(base + off), nj); });
+      bool anyCurve = false;
+      for (auto& j : oscJobs) anyCurve = anyCurve || j.curve != nullptr;
+      plan.add(LK_OTHER, [=](uint8_t* base) { launch_oscillator(st, (const OscJob*)(base + off), nj, anyCurve); });
     }
     if (!panJobs.empty()) {
       size_t off = plan.putv(panJobs);

@@ -2066,32 +2066,44 @@ __device__ __forceinline__ float osc_sample(double ph, int type) {   // Generate
   }
 }
 __global__ __launch_bounds__(64) void oscillator_kernel(const OscJob* __restrict jobs) {
-  __shared__ float tile[64][kBlock + 1];   // frequency values in, samples out
-  __shared__ double start_ph[64];
+  extern __shared__ double osc_lds[];
+  // [64] block-start phases | [64][129] floats: samples out | (curve jobs only) [64][128] doubles: phase increments
+  double* start_ph = osc_lds;
+  float (*tile)[kBlock + 1] = reinterpret_cast<float (*)[kBlock + 1]>(osc_lds + 64);
+  double* incs = osc_lds + 64 + (64 * (kBlock + 1) * sizeof(float) + 7) / 8;
   const OscJob job = jobs[blockIdx.x];
   const int lane = threadIdx.x;
   const double PI2 = 2.0 * 3.14159265358979323846;
   const double sr = (double)job.sample_rate;
+  const bool curve = job.curve != nullptr;
+  const double inc_const = (PI2 * (double)job.value) / sr;   // `(2.0 * Math.PI * freqValues[i]) / Context.SampleRate` (:140)
   double ph = *job.phase;
   const int64_t nblk = job.n / kBlock;
   for (int64_t g0 = 0; g0 < nblk; g0 += 64) {
     const int nb = (int)min<int64_t>(64, nblk - g0);
     const int64_t fg = job.f0 + g0 * kBlock;   // first frame of this group of blocks
-    // frequency of every frame of the group -> LDS (coalesced)
-    for (int r = 0; r < nb; r++) {
-      const int64_t f = fg + (int64_t)r * kBlock;
-      tile[r][lane] = job.curve ? job.curve[f + lane] : job.value;
-      tile[r][64 + lane] = job.curve ? job.curve[f + 64 + lane] : job.value;
+    if (curve) {   // the increments of the whole group, computed 64-wide (the division stays out of the serial chain)
+      for (int r = 0; r < nb; r++) {
+        const int64_t f = fg + (int64_t)r * kBlock;
+        incs[r * kBlock + lane] = (PI2 * (double)job.curve[f + lane]) / sr;
+        incs[r * kBlock + 64 + lane] = (PI2 * (double)job.curve[f + 64 + lane]) / sr;
+      }
+      __syncthreads();
     }
-    __syncthreads();
-    if (lane == 0) {   // the serial recurrence (:139-143), only the phase: `_phase += 2 pi f / sr; if (_phase >= 2 pi) _phase -= 2 pi`
+    if (lane == 0) {   // the serial recurrence (:139-143), only the phase: `_phase += inc; if (_phase >= 2 pi) _phase -= 2 pi`
       for (int r = 0; r < nb; r++) {
         start_ph[r] = ph;
         const int64_t f = fg + (int64_t)r * kBlock;
         if (f + kBlock <= job.lo || f >= job.hi) continue;
-        for (int i = 0; i < kBlock; i++) {
-          if (f + i >= job.lo && f + i < job.hi) {
-            ph += (PI2 * (double)tile[r][i]) / sr;
+        const int i0 = (int)max<int64_t>(job.lo - f, 0), i1 = (int)min<int64_t>(job.hi - f, kBlock);
+        if (curve) {
+          for (int i = i0; i < i1; i++) {
+            ph += incs[r * kBlock + i];
+            if (ph >= PI2) ph -= PI2;
+          }
+        } else {
+          for (int i = i0; i < i1; i++) {
+            ph += inc_const;
             if (ph >= PI2) ph -= PI2;
           }
         }
@@ -2105,10 +2117,10 @@ __global__ __launch_bounds__(64) void oscillator_kernel(const OscJob* __restrict
         float v = 0.f;
         if (f + i >= job.lo && f + i < job.hi) {
           v = osc_sample(p, job.type);
-          p += (PI2 * (double)tile[lane][i]) / sr;
+          p += curve ? incs[lane * kBlock + i] : inc_const;
           if (p >= PI2) p -= PI2;
         }
-        tile[lane][i] = v;   // the frequency at [lane][i] is not needed again
+        tile[lane][i] = v;
       }
     }
     __syncthreads();
@@ -2122,9 +2134,15 @@ __global__ __launch_bounds__(64) void oscillator_kernel(const OscJob* __restrict
   }
   if (lane == 0) *job.phase = ph;
 }
-void launch_oscillator(hipStream_t s, const OscJob* jobs_dev, int njobs) {
+void launch_oscillator(hipStream_t s, const OscJob* jobs_dev, int njobs, bool any_curve) {
   if (njobs <= 0) return;
-  hipLaunchKernelGGL(oscillator_kernel, dim3(njobs), dim3(64), 0, s, jobs_dev);
+  size_t lds = 64 * sizeof(double) + ((64 * (kBlock + 1) * sizeof(float) + 7) / 8) * 8 + (any_curve ? 64 * kBlock * sizeof(double) : 0);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)oscillator_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(oscillator_kernel, dim3(njobs), dim3(64), lds, s, jobs_dev);
 }
 
 __global__ __launch_bounds__(256) void stereo_panner_kernel(const PanJob* __restrict jobs) {

@@ -331,7 +331,7 @@ struct OscJob {
   int64_t f0, n;        // frames of this job (multiples of 128)
   int64_t lo, hi;       // playing window in chunk frames
 };
-void launch_oscillator(hipStream_t s, const OscJob* jobs_dev, int njobs);
+void launch_oscillator(hipStream_t s, const OscJob* jobs_dev, int njobs, bool any_curve);
 
 // StereoPannerNode.Process with a constant pan (StereoPannerNode.cs:76-153): the gains in force are tracked on the host
 // (they only change when pan changes, :92/:127), the device applies the mono or the stereo law

@@ -101,6 +101,49 @@ def config4_eq(ctx, voices=4096, frames=48000, sr=48000, src_sr=44100):
     return 2
 
 
+def kit_scene(ctx, voices=64, frames=48000, sr=48000, taps=32768):
+    """the graph shapes GraphAudio.Kit builds around the hot path.
+    Voices (Sound: source -> StereoPanner, GraphAudio.Kit Sound's panner) -> two child buses (AudioBus = one GainNode,
+    AudioBus.cs:76-91; one of them fading, AudioBus.Fade) -> master bus -> ReverbEffect (ReverbEffect.cs:63-81: inputSplit ->
+    dry -> outputMerge ; inputSplit -> downmixer (explicit mono) -> convolver -> wet -> outputMerge) -> destination.
+    The convolver sits AFTER the mix: one post-mix, non-sharded instance instead of one per voice."""
+    from graphaudio_amd import ChannelCountMode, StereoPannerNode
+    master = GainNode(ctx)
+    master.Gain.Value = 0.8
+    sfx, music = GainNode(ctx), GainNode(ctx)
+    sfx.Gain.Value = 0.9
+    music.Gain.SetValueAtTime(1.0, 0.0)                 # AudioBus.Fade: a linear ramp on the bus gain
+    music.Gain.LinearRampToValueAtTime(0.3, frames / sr * 0.6)
+    sfx.Connect(master)
+    music.Connect(master)
+    # ReverbEffect
+    split, merge, dry, wet, down = (GainNode(ctx) for _ in range(5))
+    dry.Gain.Value = 0.7
+    wet.Gain.Value = 0.4
+    down.Inputs[0].SetChannelCount(1)
+    down.Inputs[0].SetChannelCountMode(ChannelCountMode.Explicit)
+    conv = ConvolverNode(ctx)
+    conv.Buffer = PlayableAudioBuffer.FromChannelArrays([synth_ir(c, taps) for c in range(2)], sr)
+    master.Connect(split)
+    split.Connect(dry)
+    dry.Connect(merge)
+    split.Connect(down)
+    down.Connect(conv)
+    conv.Connect(wet)
+    wet.Connect(merge)
+    merge.Connect(ctx.Destination)
+    for v in range(voices):
+        s = AudioBufferSourceNode(ctx)
+        s.Buffer = PlayableAudioBuffer.FromMonoArray(voice(v, frames, 0.25 / 8), sr)
+        p = StereoPannerNode(ctx)
+        p.Inputs[0].SetChannelCount(1)
+        p.Pan.Value = -1.0 + 2.0 * v / max(voices - 1, 1)
+        s.Connect(p)
+        p.Connect(sfx if v % 2 == 0 else music)
+        s.Start(0.0 if v % 4 else 0.01)
+    return 2
+
+
 def render(ctx, channels, frames):
     out = np.zeros((channels, frames), dtype=np.float32)
     ctx.Render(out, frames)

@@ -296,3 +296,20 @@ def test_delay_ring_beyond_the_channel_count_stalls_and_resumes():
     ref, got = pair(build, 4, 128 * 20, pieces=[174, 777, 479, 286, 81], chunk=11)
     assert np.count_nonzero(ref[2]) == 128
     assert np.array_equal(ref, got)
+
+
+def test_kit_scene_buses_panners_and_post_mix_reverb():
+    """bus hierarchy + panned voices + a ReverbEffect-shaped dry/wet split behind the mix."""
+    frames = 128 * 120
+    outs = []
+    for mk in (OracleContext, OfflineAudioContext):
+        ctx = mk(SR)
+        if mk is OfflineAudioContext:
+            ctx.SetOption("max_chunk_blocks", 50)
+        ch = G.kit_scene(ctx, voices=24, frames=frames, taps=6000)
+        outs.append(G.render(ctx, ch, frames))
+        ctx.Dispose()
+    ref, got = outs
+    assert G.rms(ref) > 1e-3
+    err = G.rms(ref - got)
+    assert err <= 1e-5 and err <= 2e-6 * G.rms(ref), (err, G.rms(ref))

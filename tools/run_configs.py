@@ -37,6 +37,23 @@ elif which == "5":
         s.Connect(cv).Connect(ctx.Destination)
         s.Start()
     ch = C
+elif which == "kit":   # buses + panners + post-mix reverb
+    ch = G.kit_scene(ctx, voices=int(sys.argv[3]) if len(sys.argv) > 3 else 256, frames=frames + 256, taps=65536)
+elif which == "osc":   # oscillators + panners (8(f) rank 1 nodes at scale)
+    from graphaudio_amd import OscillatorNode, OscillatorType, StereoPannerNode, GainNode
+    n_osc = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
+    for v in range(n_osc):
+        o = OscillatorNode(ctx)
+        o.Type = OscillatorType(v % 4)
+        o.Frequency.Value = 55.0 * 2.0 ** (v / 128.0)
+        p = StereoPannerNode(ctx)
+        p.Inputs[0].SetChannelCount(1)
+        p.Pan.Value = -1.0 + 2.0 * v / max(n_osc - 1, 1)
+        g = GainNode(ctx)
+        g.Gain.Value = 1.0 / 64.0
+        o.Connect(p).Connect(g).Connect(ctx.Destination)
+        o.Start()
+    ch = 2
 else:
     raise SystemExit("unknown config")
 print(f"build {time.time() - t0:.1f} s")
