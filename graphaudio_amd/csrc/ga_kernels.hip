@@ -976,7 +976,9 @@ __global__ __launch_bounds__(256) void tap_spectra_kernel(float2* __restrict hs,
   __syncthreads();
   fft_lds<N2>(buf, tw, tid);
   float2* dst = hs + ((size_t)c * kBins + k) * N2;
-  for (int i = tid; i < N2; i += 256) dst[i] = buf[PADI(i)];
+  // stored with the 1/N2 of the inverse transform folded in (a power of two: exact)
+  const float sc = 1.0f / N2;
+  for (int i = tid; i < N2; i += 256) dst[i] = make_float2(buf[PADI(i)].x * sc, buf[PADI(i)].y * sc);
 }
 void launch_tap_spectra(hipStream_t s, float2* hs, const float* hr, const float* hi, int nch, int P, int N2, const float2* tw) {
   dim3 g(kBins, nch), b(256);
@@ -1130,7 +1132,7 @@ __global__ __launch_bounds__(256) void tconv_kernel(const ConvSetC* __restrict s
       // buffers alternate between consecutive transforms so that a fast thread never overwrites what a slower one still reads
       if (flip) fft_own<N2>(xf, bufB, bufA, tw, tid); else fft_own<N2>(xf, bufA, bufB, tw, tid);
       flip ^= 1;
-      const float scale = 1.0f / N2;
+      const float scale = 1.0f;   // 1/N2 is folded into the taps spectra (tap_spectra_kernel)
       const int nvalid = min(L, nblocks - t0);
       for (int j = 0; j < ncol; j++) {
         const float2* __restrict hs = S->hs[j] + (size_t)k * N2;
@@ -1201,6 +1203,12 @@ __device__ __forceinline__ f2 cmulp_conj(f2 a, f2 b) {   // conj(a b) = (a.x b.x
   f2 t, r;
   asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
   asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+  return r;
+}
+__device__ __forceinline__ f2 cmulp_swap(f2 a, f2 b) {   // swap(a b) = (a.x b.y + a.y b.x, a.x b.x - a.y b.y)
+  f2 t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,0]" : "=v"(t) : "v"(a), "v"(b));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
   return r;
 }
 __device__ __forceinline__ f2 rot_m45(f2 a) {   // a (1 - i) = (a.x + a.y, a.y - a.x)
@@ -1389,7 +1397,6 @@ __global__ __launch_bounds__(256, 3) void tconv16_kernel(const ConvSetC* __restr
   f2* buf = lds + PL::T2 + PL::T3 + g * TC16_PADDED(N2);
   for (int i = tid; i < PL::T2 + PL::T3; i += 256) lds[i] = f2{twg[i].x, twg[i].y};
   const int total = nsets * nseg;
-  const float scale = 1.0f / N2;
   __syncthreads();
   // work unit = (bin, step of G items); the units are dealt to the resident workgroups in contiguous, equal ranges (bin-major:
   // a workgroup stays on one bin, whose taps spectra stay in its L2)
@@ -1452,7 +1459,7 @@ __global__ __launch_bounds__(256, 3) void tconv16_kernel(const ConvSetC* __restr
       if (act) {
         const f2* __restrict hs = reinterpret_cast<const f2*>(S->hs[j] + (size_t)k * N2);
 #pragma unroll
-        for (int m = 0; m < 16; m++) y[m] = cmulp_conj(xf[m], hs[ut + T * m]);   // conj: ifft(v) = conj(fft(conj(v))) / N
+        for (int m = 0; m < 16; m++) y[m] = cmulp_swap(xf[m], hs[ut + T * m]);   // ifft(v) = swap(fft(swap(v))) / N, 1/N inside hs
       } else {
 #pragma unroll
         for (int m = 0; m < 16; m++) y[m] = f2{0.f, 0.f};
@@ -1468,8 +1475,8 @@ __global__ __launch_bounds__(256, 3) void tconv16_kernel(const ConvSetC* __restr
         for (int m = 0; m < 16; m++) {
           const int e = (int)(ut + T * m);
           if (e >= e0 && e < e1) {
-            yr[ut + T * m] = y[m].x * scale;
-            yi[ut + T * m] = -y[m].y * scale;
+            yr[ut + T * m] = y[m].y;   // swapped back
+            yi[ut + T * m] = y[m].x;
           }
         }
       }
