@@ -12,6 +12,7 @@
 // multiply-adds appear only where written explicitly (fma(), MFMA).
 
 #include "ga_kernels.hpp"
+#include <type_traits>
 
 #include <hip/hip_runtime.h>
 
@@ -1770,8 +1771,165 @@ static void launch_biquad_jpw(hipStream_t s, const BiquadJob* jobs_dev, int njob
     default: hipLaunchKernelGGL((biquad_kernel<8, JPW>), g, b, 0, s, jobs_dev, njobs, secs_dev); break;
   }
 }
+// ---- cascades of NSEC >= 2 sections: the sections of one cascade sit on NEIGHBOURING LANES -----------------------------------
+// Lane q of a group runs section q on sample k - q at step k and hands its output to lane q + 1 with one DPP row shift: a
+// software pipeline across lanes.  Per sample the wave issues ONE section's arithmetic (~10 instructions) instead of NSEC
+// sections back to back on a single lane; every section still sees exactly the reference's sample-by-sample float
+// arithmetic (BiQuadFilterNode.cs:137-141), so the result stays bit-exact.  16 / NSEC cascades per 16-lane row.
+template <int NSEC>
+__global__ __launch_bounds__(64) void biquad_pipe_kernel(const BiquadJob* __restrict jobs, int njobs, const BiquadSection* __restrict secs,
+                                                         int jpw) {
+  constexpr int GPR = 16 / NSEC;        // cascades (groups of NSEC lanes) per row
+  constexpr int MAXJ = 4 * GPR;
+  constexpr int PT = 256, TM = PT / 64;   // samples per tile: amortises the tile load / store / barriers and the pipeline fill
+  __shared__ float tile[MAXJ][PT + 1];
+  const int lane = threadIdx.x;
+  const int row = lane >> 4, lr = lane & 15;
+  const int grp = lr / NSEC, q = lr % NSEC;
+  const int slot = row * GPR + grp;                       // cascade slot of this lane inside the wave
+  const int j0 = blockIdx.x * jpw;
+  const int myj = j0 + slot;
+  const bool have = grp < GPR && slot < jpw && myj < njobs;
+  BiquadJob me{};
+  if (have) me = jobs[myj];
+  const float* inb = have ? me.in + me.f0 : nullptr;
+  float* outb = have ? me.out + me.f0 : nullptr;
+  float b0 = 0.f, b1 = 0.f, b2 = 0.f, a1 = 0.f, a2 = 0.f, w1 = 0.f, w2 = 0.f;
+  float* st = nullptr;
+  if (have) {
+    const BiquadSection sc = secs[me.sec0 + q];
+    b0 = sc.b0; b1 = sc.b1; b2 = sc.b2; a1 = sc.a1; a2 = sc.a2;
+    st = sc.state;
+    w1 = sc.state[0];
+    w2 = sc.state[1];
+  }
+  const int64_t n = have ? me.n : 0;
+  int64_t nmax = n;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) nmax = max(nmax, (int64_t)__shfl_xor((long long)nmax, m, 64));
+  const int jcount = min(jpw, njobs - j0);
+  auto lane_of = [](int r) { return (r / GPR) * 16 + (r % GPR) * NSEC; };   // lane of section 0 of slot r
+
+  float pre[MAXJ][TM];   // prefetched tile: pre[r][u] = frame (base + 64 u + lane) of cascade slot r
+  auto fetch = [&](int64_t base) {
+#pragma unroll
+    for (int r = 0; r < MAXJ; r++) {
+#pragma unroll
+      for (int u = 0; u < TM; u++) pre[r][u] = 0.f;
+      if (r < jcount) {
+        const float* p = bcast_ptr(inb, lane_of(r));
+        int64_t nr = __builtin_amdgcn_readlane((int)n, lane_of(r));
+#pragma unroll
+        for (int u = 0; u < TM; u++) {
+          int64_t fi = base + 64 * u + lane;
+          if (fi < nr) pre[r][u] = p[fi];
+        }
+      }
+    }
+  };
+  fetch(0);
+  for (int64_t base = 0; base < nmax; base += PT) {
+#pragma unroll
+    for (int r = 0; r < MAXJ; r++)
+      if (r < jcount) {
+#pragma unroll
+        for (int u = 0; u < TM; u++) tile[r][64 * u + lane] = pre[r][u];
+      }
+    __syncthreads();
+    if (base + PT < nmax) fetch(base + PT);   // next tile's loads fly during the recurrence below
+    const int cnt = (int)max<int64_t>(0, min<int64_t>(PT, n - base));
+    float y = 0.f;
+    const int srow = have ? slot : 0;
+    // one batch of 16 pipeline steps.  PRED = false is the steady state of a full tile: every section has a sample at every
+    // step, so there is nothing to mask; the last section's outputs are collected and written once per batch.
+    auto batch = [&](int k0, auto pred_tag) {
+      constexpr bool PRED = decltype(pred_tag)::value;
+      float xv[16], ov[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) xv[i] = (k0 + i < PT) ? tile[srow][k0 + i] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int k = k0 + i;
+        // the previous lane's output of the previous step (row_shr:1); section 0 takes the input sample
+        const float up = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(y), 0x111, 0xF, 0xF, false));
+        const float x = q == 0 ? xv[i] : up;
+        const float w = x - a1 * w1 - a2 * w2;            // BiQuadFilterNode.cs:137
+        const float yy = b0 * w + b1 * w1 + b2 * w2;      // :138
+        if constexpr (PRED) {
+          const bool active = k - q >= 0 && k - q < cnt;
+          w2 = active ? w1 : w2;
+          w1 = active ? w : w1;
+          y = active ? yy : y;
+        } else {
+          w2 = w1;
+          w1 = w;
+          y = yy;
+        }
+        ov[i] = yy;
+      }
+      if (have && q == NSEC - 1) {   // output of step k is sample k - (NSEC - 1)
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          const int jx = k0 + i - (NSEC - 1);
+          if (jx >= 0 && jx < (PRED ? cnt : PT)) tile[srow][jx] = ov[i];
+        }
+      }
+    };
+    constexpr int NBATCH = (PT + NSEC - 1 + 15) / 16;
+    int cntmin = have ? cnt : PT;   // a full tile for every cascade of the wave?
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) cntmin = min(cntmin, __shfl_xor(cntmin, m, 64));
+    if (cntmin == PT) {
+      batch(0, std::true_type{});                                   // pipeline fill
+#pragma unroll 1
+      for (int bq = 1; bq < NBATCH - 1; bq++) batch(16 * bq, std::false_type{});
+      batch(16 * (NBATCH - 1), std::true_type{});                   // pipeline drain
+    } else {
+#pragma unroll 1
+      for (int bq = 0; bq < NBATCH; bq++) batch(16 * bq, std::true_type{});
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < MAXJ; r++) {
+      if (r < jcount) {
+        float* o = (float*)bcast_ptr(outb, lane_of(r));
+        int64_t nr = __builtin_amdgcn_readlane((int)n, lane_of(r));
+#pragma unroll
+        for (int u = 0; u < TM; u++) {
+          int64_t fi = base + 64 * u + lane;
+          if (fi < nr) o[fi] = tile[r][64 * u + lane];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (have) {
+    st[0] = w1;
+    st[1] = w2;
+  }
+}
+template <int NSEC>
+static void launch_biquad_pipe(hipStream_t s, const BiquadJob* jobs_dev, int njobs, const BiquadSection* secs_dev) {
+  constexpr int MAXJ = 4 * (16 / NSEC);
+  // latency-bound: one wave per SIMD is the most the chip can use; more cascades than that share waves
+  int jpw = std::min(MAXJ, std::max(1, (njobs + 1023) / 1024));
+  if (const char* e = getenv("GA_BQ_JPW")) jpw = std::min(MAXJ, std::max(1, atoi(e)));
+  hipLaunchKernelGGL(biquad_pipe_kernel<NSEC>, dim3((njobs + jpw - 1) / jpw), dim3(64), 0, s, jobs_dev, njobs, secs_dev, jpw);
+}
 void launch_biquad(hipStream_t s, const BiquadJob* jobs_dev, int njobs, const BiquadSection* secs_dev, int nsec) {
   if (njobs <= 0) return;
+  static const bool pipe = !getenv("GA_BQ_NOPIPE");
+  if (pipe && nsec >= 2) {
+    switch (nsec) {
+      case 2: launch_biquad_pipe<2>(s, jobs_dev, njobs, secs_dev); return;
+      case 3: launch_biquad_pipe<3>(s, jobs_dev, njobs, secs_dev); return;
+      case 4: launch_biquad_pipe<4>(s, jobs_dev, njobs, secs_dev); return;
+      case 5: launch_biquad_pipe<5>(s, jobs_dev, njobs, secs_dev); return;
+      case 6: launch_biquad_pipe<6>(s, jobs_dev, njobs, secs_dev); return;
+      case 7: launch_biquad_pipe<7>(s, jobs_dev, njobs, secs_dev); return;
+      default: launch_biquad_pipe<8>(s, jobs_dev, njobs, secs_dev); return;
+    }
+  }
   // measured on MI355X (config 4, 8,192 cascades of 5 sections): ~512 waves on the chip (one per two SIMDs) is the sweet
   // spot -- 4 / 8 / 16 / 32 jobs per wave took 81 / 65 / 47 / 54 ms.  A wave issues one VALU instruction per ~4 cycles
   // however many lanes are busy, so fewer, fuller waves only pay once that many waves exist.
