@@ -744,15 +744,31 @@ __global__ __launch_bounds__(256) void irfft_ola_b_kernel(const ConvRowIO* __res
   const float* __restrict yr = pl.yr + (size_t)row * kBins * pl.ty;
   const float* __restrict yi = pl.yi + (size_t)row * kBins * pl.ty;
   // columns 1..nrun <- blocks ta .. tb-1 (16-byte loads, 8 lanes per 128-byte bin line); column 0 <- block ta - 1
-  for (int idx = tid; idx < kBins * 8; idx += 256) {
-    int k = idx >> 3, q = (idx & 7) * 4;
-    float4 vr = make_float4(0.f, 0.f, 0.f, 0.f), vi = vr;
-    if (ta + q < nblocks) {
-      vr = *reinterpret_cast<const float4*>(yr + (size_t)k * pl.ty + ta + q);
-      vi = *reinterpret_cast<const float4*>(yi + (size_t)k * pl.ty + ta + q);
+  {
+    // all global loads of the tile first (10 x 16 B in flight per thread), then the LDS transposition: one exposed HBM latency
+    // per workgroup instead of one per loop iteration
+    constexpr int NIT = (kBins * 8 + 255) / 256;   // 5
+    float4 vr[NIT], vi[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int idx = tid + 256 * it;
+      const int k = idx >> 3, q = (idx & 7) * 4;
+      vr[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      vi[it] = vr[it];
+      if (idx < kBins * 8 && ta + q < nblocks) {
+        vr[it] = *reinterpret_cast<const float4*>(yr + (size_t)k * pl.ty + ta + q);
+        vi[it] = *reinterpret_cast<const float4*>(yi + (size_t)k * pl.ty + ta + q);
+      }
     }
-    sr[(1 + q) * FB_KP + k] = vr.x; sr[(2 + q) * FB_KP + k] = vr.y; sr[(3 + q) * FB_KP + k] = vr.z; sr[(4 + q) * FB_KP + k] = vr.w;
-    si[(1 + q) * FB_KP + k] = vi.x; si[(2 + q) * FB_KP + k] = vi.y; si[(3 + q) * FB_KP + k] = vi.z; si[(4 + q) * FB_KP + k] = vi.w;
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int idx = tid + 256 * it;
+      const int k = idx >> 3, q = (idx & 7) * 4;
+      if (idx < kBins * 8) {
+        sr[(1 + q) * FB_KP + k] = vr[it].x; sr[(2 + q) * FB_KP + k] = vr[it].y; sr[(3 + q) * FB_KP + k] = vr[it].z; sr[(4 + q) * FB_KP + k] = vr[it].w;
+        si[(1 + q) * FB_KP + k] = vi[it].x; si[(2 + q) * FB_KP + k] = vi[it].y; si[(3 + q) * FB_KP + k] = vi[it].z; si[(4 + q) * FB_KP + k] = vi[it].w;
+      }
+    }
   }
   if (tid < kBins) {
     float vr = 0.f, vi = 0.f;
