@@ -18,6 +18,7 @@ from __future__ import annotations
 import ctypes as C
 import enum
 import math
+import weakref
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -73,7 +74,7 @@ class PlayableAudioBuffer:
                 raise ArgumentException("All channels must have the same length")
         self._channels = chans
         self._sampleRate = int(sampleRate)
-        self._ids = {}  # context -> native buffer id
+        self._ids = {}  # id(context) -> (weakref to the context, native buffer id)
 
     @staticmethod
     def FromChannelArrays(channelData, sampleRate: int) -> "PlayableAudioBuffer":  # :122-145
@@ -101,14 +102,25 @@ class PlayableAudioBuffer:
         return self._channels[channelIndex]
 
     def _native_id(self, ctx: "AudioContextBase") -> int:
-        bid = self._ids.get(id(ctx))
-        if bid is None:
-            ptrs = (C.c_void_p * len(self._channels))(*[c.ctypes.data for c in self._channels])
-            out = C.c_int(-1)
-            ctx._call("buffer_create", ptrs, len(self._channels), self.Length, self._sampleRate, C.byref(out))
-            bid = out.value
-            self._ids[id(ctx)] = bid
-        return bid
+        ent = self._ids.get(id(ctx))
+        if ent is not None and ent[0]() is ctx:
+            return ent[1]
+        ptrs = (C.c_void_p * len(self._channels))(*[c.ctypes.data for c in self._channels])
+        out = C.c_int(-1)
+        ctx._call("buffer_create", ptrs, len(self._channels), self.Length, self._sampleRate, C.byref(out))
+        self._ids[id(ctx)] = (weakref.ref(ctx), out.value)
+        return out.value
+
+    def __del__(self):
+        # the managed object is gone: tell every live context that still holds a device copy (ga_buffer_release); nodes that
+        # still play / convolve with it keep the storage alive natively
+        try:
+            for ref, bid in list(self._ids.values()):
+                ctx = ref()
+                if ctx is not None and getattr(ctx, "_h", None):
+                    ctx._api.buffer_release(ctx._h, bid)
+        except Exception:  # interpreter shutdown
+            pass
 
 
 class AudioParam:
@@ -211,6 +223,7 @@ class AudioNode:
 
     def Dispose(self):  # :207-238
         self.Context._call("node_dispose", self._id)
+        self.Context._forget(self)
 
 
 class AudioDestinationNode(AudioNode):  # Nodes/AudioDestinationNode.cs:9-75
@@ -496,6 +509,14 @@ class AudioContextBase:
         self._call("get_stats", C.byref(st))
         return st.as_dict()
 
+    def _forget(self, node):
+        """A disposed node no longer needs to be reachable from the context (it only is for Ended dispatch); dropping it lets its
+        PlayableAudioBuffer be collected, which releases the device copy."""
+        if self._nodes.get(node._id) is node:
+            del self._nodes[node._id]
+        if hasattr(node, "_buffer"):
+            node._buffer = None
+
     def _raise_ended(self):
         """Raise the Ended event (AudioBufferSourceNode.cs:378-389) of sources that finished during the last render."""
         buf = (C.c_int * 256)()
@@ -509,6 +530,7 @@ class AudioContextBase:
                     self._ended_seen.add(buf[i])
                     for cb in getattr(node, "Ended", []):
                         cb(node)
+                    self._forget(node)   # Ended is followed by Dispose() (AudioBufferSourceNode.cs:386)
             if n < 256:
                 break
 

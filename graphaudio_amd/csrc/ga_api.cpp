@@ -329,7 +329,12 @@ int ga_buffer_create(ga_context* ctx, const float* const* planar, int channels, 
   });
 }
 int ga_buffer_release(ga_context* ctx, int buffer_id) {
-  return guard(ctx, [&](Context& c) { (void)c.buffer(buffer_id); });  // storage lives until the context is destroyed
+  return guard(ctx, [&](Context& c) {   // the host dropped its handle: the storage goes once no node plays / convolves with it
+    PlayBuf* b = c.buffer(buffer_id);
+    if (!b || b->released) return;
+    b->released = true;
+    c.releasedPending.push_back(buffer_id);
+  });
 }
 
 int ga_node_create(ga_context* ctx, int node_type, int* out_id) {  // constructor defaults: 2 outputs / 2 inputs / 1.0 s

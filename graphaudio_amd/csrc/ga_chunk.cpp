@@ -1131,6 +1131,7 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
   GA_HIP(hipSetDevice(device));
   if (disposed) fail(GA_ERR_DISPOSED, "context disposed");
   drain();  // AudioContextBase.cs:57
+  if (!releasedPending.empty() || ++chunksSinceGc >= 64) collectGarbage();
   latched = true;
 
   // ---- reachability, level, convolver depth on the graph as it stands after the queued commands ----

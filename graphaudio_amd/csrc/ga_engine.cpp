@@ -61,13 +61,6 @@ Context::~Context() {
   if (stream) (void)hipStreamSynchronize(stream);
   for (auto& b : buffers)
     if (b && b->dev) (void)hipFree(b->dev);
-  for (auto& kv : irCache) {
-    if (kv.second) {
-      if (kv.second->hr) (void)hipFree(kv.second->hr);
-      if (kv.second->hi) (void)hipFree(kv.second->hi);
-      if (kv.second->hspec) (void)hipFree(kv.second->hspec);
-    }
-  }
   for (auto& g : groups) {
     if (g->histR) (void)hipFree(g->histR);
     if (g->histI) (void)hipFree(g->histI);
@@ -82,7 +75,13 @@ Context::~Context() {
     if (np && np->bHistR) (void)hipFree(np->bHistR);
     if (np && np->bHistI) (void)hipFree(np->bHistI);
     if (np && np->bOverlap) (void)hipFree(np->bOverlap);
+    if (np && np->delayHist) (void)hipFree(np->delayHist);
+    if (np && np->delayLine) (void)hipFree(np->delayLine);
+    if (np && np->oscPhase) (void)hipFree(np->oscPhase);
+    if (np && np->panDev) (void)hipFree(np->panDev);
   }
+  for (auto& kv : tw16) (void)hipFree(kv.second);
+  if (ilvDev) (void)hipFree(ilvDev);
   if (tables.p) (void)hipFree(tables.p);
   if (tablesHost) (void)hipHostFree(tablesHost);
   for (void* p : slabBlocks) (void)hipFree(p);
@@ -132,6 +131,48 @@ PlayBuf* Context::buffer(int id) {
   if (id >= (int)buffers.size() || !buffers[id]) fail(GA_ERR_INVALID_ARGUMENT, "bad buffer id");
   return buffers[id].get();
 }
+// Storage lives as long as something can still play it: PlayableAudioBuffer objects are garbage-collected in the reference, here
+// the host says when it dropped its handle (ga_buffer_release) and nodes keep what they use alive.  Runs between renders.
+void Context::collectGarbage() {
+  chunksSinceGc = 0;
+  if (!releasedPending.empty()) {
+    std::vector<char> used(buffers.size(), 0);
+    for (auto& np : nodes) {
+      if (!np || np->disposed) continue;
+      if (np->bufId >= 0 && np->bufId < (int)used.size()) used[np->bufId] = 1;
+      if (np->irBuf >= 0 && np->irBuf < (int)used.size()) used[np->irBuf] = 1;
+    }
+    std::vector<int> keep;
+    bool synced = false;
+    for (int id : releasedPending) {
+      if (id < 0 || id >= (int)buffers.size() || !buffers[id]) continue;
+      if (used[id]) {
+        keep.push_back(id);
+        continue;
+      }
+      if (!synced && stream) {
+        (void)hipStreamSynchronize(stream);
+        synced = true;
+      }
+      PlayBuf& b = *buffers[id];
+      if (b.dev) dfree(b.dev, (size_t)b.stride * b.channels * sizeof(float));
+      for (auto it = irCache.begin(); it != irCache.end();)   // spectra built from it stay with the convolvers that hold them
+        it = it->first.first == id ? irCache.erase(it) : std::next(it);
+      buffers[id].reset();
+    }
+    releasedPending.swap(keep);
+  }
+  // impulse-response spectra that only the cache still holds (their convolvers are gone or use another buffer)
+  for (auto it = irCache.begin(); it != irCache.end();) {
+    if (it->second.use_count() == 1) {
+      if (stream) (void)hipStreamSynchronize(stream);
+      it = irCache.erase(it);
+    } else {
+      ++it;
+    }
+  }
+}
+
 InputS* Context::inputOf(const InRef& r) {
   NodeS* n = nodes[r.node].get();
   if (r.input >= 0) return &n->inputs[r.input];
@@ -208,6 +249,14 @@ void Context::doDispose(int id) {
   }
   for (int p = 0; p < (int)n.params.size(); p++) inputDisconnectAll(InRef{id, -1 - p});
   // OnDispose
+  if (n.type == GA_NODE_DELAY) {   // the delay lines go with the node
+    if (stream) (void)hipStreamSynchronize(stream);
+    if (n.delayHist) dfree(n.delayHist, (size_t)n.maxDelaySamples * n.delayHistRings * sizeof(float));
+    if (n.delayLine) dfree(n.delayLine, ((size_t)n.maxDelaySamples + (size_t)n.delayCap) * n.delayLineRings * sizeof(float));
+    n.delayHist = n.delayLine = nullptr;
+    n.delayHistRings = n.delayLineRings = 0;
+    n.delayCap = 0;
+  }
   if (n.type == GA_NODE_BUFFER_SOURCE) n.bufId = -1;  // AudioBufferSourceNode.cs:412
   if (n.type == GA_NODE_CONVOLVER) {                   // ConvolverNode.cs:166-175
     n.ir.reset();
@@ -455,6 +504,8 @@ std::shared_ptr<IrSpectra> Context::irSpectra(int bufId, bool normalize) {
   float* xr = (float*)dalloc(planeBytes);
   float* xi = (float*)dalloc(planeBytes);
   size_t hBytes = (size_t)nch * kBins * P * sizeof(float);
+  sp->hBytes = hBytes;
+  sp->devBytesRef = &devBytes;
   sp->hr = (float*)dalloc(hBytes);
   sp->hi = (float*)dalloc(hBytes);
   ConvRowIO* rowsDev = (ConvRowIO*)dalloc(sizeof(ConvRowIO) * nch);
@@ -524,6 +575,7 @@ void Context::ensureTapSpectra(IrSpectra& ir) {
   if (ir.hspec) return;
   ir.N2 = tapFftSize(ir.P);
   size_t bytes = (size_t)ir.nch * kBins * ir.N2 * sizeof(float2);
+  ir.hspecBytes = bytes;
   ir.hspec = (float2*)dalloc(bytes);
   launch_tap_spectra(stream, ir.hspec, ir.hr, ir.hi, ir.nch, ir.P, ir.N2, twiddlesC(ir.N2));
   GA_HIP(hipGetLastError());

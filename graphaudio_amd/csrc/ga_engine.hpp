@@ -87,6 +87,7 @@ struct PlayBuf {
   int sampleRate = 0;
   std::vector<std::vector<float>> host;
   float* dev = nullptr;
+  bool released = false;   // ga_buffer_release: the host no longer holds the buffer; storage goes when no node refers to it
 };
 
 struct IrSpectra {  // P zero-padded 256-point spectra per IR channel (PartitionedConvolver.cs:65-91)
@@ -97,6 +98,17 @@ struct IrSpectra {  // P zero-padded 256-point spectra per IR channel (Partition
   // formulation C: N2-point spectra of the taps along the partition axis, [nch][129][N2]
   int N2 = 0;
   float2* hspec = nullptr;
+  size_t hBytes = 0, hspecBytes = 0;
+  int64_t* devBytesRef = nullptr;   // the owning context's byte counter
+  IrSpectra() = default;
+  IrSpectra(const IrSpectra&) = delete;
+  IrSpectra& operator=(const IrSpectra&) = delete;
+  ~IrSpectra() {   // shared by the convolver nodes that use it and the context's cache; the last owner frees the device memory
+    if (hr) (void)hipFree(hr);
+    if (hi) (void)hipFree(hi);
+    if (hspec) (void)hipFree(hspec);
+    if (devBytesRef) *devBytesRef -= (int64_t)(2 * hBytes + hspecBytes);
+  }
 };
 
 struct ConvGroup;   // rows sharing one IR channel's spectra
@@ -325,6 +337,9 @@ struct Context {
   NodeS* node(int id);
   ParamS* param(int node, int p);
   PlayBuf* buffer(int id);
+  std::vector<int> releasedPending;   // released buffers whose storage is still held
+  int64_t chunksSinceGc = 0;
+  void collectGarbage();              // frees released, unreferenced buffers and impulse-response spectra nobody uses
   InputS* inputOf(const InRef& r);
 
   // graph edits (Nodes/AudioNode.cs:109-150,207-238; AudioNodeOutput.cs:42-70; AudioNodeInput.cs:60-83)
