@@ -627,7 +627,8 @@ struct Sim {
       case GA_NODE_BIQUAD: {  // BiQuadFilterNode.cs:87-147
         n_.outputs[0].bufCh = ns.ins[0].bufCh;
         n_.outputs[0].silent = ns.ins[0].silent;
-        ns.bqDynamic = !n_.params[0].events.empty() || !n_.params[1].events.empty() || !n_.params[2].events.empty();
+        ns.bqDynamic = !n_.params[0].events.empty() || !n_.params[1].events.empty() || !n_.params[2].events.empty() ||
+                       !ns.pins[0].silent || !ns.pins[1].silent || !ns.pins[2].silent;   // a modulated parameter moves per sample
         if (!ns.ins[0].silent && ns.bqDynamic) {
           ns.bqActive = true;   // coefficients are refreshed per sample on the device
         } else if (!ns.ins[0].silent) {
@@ -707,7 +708,7 @@ struct Sim {
         n_.outputs[0].bufCh = 2;
         n_.outputs[0].silent = ns.ins[0].silent;
         ns.panMode = ns.ins[0].bufCh == 1 ? 1 : 2;
-        if (!ns.ins[0].silent && !n_.params[0].events.empty()) {
+        if (!ns.ins[0].silent && (!n_.params[0].events.empty() || !ns.pins[0].silent)) {
           ns.panDyn = true;   // gains follow the a-rate curve on the device (stereo_panner_dynamic_kernel)
         } else if (!ns.ins[0].silent) {
           float pan = std::min(std::max(n_.params[0].value, -1.0f), 1.0f);
@@ -756,7 +757,7 @@ struct Sim {
         // The output buffer's non-silent flag is set by the first non-zero output SAMPLE and never cleared (:72,:92,:96-97).
         // Data is not visible to the control plane: samples that came from a non-silent input block are taken to be non-zero.
         int dmin = 1, dmax = maxD;
-        if (n_.params[0].events.empty()) {
+        if (n_.params[0].events.empty() && ns.pins[0].silent) {
           int d = (int)(n_.params[0].value * (float)c.sampleRate);
           d = std::min(std::max(d, 0), maxD);
           dmin = dmax = d;
@@ -837,6 +838,7 @@ struct Exec {
   std::vector<PanJob> panJobs;
   std::vector<DelayJob> delayJobs;
   std::vector<PanDynJob> panDynJobs;
+  std::vector<ParamModJob> pmodJobs;
   std::vector<ResampleBlock> traj;  // per-chunk trajectory table (all rates + custom tail blocks)
   bool mixAligned = true;
   // conv inputs: node -> slot -> per segment view
@@ -928,6 +930,29 @@ struct Exec {
     return views;
   }
 
+  // the per-frame values of parameter p of node `ns` in segment si: the timeline curve, or -- when a non-silent signal is
+  // connected to the parameter -- clamp(intrinsic + modulation) (AudioParam.cs:123-135,148-160); null = the constant Value
+  const float* paramView(int si, const NodeSeg& ns, int p) {
+    NodeS& nd = *c.nodes[ns.id];
+    ParamS& ps = nd.params[p];
+    if (p >= (int)ns.pins.size() || ns.pins[p].silent) return ps.curve;
+    const Segment& sg = segs[si];
+    auto mv = resolveInSeg(si, ns.id, -1 - p, ns.pins[p], false, nullptr);
+    if (mv.empty() || !mv[0]) return ps.curve;
+    ParamModJob pj;
+    pj.intrinsic = ps.curve;
+    pj.mod = mv[0];
+    pj.out = slabFor(inSlab, ((uint64_t)ns.id << 16) | ((uint64_t)(200 + p) << 8));
+    pj.value = ps.value;
+    pj.vmin = ps.minv;
+    pj.vmax = ps.maxv;
+    pj.krate = ps.arate ? 0 : 1;
+    pj.f0 = sg.b0 * kBlock;
+    pj.n = (sg.b1 - sg.b0) * kBlock;
+    pmodJobs.push_back(pj);
+    return pj.out;
+  }
+
   void flushLevel() {
     // order: down-mix -> mix -> sources -> gain -> biquad (everything in one level is independent)
     size_t termsOff = plan.putv(terms);
@@ -951,6 +976,14 @@ struct Exec {
       plan.add(LK_OTHER, [=](uint8_t* base) {
         launch_mix(st, (const MixJob*)(base + off), nj, (const float* const*)(base + termsOff), mx, v4);
       });
+    }
+    if (!pmodJobs.empty()) {   // after the mixes (the modulation inputs), before the nodes that read the parameter
+      size_t off = plan.putv(pmodJobs);
+      int nj = (int)pmodJobs.size();
+      int64_t mx = 0;
+      for (auto& j : pmodJobs) mx = std::max(mx, j.n);
+      hipStream_t st = c.stream;
+      plan.add(LK_OTHER, [=](uint8_t* base) { launch_param_mod(st, (const ParamModJob*)(base + off), nj, mx); });
     }
     if (!loopJobs.empty()) {
       size_t off = plan.putv(loopJobs);
@@ -1063,6 +1096,7 @@ struct Exec {
     panJobs.clear();
     delayJobs.clear();
     panDynJobs.clear();
+    pmodJobs.clear();
     mixAligned = true;
   }
   struct RsLaunch {
@@ -1153,8 +1187,8 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
       int lvl = 0, dep = 0;
       for (auto& p : nd.params)
         if (!p.modulation.empty()) {
-          if (nd.type != GA_NODE_GAIN)
-            fail(GA_ERR_UNSUPPORTED, "audio-rate AudioParam modulation is only on the device path for GainNode.gain");
+          if (nd.type == GA_NODE_BUFFER_SOURCE)   // a modulated playbackRate makes the resampler's consumption depend on audio data
+            fail(GA_ERR_UNSUPPORTED, "audio-rate modulation of AudioBufferSourceNode.playbackRate is not on the device path");
           for (auto& m : p.modulation) {
             dfs(m.first);
             NodeS& up = *nodes[m.first];
@@ -1514,7 +1548,7 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
           case GA_NODE_CONSTANT_SOURCE: {
             if (ns.srcPhase != SRC_PLAY) break;
             ConstJob cj;
-            cj.curve = nd.params[0].curve;
+            cj.curve = ex.paramView((int)si, ns, 0);
             cj.out = ex.nodeOut(ns.id, 0);
             cj.value = nd.params[0].value;
             cj.pad_ = 0;
@@ -1529,7 +1563,7 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
           case GA_NODE_OSCILLATOR: {
             if (ns.srcPhase != SRC_PLAY) break;
             OscJob oj;
-            oj.curve = nd.params[0].curve;
+            oj.curve = ex.paramView((int)si, ns, 0);
             oj.out = ex.nodeOut(ns.id, 0);
             oj.phase = nd.oscPhase;
             oj.value = nd.params[0].value;
@@ -1563,6 +1597,7 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
             // move, DelayNode.cs:62-94), then gather
             std::vector<const float*> iv;
             if (!ns.ins[0].silent) iv = ex.resolveInput((int)si, ns, 0, false, nullptr);
+            const float* delayCurve = ex.paramView((int)si, ns, 0);
             for (int cch = 0; cch < ch; cch++) {
               float* base = nd.delayLine + (size_t)cch * pitch + maxD + nd.delayW[cch] - f0;   // base[f] = input sample of frame f
               MixJob mj;
@@ -1580,7 +1615,7 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
               ex.mixJobs.push_back(mj);
               DelayJob dj;
               dj.line = base;
-              dj.curve = nd.params[0].curve;
+              dj.curve = delayCurve;
               dj.out = ex.nodeOut(ns.id, cch);
               dj.value = nd.params[0].value;
               dj.sample_rate = sampleRate;
@@ -1604,7 +1639,7 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
               dj.in_r = ns.panMode == 2 ? (iv[1] ? iv[1] : zeros) : nullptr;
               dj.out_l = ex.nodeOut(ns.id, 0);
               dj.out_r = ex.nodeOut(ns.id, 1);
-              dj.curve = nd.params[0].curve;
+              dj.curve = ex.paramView((int)si, ns, 0);
               dj.state = nd.panDev;
               dj.init_state = PanState{nd.panLast, nd.panGL, nd.panGR, 0.f};
               dj.init = nd.panOnDevice ? 0 : 1;   // the host-tracked state is handed over once
@@ -1751,9 +1786,9 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
                 dj.out[ch] = ex.nodeOut(ns.id, ch);
                 ov[ch] = dj.out[ch];
               }
-              dj.fcurve = nd.params[0].curve;
-              dj.qcurve = nd.params[1].curve;
-              dj.gcurve = nd.params[2].curve;
+              dj.fcurve = ex.paramView((int)si, ns, 0);
+              dj.qcurve = ex.paramView((int)si, ns, 1);
+              dj.gcurve = ex.paramView((int)si, ns, 2);
               dj.fval = nd.params[0].value;
               dj.qval = nd.params[1].value;
               dj.gval = nd.params[2].value;

@@ -2469,4 +2469,20 @@ void launch_interleave(hipStream_t s, float* dst, InterleaveSrc src, int channel
   hipLaunchKernelGGL(interleave_kernel, dim3(gx), dim3(256), 0, s, dst, src, channels, used, f0, n);
 }
 
+
+__global__ __launch_bounds__(256) void param_mod_kernel(const ParamModJob* __restrict jobs) {
+  const ParamModJob job = jobs[blockIdx.y];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < job.n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t f = job.f0 + i;
+    const int64_t fs = job.krate ? f - (f % kBlock) : f;   // k-rate: `_input.Buffer.GetChannelSpan(0)[0]` and the block-start value
+    const float intr = job.intrinsic ? job.intrinsic[fs] : job.value;
+    job.out[f] = fminf(fmaxf(intr + job.mod[fs], job.vmin), job.vmax);   // Math.Clamp(intrinsicValue + modulation, min, max)
+  }
+}
+void launch_param_mod(hipStream_t s, const ParamModJob* jobs_dev, int njobs, int64_t max_n) {
+  if (njobs <= 0 || max_n <= 0) return;
+  int gx = (int)std::min<int64_t>((max_n + 255) / 256, 1024);
+  hipLaunchKernelGGL(param_mod_kernel, dim3(gx, njobs), dim3(256), 0, s, jobs_dev);
+}
+
 }  // namespace ga

@@ -382,6 +382,18 @@ struct DelayJob {
 };
 void launch_delay(hipStream_t s, const DelayJob* jobs_dev, int njobs, int64_t max_n);
 
+// AudioParam.ComputeARate / ComputeKRate with a non-silent modulation input (AudioParam.cs:123-135,148-160):
+//   a-rate: out[f] = clamp(intrinsic[f] + mod[f], min, max) ; k-rate: the block's first sample of both, repeated over the block
+struct ParamModJob {
+  const float* intrinsic;   // timeline curve (chunk-frame indexed) or null -> `value`
+  const float* mod;         // channel 0 of the mixed modulation input
+  float* out;
+  float value, vmin, vmax;
+  int krate;
+  int64_t f0, n;
+};
+void launch_param_mod(hipStream_t s, const ParamModJob* jobs_dev, int njobs, int64_t max_n);
+
 // ProcessBlockInterleaved (AudioContextBase.cs:125-155): dst[(f0 + i) * channels + ch] = ch < used ? src[ch][f0 + i] : 0
 struct InterleaveSrc {
   const float* ch[32];

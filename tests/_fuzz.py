@@ -279,12 +279,19 @@ def run_random_session(ctx, seed, frames=128 * 48, max_piece=128 * 9, keep=None)
                     c.Buffer = PlayableAudioBuffer.FromChannelArrays(
                         [(rng.standard_normal(taps) * 0.1).astype(np.float32) for _ in range(int(rng.choice([1, 2])))], SR)
         elif kind == "modulate":
-            g = pick(gains)
-            if g:
+            # an audio-rate signal into a parameter: GainNode.gain, or a parameter of a panner / delay / biquad / scheduled source
+            cands = [(g, g.Gain, 0.3) for g in gains if id(g) not in dead]
+            cands += [(n, n.Pan, 0.5) for n in h.get("StereoPannerNode", []) if id(n) not in dead]
+            cands += [(n, n.DelayTime, 0.003) for n in h.get("DelayNode", []) if id(n) not in dead]
+            cands += [(n, n.Frequency, 300.0) for n in biquads if id(n) not in dead]
+            cands += [(n, n.Frequency if isinstance(n, OscillatorNode) else n.Offset, 50.0 if isinstance(n, OscillatorNode) else 0.2)
+                      for n in h.get("scheduled", []) if id(n) not in dead]
+            if cands:
+                _, prm, depth = cands[int(rng.integers(0, len(cands)))]
                 lfo = AudioBufferSourceNode(ctx)
-                lfo.Buffer = PlayableAudioBuffer.FromMonoArray((rng.standard_normal(700) * 0.3).astype(np.float32), SR)
+                lfo.Buffer = PlayableAudioBuffer.FromMonoArray((rng.standard_normal(700) * depth).astype(np.float32), SR)
                 lfo.Loop = True
-                lfo.Connect(g.Gain)
+                lfo.Connect(prm)
                 lfo.Start(now)
                 sources.append(lfo)
         elif kind == "dest_ch":

@@ -313,3 +313,69 @@ def test_kit_scene_buses_panners_and_post_mix_reverb():
     assert G.rms(ref) > 1e-3
     err = G.rms(ref - got)
     assert err <= 1e-5 and err <= 2e-6 * G.rms(ref), (err, G.rms(ref))
+
+
+def test_audio_rate_modulation_of_oscillator_panner_delay_biquad_and_offset():
+    """AudioParam._input (AudioParam.cs:97-101,123-135,148-160): a ConstantSourceNode / an LFO buffer drives the parameters of
+    the new nodes and of a biquad; values are clamp(intrinsic + modulation) while the modulator is non-silent."""
+    from graphaudio_amd import DelayNode
+
+    def build(ctx):
+        rng = np.random.default_rng(31)
+        lfo = AudioBufferSourceNode(ctx)                       # slow bipolar LFO, audio rate
+        lfo.Buffer = PlayableAudioBuffer.FromMonoArray((0.4 * np.sin(2 * np.pi * np.arange(4800) / 1200.0)).astype(np.float32), SR)
+        lfo.Loop = True
+        cs = ConstantSourceNode(ctx)                           # a ramping control signal, starts late and stops early
+        cs.Offset.SetValueAtTime(0.0, 0.0)
+        cs.Offset.LinearRampToValueAtTime(300.0, 0.05)
+        # FM: oscillator frequency = 440 + cs (0..300 Hz); clamped to [0, sr/2]
+        osc = OscillatorNode(ctx)
+        osc.Frequency.Value = 440.0
+        cs.Connect(osc.Frequency)
+        g = GainNode(ctx)
+        g.Gain.Value = 0.2
+        # auto-pan: pan = 0.1 + lfo
+        pan = StereoPannerNode(ctx)
+        pan.Pan.Value = 0.1
+        lfo.Connect(pan.Pan)
+        osc.Connect(g)
+        g.Connect(pan)
+        pan.Connect(ctx.Destination)
+        # vibrato: delayTime = 0.004 + 0.005 * lfo ; wah: biquad frequency = 1200 + 2000 * lfo
+        voice = AudioBufferSourceNode(ctx)
+        voice.Buffer = PlayableAudioBuffer.FromMonoArray((rng.standard_normal(128 * 70) * 0.2).astype(np.float32), SR)
+        lg1, lg2 = GainNode(ctx), GainNode(ctx)
+        lg1.Gain.Value = 0.005
+        lg2.Gain.Value = 2000.0
+        lfo.Connect(lg1)
+        lfo.Connect(lg2)
+        d = DelayNode(ctx, 0.02)
+        d.DelayTime.Value = 0.004
+        lg1.Connect(d.DelayTime)
+        bq = BiQuadFilterNode(ctx)
+        bq.Frequency.Value = 1200.0
+        bq.Q.Value = 2.0
+        lg2.Connect(bq.Frequency)
+        voice.Connect(d)
+        d.Connect(bq)
+        bq.Connect(ctx.Destination)
+        # a constant source whose offset is itself modulated
+        cs2 = ConstantSourceNode(ctx)
+        cs2.Offset.Value = 0.05
+        lfo.Connect(cs2.Offset)
+        cs2.Connect(ctx.Destination)
+        lfo.Start(0.0)
+        cs.Start(0.005)
+        cs.Stop(0.1)
+        osc.Start(0.0)
+        voice.Start(0.0)
+        cs2.Start(0.01)
+        return (lfo, cs, osc, g, pan, voice, lg1, lg2, d, bq, cs2)
+    ref, got = pair(build, 2, 128 * 64, pieces=[3000, 128 * 20], chunk=13)
+    assert G.rms(ref) > 1e-2
+    err = G.rms(ref - got)
+    # the curves are exact (float add + clamp); what differs is device sinf/cosf (pan gains, biquad coefficients), the
+    # oscillator's sin(double), and -- at isolated samples -- a delay read one sample off where (int)(delayTime * sr) sits on an
+    # integer boundary
+    assert err <= 5e-4 * G.rms(ref), (err, G.rms(ref))
+    assert np.mean(np.abs(ref - got) > 1e-4) < 5e-3
