@@ -65,6 +65,65 @@ def case_scheduling(ctx):
     return 1
 
 
+def case_source_replay(ctx):
+    """Looping + resampling, a k-rate playbackRate ramp, a start offset beyond the loop end (general source replay)."""
+    ctx.Destination.SetChannelCount(1)
+    ctx.Destination.Inputs[0].SetChannelCount(1)
+    a = AudioBufferSourceNode(ctx)
+    a.Buffer = PlayableAudioBuffer.FromMonoArray(G.voice(300, 2000), 44100)
+    a.Loop = True
+    a.LoopStart = 300 / 44100
+    a.LoopEnd = 1500 / 44100
+    a.PlaybackRate.SetValueAtTime(0.8, 0.0)
+    a.PlaybackRate.LinearRampToValueAtTime(1.6, 0.04)
+    a.Connect(ctx.Destination)
+    a.Start(0.0)
+    b = AudioBufferSourceNode(ctx)
+    b.Buffer = PlayableAudioBuffer.FromMonoArray(G.voice(301, 900), SR)
+    b.Loop = True
+    b.LoopStart = 100 / SR
+    b.LoopEnd = 400 / SR
+    b.Connect(ctx.Destination)
+    b.Start(0.005, 600 / SR)      # offset beyond the loop end
+    return 1
+
+
+def case_core_nodes(ctx):
+    """The remaining pure-Core nodes: oscillator -> panner, constant source on a gain, splitter / merger swap, delay."""
+    from graphaudio_amd import (ChannelMergerNode, ChannelSplitterNode, ConstantSourceNode, DelayNode, OscillatorNode,
+                                OscillatorType, StereoPannerNode)
+    o = OscillatorNode(ctx)
+    o.Type = OscillatorType.Sawtooth
+    o.Frequency.Value = 311.0
+    p = StereoPannerNode(ctx)
+    p.Inputs[0].SetChannelCount(1)
+    p.Pan.Value = -0.35
+    g = GainNode(ctx)
+    g.Gain.Value = 0.0
+    cs = ConstantSourceNode(ctx)
+    cs.Offset.SetValueAtTime(0.0, 0.0)
+    cs.Offset.LinearRampToValueAtTime(0.3, 0.03)
+    cs.Connect(g.Gain)                       # fade-in driven by the constant source
+    o.Connect(p).Connect(g).Connect(ctx.Destination)
+    s = AudioBufferSourceNode(ctx)
+    s.Buffer = PlayableAudioBuffer.FromStereoArrays(G.voice(310, 128 * 30), G.voice(311, 128 * 30), SR)
+    sp = ChannelSplitterNode(ctx, 2)
+    mg = ChannelMergerNode(ctx, 2)
+    d = DelayNode(ctx, 0.05)
+    d.Inputs[0].SetChannelCount(1)
+    d.DelayTime.Value = 0.0123
+    s.Connect(sp)
+    sp.Connect(mg, 0, 1)                     # L -> right channel, dry
+    sp.Connect(d, 1, 0)
+    d.Connect(mg, 0, 0)                      # R -> delay -> left channel
+    mg.Connect(ctx.Destination)
+    o.Start(0.002)
+    o.Stop(0.07)
+    cs.Start(0.0)
+    s.Start(0.0)
+    return 2
+
+
 CASES = {
     "plumbing": (case_plumbing, 128 * 8),
     "biquad": (case_biquad, 128 * 16),
@@ -72,4 +131,6 @@ CASES = {
     "eq_resample": (case_eq_resample, 128 * 20),
     "true_stereo": (case_true_stereo, 128 * 24),
     "scheduling": (case_scheduling, 128 * 30),
+    "source_replay": (case_source_replay, 128 * 24),
+    "core_nodes": (case_core_nodes, 128 * 32),
 }

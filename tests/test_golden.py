@@ -30,7 +30,7 @@ def test_oracle_reproduces_golden(golden, name):
     assert np.array_equal(out, golden[name])
 
 
-EXACT = {"plumbing", "biquad", "scheduling"}
+EXACT = {"plumbing", "biquad", "scheduling", "source_replay"}
 
 
 @pytest.mark.gpu
