@@ -725,6 +725,7 @@ int ga_convolver_set_buffer(ga_context* ctx, int node, int buffer_id) {
       cp->releaseConvState(nd);
       nd.irBuf = buffer_id;
       nd.ir = sp;
+      cp->graphVersion++;
       int channels = sp->nch;
       nd.isTrueStereo = (channels == 4 && nd.enableTrueStereo);
       nd.effectiveOutCh = nd.isTrueStereo ? 2 : channels;

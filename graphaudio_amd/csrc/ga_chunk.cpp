@@ -844,7 +844,10 @@ struct Exec {
   // conv inputs: node -> slot -> per segment view
   std::unordered_map<int, std::vector<std::vector<const float*>>> convIn;
 
-  Exec(Context& c_, int64_t n_, std::vector<Segment>& s) : c(c_), n(n_), frames(n_ * kBlock), segs(s) {}
+  Exec(Context& c_, int64_t n_, std::vector<Segment>& s) : c(c_), n(n_), frames(n_ * kBlock), segs(s) {
+    nodeSlab.reserve(c.nodes.size() * 2 + 64);
+    inSlab.reserve(c.nodes.size() + 64);
+  }
 
   float* slabFor(std::unordered_map<uint64_t, float*>& m, uint64_t key) {
     auto it = m.find(key);
@@ -1169,13 +1172,17 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
   latched = true;
 
   // ---- reachability, level, convolver depth on the graph as it stands after the queued commands ----
+  // (cached while no connection, disposal or impulse response changed since the last chunk)
+  std::vector<int> topo;
+  if (topoVersion == graphVersion && !topoCache.empty()) {
+    topo = topoCache;
+  } else {
   for (auto& np : nodes) {
     np->reachable = false;
     np->isProcessing = false;
     np->level = 0;
     np->depth = 0;
   }
-  std::vector<int> topo;
   {
     std::vector<int> color(nodes.size(), 0);
     std::function<void(int)> dfs = [&](int id) {
@@ -1210,6 +1217,9 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
     };
     dfs(0);
   }
+  topoCache = topo;
+  topoVersion = graphVersion;
+  }
   int maxDepth = 0, maxLevel = 0;
   for (int id : topo) {
     maxDepth = std::max(maxDepth, nodes[id]->depth);
@@ -1238,6 +1248,7 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
     }
   }
 
+  const double tmTopo = nowMs();
   // ---- block clock (accumulated, AudioContextBase.cs:78-79) ----
   std::vector<double> bt(n + 1);
   bt[0] = currentTime;
@@ -1267,6 +1278,7 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
   for (size_t i = 0; i < srcIds.size(); i++)
     if (srcPlans[i].gone && srcPlans[i].goneAt < n) goneAt[srcPlans[i].goneAt].push_back(srcIds[i]);
 
+  const double tmSrc = nowMs();
   // ---- simulate ----
   std::vector<Segment> segs;
   Sim sim{*this, n};
@@ -1295,6 +1307,7 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
         sim.evalNode(0);
       } catch (...) {
         inRender = false;
+        topoVersion = 0;   // nodes may be left marked as processing: rebuild (and reset) everything next time
         throw;
       }
       inRender = false;
@@ -1384,6 +1397,7 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
     while ((int)busSlabs.size() < mx) busSlabs.push_back((float*)dalloc((size_t)busCapFrames * 4));
   }
 
+  const double tmRes = nowMs();
   Exec ex(*this, n, segs);
   ex.outViews.resize(segs.size());
   ex.plan.host.resize(16);  // reserved header
@@ -1486,6 +1500,7 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
     bn.bqState = (float*)((char*)bn.bqDyn + 24);
     bqUsed += per;
   };
+  const double tmPre = nowMs();
   // ---- stages: convolver depth d ; inside a stage every segment is executed level by level ----
   for (int d = 0; d <= maxDepth; d++) {
     for (size_t si = 0; si < segs.size(); si++) {
@@ -1499,25 +1514,45 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
       std::stable_sort(todo.begin(), todo.end(), [&](const NodeSeg* a, const NodeSeg* b2) { return nodes[a->id]->level < nodes[b2->id]->level; });
       // biquad cascade fusion: A is absorbed by B when B's only input term is A, A's only consumer is B and both run
       // (non-silent) with the same channel count; chains are capped at kMaxBiquadSections
-      std::unordered_map<int, const NodeSeg*> segNode;
-      std::unordered_map<int, int> absorbedBy, chainLen;
-      for (const NodeSeg* nsp : todo) segNode[nsp->id] = nsp;
+      // (dense tables indexed by node id, validated by a per-(stage, segment) stamp: no hashing on the per-node path)
+      if (fuseStamp.size() < nodes.size()) {
+        fuseStamp.assign(nodes.size(), 0);
+        fuseSeg.assign(nodes.size(), nullptr);
+        fuseAbs.assign(nodes.size(), -1);
+        fuseLen.assign(nodes.size(), 0);
+      }
+      const uint32_t stamp = ++fuseEpoch;
+      struct DenseSeg {
+        std::vector<uint32_t>& st; std::vector<const NodeSeg*>& v; uint32_t e;
+        const NodeSeg* find(int id) const { return st[id] == e ? v[id] : nullptr; }
+      } segNode{fuseStamp, fuseSeg, stamp};
+      struct DenseInt {
+        std::vector<uint32_t>& st; std::vector<int>& v; uint32_t e; int def;
+        int get(int id) const { return st[id] == e ? v[id] : def; }
+      };
+      for (const NodeSeg* nsp : todo) {
+        fuseStamp[nsp->id] = stamp;
+        fuseSeg[nsp->id] = nsp;
+        fuseAbs[nsp->id] = -1;
+        fuseLen[nsp->id] = 0;
+      }
+      DenseInt absorbedBy{fuseStamp, fuseAbs, stamp, -1}, chainLen{fuseStamp, fuseLen, stamp, 0};
       for (const NodeSeg* nsp : todo) {
         const NodeSeg& b_ = *nsp;
         if (nodes[b_.id]->type != GA_NODE_BIQUAD || !b_.bqActive || b_.bqDynamic) continue;
-        chainLen[b_.id] = 1;
+        fuseLen[b_.id] = 1;
         if (b_.ins[0].terms.size() != 1) continue;
         const TermS& t = b_.ins[0].terms[0];
-        auto ia = segNode.find(t.node);
-        if (ia == segNode.end()) continue;
-        const NodeSeg& a_ = *ia->second;
+        const NodeSeg* ia = segNode.find(t.node);
+        if (!ia) continue;
+        const NodeSeg& a_ = *ia;
         NodeS& an = *nodes[a_.id];
         if (an.type != GA_NODE_BIQUAD || !a_.bqActive || a_.bqDynamic || t.ch != b_.ins[0].bufCh || a_.outCh != b_.outCh) continue;
         if (an.outputs[0].connectedInputs.size() != 1) continue;
-        int la_ = chainLen.count(a_.id) ? chainLen[a_.id] : 1;
+        int la_ = chainLen.get(a_.id) ? chainLen.get(a_.id) : 1;
         if (la_ >= kMaxBiquadSections) continue;
-        absorbedBy[a_.id] = b_.id;
-        chainLen[b_.id] = la_ + 1;
+        fuseAbs[a_.id] = b_.id;
+        fuseLen[b_.id] = la_ + 1;
       }
       int curLevel = -1;
       for (const NodeSeg* nsp : todo) {
@@ -1810,16 +1845,15 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
               ex.bqDynJobs.push_back(dj);
               break;
             }
-            if (absorbedBy.count(ns.id)) break;  // evaluated inside the cascade job of a downstream biquad
+            if (absorbedBy.get(ns.id) >= 0) break;  // evaluated inside the cascade job of a downstream biquad
             // chain head ... this node: biquads connected output -> single input with equal channel counts
             std::vector<const NodeSeg*> chain{&ns};
             while (true) {
               const NodeSeg* h = chain.front();
               if (h->ins[0].terms.size() != 1) break;
               int up = h->ins[0].terms[0].node;
-              auto ab = absorbedBy.find(up);
-              if (ab == absorbedBy.end() || ab->second != h->id) break;
-              chain.insert(chain.begin(), segNode[up]);
+              if (absorbedBy.get(up) != h->id) break;
+              chain.insert(chain.begin(), segNode.find(up));
             }
             auto iv = ex.resolveInput((int)si, *chain.front(), 0, false, nullptr);
             for (const NodeSeg* cn : chain) {
@@ -2244,6 +2278,9 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
   GA_HIP(hipGetLastError());
   tmLaunch = nowMs();
   GA_HIP(hipStreamSynchronize(stream));
+  if (timing)
+    fprintf(stderr, "[ga]   host detail: topo %.2f, sources %.2f, sim %.2f | resources %.2f, params %.2f, exec %.2f ms\n", tmTopo - tm0,
+            tmSrc - tmTopo, tmSim - tmSrc, tmRes - tmSim, tmPre - tmRes, tmPlan - tmPre);
   if (timing)
     fprintf(stderr, "[ga] chunk %lld blocks: sim %.2f ms, plan %.2f ms, enqueue %.2f ms, wait %.2f ms\n", (long long)n, tmSim - tm0,
             tmPlan - tmSim, tmLaunch - tmPlan, nowMs() - tmLaunch);

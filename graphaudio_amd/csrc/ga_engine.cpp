@@ -182,6 +182,7 @@ InputS* Context::inputOf(const InRef& r) {
 // ---- connections: AudioNodeOutput.ConnectTo / DisconnectFrom / DisconnectAll (AudioNodeOutput.cs:42-70) and
 //      AudioNodeInput.AddConnection / RemoveConnection / DisconnectAll (AudioNodeInput.cs:60-83) ----
 void Context::connectTo(int src, int out, InRef in) {
+  graphVersion++;
   if (in.node == src) fail(GA_ERR_INVALID_OPERATION, "Cannot connect a node to itself");
   OutputS& o = nodes[src]->outputs[out];
   if (std::find(o.connectedInputs.begin(), o.connectedInputs.end(), in) != o.connectedInputs.end()) return;
@@ -214,6 +215,7 @@ static void removeFromInput(Context& c, int src, int out, InRef in) {
   }
 }
 void Context::disconnectFrom(int src, int out, InRef in) {
+  graphVersion++;
   OutputS& o = nodes[src]->outputs[out];
   auto it = std::find(o.connectedInputs.begin(), o.connectedInputs.end(), in);
   if (it != o.connectedInputs.end()) {
@@ -239,6 +241,7 @@ void Context::inputDisconnectAll(InRef in) {
 }
 // DoDispose, Nodes/AudioNode.cs:212-235
 void Context::doDispose(int id) {
+  graphVersion++;
   NodeS& n = *nodes[id];
   if (n.disposed) return;
   n.disposed = true;
@@ -267,6 +270,7 @@ void Context::doDispose(int id) {
 
 // a node loses its PartitionedConvolver instances (Buffer reassigned / disposed): rows and private state are released
 void Context::releaseConvState(NodeS& n) {
+  graphVersion++;   // the node's impulse response (hence its convolver depth contribution) changes
   for (auto& r : n.convRows)
     if (r.group) r.group->rows[r.idx] = {-1, 0};
   n.convRows.clear();

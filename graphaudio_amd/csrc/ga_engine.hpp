@@ -374,6 +374,14 @@ struct Context {
   size_t ilvBytes = 0;
   void processBlocks(float* const* outPlanar, float* outInterleaved, int channels, int64_t blockCount, bool deviceOut);
   int64_t chunkLimit(int64_t nblk);
+  // per-chunk scratch of the biquad fusion pre-pass (dense, stamp-validated)
+  std::vector<uint32_t> fuseStamp;
+  std::vector<const NodeSeg*> fuseSeg;
+  std::vector<int> fuseAbs, fuseLen;
+  uint32_t fuseEpoch = 0;
+  uint64_t graphVersion = 1, topoVersion = 0;   // connections / disposals / IR changes bump graphVersion
+  std::vector<int> topoCache;
+  int topoMaxDepth = 0, topoMaxLevel = 0;
   std::deque<int> endedQueue;  // sources whose Ended was raised and not yet reported through ga_poll_ended
   uint64_t lastHash = 0;       // control-state hash of the last block of the previous chunk
   int chunkMinDestCh = 0;      // smallest destination channel count over the blocks of the last chunk
