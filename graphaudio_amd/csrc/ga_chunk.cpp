@@ -1406,6 +1406,7 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
   {
     std::vector<ParamJob> pjobs;
     std::vector<ParamEvent> events;
+    std::unordered_map<std::string, float*> curveOf;
     for (int id : topo) {
       NodeS& nd = *nodes[id];
       for (auto& p : nd.params) p.curve = nullptr;
@@ -1414,7 +1415,17 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
         continue;
       for (ParamS& p : nd.params) {
         if (p.events.empty()) continue;
+        // identical timelines (same events, value and rate -- e.g. the same fade on every voice) share one curve
+        std::string key((const char*)p.events.data(), p.events.size() * sizeof(ParamEvent));
+        key.append((const char*)&p.value, sizeof(float));
+        key.push_back(p.arate ? 1 : 0);
+        auto seen = curveOf.find(key);
+        if (seen != curveOf.end()) {
+          p.curve = seen->second;
+          continue;
+        }
         p.curve = getSlab(*this);
+        curveOf.emplace(std::move(key), p.curve);
         ParamJob pj;
         pj.out = p.curve;
         pj.ev0 = (int)events.size();
