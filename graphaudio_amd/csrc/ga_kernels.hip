@@ -1667,7 +1667,10 @@ __device__ __forceinline__ const float* bcast_ptr(const float* p, int srcLane) {
 // handful of waves.  All 64 lanes still cooperate on the coalesced 256-byte row loads / stores of the JPW x 64 tile.
 template <int NSEC, int JPW>
 __global__ __launch_bounds__(64) void biquad_kernel(const BiquadJob* __restrict jobs, int njobs, const BiquadSection* __restrict secs) {
-  __shared__ float tile[JPW][BQ_TILE + 1];
+  // tile length: long tiles amortise the load / barrier / store overhead of a tile when few chains share a wavefront
+  constexpr int TL = JPW <= 8 ? 256 : BQ_TILE, TM = TL / 64;
+  __shared__ float tile[JPW][TL + 1];
+  __shared__ float prevw[JPW][2];   // NSEC == 1: W1, W2 at the start of the tile (the FIR half needs w[-1], w[-2])
   const int lane = threadIdx.x;
   const int j0 = blockIdx.x * JPW;
   const int myj = j0 + lane;
@@ -1697,28 +1700,92 @@ __global__ __launch_bounds__(64) void biquad_kernel(const BiquadJob* __restrict 
   for (int m = 32; m >= 1; m >>= 1) nmax = max(nmax, (int64_t)__shfl_xor((long long)nmax, m, 64));
   const int jcount = min(JPW, njobs - j0);
 
-  float pre[JPW];   // prefetched tile: pre[r] = frame (base + lane) of job j0 + r
+  float pre[JPW][TM];   // prefetched tile: pre[r][u] = frame (base + 64 u + lane) of job j0 + r
   auto fetch = [&](int64_t base) {
 #pragma unroll
     for (int r = 0; r < JPW; r++) {
       const float* p = bcast_ptr(inb, r);
       int64_t nr = __builtin_amdgcn_readlane((int)n, r);   // n < 2^31 frames per segment
-      int64_t fi = base + lane;
-      pre[r] = (r < jcount && fi < nr) ? p[fi] : 0.f;
+#pragma unroll
+      for (int u = 0; u < TM; u++) {
+        int64_t fi = base + 64 * u + lane;
+        pre[r][u] = (r < jcount && fi < nr) ? p[fi] : 0.f;
+      }
     }
   };
   fetch(0);
-  for (int64_t base = 0; base < nmax; base += BQ_TILE) {
+  for (int64_t base = 0; base < nmax; base += TL) {
 #pragma unroll
-    for (int r = 0; r < JPW; r++) tile[r][lane] = pre[r];
+    for (int r = 0; r < JPW; r++)
+#pragma unroll
+      for (int u = 0; u < TM; u++) tile[r][64 * u + lane] = pre[r][u];
     __syncthreads();
-    if (base + BQ_TILE < nmax) fetch(base + BQ_TILE);   // next tile's loads fly during the serial recurrence below
-    const int cnt = (int)max<int64_t>(0, min<int64_t>(BQ_TILE, n - base));
-    if (lane < JPW) {
-      if (cnt == BQ_TILE) {
+    if (base + TL < nmax) fetch(base + TL);   // next tile's loads fly during the serial recurrence below
+    const int cnt = (int)max<int64_t>(0, min<int64_t>(TL, n - base));
+    if constexpr (NSEC == 1) {
+      // A single section splits into a RECURSIVE half  w[n] = x[n] - a1 w[n-1] - a2 w[n-2]  (serial, one lane per chain) and a
+      // FIR half  y[n] = b0 w[n] + b1 w[n-1] + b2 w[n-2]  (no recurrence: all 64 lanes, one sample each).  The same products
+      // and sums in the same order as BiQuadFilterNode.cs:137-138 -> bit-exact, with 4 instead of 9 flops on the serial chain.
+      if (lane < JPW) {
+        prevw[lane][0] = w1[0];
+        prevw[lane][1] = w2[0];
+        float ww1 = w1[0], ww2 = w2[0];
+        const float ca1 = a1[0], ca2 = a2[0];
+        // the chain  a1 w1 -> (x - .) -> (. - a2 w2)  is three dependent VALU results per sample (~20 cycles each on gfx950): keep
+        // everything else -- the select of a partial tile included -- off it
+        if (cnt == TL) {
+#pragma unroll
+          for (int i0 = 0; i0 < TL; i0 += 16) {
+            float xv[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) xv[i] = tile[lane][i0 + i];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+              const float w = xv[i] - ca1 * ww1 - ca2 * ww2;
+              ww2 = ww1;
+              ww1 = w;
+              xv[i] = w;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++) tile[lane][i0 + i] = xv[i];
+          }
+        } else {
+          for (int i = 0; i < cnt; i++) {
+            const float w = tile[lane][i] - ca1 * ww1 - ca2 * ww2;
+            ww2 = ww1;
+            ww1 = w;
+            tile[lane][i] = w;
+          }
+        }
+        w1[0] = ww1;
+        w2[0] = ww2;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < JPW; r++) {
+        if (r < jcount) {
+          const float cb0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b0[0]), r));
+          const float cb1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b1[0]), r));
+          const float cb2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b2[0]), r));
+          float yv[TM];
+#pragma unroll
+          for (int u = 0; u < TM; u++) {
+            const int x = 64 * u + lane;
+            const float w0 = tile[r][x];
+            const float wm1 = x >= 1 ? tile[r][x - 1] : prevw[r][0];
+            const float wm2 = x >= 2 ? tile[r][x - 2] : prevw[r][1 - x];   // x = 1: w[-1] ; x = 0: w[-2]
+            yv[u] = cb0 * w0 + cb1 * wm1 + cb2 * wm2;
+          }
+          // (one wavefront: its LDS reads above are served before the writes below)
+#pragma unroll
+          for (int u = 0; u < TM; u++) tile[r][64 * u + lane] = yv[u];
+        }
+      }
+    } else if (lane < JPW) {
+      if (cnt == TL) {
         // register batches of 16 keep LDS latency off the W1/W2 dependency chains
 #pragma unroll
-        for (int i0 = 0; i0 < BQ_TILE; i0 += 16) {
+        for (int i0 = 0; i0 < TL; i0 += 16) {
           float xv[16];
 #pragma unroll
           for (int i = 0; i < 16; i++) xv[i] = tile[lane][i0 + i];
@@ -1759,8 +1826,11 @@ __global__ __launch_bounds__(64) void biquad_kernel(const BiquadJob* __restrict 
       if (r < jcount) {
         float* q = (float*)bcast_ptr(outb, r);
         int64_t nr = __builtin_amdgcn_readlane((int)n, r);
-        int64_t fi = base + lane;
-        if (fi < nr) q[fi] = tile[r][lane];
+#pragma unroll
+        for (int u = 0; u < TM; u++) {
+          int64_t fi = base + 64 * u + lane;
+          if (fi < nr) q[fi] = tile[r][64 * u + lane];
+        }
       }
     }
     __syncthreads();
