@@ -83,3 +83,28 @@ def test_errors_after_dispose_and_bad_arguments():
     ctx.Dispose()
     with pytest.raises(ObjectDisposedException):
         ctx.Render(out, 256)
+
+
+def test_many_control_segments_in_one_render():
+    """150 voices that start and end at different blocks: far more than 96 control segments, so the engine closes chunks early
+    (kMaxSegs) and continues -- the result must not depend on where the chunks end."""
+    def run(ctx):
+        ctx.Destination.SetChannelCount(1)
+        ctx.Destination.Inputs[0].SetChannelCount(1)
+        for v in range(150):
+            s = AudioBufferSourceNode(ctx)
+            s.Buffer = PlayableAudioBuffer.FromMonoArray(G.voice(400 + v, 128 * (3 + v % 17) + 11 * v), SR)
+            g = GainNode(ctx)
+            g.Inputs[0].SetChannelCount(1)
+            g.Gain.Value = 0.05
+            s.Connect(g)
+            g.Connect(ctx.Destination)
+            s.Start((2 * v + 0.5) * 128 / SR)
+        out = np.zeros((1, 128 * 340), np.float32)
+        ctx.Render(out, 128 * 340)
+        segs = ctx.GetStats()["segments"] if hasattr(ctx, "GetStats") else 0
+        return out, segs
+    (ro, _), (go, segs) = both(run)
+    assert G.rms(ro) > 1e-3
+    assert np.array_equal(ro, go)
+    assert segs > 300
