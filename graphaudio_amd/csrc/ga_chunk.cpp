@@ -1482,10 +1482,19 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
       ensure(planes[2], yMax);
       ensure(planes[3], yMax);
     }
-    if (bx) {  // formulation B scratch: [row][bin][block]
+    bRowX = bRowY = 0;
+    if (bx) {  // formulation B scratch: [row][bin][block]; x planes alternate between two pairs (flushPlaneHistories)
       const size_t txb = (size_t)roundup(bHistMax, 4) + roundup(n, 16) + 16, tyb = (size_t)roundup(n, 256);
-      ensure(planesB[0], bx * kBins * txb * sizeof(float));
-      ensure(planesB[1], bx * kBins * txb * sizeof(float));
+      bPairWrite = bPairCur ^ 1;
+      flushPlaneHistories(bPairWrite);
+      // both pairs grow together (a render that continues reaches the other pair in its next chunk; growing it then would
+      // put an allocation into the steady state), but only a pair without residents can be reallocated
+      const size_t xb = bx * kBins * txb * sizeof(float);
+      if (planesB[0].bytes < xb || planesBalt[0].bytes < xb) flushPlaneHistories(bPairCur);
+      ensure(planesB[0], xb);
+      ensure(planesB[1], xb);
+      ensure(planesBalt[0], xb);
+      ensure(planesBalt[1], xb);
       ensure(planesB[2], by * kBins * tyb * sizeof(float));
       ensure(planesB[3], by * kBins * tyb * sizeof(float));
     }
@@ -2044,11 +2053,14 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
     if (!bNodes.empty()) {
       const int hist = (int)roundup(bHistMax, 4);   // plane time origin, 16-byte aligned rows
       const int txb = hist + (int)roundup(n, 16) + 16, tyb = (int)roundup(n, 256);
-      ConvPlanesB plb{(float*)planesB[0].p, (float*)planesB[1].p, (float*)planesB[2].p, (float*)planesB[3].p, txb, tyb};
+      // rows of this depth start after the rows of the depths before it: a node's spectra stay intact for the next chunk
+      const size_t rowX0 = bRowX, rowY0 = bRowY;
+      ConvPlanesB plb{xPlane(bPairWrite, 0) + rowX0 * kBins * txb, xPlane(bPairWrite, 1) + rowX0 * kBins * txb,
+                      (float*)planesB[2].p + rowY0 * kBins * tyb, (float*)planesB[3].p + rowY0 * kBins * tyb, txb, tyb};
       std::vector<ConvRowIO> xrows, yrows;
       std::vector<ConvSetB> sets;
       std::map<int, std::vector<ConvSetC>> setsC;   // by P: one launch per distinct segment length
-      std::vector<HistJobB> restore, save;
+      std::vector<HistJobB> restore;
       std::vector<const float*> ovIn;
       std::vector<float*> ovOut;
       double flops = 0;
@@ -2091,7 +2103,7 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
         const size_t hstride = (size_t)kBins * std::max(h, 1);
         if (nd.bShared && !allSame) {
           // the channels start to differ: every channel inherits the (so far common) history of channel 0
-          if (!nd.bHistZero && h > 0)
+          if (!nd.bHistZero && h > 0 && nd.bHistPlane < 0)   // (a plane-resident shared row is simply read by every channel)
             for (int c = 1; c < nd.bInCh; c++) {
               GA_HIP(hipMemcpyAsync(nd.bHistR + c * hstride, nd.bHistR, hstride * 4, hipMemcpyDeviceToDevice, stream));
               GA_HIP(hipMemcpyAsync(nd.bHistI + c * hstride, nd.bHistI, hstride * 4, hipMemcpyDeviceToDevice, stream));
@@ -2111,10 +2123,20 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
             restore.push_back(HistJobB{xi_row, nullptr, txb, 0, hist - h, 0});
           }
           if (h > 0) {
-            restore.push_back(HistJobB{xr_row + (hist - h), nd.bHistZero ? nullptr : nd.bHistR + c * hstride, txb, h, h, 0});
-            restore.push_back(HistJobB{xi_row + (hist - h), nd.bHistZero ? nullptr : nd.bHistI + c * hstride, txb, h, h, 0});
-            save.push_back(HistJobB{nd.bHistR + c * hstride, xr_row + (hist + (int)n - h), h, txb, h, 0});
-            save.push_back(HistJobB{nd.bHistI + c * hstride, xi_row + (hist + (int)n - h), h, txb, h, 0});
+            const float *srcR = nullptr, *srcI = nullptr;
+            int sstride = h;
+            if (nd.bHistZero) {
+            } else if (nd.bHistPlane >= 0) {   // the previous chunk's x planes (never the pair being written: flushed above)
+              const size_t off = (size_t)(nd.bHistRow + (nd.bHistNx == 1 ? 0 : c)) * kBins * nd.bHistTxb + nd.bHistOff;
+              srcR = xPlane(nd.bHistPlane, 0) + off;
+              srcI = xPlane(nd.bHistPlane, 1) + off;
+              sstride = nd.bHistTxb;
+            } else {
+              srcR = nd.bHistR + c * hstride;
+              srcI = nd.bHistI + c * hstride;
+            }
+            restore.push_back(HistJobB{xr_row + (hist - h), srcR, txb, sstride, h, 0});
+            restore.push_back(HistJobB{xi_row + (hist - h), srcI, txb, sstride, h, 0});
           }
           const int tailn = txb - (hist + (int)n);
           restore.push_back(HistJobB{xr_row + hist + (int)n, nullptr, txb, 0, tailn, 0});
@@ -2165,12 +2187,24 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
         }
         nd.bOvCur ^= 1;
         nd.bHistZero = false;
+        if (h > 0) {   // the history of the next chunk: the last h spectra of these rows
+          if (nd.bHistPlane == bPairWrite) fail(GA_ERR_DEVICE, "internal: convolver history lives in the planes being written");
+          nd.bHistPlane = bPairWrite;
+          nd.bHistRow = (int)rowX0 + x0;
+          nd.bHistNx = nxr;
+          nd.bHistOff = hist + (int)n - h;
+          nd.bHistTxb = txb;
+          bResidents[bPairWrite].push_back(id);
+        }
         flops += 8.0 * P * kBins * (double)nd.bSlots * (double)n;
       }
+      bRowX += xrows.size();
+      bRowY += yrows.size();
+      bPairCur = bPairWrite;
       ex.flushLevel();
       size_t xo = ex.plan.putv(xrows), yo = ex.plan.putv(yrows), so = ex.plan.putv(sets), ro = ex.plan.putv(restore),
-             sv = ex.plan.putv(save), oi = ex.plan.putv(ovIn), oo = ex.plan.putv(ovOut);
-      const int nx = (int)xrows.size(), ny = (int)yrows.size(), ns_ = (int)sets.size(), nr = (int)restore.size(), nsv = (int)save.size();
+             oi = ex.plan.putv(ovIn), oo = ex.plan.putv(ovOut);
+      const int nx = (int)xrows.size(), ny = (int)yrows.size(), ns_ = (int)sets.size(), nr = (int)restore.size();
       hipStream_t st = stream;
       Twiddles tw{w128, w256};
       const int nn = (int)n;
@@ -2200,7 +2234,6 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
       }
       ex.plan.add(LK_FFT, [=](uint8_t* base) {
         launch_irfft_ola_b(st, (const ConvRowIO*)(base + yo), ny, nn, plb, (const float* const*)(base + oi), (float* const*)(base + oo), tw, f64);
-        launch_hist_copy_b(st, (const HistJobB*)(base + sv), nsv, std::max(hist, 1));
       });
       stats.mac_flops_total += flops;
       // streaming-formulation bytes: per channel-instance per block FDL read + write + input; every distinct

@@ -71,6 +71,8 @@ Context::~Context() {
     if (a.p) (void)hipFree(a.p);
   for (auto& a : planesB)
     if (a.p) (void)hipFree(a.p);
+  for (auto& a : planesBalt)
+    if (a.p) (void)hipFree(a.p);
   for (auto& np : nodes) {
     if (np && np->bHistR) (void)hipFree(np->bHistR);
     if (np && np->bHistI) (void)hipFree(np->bHistI);
@@ -287,10 +289,41 @@ void Context::releaseConvState(NodeS& n) {
     dfree(n.bOverlap, (size_t)n.bSlots * 2 * kBlock * sizeof(float));
   }
   n.bHistR = n.bHistI = n.bOverlap = nullptr;
+  n.bHistPlane = -1;
   n.convPath = 0;
   n.bShared = true;
   n.bHistZero = true;
   n.bOvCur = 0;
+}
+
+// Formulation B/C keeps the last P-1 input spectra of a node in the x planes of the chunk that produced them; the next
+// chunk writes the OTHER pair of planes and reads them from there.  A node that did not run in that next chunk would lose
+// them one chunk later, so before a pair is rewritten its remaining residents move to their private stores.
+void Context::flushPlaneHistories(int pair) {
+  std::vector<HistJobB> jobs;
+  int maxh = 1;
+  for (int id : bResidents[pair]) {
+    NodeS* n = node(id);
+    if (!n || n->bHistPlane != pair || !n->ir || !n->bHistR) continue;
+    const int h = n->ir->P - 1;
+    const size_t hstride = (size_t)kBins * std::max(h, 1);
+    for (int c = 0; c < n->bHistNx && h > 0; c++) {
+      const size_t off = (size_t)(n->bHistRow + c) * kBins * n->bHistTxb + n->bHistOff;
+      jobs.push_back(HistJobB{n->bHistR + c * hstride, xPlane(pair, 0) + off, h, n->bHistTxb, h, 0});
+      jobs.push_back(HistJobB{n->bHistI + c * hstride, xPlane(pair, 1) + off, h, n->bHistTxb, h, 0});
+    }
+    maxh = std::max(maxh, h);
+    n->bHistPlane = -1;
+  }
+  bResidents[pair].clear();
+  if (jobs.empty()) return;
+  HistJobB* tab = nullptr;
+  GA_HIP(hipHostMalloc((void**)&tab, jobs.size() * sizeof(HistJobB), hipHostMallocDefault));
+  memcpy(tab, jobs.data(), jobs.size() * sizeof(HistJobB));
+  launch_hist_copy_b(stream, tab, (int)jobs.size(), maxh);
+  GA_HIP(hipGetLastError());
+  GA_HIP(hipStreamSynchronize(stream));
+  GA_HIP(hipHostFree(tab));
 }
 
 // one row (= one PartitionedConvolver instance) in the shared-IR group of (IR, IR channel, convolver depth)

@@ -211,6 +211,10 @@ struct NodeS {
   float* bOverlap = nullptr;       // [bSlots][2][128] double-buffered overlap
   int bOvCur = 0;
   bool bShared = true;             // all input channels have carried identical signals so far (one x-row serves all)
+  // where the last P-1 input spectra live: -1 = bHistR/bHistI (or all zero), 0/1 = still in that pair of x planes, at
+  // rows [bHistRow, bHistRow + bHistNx), time offset bHistOff, row pitch bHistTxb (the next chunk reads them from there)
+  int bHistPlane = -1;
+  int bHistRow = 0, bHistNx = 1, bHistOff = 0, bHistTxb = 0;
   bool bHistZero = true;
 };
 
@@ -307,7 +311,14 @@ struct Context {
   float* zeros = nullptr;  // zero page (chunk frames)
   int64_t zerosLen = 0;
   DevArena planes[4];      // xr, xi, yr, yi scratch shared by all groups
-  DevArena planesB[4];     // formulation B scratch
+  DevArena planesB[4];     // formulation B scratch: x planes of pair 0 (re, im), y planes (re, im)
+  DevArena planesBalt[2];  // x planes of pair 1: chunks alternate between the pairs, so the previous chunk's spectra stay readable
+  int bPairCur = 0;        // pair written by the last chunk that ran a formulation B/C convolver
+  int bPairWrite = 0;      // pair this chunk writes
+  size_t bRowX = 0, bRowY = 0;        // next free x / y row of this chunk (convolver depths share the planes)
+  std::vector<int> bResidents[2];     // nodes whose history lives in pair p
+  float* xPlane(int pair, int im) { return (float*)(pair == 0 ? planesB[im].p : planesBalt[im].p); }
+  void flushPlaneHistories(int pair); // moves them to the nodes' private stores (before the pair is rewritten)
   DevArena tables;         // per-chunk job tables
   void* tablesHost = nullptr;
   size_t tablesHostBytes = 0;
