@@ -21,6 +21,14 @@
 
 namespace ga {
 
+// phase timestamps for tools/micro/rfft_phase.hip (compiled out of the product)
+#ifdef GA_EXP_TIMELINE
+__device__ unsigned long long* ga_tl = nullptr;
+#define GA_TL(i) do { if (ga_tl && threadIdx.x == 0) ga_tl[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GA_TL(i) do { } while (0)
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // =====================================================================================================
@@ -515,14 +523,22 @@ void launch_spectral_mac_shared(hipStream_t s, ConvPlanes pl, const float* hr, c
 //  Formulation B kernels (see ga_kernels.hpp): planes [row][bin][block], block index fastest.
 // =====================================================================================================
 constexpr int FB_RUN = 32;            // blocks per workgroup in the B-layout FFT kernels: 32 blocks = one 128-byte line per bin
-constexpr int FB_KP = 130;            // staging pitch of a [block][bin] tile: 129 bins + 1, even, == 2 (mod 32)
+// Staging tile [block][bin] in LDS (64 banks of 4 bytes).  A lane of the 128-point transforms owns bins (2m, 2m + 1) with
+// m = rev6(lane) and needs their mirrors (128 - 2m, 127 - 2m): with the bins in natural order every one of those accesses
+// is a 2-way bank conflict (64 lanes on the even or the odd banks only).  So a column keeps its even bins packed in
+// E[0..64] (bin 2e at e) and its odd bins in O[0..63] (bin 2o + 1 at FB_OB + o): all four accesses become 4-byte operations
+// whose 64 lanes hit 64 different banks (m, 64 - m, FB_OB + m, FB_OB + 63 - m are permutations of the banks).
+// FB_OB == 4 (mod 8) and FB_KP == 18 (mod 64) keep the transposed side conflict-free too: a wave covers 8 consecutive bins
+// (banks b..b+3 from E, b+4..b+7 from O) of 8 columns 4 apart (4 * FB_KP == 8 mod 64).
+constexpr int FB_OB = 68;
+constexpr int FB_KP = 146;
+__device__ __forceinline__ int fb_pos(int k) { return (k & 1) * FB_OB + (k >> 1); }
 
 // forward: workgroup = (x-row, run of 32 blocks); wave w transforms blocks w, w+4, ..., w+28 of the run, 4 in flight
 template <class T>
 __global__ __launch_bounds__(256) void rfft_fwd_b_kernel(const ConvRowIO* __restrict xrows, int nx, int nblocks, int hist,
                                                          ConvPlanesB pl, Twiddles tw, int row0) {
-  // staging tile [block of the run][bin], pitch FB_KP = 130 floats: a lane's bins (k0, k0 + 1) are one aligned 8-byte
-  // access and the 32 lanes of a group land on distinct bank pairs (2-way at worst); same for the transposed reads below
+  // staging tile [block of the run][bin] in the even/odd layout described at FB_KP
   __shared__ __attribute__((aligned(16))) float st_r[FB_RUN * FB_KP];
   __shared__ __attribute__((aligned(16))) float st_i[FB_RUN * FB_KP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -536,6 +552,7 @@ __global__ __launch_bounds__(256) void rfft_fwd_b_kernel(const ConvRowIO* __rest
   const T wk0x = (T)tw.w256[k0].x, wk0y = (T)tw.w256[k0].y;
   const T wk1x = (T)tw.w256[k1].x, wk1y = (T)tw.w256[k1].y;
   const float* in = xrows[xrow].in;
+  GA_TL(0);
 
   // all eight input blocks of this wave are requested up front: their HBM latency overlaps the first batch of transforms
   float inr[FB_RUN / 4], ini[FB_RUN / 4];
@@ -560,6 +577,7 @@ __global__ __launch_bounds__(256) void rfft_fwd_b_kernel(const ConvRowIO* __rest
       s1r[u] = fma(s0r[u], ltw.c1, -(s0i[u] * ltw.s1));
       s1i[u] = fma(s0r[u], ltw.s1, s0i[u] * ltw.c1);
     }
+#ifndef GA_EXP_SKIP_FFT
 #pragma unroll
     for (int u = 0; u < 4; u++) { dif_stage<32, 0>(s0r[u], s0i[u], ltw); dif_stage<32, 0>(s1r[u], s1i[u], ltw); }
 #pragma unroll
@@ -572,6 +590,8 @@ __global__ __launch_bounds__(256) void rfft_fwd_b_kernel(const ConvRowIO* __rest
     for (int u = 0; u < 4; u++) { dif_stage<2, 4>(s0r[u], s0i[u], ltw); dif_stage<2, 4>(s1r[u], s1i[u], ltw); }
 #pragma unroll
     for (int u = 0; u < 4; u++) { dif_stage<1, 5>(s0r[u], s0i[u], ltw); dif_stage<1, 5>(s1r[u], s1i[u], ltw); }
+#endif
+
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const int tl = wave + 4 * (bq * 4 + u);   // block within the run
@@ -585,8 +605,8 @@ __global__ __launch_bounds__(256) void rfft_fwd_b_kernel(const ConvRowIO* __rest
         float xr = (float)(er + pi), xi = (float)(ei - pr);
         if (k0 == 0) {
           xi = 0.f;
-          st_r[tl * FB_KP + 128] = (float)(ax - ay);
-          st_i[tl * FB_KP + 128] = 0.f;
+          st_r[tl * FB_KP + 64] = (float)(ax - ay);   // bin 128 = E[64]
+          st_i[tl * FB_KP + 64] = 0.f;
         }
         x0r = xr;
         x0i = xi;
@@ -597,21 +617,30 @@ __global__ __launch_bounds__(256) void rfft_fwd_b_kernel(const ConvRowIO* __rest
         T er = (T)0.5 * (ax + bx), ei = (T)0.5 * (ay - by);
         T dr = (T)0.5 * (ax - bx), di = (T)0.5 * (ay + by);
         T pr = fma(dr, wk1x, -(di * wk1y)), pi = fma(dr, wk1y, di * wk1x);
-        *reinterpret_cast<float2*>(&st_r[tl * FB_KP + k0]) = make_float2(x0r, (float)(er + pi));
-        *reinterpret_cast<float2*>(&st_i[tl * FB_KP + k0]) = make_float2(x0i, (float)(ei - pr));
+        st_r[tl * FB_KP + m] = x0r;                           // bin 2m
+        st_i[tl * FB_KP + m] = x0i;
+        st_r[tl * FB_KP + FB_OB + m] = (float)(er + pi);      // bin 2m + 1
+        st_i[tl * FB_KP + FB_OB + m] = (float)(ei - pr);
       }
     }
   }
+  GA_TL(1);
   __syncthreads();
+  GA_TL(2);
   // store: per bin 32 consecutive blocks = 128 bytes, 8 lanes x 16 B
   const size_t rowbase = (size_t)xrow * kBins * pl.tx + hist + t0;
   for (int idx = tid; idx < kBins * 8; idx += 256) {
     int k = idx >> 3, q = (idx & 7) * 4;
     if (t0 + q >= nblocks) continue;
     size_t o = rowbase + (size_t)k * pl.tx + q;
-    *reinterpret_cast<float4*>(pl.xr + o) = make_float4(st_r[q * FB_KP + k], st_r[(q + 1) * FB_KP + k], st_r[(q + 2) * FB_KP + k], st_r[(q + 3) * FB_KP + k]);
-    *reinterpret_cast<float4*>(pl.xi + o) = make_float4(st_i[q * FB_KP + k], st_i[(q + 1) * FB_KP + k], st_i[(q + 2) * FB_KP + k], st_i[(q + 3) * FB_KP + k]);
+#ifdef GA_EXP_CONTIG
+    o = ((size_t)(xrow * gridDim.x + blockIdx.x) * kBins + k) * 32 + q;
+#endif
+    const int pk = q * FB_KP + fb_pos(k);
+    *reinterpret_cast<float4*>(pl.xr + o) = make_float4(st_r[pk], st_r[pk + FB_KP], st_r[pk + 2 * FB_KP], st_r[pk + 3 * FB_KP]);
+    *reinterpret_cast<float4*>(pl.xi + o) = make_float4(st_i[pk], st_i[pk + FB_KP], st_i[pk + 2 * FB_KP], st_i[pk + 3 * FB_KP]);
   }
+  GA_TL(3);
 }
 void launch_rfft_fwd_b(hipStream_t s, const ConvRowIO* xrows_dev, int nx, int nblocks, int hist, ConvPlanesB pl, Twiddles tw, bool fp64) {
   if (nx <= 0 || nblocks <= 0) return;
@@ -720,16 +749,17 @@ void launch_spectral_mac_b(hipStream_t s, const ConvSetB* sets_dev, int nsets, i
 }
 
 // inverse + overlap-add, B layout: workgroup = (y-row, run of 32 blocks).  All 33 inverse transforms of the run (the extra
-// one recovers the tail of the block before the run) are independent: 4 waves x up to 3 batches of 4.  Heads and tails land
-// in LDS, then out[t] = (float)head[t] + tail[t-1] is written as one contiguous, fully coalesced 16 KB range.
+// one recovers the tail of the block before the run) are independent: 4 waves x 2 batches of 4, and the 33rd alone on one
+// wave.  Heads and tails land in LDS, then
+// out[t] = (float)head[t] + tail[t-1] is written as one contiguous, fully coalesced 16 KB range.
 template <class T>
 __global__ __launch_bounds__(256) void irfft_ola_b_kernel(const ConvRowIO* __restrict yrows, int ny, int nblocks, ConvPlanesB pl,
                                                           const float* const* __restrict overlap_in, float* const* __restrict overlap_out,
                                                           Twiddles tw, int row0) {
-  // staging tile [33 columns][bin] (pitch 130, see the forward kernel): column c <-> block ta - 1 + c ; the memory is
-  // reused for the head/tail tiles afterwards
+  // staging tile [33 columns][bin] (even/odd layout, see FB_KP): column c <-> block ta - 1 + c ; the memory is reused for
+  // the head/tail tiles afterwards
   constexpr int NC = FB_RUN + 1;
-  __shared__ __attribute__((aligned(16))) float smem[2 * NC * FB_KP];   // 8580 floats >= (33 + 33) * 128 = 8448
+  __shared__ __attribute__((aligned(16))) float smem[2 * NC * FB_KP];   // 9636 floats >= (33 + 33) * 128 = 8448
   float* sr = smem;
   float* si = smem + NC * FB_KP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -743,6 +773,7 @@ __global__ __launch_bounds__(256) void irfft_ola_b_kernel(const ConvRowIO* __res
   const T wk1x = (T)tw.w256[k1].x, wk1y = (T)tw.w256[k1].y;
   const float* __restrict yr = pl.yr + (size_t)row * kBins * pl.ty;
   const float* __restrict yi = pl.yi + (size_t)row * kBins * pl.ty;
+  GA_TL(0);
   // columns 1..nrun <- blocks ta .. tb-1 (16-byte loads, 8 lanes per 128-byte bin line); column 0 <- block ta - 1
   {
     // all global loads of the tile first (10 x 16 B in flight per thread), then the LDS transposition: one exposed HBM latency
@@ -756,8 +787,13 @@ __global__ __launch_bounds__(256) void irfft_ola_b_kernel(const ConvRowIO* __res
       vr[it] = make_float4(0.f, 0.f, 0.f, 0.f);
       vi[it] = vr[it];
       if (idx < kBins * 8 && ta + q < nblocks) {
+#ifdef GA_EXP_CONTIG   // (measurement only: the tile as one contiguous 16.5 KB range per plane)
+        vr[it] = *reinterpret_cast<const float4*>(pl.yr + ((size_t)(row * gridDim.x + blockIdx.x) * kBins + k) * 32 + q);
+        vi[it] = *reinterpret_cast<const float4*>(pl.yi + ((size_t)(row * gridDim.x + blockIdx.x) * kBins + k) * 32 + q);
+#else
         vr[it] = *reinterpret_cast<const float4*>(yr + (size_t)k * pl.ty + ta + q);
         vi[it] = *reinterpret_cast<const float4*>(yi + (size_t)k * pl.ty + ta + q);
+#endif
       }
     }
 #pragma unroll
@@ -765,8 +801,9 @@ __global__ __launch_bounds__(256) void irfft_ola_b_kernel(const ConvRowIO* __res
       const int idx = tid + 256 * it;
       const int k = idx >> 3, q = (idx & 7) * 4;
       if (idx < kBins * 8) {
-        sr[(1 + q) * FB_KP + k] = vr[it].x; sr[(2 + q) * FB_KP + k] = vr[it].y; sr[(3 + q) * FB_KP + k] = vr[it].z; sr[(4 + q) * FB_KP + k] = vr[it].w;
-        si[(1 + q) * FB_KP + k] = vi[it].x; si[(2 + q) * FB_KP + k] = vi[it].y; si[(3 + q) * FB_KP + k] = vi[it].z; si[(4 + q) * FB_KP + k] = vi[it].w;
+        const int pk = (1 + q) * FB_KP + fb_pos(k);
+        sr[pk] = vr[it].x; sr[pk + FB_KP] = vr[it].y; sr[pk + 2 * FB_KP] = vr[it].z; sr[pk + 3 * FB_KP] = vr[it].w;
+        si[pk] = vi[it].x; si[pk + FB_KP] = vi[it].y; si[pk + 2 * FB_KP] = vi[it].z; si[pk + 3 * FB_KP] = vi[it].w;
       }
     }
   }
@@ -776,83 +813,96 @@ __global__ __launch_bounds__(256) void irfft_ola_b_kernel(const ConvRowIO* __res
       vr = yr[(size_t)tid * pl.ty + ta - 1];
       vi = yi[(size_t)tid * pl.ty + ta - 1];
     }
-    sr[tid] = vr;
-    si[tid] = vi;
+    sr[fb_pos(tid)] = vr;
+    si[fb_pos(tid)] = vi;
   }
+  GA_TL(1);
   __syncthreads();
-  // transform columns c = 0..nrun (c = 0 only when ta > 0); results kept in registers until the staging tile is dead
+  GA_TL(2);
+  // transform columns c = 0..nrun (c = 0 only when ta > 0); results kept in registers until the staging tile is dead.
+  // Batches 0 and 1: column (4 * bq + u) * 4 + wave ; batch 2: column 32 alone, on wave (run & 3) -- which wave takes it
+  // rotates with the run, so the extra work spreads over the SIMDs.  (As a fifth transform of batch 1 it costs 50 more
+  // VGPRs and a wave of occupancy: slower.)
+  const int m = rev6(lane);
   float hd[3][4][2], tl[3][4][2];
-  int cc[3][4];
 #pragma unroll
   for (int bq = 0; bq < 3; bq++) {
-    T s0r[4], s0i[4], s1r[4], s1i[4];
+    constexpr int kFull = 4;
+    const int NU = bq < 2 ? kFull : 1;
+    const bool act = bq < 2 ? (bq * 16 <= nrun) : (wave == (int)(blockIdx.x & 3) && nrun == FB_RUN);   // wave uniform
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      int c = (bq * 4 + u) * 4 + wave;
-      cc[bq][u] = c;
-      const int cl = min(c, FB_RUN);
-      float x1r, x1i;
-      {
-        const float2 pr2 = *reinterpret_cast<const float2*>(&sr[cl * FB_KP + k0]);   // bins k0, k0 + 1
-        const float2 pi2 = *reinterpret_cast<const float2*>(&si[cl * FB_KP + k0]);
-        x1r = pr2.y;
-        x1i = pi2.y;
-        T ar = pr2.x, ai = pi2.x;
-        T br = sr[cl * FB_KP + (128 - k0)], bi = -(T)si[cl * FB_KP + (128 - k0)];
-        if (k0 == 0) { ai = (T)0.0; bi = (T)0.0; }
-        T er = ar + br, ei = ai + bi, dr = ar - br, di = ai - bi;
-        T pr = fma(dr, wk0x, di * wk0y), pi = fma(di, wk0x, -(dr * wk0y));
-        s0r[u] = er - pi;
-        s0i[u] = ei + pr;
+    for (int u = 0; u < kFull; u++) hd[bq][u][0] = hd[bq][u][1] = tl[bq][u][0] = tl[bq][u][1] = 0.f;
+    if (act) {
+      T s0r[kFull], s0i[kFull], s1r[kFull], s1i[kFull];
+#pragma unroll
+      for (int u = 0; u < NU; u++) {
+        const int c = bq < 2 ? (bq * 4 + u) * 4 + wave : FB_RUN;
+        const float* cr = sr + c * FB_KP;
+        const float* ci = si + c * FB_KP;
+        {
+          T ar = cr[m], ai = ci[m];                               // bin 2m
+          T br = cr[64 - m], bi = -(T)ci[64 - m];                 // bin 128 - 2m
+          if (m == 0) { ai = (T)0.0; bi = (T)0.0; }
+          T er = ar + br, ei = ai + bi, dr = ar - br, di = ai - bi;
+          T pr = fma(dr, wk0x, di * wk0y), pi = fma(di, wk0x, -(dr * wk0y));
+          s0r[u] = er - pi;
+          s0i[u] = ei + pr;
+        }
+        {
+          T ar = cr[FB_OB + m], ai = ci[FB_OB + m];               // bin 2m + 1
+          T br = cr[FB_OB + 63 - m], bi = -(T)ci[FB_OB + 63 - m]; // bin 127 - 2m
+          T er = ar + br, ei = ai + bi, dr = ar - br, di = ai - bi;
+          T pr = fma(dr, wk1x, di * wk1y), pi = fma(di, wk1x, -(dr * wk1y));
+          s1r[u] = er - pi;
+          s1i[u] = ei + pr;
+        }
       }
-      {
-        T ar = x1r, ai = x1i;
-        T br = sr[cl * FB_KP + (128 - k1)], bi = -(T)si[cl * FB_KP + (128 - k1)];
-        T er = ar + br, ei = ai + bi, dr = ar - br, di = ai - bi;
-        T pr = fma(dr, wk1x, di * wk1y), pi = fma(di, wk1x, -(dr * wk1y));
-        s1r[u] = er - pi;
-        s1i[u] = ei + pr;
+#ifndef GA_EXP_SKIP_FFT
+#pragma unroll
+      for (int u = 0; u < NU; u++) { dit_stage<1, 5>(s0r[u], s0i[u], ltw); dit_stage<1, 5>(s1r[u], s1i[u], ltw); }
+#pragma unroll
+      for (int u = 0; u < NU; u++) { dit_stage<2, 4>(s0r[u], s0i[u], ltw); dit_stage<2, 4>(s1r[u], s1i[u], ltw); }
+#pragma unroll
+      for (int u = 0; u < NU; u++) { dit_stage<4, 3>(s0r[u], s0i[u], ltw); dit_stage<4, 3>(s1r[u], s1i[u], ltw); }
+#pragma unroll
+      for (int u = 0; u < NU; u++) { dit_stage<8, 2>(s0r[u], s0i[u], ltw); dit_stage<8, 2>(s1r[u], s1i[u], ltw); }
+#pragma unroll
+      for (int u = 0; u < NU; u++) { dit_stage<16, 1>(s0r[u], s0i[u], ltw); dit_stage<16, 1>(s1r[u], s1i[u], ltw); }
+#pragma unroll
+      for (int u = 0; u < NU; u++) { dit_stage<32, 0>(s0r[u], s0i[u], ltw); dit_stage<32, 0>(s1r[u], s1i[u], ltw); }
+#endif
+#pragma unroll
+      for (int u = 0; u < NU; u++) {
+        T qr = fma(s1r[u], ltw.c1, s1i[u] * ltw.s1), qi = fma(s1i[u], ltw.c1, -(s1r[u] * ltw.s1));
+        const T scale = (T)(1.0 / 256.0);
+        hd[bq][u][0] = (float)((s0r[u] + qr) * scale);   // time samples 2l, 2l+1
+        hd[bq][u][1] = (float)((s0i[u] + qi) * scale);
+        tl[bq][u][0] = (float)((s0r[u] - qr) * scale);   // time samples 128+2l, 128+2l+1
+        tl[bq][u][1] = (float)((s0i[u] - qi) * scale);
       }
-    }
-    if (bq * 16 <= nrun) {   // wave uniform: skip batches entirely beyond the run
-#pragma unroll
-      for (int u = 0; u < 4; u++) { dit_stage<1, 5>(s0r[u], s0i[u], ltw); dit_stage<1, 5>(s1r[u], s1i[u], ltw); }
-#pragma unroll
-      for (int u = 0; u < 4; u++) { dit_stage<2, 4>(s0r[u], s0i[u], ltw); dit_stage<2, 4>(s1r[u], s1i[u], ltw); }
-#pragma unroll
-      for (int u = 0; u < 4; u++) { dit_stage<4, 3>(s0r[u], s0i[u], ltw); dit_stage<4, 3>(s1r[u], s1i[u], ltw); }
-#pragma unroll
-      for (int u = 0; u < 4; u++) { dit_stage<8, 2>(s0r[u], s0i[u], ltw); dit_stage<8, 2>(s1r[u], s1i[u], ltw); }
-#pragma unroll
-      for (int u = 0; u < 4; u++) { dit_stage<16, 1>(s0r[u], s0i[u], ltw); dit_stage<16, 1>(s1r[u], s1i[u], ltw); }
-#pragma unroll
-      for (int u = 0; u < 4; u++) { dit_stage<32, 0>(s0r[u], s0i[u], ltw); dit_stage<32, 0>(s1r[u], s1i[u], ltw); }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      T qr = fma(s1r[u], ltw.c1, s1i[u] * ltw.s1), qi = fma(s1i[u], ltw.c1, -(s1r[u] * ltw.s1));
-      const T scale = (T)(1.0 / 256.0);
-      hd[bq][u][0] = (float)((s0r[u] + qr) * scale);   // time samples 2l, 2l+1
-      hd[bq][u][1] = (float)((s0i[u] + qi) * scale);
-      tl[bq][u][0] = (float)((s0r[u] - qr) * scale);   // time samples 128+2l, 128+2l+1
-      tl[bq][u][1] = (float)((s0i[u] - qi) * scale);
     }
   }
+  GA_TL(3);
   __syncthreads();   // every wave is done reading the staging tile: reuse it as head[33][128] | tail[33][128]
+  GA_TL(4);
   float* head = smem;
   float* tail = smem + 33 * kBlock;
 #pragma unroll
-  for (int bq = 0; bq < 3; bq++)
+  for (int bq = 0; bq < 3; bq++) {
+    const int NU = bq < 2 ? 4 : 1;
+    const bool mine = bq < 2 || wave == (int)(blockIdx.x & 3);
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int c = cc[bq][u];
-      if (c <= nrun && (c > 0 || ta > 0)) {
+    for (int u = 0; u < NU; u++) {
+      const int c = bq < 2 ? (bq * 4 + u) * 4 + wave : FB_RUN;
+      if (mine && c <= nrun && (c > 0 || ta > 0)) {
         *reinterpret_cast<float2*>(&head[c * kBlock + 2 * lane]) = make_float2(hd[bq][u][0], hd[bq][u][1]);
         *reinterpret_cast<float2*>(&tail[c * kBlock + 2 * lane]) = make_float2(tl[bq][u][0], tl[bq][u][1]);
       }
     }
+  }
   if (ta == 0 && tid < kBlock) tail[tid] = overlap_in[row][tid];   // incoming overlap of the chunk's first block
   __syncthreads();
+  GA_TL(5);
   float* out = yrows[row].out;
   if (out) {
     float4* o4 = reinterpret_cast<float4*>(out + (int64_t)ta * kBlock);
@@ -864,6 +914,7 @@ __global__ __launch_bounds__(256) void irfft_ola_b_kernel(const ConvRowIO* __res
     }
   }
   if (tb == nblocks && tid < kBlock) overlap_out[row][tid] = tail[nrun * kBlock + tid];   // overlap[i] = (float)y[i+128]  (:149)
+  GA_TL(6);
 }
 void launch_irfft_ola_b(hipStream_t s, const ConvRowIO* yrows_dev, int ny, int nblocks, ConvPlanesB pl,
                         const float* const* overlap_in_dev, float* const* overlap_out_dev, Twiddles tw, bool fp64) {
