@@ -132,7 +132,10 @@ def main():
         ctx.SetOption("time_fft", 0)
     build_graph(ctx, shard, v0, args.taps, frames, G)
 
-    host_out = np.zeros((2, frames), np.float32)
+    # the caller's output buffer is page-locked host memory (the D2H copy of the 3.8 MB bus is inside the timed region: a
+    # pageable destination costs an extra staging pass per step, INTEGRATION.md "Output buffers")
+    host_pin = torch.zeros((2, frames), dtype=torch.float32).pin_memory()
+    host_out = host_pin.numpy()
     if use_dist:
         dev_out = torch.zeros((2, frames), dtype=torch.float32, device=f"cuda:{local_rank}")
 
@@ -143,7 +146,7 @@ def main():
             ctx.RenderDevice([dev_out[0].data_ptr(), dev_out[1].data_ptr()], frames)
             dist.reduce(dev_out, dst=0, op=dist.ReduceOp.SUM)   # the destination-bus sum, RCCL over xGMI
             if rank == 0:
-                host_out[:] = dev_out.cpu().numpy()
+                host_pin.copy_(dev_out)   # blocking D2H into the page-locked output buffer
 
     def sync():
         torch.cuda.synchronize()
