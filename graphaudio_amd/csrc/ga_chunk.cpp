@@ -2217,9 +2217,7 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
       if (ns_ > 0) ex.plan.add(LK_MAC, [=](uint8_t* base) { launch_spectral_mac_b(st, (const ConvSetB*)(base + so), ns_, nn, hist, plb); });
       for (auto& kv : setsC) {
         const int Pc = kv.first;
-        int N2 = 1;
-        while (N2 < Pc) N2 <<= 1;
-        N2 *= 4;
+        const int N2 = tapFftSize(Pc);
         const int Lc = N2 - (Pc - 1);
         const int nseg = (nn + Lc - 1) / Lc;
         size_t co = ex.plan.putv(kv.second);

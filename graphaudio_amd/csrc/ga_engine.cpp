@@ -226,6 +226,7 @@ void Context::disconnectFrom(int src, int out, InRef in) {
   }
 }
 void Context::outputDisconnectAll(int src, int out) {
+  graphVersion++;
   OutputS& o = nodes[src]->outputs[out];
   std::vector<InRef> ins = o.connectedInputs;
   o.connectedInputs.clear();
@@ -601,12 +602,6 @@ const float2* Context::twiddlesC(int N2) {
   GA_HIP(hipMemcpy(d, t.data(), sizeof(float2) * N2, hipMemcpyHostToDevice));
   twC[N2] = d;
   return d;
-}
-// N2 = 4 * 2^ceil(log2 P): segment efficiency (N2 - P + 1) / N2 >= 75 %
-static int tapFftSize(int P) {
-  int n = 1;
-  while (n < P) n <<= 1;
-  return 4 * n;
 }
 void Context::ensureTapSpectra(IrSpectra& ir) {
   if (ir.hspec) return;

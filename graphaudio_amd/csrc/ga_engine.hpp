@@ -12,6 +12,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <deque>
@@ -265,6 +266,14 @@ struct ConvGroup {
   int ovCur = 0;
   bool histZero = true;
 };
+
+// FFT length of formulation C for P partitions: N2 = 4 * 2^ceil(log2 P), so that the valid part of a segment is
+// (N2 - P + 1) / N2 >= 75 %; the kernels exist for 1024, 2048 and 4096 points (65 <= P <= 128 runs with 1024)
+inline int tapFftSize(int P) {
+  int n = 1;
+  while (n < P) n <<= 1;
+  return std::max(1024, 4 * n);
+}
 
 struct DevArena {  // grow-only device scratch
   void* p = nullptr;

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 namespace ga {
@@ -1052,7 +1053,8 @@ void launch_tap_spectra(hipStream_t s, float2* hs, const float* hr, const float*
   dim3 g(kBins, nch), b(256);
   if (N2 == 1024) hipLaunchKernelGGL(tap_spectra_kernel<1024>, g, b, 0, s, hs, hr, hi, P, tw);
   else if (N2 == 2048) hipLaunchKernelGGL(tap_spectra_kernel<2048>, g, b, 0, s, hs, hr, hi, P, tw);
-  else hipLaunchKernelGGL(tap_spectra_kernel<4096>, g, b, 0, s, hs, hr, hi, P, tw);
+  else if (N2 == 4096) hipLaunchKernelGGL(tap_spectra_kernel<4096>, g, b, 0, s, hs, hr, hi, P, tw);
+  else { fprintf(stderr, "graphaudio_hip: no taps-spectrum kernel for %d points\n", N2); abort(); }
 }
 
 // ---- register/LDS hybrid FFT for the tconv kernel -------------------------------------------------------------------
@@ -1242,7 +1244,8 @@ void launch_tconv(hipStream_t s, const ConvSetC* sets_dev, int nsets, int nblock
   dim3 grid(gx, kBins), block(256);
   if (N2 == 1024) hipLaunchKernelGGL(tconv_kernel<1024>, grid, block, lds, s, sets_dev, nsets, nseg, nblocks, hist, pl, tw);
   else if (N2 == 2048) hipLaunchKernelGGL(tconv_kernel<2048>, grid, block, lds, s, sets_dev, nsets, nseg, nblocks, hist, pl, tw);
-  else hipLaunchKernelGGL(tconv_kernel<4096>, grid, block, lds, s, sets_dev, nsets, nseg, nblocks, hist, pl, tw);
+  else if (N2 == 4096) hipLaunchKernelGGL(tconv_kernel<4096>, grid, block, lds, s, sets_dev, nsets, nseg, nblocks, hist, pl, tw);
+  else { fprintf(stderr, "graphaudio_hip: no block-axis FFT kernel for %d points\n", N2); abort(); }
 }
 
 // ---- packed float2 arithmetic --------------------------------------------------------------------------------------
@@ -1575,7 +1578,8 @@ void launch_tconv16(hipStream_t s, const ConvSetC* sets_dev, int nsets, int nblo
   if (nsets <= 0 || nblocks <= 0) return;
   if (N2 == 1024) launch_tconv16_n<1024>(s, sets_dev, nsets, nblocks, hist, pl, tw16, nseg);
   else if (N2 == 2048) launch_tconv16_n<2048>(s, sets_dev, nsets, nblocks, hist, pl, tw16, nseg);
-  else launch_tconv16_n<4096>(s, sets_dev, nsets, nblocks, hist, pl, tw16, nseg);
+  else if (N2 == 4096) launch_tconv16_n<4096>(s, sets_dev, nsets, nblocks, hist, pl, tw16, nseg);
+  else { fprintf(stderr, "graphaudio_hip: no block-axis FFT kernel for %d points\n", N2); abort(); }
 }
 
 // ---- plane utilities ----------------------------------------------------------------------------------

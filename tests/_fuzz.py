@@ -335,6 +335,29 @@ def run_random_session(ctx, seed, frames=128 * 48, max_piece=128 * 9, keep=None)
                     s.PlaybackRate.LinearRampToValueAtTime(float(rng.uniform(0.5, 2.0)), now + float(rng.uniform(0.01, 0.04)))
         return kind
 
+    # nodes taken out of the graph for a while (not reachable from the destination = not processed, state frozen) and put back
+    # later; decided by a generator of its own so that the sessions of earlier sweeps keep their action sequences
+    rng3 = np.random.default_rng(seed ^ 0x0F0F)
+    parked = []
+
+    def unplug_or_replug():
+        if parked and rng3.random() < 0.5:
+            n = parked.pop(int(rng3.integers(0, len(parked))))
+            if id(n) in dead:
+                return "replug_dead"
+            buses = [b for b in h["buses"] if id(b) not in dead and b is not n]
+            tgt = buses[int(rng3.integers(0, len(buses)))] if buses and rng3.random() < 0.5 else None
+            n.Connect(tgt if tgt is not None else ctx.Destination)
+            return "replug"
+        cands = [x for x in gains + biquads + convs + h.get("StereoPannerNode", []) + h.get("DelayNode", [])
+                 if id(x) not in dead and not any(x is q for q in parked)]
+        if not cands:
+            return "unplug_none"
+        n = cands[int(rng3.integers(0, len(cands)))]
+        n.Disconnect()
+        parked.append(n)
+        return "unplug"
+
     global last_pieces, details
     last_pieces = []
     details = []
@@ -346,6 +369,11 @@ def run_random_session(ctx, seed, frames=128 * 48, max_piece=128 * 9, keep=None)
         pos += n
         piece += 1
         last_pieces.append(pos)
+        if rng3.random() < 0.2:
+            try:
+                log.append((piece, unplug_or_replug(), None))
+            except Exception as e:
+                log.append((piece, "?", type(e).__name__))
         for _ in range(int(rng.integers(0, 4))):
             try:
                 k = act(ctx.CurrentTime)

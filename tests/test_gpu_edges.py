@@ -108,3 +108,44 @@ def test_many_control_segments_in_one_render():
     assert G.rms(ro) > 1e-3
     assert np.array_equal(ro, go)
     assert segs > 300
+
+
+@pytest.mark.parametrize("taps", [128 * 9, 128 * 70])   # per-node matrix-core path / block-axis FFT path
+def test_convolver_unplugged_for_a_while_keeps_its_state(taps):
+    """A convolver that is not reachable from the destination is not processed (pull model): its frequency-domain delay
+    line freezes and continues when it is connected again.  On the device the delay line of a convolver lives in the
+    spectra planes of the chunk that last ran it -- it has to survive the chunks in which other convolvers reuse them."""
+    def run(ctx):
+        if isinstance(ctx, OfflineAudioContext):
+            ctx.SetOption("max_chunk_blocks", 2)
+        ctx.Destination.SetChannelCount(2)
+        convs = []
+        for v in range(3):
+            s = AudioBufferSourceNode(ctx)
+            s.Buffer = PlayableAudioBuffer.FromMonoArray(G.voice(70 + v, 128 * 40), SR)
+            c = ConvolverNode(ctx)
+            c.Buffer = PlayableAudioBuffer.FromChannelArrays([G.synth_ir(ch, taps, seed0=50 + 10 * v) for ch in range(2)], SR)
+            s.Connect(c)
+            c.Connect(ctx.Destination)
+            s.Start()
+            convs.append(c)
+        out = np.zeros((2, 128 * 40), np.float32)
+        pos = 0
+        def piece(nblk):
+            nonlocal pos
+            ctx.Render(out, 128 * nblk, pos)
+            pos += 128 * nblk
+        piece(5)
+        convs[1].Disconnect()          # node 1 drops out: nodes 0 and 2 keep running (their rows move up)
+        piece(3)
+        convs[0].Disconnect()
+        piece(4)
+        convs[1].Connect(ctx.Destination)
+        piece(7)
+        convs[0].Connect(ctx.Destination)
+        piece(21)
+        return out
+    ro, go = both(run)
+    assert G.rms(ro) > 1e-3
+    err = G.rms(ro - go)
+    assert err <= 2e-6 * max(G.rms(ro), 1e-3), err
