@@ -86,8 +86,12 @@ def build_random_graph(ctx, seed, frames, keep=None, handles=None):
                 taps = int(rng.integers(10, 700))
                 n.Normalize = bool(rng.random() < 0.7)
                 n.EnableTrueStereo = bool(rng.random() < 0.7)
-                n.Buffer = PlayableAudioBuffer.FromChannelArrays(
-                    [(rng.standard_normal(taps) * 0.1).astype(np.float32) for _ in range(c)], SR)
+                ir = [(rng.standard_normal(taps) * 0.1).astype(np.float32) for _ in range(c)]
+                if rng2.random() < 0.25:   # more than 64 partitions: the block-axis FFT formulation (1024 / 2048 points)
+                    taps = int(rng2.integers(128 * 64 + 1, 128 * 300))
+                    env = np.exp(-6.0 * np.arange(taps) / taps)
+                    ir = [(rng2.standard_normal(taps) * 0.02 * env).astype(np.float32) for _ in range(c)]
+                n.Buffer = PlayableAudioBuffer.FromChannelArrays(ir, SR)
             if rng.random() < 0.25 and not isinstance(n, ConvolverNode):
                 n.Inputs[0].SetChannelCount(int(rng.choice([1, 2, 3])))
                 n.Inputs[0].SetChannelCountMode(ChannelCountMode(int(rng.integers(0, 3))))
