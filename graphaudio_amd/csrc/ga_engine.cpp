@@ -364,18 +364,15 @@ ConvRowRef Context::addGroupRow(const std::shared_ptr<IrSpectra>& ir, int ch, in
 void Context::assignConvPaths(const std::vector<int>& topo) {
   std::map<IrSpectra*, int> users;
   std::map<IrSpectra*, bool> hasA;
-  for (int id : topo) {
-    NodeS& nd = *nodes[id];
-    if (nd.type != GA_NODE_CONVOLVER || !nd.ir) continue;
-    users[nd.ir.get()]++;
-    if (nd.convPath == 1) {
-      hasA[nd.ir.get()] = true;
-      // a group is executed once per chunk at ONE convolver depth; a graph edit that moved this node to another depth
-      // moves its rows (FDL column + overlap tail) to the group of that depth
+  // a group is executed once per chunk at ONE convolver depth, for all of its rows; a graph edit that moved a node to another
+  // depth moves its rows (FDL column + overlap tail) to the group of that depth.  A node that is no longer reachable from the
+  // destination is not processed at all (pull model): its rows wait in a group of their own (depth -1, never executed), so
+  // that the delay line keeps its content, and come back the same way when the node is connected again.
+  auto moveRows = [&](NodeS& nd, int id, int depth) {
       for (size_t slot = 0; slot < nd.convRows.size(); slot++) {
         ConvRowRef old = nd.convRows[slot];
-        if (old.group->depth == nd.depth) continue;
-        ConvRowRef nw = addGroupRow(nd.ir, old.group->irCh, nd.depth, id);
+        if (old.group->depth == depth) continue;
+        ConvRowRef nw = addGroupRow(nd.ir, old.group->irCh, depth, id);
         ensureGroupState(*nw.group);
         ConvGroup& og = *old.group;
         ConvGroup& ng = *nw.group;
@@ -393,6 +390,19 @@ void Context::assignConvPaths(const std::vector<int>& topo) {
         og.rows[old.idx] = {-1, 0};
         nd.convRows[slot] = nw;
       }
+  };
+  for (auto& np : nodes) {
+    if (!np) continue;
+    NodeS& nd = *np;
+    if (nd.type == GA_NODE_CONVOLVER && nd.ir && nd.convPath == 1 && !nd.reachable && !nd.disposed) moveRows(nd, nd.id, -1);
+  }
+  for (int id : topo) {
+    NodeS& nd = *nodes[id];
+    if (nd.type != GA_NODE_CONVOLVER || !nd.ir) continue;
+    users[nd.ir.get()]++;
+    if (nd.convPath == 1) {
+      hasA[nd.ir.get()] = true;
+      moveRows(nd, id, nd.depth);
     }
   }
   for (int id : topo) {

@@ -352,7 +352,7 @@ def run_random_session(ctx, seed, frames=128 * 48, max_piece=128 * 9, keep=None)
             buses = [b for b in h["buses"] if id(b) not in dead and b is not n]
             tgt = buses[int(rng3.integers(0, len(buses)))] if buses and rng3.random() < 0.5 else None
             n.Connect(tgt if tgt is not None else ctx.Destination)
-            return "replug"
+            return "replug:" + type(n).__name__
         cands = [x for x in gains + biquads + convs + h.get("StereoPannerNode", []) + h.get("DelayNode", [])
                  if id(x) not in dead and not any(x is q for q in parked)]
         if not cands:
@@ -360,7 +360,7 @@ def run_random_session(ctx, seed, frames=128 * 48, max_piece=128 * 9, keep=None)
         n = cands[int(rng3.integers(0, len(cands)))]
         n.Disconnect()
         parked.append(n)
-        return "unplug"
+        return "unplug:" + type(n).__name__
 
     global last_pieces, details
     last_pieces = []

@@ -110,8 +110,8 @@ def test_many_control_segments_in_one_render():
     assert segs > 300
 
 
-@pytest.mark.parametrize("taps", [128 * 9, 128 * 70])   # per-node matrix-core path / block-axis FFT path
-def test_convolver_unplugged_for_a_while_keeps_its_state(taps):
+@pytest.mark.parametrize("taps,shared", [(128 * 9, False), (128 * 70, False), (128 * 9, True)])
+def test_convolver_unplugged_for_a_while_keeps_its_state(taps, shared):   # per-node MFMA path / block-axis FFT / shared-IR GEMM rows
     """A convolver that is not reachable from the destination is not processed (pull model): its frequency-domain delay
     line freezes and continues when it is connected again.  On the device the delay line of a convolver lives in the
     spectra planes of the chunk that last ran it -- it has to survive the chunks in which other convolvers reuse them."""
@@ -120,11 +120,13 @@ def test_convolver_unplugged_for_a_while_keeps_its_state(taps):
             ctx.SetOption("max_chunk_blocks", 2)
         ctx.Destination.SetChannelCount(2)
         convs = []
-        for v in range(3):
+        common = PlayableAudioBuffer.FromChannelArrays([G.synth_ir(ch, taps, seed0=40) for ch in range(2)], SR)
+        for v in range(9 if shared else 3):   # 8 or more users of one impulse response become rows of one group
             s = AudioBufferSourceNode(ctx)
             s.Buffer = PlayableAudioBuffer.FromMonoArray(G.voice(70 + v, 128 * 40), SR)
             c = ConvolverNode(ctx)
-            c.Buffer = PlayableAudioBuffer.FromChannelArrays([G.synth_ir(ch, taps, seed0=50 + 10 * v) for ch in range(2)], SR)
+            c.Buffer = common if shared else PlayableAudioBuffer.FromChannelArrays(
+                [G.synth_ir(ch, taps, seed0=50 + 10 * v) for ch in range(2)], SR)
             s.Connect(c)
             c.Connect(ctx.Destination)
             s.Start()
