@@ -60,7 +60,8 @@ def _session_pair(seed, chunk=11):
     return ref, ref_log, got, got_log
 
 
-@pytest.mark.parametrize("seed", list(range(60)))
+# 2850: a shared-IR convolver taken out of the graph for 17 blocks and plugged back (its delay line has to freeze)
+@pytest.mark.parametrize("seed", list(range(60)) + [2850])
 def test_random_edit_session_matches_oracle(seed):
     """The graph is edited between render pieces (parameter writes, automation, stop, new voices, dispose, rewiring,
     impulse-response swaps, audio-rate modulation, channel settings): same output and the same exceptions."""
