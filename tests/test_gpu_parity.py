@@ -210,6 +210,7 @@ def test_gain_audio_rate_modulation_bit_exact():
 
 
 @pytest.mark.parametrize("taps,voices,time_fft", [
+    (9000, 3, 1),      # P = 71   -> block-axis FFT, smallest kernel (N2 = 1024 although 4 * 128 = 512 would do)
     (20000, 3, 1),     # P = 157  -> block-axis FFT with N2 = 1024
     (100000, 2, 1),    # P = 782  -> N2 = 4096 (104 KB of LDS)
     (40000, 3, 0),     # P = 313  -> formulation B, two tap segments of 256
