@@ -2064,12 +2064,15 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
       std::vector<const float*> ovIn;
       std::vector<float*> ovOut;
       double flops = 0;
+      std::vector<const float*> chIn;   // (scratch vectors live outside the node loop: a thousand convolvers per chunk)
+      std::vector<float*> slotOut;
+      std::vector<int> cols;
       for (int id : bNodes) {
         NodeS& nd = *nodes[id];
         const int P = nd.ir->P, h = P - 1;
         auto& ci = ex.convIn[id];
         // chunk-long input pointer of every input channel (stable view, or a materialised copy)
-        std::vector<const float*> chIn(nd.bInCh, nullptr);
+        chIn.assign(nd.bInCh, nullptr);
         for (int c = 0; c < nd.bInCh; c++) {
           const float* stable = nullptr;
           bool same = true, first = true;
@@ -2143,7 +2146,7 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
           restore.push_back(HistJobB{xi_row + hist + (int)n, nullptr, txb, 0, tailn, 0});
         }
         // slots: discrete -> slot c reads input c, IR channel c ; true stereo -> (L,h0) (L,h1) (R,h2) (R,h3)
-        std::vector<float*> slotOut(nd.bSlots, nullptr);
+        slotOut.assign(nd.bSlots, nullptr);
         for (int slot = 0; slot < nd.bSlots; slot++) {
           if (nd.isTrueStereo) {
             float* tmp = getSlab(*this);
@@ -2157,7 +2160,7 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
         }
         // sets: columns grouped by the x-row they read, at most 16 per set, y rows consecutive per set
         for (int xc = 0; xc < nxr; xc++) {
-          std::vector<int> cols;
+          cols.clear();
           for (int slot = 0; slot < nd.bSlots; slot++) {
             int inc = nd.isTrueStereo ? (slot >> 1) : slot;
             if (nd.bShared || inc == xc) cols.push_back(slot);
