@@ -2059,7 +2059,9 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
                       (float*)planesB[2].p + rowY0 * kBins * tyb, (float*)planesB[3].p + rowY0 * kBins * tyb, txb, tyb};
       std::vector<ConvRowIO> xrows, yrows;
       std::vector<ConvSetB> sets;
-      std::map<int, std::vector<ConvSetC>> setsC;   // by P: one launch per distinct segment length
+      std::map<int, std::vector<ConvSetC>> setsC;   // by P: launches per distinct segment length
+      struct SetTaps { IrSpectra* ir; int slot[16]; };
+      std::map<int, std::vector<SetTaps>> setsCTaps;   // which taps spectra each column of a set needs (filled per FFT length)
       std::vector<HistJobB> restore;
       std::vector<const float*> ovIn;
       std::vector<float*> ovOut;
@@ -2180,12 +2182,19 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
               int slot = cols[c0 + j];
               st.hr[j] = nd.ir->hr + (size_t)slot * kBins * P;   // slot index == IR channel index in both modes
               st.hi[j] = nd.ir->hi + (size_t)slot * kBins * P;
-              if (nd.convPath == 3) sc.hs[j] = nd.ir->hspec + (size_t)slot * kBins * nd.ir->N2;
+              sc.hs[j] = nullptr;   // per FFT length, below
               yrows.push_back(ConvRowIO{nullptr, slotOut[slot]});
               ovIn.push_back(nd.bOverlap + ((size_t)slot * 2 + nd.bOvCur) * kBlock);
               ovOut.push_back(nd.bOverlap + ((size_t)slot * 2 + (nd.bOvCur ^ 1)) * kBlock);
             }
-            if (nd.convPath == 3) setsC[P].push_back(sc); else sets.push_back(st);
+            if (nd.convPath == 3) {
+              SetTaps tp{nd.ir.get(), {}};
+              for (int j = 0; j < st.ncol; j++) tp.slot[j] = cols[c0 + j];
+              setsC[P].push_back(sc);
+              setsCTaps[P].push_back(tp);
+            } else {
+              sets.push_back(st);
+            }
           }
         }
         nd.bOvCur ^= 1;
@@ -2220,18 +2229,32 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
       if (ns_ > 0) ex.plan.add(LK_MAC, [=](uint8_t* base) { launch_spectral_mac_b(st, (const ConvSetB*)(base + so), ns_, nn, hist, plb); });
       for (auto& kv : setsC) {
         const int Pc = kv.first;
-        const int N2 = tapFftSize(Pc);
-        const int Lc = N2 - (Pc - 1);
-        const int nseg = (nn + Lc - 1) / Lc;
-        size_t co = ex.plan.putv(kv.second);
-        const int nc = (int)kv.second.size();
-        static const char* r16env = getenv("GA_TCONV_RADIX16");   // A/B switch for measurements
+        static const char* r16env = getenv("GA_TCONV_RADIX16");   // A/B switches for measurements
+        static const char* planenv = getenv("GA_TCONV_MIXED");
         const bool r16 = r16env ? atoi(r16env) != 0 : useRadix16;
-        const float2* twc = r16 ? twiddles16(N2) : twiddlesC(N2);
-        ex.plan.add(LK_MAC, [=](uint8_t* base) {
-          if (r16) launch_tconv16(st, (const ConvSetC*)(base + co), nc, nn, hist, plb, N2, twc, nseg);
-          else launch_tconv(st, (const ConvSetC*)(base + co), nc, nn, hist, plb, N2, twc, nseg);
-        });
+        std::vector<TconvLaunch> tplan;
+        if (r16 && !(planenv && atoi(planenv) == 0)) {
+          tplan = tconvPlan(nn, Pc);
+        } else {   // one FFT length for the whole chunk
+          const int N2 = tapFftSize(Pc), Lc = N2 - (Pc - 1);
+          tplan.push_back(TconvLaunch{N2, 0, (nn + Lc - 1) / Lc});
+        }
+        const std::vector<SetTaps>& taps = setsCTaps[Pc];
+        for (const TconvLaunch& tl : tplan) {
+          std::vector<ConvSetC> sv = kv.second;
+          for (size_t i = 0; i < sv.size(); i++) {
+            const float2* hsp = ensureTapSpectra(*taps[i].ir, tl.N2);
+            for (int j = 0; j < sv[i].ncol; j++) sv[i].hs[j] = hsp + (size_t)taps[i].slot[j] * kBins * tl.N2;
+          }
+          size_t co = ex.plan.putv(sv);
+          const int nc = (int)sv.size();
+          const int N2 = tl.N2, tbase = tl.tbase, nseg = tl.nseg;
+          const float2* twc = r16 ? twiddles16(N2) : twiddlesC(N2);
+          ex.plan.add(LK_MAC, [=](uint8_t* base) {
+            if (r16) launch_tconv16(st, (const ConvSetC*)(base + co), nc, nn, hist, plb, N2, twc, nseg, tbase);
+            else launch_tconv(st, (const ConvSetC*)(base + co), nc, nn, hist, plb, N2, twc, nseg);
+          });
+        }
       }
       ex.plan.add(LK_FFT, [=](uint8_t* base) {
         launch_irfft_ola_b(st, (const ConvRowIO*)(base + yo), ny, nn, plb, (const float* const*)(base + oi), (float* const*)(base + oo), tw, f64);

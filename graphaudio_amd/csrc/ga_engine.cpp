@@ -430,7 +430,6 @@ void Context::assignConvPaths(const std::vector<int>& topo) {
       nd.bHistZero = true;
       nd.bOvCur = 0;
       nd.convPath = pathC ? 3 : 2;
-      if (pathC) ensureTapSpectra(*nd.ir);
     }
   }
 }
@@ -613,14 +612,55 @@ const float2* Context::twiddlesC(int N2) {
   twC[N2] = d;
   return d;
 }
-void Context::ensureTapSpectra(IrSpectra& ir) {
-  if (ir.hspec) return;
-  ir.N2 = tapFftSize(ir.P);
-  size_t bytes = (size_t)ir.nch * kBins * ir.N2 * sizeof(float2);
-  ir.hspecBytes = bytes;
-  ir.hspec = (float2*)dalloc(bytes);
-  launch_tap_spectra(stream, ir.hspec, ir.hr, ir.hi, ir.nch, ir.P, ir.N2, twiddlesC(ir.N2));
+const float2* Context::ensureTapSpectra(IrSpectra& ir, int N2) {
+  float2*& h = ir.hspecN[IrSpectra::n2Index(N2)];
+  if (h) return h;
+  size_t bytes = (size_t)ir.nch * kBins * N2 * sizeof(float2);
+  ir.hspecBytes += bytes;
+  h = (float2*)dalloc(bytes);
+  launch_tap_spectra(stream, h, ir.hr, ir.hi, ir.nch, ir.P, N2, twiddlesC(N2));
   GA_HIP(hipGetLastError());
+  return h;
+}
+
+// Segments of the overlap-save convolution along the block axis: a segment of N2 points yields N2 - P + 1 blocks.  The chunk
+// is covered by the cheapest mix of the three kernel sizes.  Cost model fitted to MI355X measurements at 1024 rows (config 3
+// and its 32,768 / 131,072-tap variants): time = alpha(N2) x points + beta x valid blocks; beta is the same for every plan, so
+// only alpha counts (ms per 1000 points: 0.58 for 1024 and 2048, 0.70 for 4096, which runs one transform per workgroup).
+// P = 512, 3750 blocks -> one segment of 4096 + one of 1024 instead of three of 2048 (measured 4.46 vs 4.56 ms); a 128-block
+// render with P = 512 takes one 1024-point segment instead of a 2048-point one.  Larger sizes first, equal sizes in one launch.
+std::vector<Context::TconvLaunch> Context::tconvPlan(int nblocks, int P) const {
+  static const int sizes[3] = {1024, 2048, 4096};
+  static const double perPoint[3] = {0.577, 0.583, 0.70};
+  std::vector<double> best(nblocks + 1, 0.0);
+  std::vector<int> pick(nblocks + 1, -1);
+  for (int rem = 1; rem <= nblocks; rem++) {
+    best[rem] = 1e300;
+    for (int i = 0; i < 3; i++) {
+      const int L = sizes[i] - (P - 1);
+      if (L < sizes[i] / 4) continue;   // at least a quarter of a segment has to be output
+      const double c = sizes[i] * perPoint[i] + best[std::max(0, rem - L)];
+      if (c < best[rem]) { best[rem] = c; pick[rem] = i; }
+    }
+    if (pick[rem] < 0) {   // P too large for every size (cannot happen for P <= 1024): one size fits all
+      pick[rem] = 2;
+      best[rem] = 0;
+    }
+  }
+  int count[3] = {0, 0, 0};
+  for (int rem = nblocks; rem > 0;) {
+    const int i = pick[rem];
+    count[i]++;
+    rem -= std::min(rem, sizes[i] - (P - 1));
+  }
+  std::vector<TconvLaunch> plan;
+  int tbase = 0;
+  for (int i = 2; i >= 0; i--)
+    if (count[i] > 0) {
+      plan.push_back(TconvLaunch{sizes[i], tbase, count[i]});
+      tbase += count[i] * (sizes[i] - (P - 1));
+    }
+  return plan;
 }
 
 // host replay of the CubicResampler position recurrence for unbounded input (CubicResampler.cs:31-60)

@@ -96,9 +96,10 @@ struct IrSpectra {  // P zero-padded 256-point spectra per IR channel (Partition
   int nch = 0;
   float* hr = nullptr;  // [nch][129][P]
   float* hi = nullptr;
-  // formulation C: N2-point spectra of the taps along the partition axis, [nch][129][N2]
-  int N2 = 0;
-  float2* hspec = nullptr;
+  // formulation C: N2-point spectra of the taps along the partition axis, [nch][129][N2], for N2 = 1024, 2048, 4096
+  // (built on first use: the segment plan of a chunk may mix FFT lengths)
+  float2* hspecN[3] = {nullptr, nullptr, nullptr};
+  static int n2Index(int N2) { return N2 == 1024 ? 0 : N2 == 2048 ? 1 : 2; }
   size_t hBytes = 0, hspecBytes = 0;
   int64_t* devBytesRef = nullptr;   // the owning context's byte counter
   IrSpectra() = default;
@@ -107,7 +108,8 @@ struct IrSpectra {  // P zero-padded 256-point spectra per IR channel (Partition
   ~IrSpectra() {   // shared by the convolver nodes that use it and the context's cache; the last owner frees the device memory
     if (hr) (void)hipFree(hr);
     if (hi) (void)hipFree(hi);
-    if (hspec) (void)hipFree(hspec);
+    for (float2* h : hspecN)
+      if (h) (void)hipFree(h);
     if (devBytesRef) *devBytesRef -= (int64_t)(2 * hBytes + hspecBytes);
   }
 };
@@ -378,7 +380,9 @@ struct Context {
   const float2* twiddles16(int N2);
   std::map<int, float2*> tw16;
   bool useRadix16 = true;   // option `tconv_radix16`
-  void ensureTapSpectra(IrSpectra& ir);
+  const float2* ensureTapSpectra(IrSpectra& ir, int N2);
+  struct TconvLaunch { int N2, tbase, nseg; };
+  std::vector<TconvLaunch> tconvPlan(int nblocks, int P) const;   // FFT lengths of the segments that cover a chunk
   bool fft64 = false;            // option "fft64": double-precision 256-point transforms in the B-layout kernels (reference-like)
   bool useTimeFft = true;        // option "time_fft": formulation C for 64 < P <= 1024
   void updateBiquadCoefficients(NodeS& n, float frequency, float q, float gain);

@@ -1454,7 +1454,7 @@ __device__ __forceinline__ void fft16_own(f2 (&own)[16], f2* __restrict buf, con
 // Persistent workgroups (one per resident slot).  The G transforms of a workgroup serve G different (set, segment) items.
 template <int N2>
 __global__ __launch_bounds__(256, 3) void tconv16_kernel(const ConvSetC* __restrict sets, int nsets, int nseg, int nblocks, int hist,
-                                                      ConvPlanesB pl, const float2* __restrict twg) {
+                                                      ConvPlanesB pl, const float2* __restrict twg, int tbase) {
   using PL = R16Plan<N2>;
   constexpr int T = PL::T, G = PL::G;
   extern __shared__ f2 lds16[];
@@ -1485,7 +1485,7 @@ __global__ __launch_bounds__(256, 3) void tconv16_kernel(const ConvSetC* __restr
     const ConvSetC* __restrict S = &sets[live ? item / nseg : 0];
     const int seg = live ? item % nseg : 0;
     const int P = S->P;
-    const int t0 = seg * (N2 - (P - 1));
+    const int t0 = tbase + seg * (N2 - (P - 1));
     // window element e = t + T m is block t0 - (P - 1) + e; plane index hist + block >= 0 because hist >= P - 1
     const int first = hist + t0 - (P - 1);
     const int lim = (live && t0 < nblocks) ? nblocks - (t0 - (P - 1)) : 0;   // elements at or beyond `lim` are zero padding
@@ -1509,13 +1509,13 @@ __global__ __launch_bounds__(256, 3) void tconv16_kernel(const ConvSetC* __restr
     const int P = S->P;
     const int ncol = live ? S->ncol : 0;
     const int L = N2 - (P - 1);
-    const int t0 = seg * L;
+    const int t0 = tbase + seg * L;
     const bool work = live && t0 < nblocks;
     int maxcol = 0;   // the same for every thread of the workgroup: barriers inside fft16_own
 #pragma unroll
     for (int gg = 0; gg < G; gg++) {
       const int it = base + gg;
-      if (it < total && (it % nseg) * L < nblocks) maxcol = max(maxcol, sets[it / nseg].ncol);
+      if (it < total && tbase + (it % nseg) * L < nblocks) maxcol = max(maxcol, sets[it / nseg].ncol);
     }
     if (maxcol == 0) {
       if (w + 1 < w1) load_window(w + 1, xf);
@@ -1557,7 +1557,7 @@ __global__ __launch_bounds__(256, 3) void tconv16_kernel(const ConvSetC* __restr
 }
 template <int N2>
 static void launch_tconv16_n(hipStream_t s, const ConvSetC* sets_dev, int nsets, int nblocks, int hist, ConvPlanesB pl, const float2* tw16,
-                             int nseg) {
+                             int nseg, int tbase) {
   using PL = R16Plan<N2>;
   const size_t lds = (size_t)(PL::T2 + PL::T3 + PL::G * TC16_PADDED(N2)) * sizeof(float2);
   static int groups = 0;
@@ -1571,14 +1571,14 @@ static void launch_tconv16_n(hipStream_t s, const ConvSetC* sets_dev, int nsets,
   }
   const long long steps = ((long long)nsets * nseg + PL::G - 1) / PL::G;
   dim3 grid((unsigned)std::min<long long>(steps * kBins, groups)), block(256);
-  hipLaunchKernelGGL(tconv16_kernel<N2>, grid, block, lds, s, sets_dev, nsets, nseg, nblocks, hist, pl, tw16);
+  hipLaunchKernelGGL(tconv16_kernel<N2>, grid, block, lds, s, sets_dev, nsets, nseg, nblocks, hist, pl, tw16, tbase);
 }
 void launch_tconv16(hipStream_t s, const ConvSetC* sets_dev, int nsets, int nblocks, int hist, ConvPlanesB pl, int N2, const float2* tw16,
-                    int nseg) {
-  if (nsets <= 0 || nblocks <= 0) return;
-  if (N2 == 1024) launch_tconv16_n<1024>(s, sets_dev, nsets, nblocks, hist, pl, tw16, nseg);
-  else if (N2 == 2048) launch_tconv16_n<2048>(s, sets_dev, nsets, nblocks, hist, pl, tw16, nseg);
-  else if (N2 == 4096) launch_tconv16_n<4096>(s, sets_dev, nsets, nblocks, hist, pl, tw16, nseg);
+                    int nseg, int tbase) {
+  if (nsets <= 0 || nblocks <= 0 || nseg <= 0) return;
+  if (N2 == 1024) launch_tconv16_n<1024>(s, sets_dev, nsets, nblocks, hist, pl, tw16, nseg, tbase);
+  else if (N2 == 2048) launch_tconv16_n<2048>(s, sets_dev, nsets, nblocks, hist, pl, tw16, nseg, tbase);
+  else if (N2 == 4096) launch_tconv16_n<4096>(s, sets_dev, nsets, nblocks, hist, pl, tw16, nseg, tbase);
   else { fprintf(stderr, "graphaudio_hip: no block-axis FFT kernel for %d points\n", N2); abort(); }
 }
 

@@ -101,8 +101,9 @@ void launch_tap_spectra(hipStream_t s, float2* hs, const float* hr, const float*
 void launch_tconv(hipStream_t s, const ConvSetC* sets_dev, int nsets, int nblocks, int hist, ConvPlanesB pl, int N2, const float2* tw,
                   int nseg);
 // radix-16 variant; tw16 = [15][16] W_256^(kk m) followed by [N2/256 - 1][256] W_N2^(j m) (Context::twiddles16)
+// the launch covers the nseg segments that start at block `tbase` (a chunk may be covered by launches of different N2)
 void launch_tconv16(hipStream_t s, const ConvSetC* sets_dev, int nsets, int nblocks, int hist, ConvPlanesB pl, int N2, const float2* tw16,
-                    int nseg);
+                    int nseg, int tbase);
 
 // ---- graph plumbing kernels ------------------------------------------------------------------------
 // out[f0 + i] = ((0 + t0[f0+i]) + t1[f0+i]) + ...  in term order (AudioNodeInput.cs:118-132,182-244)

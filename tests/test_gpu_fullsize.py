@@ -102,3 +102,20 @@ def test_superposition_and_time_invariance(time_fft):
     # FFT-based formulations leave ~1e-9 of circular-convolution rounding where the direct sum gives exact zeros
     assert np.abs(delayed[:, : k * 128]).max() <= (1e-6 if time_fft else 0.0)
     assert close(delayed[:, k * 128:], bus[:, : frames - k * 128], exact=not time_fft)
+
+
+@pytest.mark.parametrize("blocks", [1700, 3750])
+def test_mixed_segment_lengths_of_the_block_axis_fft(blocks):
+    """One chunk of 1,700 blocks is covered by a 2048-point + a 1024-point segment, the bench's 3,750 blocks by 4096 + 1024
+    (Context::tconvPlan): the second launch starts in the middle of the chunk.  Whole-render parity against the oracle."""
+    frames = blocks * 128
+    outs = []
+    for mk in (OracleContext, OfflineAudioContext):
+        ctx = mk(SR)
+        build(ctx, range(2), frames)
+        outs.append(G.render(ctx, 2, frames))
+    ref, got = outs
+    err = G.rms(ref - got)
+    assert err <= 1e-5 and err / G.rms(ref) < 2e-6
+    last = slice((blocks - 100) * 128, None)      # the blocks the trailing short segment produced
+    assert G.rms(ref[:, last] - got[:, last]) / G.rms(ref[:, last]) < 2e-6
