@@ -178,14 +178,14 @@ def main():
         ach_tflops = d["mac_flops_total"] / mac_s / 1e12 if mac_s > 0 else 0.0
         ach_gbs = d["mac_bytes_total"] / mac_s / 1e9 if mac_s > 0 else 0.0
         blocks = frames // 128
-        # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes of this exact workload
-        # (profiles/r01_pmc_hbm_traffic_v3_radix16.json: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE calibrated per kernel on
-        # a known byte count as MI355X_MICROARCH.md prescribes for gfx950); null for other shapes
+        # HBM bytes per step of the dominant stage from rocprofv3 PMC passes of this exact workload
+        # (profiles/r01_pmc_hbm_traffic_v4_mixed_plan.json: separate FETCH_SIZE / WRITE_SIZE passes as MI355X_MICROARCH.md prescribes;
+        # the stage is two launches of one kernel template, 4096- and 1024-point segments); null for other shapes
         traffic = None
         try:
             if world == 1 and voices_total == 1024 and args.taps == 65536 and blocks == 3750 and not args.direct:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_v3_radix16.json")))
-                traffic = pm["tconv16_kernel_hbm_bytes_per_launch"]["total"]
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_v4_mixed_plan.json")))
+                traffic = pm["tconv16_stage_hbm_bytes_per_step"]["total"]
             elif world == 1 and voices_total == 1024 and args.taps == 65536 and blocks == 3750:
                 pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
                 traffic = pm["spectral_mac_shared_kernel_hbm_bytes_per_launch"]["total"]
@@ -199,7 +199,8 @@ def main():
             form = ("direct partition sum, time-batched on the f32 matrix cores; dense f32 MFMA peak 157.3 TFLOP/s is the "
                     "binding roofline: see roofline_flops")
         else:
-            kernel = "tconv16_kernel<2048> (overlap-save FFT convolution along the block axis: radix 16-16-8 Stockham, packed f32, two LDS round trips)"
+            kernel = ("tconv16_kernel<N2> (overlap-save FFT convolution along the block axis: radix 16-16-R Stockham, packed f32, two LDS "
+                      "round trips); one step = one 4096-point segment launch + one 1024-point launch, timed together")
             form = ("partition sum evaluated as an FFT convolution over the block index (formulation C, DESIGN.md): ~20x "
                     "fewer flops than the direct sum, so the stage is bound by HBM traffic of the spectra planes")
         rec = {
