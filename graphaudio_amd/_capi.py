@@ -133,6 +133,7 @@ SIGNATURES = {
     "process_blocks": (_i, [_vp, _pp, _i, _i64, _i]),
     "process_blocks_interleaved": (_i, [_vp, C.POINTER(C.c_float), _i, _i64, _i]),
     "context_set_stream": (_i, [_vp, _vp]),
+    "synchronize": (_i, [_vp]),
 }
 
 

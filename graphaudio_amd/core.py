@@ -600,6 +600,10 @@ class OfflineAudioContext(AudioContextBase):
     def SetStream(self, hip_stream: int):
         self._call("context_set_stream", C.c_void_p(int(hip_stream)))
 
+    def Synchronize(self):
+        """Wait for the renders enqueued under ``SetOption("async", 1)`` (include/graphaudio_hip.h, ga_synchronize)."""
+        self._call("synchronize")
+
 
 # The reference's class name for the stock CPU context is OfflineAudioContext; the drop-in replacement a C# user
 # instantiates is HipOfflineAudioContext (bindings/csharp/HipOfflineAudioContext.cs).  Same object here.

@@ -184,7 +184,7 @@ void Context::render(float* const* out, int channels, int64_t frameCount, int64_
     for (int ch = 0; ch < channels; ch++)
       GA_HIP(hipMemcpyAsync(out[ch] + startIndex, cacheDev + (size_t)ch * kBlock + (kBlock - cachedFrames), sizeof(float) * toCopy,
                             kind, stream));
-    GA_HIP(hipStreamSynchronize(stream));
+    if (!asyncMode) GA_HIP(hipStreamSynchronize(stream));
     written = toCopy;
     cachedFrames -= toCopy;
   }
@@ -210,7 +210,7 @@ void Context::render(float* const* out, int channels, int64_t frameCount, int64_
                               hipMemcpyDeviceToDevice, stream));
       cachedFrames = (int)excess;
     }
-    GA_HIP(hipStreamSynchronize(stream));
+    if (!asyncMode) GA_HIP(hipStreamSynchronize(stream));
     written += toCopy;
   }
   stats.device_bytes_in_use = devBytes;
@@ -278,6 +278,10 @@ int ga_set_option(ga_context* ctx, const char* key, double value) {
     else if (k == "time_fft") c.useTimeFft = value != 0;
     else if (k == "fft64") c.fft64 = value != 0;
     else if (k == "tconv_radix16") c.useRadix16 = value != 0;
+    else if (k == "async") {
+      if (c.asyncMode && value == 0) c.synchronize();
+      c.asyncMode = value != 0;
+    }
     else if (k == "mem_budget_fraction") c.memBudgetFraction = std::min(0.95, std::max(0.05, value));
     else fail(GA_ERR_INVALID_ARGUMENT, "unknown option " + k);
   });
@@ -285,6 +289,7 @@ int ga_set_option(ga_context* ctx, const char* key, double value) {
 int ga_get_stats(ga_context* ctx, ga_stats* out) {
   return guard(ctx, [&](Context& c) {
     if (!out) fail(GA_ERR_INVALID_ARGUMENT, "null pointer");
+    c.harvestProfile(true);
     c.stats.device_bytes_in_use = c.devBytes;
     c.stats.n_nodes = (int)c.nodes.size();
     int rows = 0;
@@ -292,6 +297,9 @@ int ga_get_stats(ga_context* ctx, ga_stats* out) {
     c.stats.n_conv_rows = rows;
     *out = c.stats;
   });
+}
+int ga_synchronize(ga_context* ctx) {
+  return guard(ctx, [&](Context& c) { c.synchronize(); });
 }
 int ga_context_set_stream(ga_context* ctx, void* hip_stream) {
   return guard(ctx, [&](Context& c) {

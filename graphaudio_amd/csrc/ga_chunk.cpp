@@ -21,7 +21,6 @@ static inline int64_t roundup(int64_t v, int64_t m) { return (v + m - 1) / m * m
 // ======================================================================================================
 // job tables: built on the host while planning, uploaded once, then every recorded launch runs in order
 // ======================================================================================================
-enum LaunchKind { LK_OTHER = 0, LK_FFT = 1, LK_MAC = 2 };
 struct Plan {
   std::vector<uint8_t> host;
   struct L {
@@ -1228,6 +1227,7 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
     if (nd.type == GA_NODE_STEREO_PANNER && nd.panOnDevice && nd.params[0].events.empty()) {
       PanState tmp;   // back to a constant pan: the gains the automated run left on the device are the node's state
       GA_HIP(hipStreamSynchronize(stream));
+      if (asyncMode) GA_HIP(hipStreamSynchronize(stream));   // the state the previous chunk left
       GA_HIP(hipMemcpy(&tmp, nd.panDev, sizeof(PanState), hipMemcpyDeviceToHost));
       nd.panLast = tmp.last_pan;
       nd.panGL = tmp.gain_l;
@@ -1240,6 +1240,7 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
       if (!automated) {  // back to constant parameters: fetch the coefficients the automated run left on the device
         BiquadDynState tmp;
         GA_HIP(hipStreamSynchronize(stream));
+        if (asyncMode) GA_HIP(hipStreamSynchronize(stream));
         GA_HIP(hipMemcpy(&tmp, nd.bqDyn, 24, hipMemcpyDeviceToHost));
         nd.b0 = tmp.b0; nd.b1 = tmp.b1; nd.b2 = tmp.b2; nd.a1 = tmp.a1; nd.a2 = tmp.a2;
         nd.coefDirty = tmp.dirty != 0;
@@ -2306,17 +2307,21 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
   // ---- upload tables, run ----
   ex.trajOffFinal = ex.plan.putv(ex.traj);
   size_t tbytes = ex.plan.host.size();
-  if (tablesHostBytes < tbytes) {
-    if (tablesHost) {
+  const int slot = asyncMode ? (int)(chunkSeq & 1) : 0;   // async: the other buffer may still be waiting for its upload
+  void*& thost = slot ? tablesHostB : tablesHost;
+  size_t& thostBytes = slot ? tablesHostBBytes : tablesHostBytes;
+  if (asyncMode && chunkDone[slot]) GA_HIP(hipEventSynchronize(chunkDone[slot]));   // chunk k - 2 is done: its staging is free
+  if (thostBytes < tbytes) {
+    if (thost) {
       GA_HIP(hipStreamSynchronize(stream));
-      (void)hipHostFree(tablesHost);
+      (void)hipHostFree(thost);
     }
-    tablesHostBytes = tbytes + tbytes / 4 + 4096;
-    GA_HIP(hipHostMalloc(&tablesHost, tablesHostBytes, hipHostMallocDefault));
+    thostBytes = tbytes + tbytes / 4 + 4096;
+    GA_HIP(hipHostMalloc(&thost, thostBytes, hipHostMallocDefault));
   }
-  ensure(tables, tablesHostBytes);
-  std::memcpy(tablesHost, ex.plan.host.data(), tbytes);
-  GA_HIP(hipMemcpyAsync(tables.p, tablesHost, tbytes, hipMemcpyHostToDevice, stream));
+  ensure(tables, std::max(tablesHostBytes, tablesHostBBytes));
+  std::memcpy(thost, ex.plan.host.data(), tbytes);
+  GA_HIP(hipMemcpyAsync(tables.p, thost, tbytes, hipMemcpyHostToDevice, stream));
   uint8_t* base = (uint8_t*)tables.p;
 
   std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
@@ -2345,28 +2350,22 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
   if (profile) GA_HIP(hipEventRecord(evEnd, stream));
   GA_HIP(hipGetLastError());
   tmLaunch = nowMs();
-  GA_HIP(hipStreamSynchronize(stream));
+  if (profile) pendingProf.push_back(ProfBatch{evBegin, evEnd, std::move(evs), std::move(evKind)});
+  if (asyncMode) {
+    if (!chunkDone[slot]) GA_HIP(hipEventCreateWithFlags(&chunkDone[slot], hipEventDisableTiming));
+    GA_HIP(hipEventRecord(chunkDone[slot], stream));
+    harvestProfile(false);
+  } else {
+    GA_HIP(hipStreamSynchronize(stream));
+    harvestProfile(true);
+  }
+  chunkSeq++;
   if (timing)
     fprintf(stderr, "[ga]   host detail: topo %.2f, sources %.2f, sim %.2f | resources %.2f, params %.2f, exec %.2f ms\n", tmTopo - tm0,
             tmSrc - tmTopo, tmSim - tmSrc, tmRes - tmSim, tmPre - tmRes, tmPlan - tmPre);
   if (timing)
     fprintf(stderr, "[ga] chunk %lld blocks: sim %.2f ms, plan %.2f ms, enqueue %.2f ms, wait %.2f ms\n", (long long)n, tmSim - tm0,
             tmPlan - tmSim, tmLaunch - tmPlan, nowMs() - tmLaunch);
-  if (profile) {
-    float ms = 0;
-    GA_HIP(hipEventElapsedTime(&ms, evBegin, evEnd));
-    stats.device_ms_total += ms;
-    for (size_t i = 0; i < evs.size(); i++) {
-      GA_HIP(hipEventElapsedTime(&ms, evs[i].first, evs[i].second));
-      if (evKind[i] == LK_MAC) stats.mac_ms_total += ms;
-      else if (evKind[i] == LK_FFT) stats.fft_ms_total += ms;
-      else stats.other_ms_total += ms;
-      (void)hipEventDestroy(evs[i].first);
-      (void)hipEventDestroy(evs[i].second);
-    }
-    (void)hipEventDestroy(evBegin);
-    (void)hipEventDestroy(evEnd);
-  }
 
   // ---- commit the control state to the end of the chunk ----
   for (size_t i = 0; i < srcIds.size(); i++) {

@@ -86,6 +86,14 @@ Context::~Context() {
   if (ilvDev) (void)hipFree(ilvDev);
   if (tables.p) (void)hipFree(tables.p);
   if (tablesHost) (void)hipHostFree(tablesHost);
+  if (tablesHostB) (void)hipHostFree(tablesHostB);
+  for (auto& e : chunkDone)
+    if (e) (void)hipEventDestroy(e);
+  for (auto& b : pendingProf) {
+    (void)hipEventDestroy(b.begin);
+    (void)hipEventDestroy(b.end);
+    for (auto& e : b.evs) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  }
   for (void* p : slabBlocks) (void)hipFree(p);
   for (void* p : bqBlocks) (void)hipFree(p);
   for (float* p : busSlabs) (void)hipFree(p);
@@ -179,6 +187,33 @@ InputS* Context::inputOf(const InRef& r) {
   NodeS* n = nodes[r.node].get();
   if (r.input >= 0) return &n->inputs[r.input];
   return nullptr;  // param modulation inputs keep their list in ParamS::modulation
+}
+
+void Context::harvestProfile(bool wait) {
+  while (!pendingProf.empty()) {
+    ProfBatch& b = pendingProf.front();
+    if (wait) GA_HIP(hipEventSynchronize(b.end));
+    else if (hipEventQuery(b.end) != hipSuccess) { (void)hipGetLastError(); break; }
+    float ms = 0;
+    GA_HIP(hipEventElapsedTime(&ms, b.begin, b.end));
+    stats.device_ms_total += ms;
+    for (size_t i = 0; i < b.evs.size(); i++) {
+      GA_HIP(hipEventElapsedTime(&ms, b.evs[i].first, b.evs[i].second));
+      if (b.kinds[i] == LK_MAC) stats.mac_ms_total += ms;
+      else if (b.kinds[i] == LK_FFT) stats.fft_ms_total += ms;
+      else stats.other_ms_total += ms;
+      (void)hipEventDestroy(b.evs[i].first);
+      (void)hipEventDestroy(b.evs[i].second);
+    }
+    (void)hipEventDestroy(b.begin);
+    (void)hipEventDestroy(b.end);
+    pendingProf.pop_front();
+  }
+}
+void Context::synchronize() {
+  GA_HIP(hipSetDevice(device));
+  GA_HIP(hipStreamSynchronize(stream));
+  harvestProfile(true);
 }
 
 // ---- connections: AudioNodeOutput.ConnectTo / DisconnectFrom / DisconnectAll (AudioNodeOutput.cs:42-70) and

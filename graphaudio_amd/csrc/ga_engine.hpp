@@ -277,6 +277,8 @@ inline int tapFftSize(int P) {
   return std::max(1024, 4 * n);
 }
 
+enum LaunchKind { LK_OTHER = 0, LK_FFT = 1, LK_MAC = 2 };   // which statistics bucket a recorded launch belongs to
+
 struct DevArena {  // grow-only device scratch
   void* p = nullptr;
   size_t bytes = 0;
@@ -331,8 +333,24 @@ struct Context {
   float* xPlane(int pair, int im) { return (float*)(pair == 0 ? planesB[im].p : planesBalt[im].p); }
   void flushPlaneHistories(int pair); // moves them to the nodes' private stores (before the pair is rewritten)
   DevArena tables;         // per-chunk job tables
-  void* tablesHost = nullptr;
+  void* tablesHost = nullptr;      // pinned staging of the job tables (buffer 0)
   size_t tablesHostBytes = 0;
+  // option "async": render calls return after the work is enqueued (the host simulation and planning of the next call
+  // overlap the device execution of this one); ga_synchronize waits.  The host may run one chunk ahead: the job tables are
+  // staged in two pinned buffers and chunk k + 1 is not planned before chunk k - 1 has finished.
+  bool asyncMode = false;
+  void* tablesHostB = nullptr;     // buffer 1 (async mode)
+  size_t tablesHostBBytes = 0;
+  uint64_t chunkSeq = 0;
+  hipEvent_t chunkDone[2] = {nullptr, nullptr};
+  struct ProfBatch {
+    hipEvent_t begin, end;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
+    std::vector<int> kinds;
+  };
+  std::deque<ProfBatch> pendingProf;
+  void harvestProfile(bool wait);   // folds finished event batches into `stats`
+  void synchronize();
   std::vector<float*> slabFree, slabAll;
   int64_t slabFrames = 0;
   std::vector<void*> slabBlocks;

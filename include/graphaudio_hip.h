@@ -193,6 +193,12 @@ GA_EXPORT int GA_FN(process_blocks_interleaved)(ga_context* ctx, float* interlea
 
 /* Run the render on this HIP stream (a hipStream_t passed as void*) instead of the context's own stream. */
 GA_EXPORT int GA_FN(context_set_stream)(ga_context* ctx, void* hip_stream);
+/* Pipelined rendering (no counterpart in the reference, whose Render is synchronous, OfflineAudioContext.cs:30-102): with
+   ga_set_option(ctx, "async", 1) ga_render / ga_render_device return as soon as the work of the call is enqueued on the
+   context's stream, so the host-side graph simulation of the next call overlaps the device execution of this one (the host
+   runs at most one chunk ahead).  Output arrays (page-locked host memory or device memory) are complete after
+   ga_synchronize, or after any later work on the same stream.  The default is synchronous, as in the reference. */
+GA_EXPORT int GA_FN(synchronize)(ga_context* ctx);
 
 #ifdef __cplusplus
 }

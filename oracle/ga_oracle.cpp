@@ -1650,6 +1650,7 @@ int gao_get_stats(ga_context* ctx, ga_stats* out) {
   return GA_OK;
 }
 int gao_context_set_stream(ga_context*, void*) { return GA_ERR_UNSUPPORTED; }
+int gao_synchronize(ga_context* ctx) { return ctx ? GA_OK : GA_ERR_INVALID_ARGUMENT; }   // the CPU restatement is synchronous
 
 int gao_buffer_create(ga_context* ctx, const float* const* planar, int channels, int64_t frames, int sample_rate,
                       int* out_id) {

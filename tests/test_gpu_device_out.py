@@ -59,3 +59,48 @@ def test_process_blocks_into_device_memory():
     inter = torch.zeros(128 * 16 * ch, dtype=torch.float32, device="cuda")
     ctx2._call("process_blocks_interleaved", C.cast(C.c_void_p(inter.data_ptr()), C.POINTER(C.c_float)), ch, 16, 1)
     assert np.array_equal(inter.cpu().numpy().reshape(128 * 16, ch).T, ref)
+
+
+def test_async_renders_match_synchronous_ones():
+    """SetOption("async", 1): render calls return once their work is enqueued; the graph is edited between the calls and the
+    output (page-locked host memory) is read after Synchronize().  Same kernels, same order -> bit-identical."""
+    torch = _torch()
+    from tests import _graphs as G
+    from graphaudio_amd import AudioBufferSourceNode, ConvolverNode, GainNode, PlayableAudioBuffer
+
+    def run(async_mode):
+        ctx = OfflineAudioContext(48000)
+        ctx.SetOption("max_chunk_blocks", 7)
+        ctx.SetOption("profile", 1)
+        if async_mode:
+            ctx.SetOption("async", 1)
+        frames = 128 * 60
+        ir = PlayableAudioBuffer.FromChannelArrays([G.synth_ir(c, 128 * 70) for c in range(2)], 48000)
+        gains = []
+        for v in range(6):
+            s = AudioBufferSourceNode(ctx)
+            s.Buffer = PlayableAudioBuffer.FromMonoArray(G.voice(300 + v, frames), 48000)
+            cv = ConvolverNode(ctx)
+            cv.Buffer = ir if v % 2 else PlayableAudioBuffer.FromChannelArrays([G.synth_ir(c, 900, seed0=9 + v) for c in range(2)], 48000)
+            g = GainNode(ctx)
+            g.Gain.Value = 0.5
+            s.Connect(cv).Connect(g).Connect(ctx.Destination)
+            s.Start(v * 0.003)
+            gains.append(g)
+        pin = torch.zeros((2, frames), dtype=torch.float32).pin_memory()
+        out = pin.numpy()
+        pos = 0
+        for i, n in enumerate((128 * 9 + 17, 128 * 20 - 17, 128 * 11, 128 * 20)):
+            ctx.Render(out, n, pos)
+            pos += n
+            gains[i].Gain.Value = 0.25 + 0.1 * i
+            if i == 1:
+                gains[4].Gain.LinearRampToValueAtTime(0.0, pos / 48000 + 0.05)
+        ctx.Synchronize()
+        st = ctx.GetStats()
+        assert st["chunks"] >= 9 and st["device_ms_total"] > 0
+        return out.copy()
+
+    a, b = run(False), run(True)
+    assert G.rms(a) > 1e-3
+    assert np.array_equal(a, b)
