@@ -124,6 +124,9 @@ internal static unsafe partial class GraphAudioHip
     [LibraryImport(Lib, EntryPoint = "ga_render")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]
     public static partial int ga_render(IntPtr ctx, float** outPlanar, int outChannels, long frameCount, long startIndex);
 
+    [LibraryImport(Lib, EntryPoint = "ga_synchronize")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]
+    public static partial int ga_synchronize(IntPtr ctx);   // with option "async": waits for the enqueued renders
+
     /// <summary>Maps a negative result code to the exception the stock CPU context throws in the same situation.</summary>
     public static void Check(IntPtr ctx, int code)
     {
