@@ -90,8 +90,8 @@ def _cpu_name():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--seconds", type=float, default=10.0, help="audio seconds rendered per step")
     ap.add_argument("--voices", type=int, default=1024)
     ap.add_argument("--taps", type=int, default=65536)

@@ -5,7 +5,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 TAG=${1:-r01_v4}
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o st -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_bench_under_rocprof.json 2> gpurun_out/${TAG}_stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o st -- python3 bench.py > gpurun_out/${TAG}_bench_under_rocprof.json 2> gpurun_out/${TAG}_stats.err
 cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) gpurun_out/${TAG}_kernel_stats.csv
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/prof_f -o f -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> gpurun_out/${TAG}_f.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/prof_w -o w -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> gpurun_out/${TAG}_w.err
