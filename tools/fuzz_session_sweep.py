@@ -5,6 +5,8 @@ from graphaudio_amd import OfflineAudioContext, NotSupportedException
 from tests import _graphs as G
 from tests._fuzz import run_random_session
 from tests._oracle import OracleContext
+import os
+ASYNC = os.environ.get("GA_FUZZ_ASYNC") == "1"
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 bad = []; skipped = 0
 for seed in range(lo, hi):
@@ -13,7 +15,10 @@ for seed in range(lo, hi):
     except Exception as e:
         print("oracle raised", seed, type(e).__name__, e); continue
     try:
-        h = OfflineAudioContext(48000); h.SetOption("max_chunk_blocks", 11); got, gl = run_random_session(h, seed)
+        h = OfflineAudioContext(48000); h.SetOption("max_chunk_blocks", 11)
+        if ASYNC: h.SetOption("async", 1)   # GA_FUZZ_ASYNC=1: pipelined renders, synchronised once at the end
+        got, gl = run_random_session(h, seed)
+        if ASYNC: h.Synchronize()
     except NotSupportedException as e:
         skipped += 1; continue
     except Exception as e:
