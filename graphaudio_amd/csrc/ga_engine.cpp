@@ -3,6 +3,7 @@
 #include "ga_engine.hpp"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 
 namespace ga {
@@ -687,6 +688,13 @@ std::vector<Context::TconvLaunch> Context::tconvPlan(int nblocks, int P) const {
     const int i = pick[rem];
     count[i]++;
     rem -= std::min(rem, sizes[i] - (P - 1));
+  }
+  if (const char* e = getenv("GA_TCONV_PLAN")) {   // measurement only: "n1024,n2048,n4096" segment counts (must cover the chunk)
+    int c0 = 0, c1 = 0, c2 = 0;
+    if (sscanf(e, "%d,%d,%d", &c0, &c1, &c2) == 3 &&
+        (long long)c0 * (1024 - (P - 1)) + (long long)c1 * (2048 - (P - 1)) + (long long)c2 * (4096 - (P - 1)) >= nblocks) {
+      count[0] = c0; count[1] = c1; count[2] = c2;
+    }
   }
   std::vector<TconvLaunch> plan;
   int tbase = 0;
