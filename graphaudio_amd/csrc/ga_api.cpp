@@ -177,6 +177,21 @@ void Context::render(float* const* out, int channels, int64_t frameCount, int64_
   if (disposed) fail(GA_ERR_DISPOSED, "context disposed");
   GA_HIP(hipSetDevice(device));
   const hipMemcpyKind kind = deviceOut ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  // A render that spans several chunks is pipelined inside the call even when the context is synchronous: chunk k + 1 is
+  // simulated and planned while chunk k executes, and the call waits once, at its end.
+  struct Pipelined {
+    Context& c;
+    const bool callerAsync;
+    explicit Pipelined(Context& cc) : c(cc), callerAsync(cc.asyncMode) { c.asyncMode = true; }
+    ~Pipelined() { c.asyncMode = callerAsync; }
+  } pipelined(*this);
+  struct Drain {   // a blocking render never leaves work in flight, not even when it throws
+    Context& c;
+    const bool blocking;
+    ~Drain() {
+      if (blocking && c.stream) (void)hipStreamSynchronize(c.stream);
+    }
+  } drain{*this, !pipelined.callerAsync};
   int64_t written = 0;
   if (cachedFrames > 0) {  // leftover frames of the previous call's last block (:55-75)
     if (channels > cachedCh) fail(GA_ERR_OUT_OF_RANGE, "channelIndex");
@@ -212,6 +227,10 @@ void Context::render(float* const* out, int channels, int64_t frameCount, int64_
     }
     if (!asyncMode) GA_HIP(hipStreamSynchronize(stream));
     written += toCopy;
+  }
+  if (!pipelined.callerAsync) {
+    GA_HIP(hipStreamSynchronize(stream));
+    harvestProfile(true);
   }
   stats.device_bytes_in_use = devBytes;
 }
