@@ -927,16 +927,24 @@ void launch_irfft_ola_b(hipStream_t s, const ConvRowIO* yrows_dev, int ny, int n
   }
 }
 
-__global__ void hist_copy_b_kernel(const HistJobB* __restrict jobs) {
+// one wavefront per (job, bin): 4 bins per workgroup (a workgroup per bin moved 2 KB and was launch-rate bound)
+__global__ __launch_bounds__(256) void hist_copy_b_kernel(const HistJobB* __restrict jobs) {
   const HistJobB j = jobs[blockIdx.y];
-  const int k = blockIdx.x;
-  for (int i = threadIdx.x; i < j.n; i += blockDim.x) j.dst[(size_t)k * j.dst_stride + i] = j.src ? j.src[(size_t)k * j.src_stride + i] : 0.f;
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (k >= kBins) return;
+  float* __restrict d = j.dst + (size_t)k * j.dst_stride;
+  if (j.src) {
+    const float* __restrict sp = j.src + (size_t)k * j.src_stride;
+    for (int i = lane; i < j.n; i += 64) d[i] = sp[i];
+  } else {
+    for (int i = lane; i < j.n; i += 64) d[i] = 0.f;
+  }
 }
 void launch_hist_copy_b(hipStream_t s, const HistJobB* jobs_dev, int njobs, int max_n) {
   if (njobs <= 0 || max_n <= 0) return;
   for (int j0 = 0; j0 < njobs; j0 += 32768) {
     int nj = std::min(32768, njobs - j0);
-    hipLaunchKernelGGL(hist_copy_b_kernel, dim3(kBins, nj), dim3(128), 0, s, jobs_dev + j0);
+    hipLaunchKernelGGL(hist_copy_b_kernel, dim3((kBins + 3) / 4, nj), dim3(256), 0, s, jobs_dev + j0);
   }
 }
 
