@@ -381,3 +381,23 @@ def test_source_general_replay_bit_exact(case):
     ref, got = outs
     assert G.rms(ref) > 1e-3
     assert np.array_equal(ref, got)
+
+
+@pytest.mark.parametrize("option,value", [("fft64", 1), ("tconv_radix16", 0), ("time_fft", 0)])
+def test_convolver_kernel_variants_behind_options(option, value):
+    """The documented options select other kernels for the same arithmetic: double-precision 256-point transforms, the
+    radix-8 block-axis kernel (one FFT length per chunk), the direct matrix-core formulation.  Several chunks, so that the
+    history hand-over between the plane pairs runs with each of them."""
+    frames = 128 * 150
+    outs = []
+    for mk in (OracleContext, OfflineAudioContext):
+        ctx = mk(48000)
+        ctx.SetOption(option, value)
+        ctx.SetOption("max_chunk_blocks", 64)
+        ch = G.config3_convolver(ctx, voices=3, taps=20000, frames=frames)
+        outs.append(G.render(ctx, ch, frames))
+        ctx.Dispose()
+    ref, got = outs
+    err = G.rms(ref - got)
+    assert G.rms(ref) > 1e-4
+    assert err <= TOL_RMS and err / G.rms(ref) < 2e-6, (err, err / G.rms(ref))
