@@ -1160,7 +1160,31 @@ static double nowMs() {
   clock_gettime(CLOCK_MONOTONIC, &ts);
   return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
-void Context::runChunk(int64_t n, float* const* /*unused*/) {
+// A chunk is planned in passes that advance persistent control state (queued disposals, lagged channel counts and silence
+// flags, overlap / history double buffers) before the first launch, so a failure after the simulation has started leaves
+// the context between two blocks.  Such a failure is STICKY: every later render on this context returns
+// GA_ERR_INVALID_OPERATION until the context is recreated (include/graphaudio_hip.h, "Errors").  Failures of the argument
+// and graph checks that run before any state moves (disposed context, cycle, unsupported node) leave the context usable.
+void Context::runChunk(int64_t n, float* const* bus) {
+  if (faulted) fail(GA_ERR_INVALID_OPERATION, "context is faulted by an earlier render error (" + faultMsg + "); create a new context");
+  chunkPhase = 0;
+  try {
+    runChunkImpl(n, bus);
+  } catch (const Err& e) {
+    if (chunkPhase > 0) {
+      faulted = true;
+      faultMsg = e.msg;
+    }
+    throw;
+  } catch (...) {
+    if (chunkPhase > 0) {
+      faulted = true;
+      faultMsg = "unexpected exception";
+    }
+    throw;
+  }
+}
+void Context::runChunkImpl(int64_t n, float* const* /*unused*/) {
   static const bool timing = getenv("GA_TIMING") != nullptr;
   const double tm0 = nowMs();
   double tmSim = 0, tmPlan = 0, tmLaunch = 0;
@@ -1280,6 +1304,7 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
     if (srcPlans[i].gone && srcPlans[i].goneAt < n) goneAt[srcPlans[i].goneAt].push_back(srcIds[i]);
 
   const double tmSrc = nowMs();
+  chunkPhase = 1;   // from here on persistent control state moves: a failure is sticky (see runChunk)
   // ---- simulate ----
   std::vector<Segment> segs;
   Sim sim{*this, n};
@@ -2234,7 +2259,10 @@ void Context::runChunk(int64_t n, float* const* /*unused*/) {
         static const char* planenv = getenv("GA_TCONV_MIXED");
         const bool r16 = r16env ? atoi(r16env) != 0 : useRadix16;
         std::vector<TconvLaunch> tplan;
-        if (r16 && !(planenv && atoi(planenv) == 0)) {
+        if (debugTconvN2 > 0) {   // tests: a length no kernel exists for must come back as an error code, not abort the host
+          const int Lc = std::max(1, debugTconvN2 - (Pc - 1));
+          tplan.push_back(TconvLaunch{debugTconvN2, 0, (nn + Lc - 1) / Lc});
+        } else if (r16 && !(planenv && atoi(planenv) == 0)) {
           tplan = tconvPlan(nn, Pc);
         } else {   // one FFT length for the whole chunk
           const int N2 = tapFftSize(Pc), Lc = N2 - (Pc - 1);

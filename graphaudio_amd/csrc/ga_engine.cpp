@@ -8,6 +8,8 @@
 
 namespace ga {
 
+void launch_fail(const char* what) { fail(GA_ERR_INVALID_OPERATION, std::string("internal: ") + what); }
+
 // ------------------------------------------------------------------------------------------------------
 // device resources
 // ------------------------------------------------------------------------------------------------------
@@ -301,9 +303,9 @@ void Context::doDispose(int id) {
   }
   if (n.type == GA_NODE_BUFFER_SOURCE) n.bufId = -1;  // AudioBufferSourceNode.cs:412
   if (n.type == GA_NODE_CONVOLVER) {                   // ConvolverNode.cs:166-175
+    releaseConvState(n);   // while n.ir still tells the size of the private history (device byte accounting)
     n.ir.reset();
     n.irBuf = -1;
-    releaseConvState(n);
   }
 }
 
@@ -649,6 +651,7 @@ const float2* Context::twiddlesC(int N2) {
   return d;
 }
 const float2* Context::ensureTapSpectra(IrSpectra& ir, int N2) {
+  if (N2 != 1024 && N2 != 2048 && N2 != 4096) fail(GA_ERR_INVALID_OPERATION, "internal: no block-axis FFT of " + std::to_string(N2) + " points");
   float2*& h = ir.hspecN[IrSpectra::n2Index(N2)];
   if (h) return h;
   size_t bytes = (size_t)ir.nch * kBins * N2 * sizeof(float2);

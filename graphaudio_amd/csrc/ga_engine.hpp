@@ -398,6 +398,9 @@ struct Context {
   const float2* twiddles16(int N2);
   std::map<int, float2*> tw16;
   bool useRadix16 = true;   // option `tconv_radix16`
+  bool useCoarse = true;          // option `coarse`: formulation D (coarse partitions, voice sum fused) for long impulse responses
+  int64_t coarseMinBlocks = 256;  // option `coarse_min_blocks`: a convolver takes formulation D when its first chunk has at least this many blocks
+  int debugTconvN2 = 0;     // option `debug_tconv_n2` (tests of the error path only)
   const float2* ensureTapSpectra(IrSpectra& ir, int N2);
   struct TconvLaunch { int N2, tbase, nseg; };
   std::vector<TconvLaunch> tconvPlan(int nblocks, int P) const;   // FFT lengths of the segments that cover a chunk
@@ -407,6 +410,10 @@ struct Context {
 
   void render(float* const* out, int channels, int64_t frames, int64_t start, bool deviceOut);
   void runChunk(int64_t nblocks, float* const* bus);
+  void runChunkImpl(int64_t nblocks, float* const* bus);
+  bool faulted = false;      // a render failed after control state had moved: the context refuses further renders
+  std::string faultMsg;
+  int chunkPhase = 0;        // 0 = checks only (a failure leaves the context usable), 1 = state is moving
 
   int64_t busCapFrames = 0;
   std::vector<float*> busSlabs;

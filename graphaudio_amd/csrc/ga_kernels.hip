@@ -22,6 +22,13 @@
 
 namespace ga {
 
+// gridDim.y is limited to 65535: a level of a fragmented chunk (thousands of voices x tens of segments) can hold more jobs than
+// that, so every (x = frames, y = job) launcher walks the job table in windows.  Kernels index `jobs[blockIdx.y]`.
+constexpr int kMaxGridY = 32768;
+#define GA_LAUNCH_JOBS(kernel, gx_, block_, jobs_, njobs_, ...)                                                      \
+  for (int j0_ = 0; j0_ < (njobs_); j0_ += kMaxGridY)                                                                \
+    hipLaunchKernelGGL(kernel, dim3((gx_), std::min(kMaxGridY, (njobs_) - j0_)), dim3(block_), 0, s, (jobs_) + j0_, ##__VA_ARGS__)
+
 // phase timestamps for tools/micro/rfft_phase.hip (compiled out of the product)
 #ifdef GA_EXP_TIMELINE
 __device__ unsigned long long* ga_tl = nullptr;
@@ -1062,7 +1069,7 @@ void launch_tap_spectra(hipStream_t s, float2* hs, const float* hr, const float*
   if (N2 == 1024) hipLaunchKernelGGL(tap_spectra_kernel<1024>, g, b, 0, s, hs, hr, hi, P, tw);
   else if (N2 == 2048) hipLaunchKernelGGL(tap_spectra_kernel<2048>, g, b, 0, s, hs, hr, hi, P, tw);
   else if (N2 == 4096) hipLaunchKernelGGL(tap_spectra_kernel<4096>, g, b, 0, s, hs, hr, hi, P, tw);
-  else { fprintf(stderr, "graphaudio_hip: no taps-spectrum kernel for %d points\n", N2); abort(); }
+  else launch_fail("no taps-spectrum kernel for this block-axis FFT length");
 }
 
 // ---- register/LDS hybrid FFT for the tconv kernel -------------------------------------------------------------------
@@ -1241,11 +1248,8 @@ void launch_tconv(hipStream_t s, const ConvSetC* sets_dev, int nsets, int nblock
                   int nseg) {
   if (nsets <= 0 || nblocks <= 0) return;
   size_t lds = ((size_t)3 * TC_PADDED(N2)) * sizeof(float2);
-  static bool attr_set = false;
-  if (!attr_set) {   // N2 = 4096 needs 104 KB of dynamic LDS (gfx950 has 160 KB per CU)
-    (void)hipFuncSetAttribute((const void*)tconv_kernel<4096>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-    attr_set = true;
-  }
+  // N2 = 4096 needs 104 KB of dynamic LDS (gfx950 has 160 KB per CU); per device, so set on every launch of this legacy path
+  if (N2 == 4096) (void)hipFuncSetAttribute((const void*)tconv_kernel<4096>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
   // every set of one launch has the same P, hence the same segment length L = N2 - P + 1
   const long long total = (long long)nsets * nseg;
   const int gx = (int)std::min<long long>(total, TC_GROUPS);
@@ -1253,7 +1257,7 @@ void launch_tconv(hipStream_t s, const ConvSetC* sets_dev, int nsets, int nblock
   if (N2 == 1024) hipLaunchKernelGGL(tconv_kernel<1024>, grid, block, lds, s, sets_dev, nsets, nseg, nblocks, hist, pl, tw);
   else if (N2 == 2048) hipLaunchKernelGGL(tconv_kernel<2048>, grid, block, lds, s, sets_dev, nsets, nseg, nblocks, hist, pl, tw);
   else if (N2 == 4096) hipLaunchKernelGGL(tconv_kernel<4096>, grid, block, lds, s, sets_dev, nsets, nseg, nblocks, hist, pl, tw);
-  else { fprintf(stderr, "graphaudio_hip: no block-axis FFT kernel for %d points\n", N2); abort(); }
+  else launch_fail("no block-axis FFT kernel for this length");
 }
 
 // ---- packed float2 arithmetic --------------------------------------------------------------------------------------
@@ -1568,15 +1572,20 @@ static void launch_tconv16_n(hipStream_t s, const ConvSetC* sets_dev, int nsets,
                              int nseg, int tbase) {
   using PL = R16Plan<N2>;
   const size_t lds = (size_t)(PL::T2 + PL::T3 + PL::G * TC16_PADDED(N2)) * sizeof(float2);
-  static int groups = 0;
-  if (!groups) {
-    (void)hipFuncSetAttribute((const void*)tconv16_kernel<N2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-    int occ = 0, dev = 0, cus = 256;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, tconv16_kernel<N2>, 256, lds);
-    (void)hipGetDevice(&dev);
+  // resident workgroups per device (a process may drive several devices: the attribute and the occupancy are per device)
+  static int groupsOf[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) launch_fail("device ordinal out of range");
+  if (!groupsOf[dev]) {
+    if (hipFuncSetAttribute((const void*)tconv16_kernel<N2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096) != hipSuccess)
+      launch_fail("cannot raise the dynamic LDS limit of the block-axis FFT kernel");
+    int occ = 0, cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, tconv16_kernel<N2>, 256, lds) != hipSuccess || occ < 1)
+      launch_fail("block-axis FFT kernel does not fit a compute unit");
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    groups = std::max(occ, 1) * cus;   // exactly one resident round
+    groupsOf[dev] = occ * cus;   // exactly one resident round
   }
+  const int groups = groupsOf[dev];
   const long long steps = ((long long)nsets * nseg + PL::G - 1) / PL::G;
   dim3 grid((unsigned)std::min<long long>(steps * kBins, groups)), block(256);
   hipLaunchKernelGGL(tconv16_kernel<N2>, grid, block, lds, s, sets_dev, nsets, nseg, nblocks, hist, pl, tw16, tbase);
@@ -1587,7 +1596,7 @@ void launch_tconv16(hipStream_t s, const ConvSetC* sets_dev, int nsets, int nblo
   if (N2 == 1024) launch_tconv16_n<1024>(s, sets_dev, nsets, nblocks, hist, pl, tw16, nseg, tbase);
   else if (N2 == 2048) launch_tconv16_n<2048>(s, sets_dev, nsets, nblocks, hist, pl, tw16, nseg, tbase);
   else if (N2 == 4096) launch_tconv16_n<4096>(s, sets_dev, nsets, nblocks, hist, pl, tw16, nseg, tbase);
-  else { fprintf(stderr, "graphaudio_hip: no block-axis FFT kernel for %d points\n", N2); abort(); }
+  else launch_fail("no block-axis FFT kernel for this length");
 }
 
 // ---- plane utilities ----------------------------------------------------------------------------------
@@ -1674,9 +1683,9 @@ void launch_mix(hipStream_t s, const MixJob* jobs_dev, int njobs, const float* c
   int64_t nv = vec4 ? (max_n + 3) / 4 : max_n;
   int gx = (int)std::min<int64_t>((nv + 255) / 256, 2048);
   if (vec4)
-    hipLaunchKernelGGL(mix_kernel<4>, dim3(gx, njobs), dim3(256), 0, s, jobs_dev, terms_dev);
+    GA_LAUNCH_JOBS(mix_kernel<4>, gx, 256, jobs_dev, njobs, terms_dev);
   else
-    hipLaunchKernelGGL(mix_kernel<1>, dim3(gx, njobs), dim3(256), 0, s, jobs_dev, terms_dev);
+    GA_LAUNCH_JOBS(mix_kernel<1>, gx, 256, jobs_dev, njobs, terms_dev);
 }
 
 __global__ __launch_bounds__(256) void downmix_kernel(const DownmixJob* __restrict jobs, const float* const* __restrict terms) {
@@ -1692,7 +1701,7 @@ __global__ __launch_bounds__(256) void downmix_kernel(const DownmixJob* __restri
 void launch_downmix(hipStream_t s, const DownmixJob* jobs_dev, int njobs, const float* const* terms_dev, int64_t max_n) {
   if (njobs <= 0 || max_n <= 0) return;
   int gx = (int)std::min<int64_t>((max_n + 255) / 256, 2048);
-  hipLaunchKernelGGL(downmix_kernel, dim3(gx, njobs), dim3(256), 0, s, jobs_dev, terms_dev);
+  GA_LAUNCH_JOBS(downmix_kernel, gx, 256, jobs_dev, njobs, terms_dev);
 }
 
 // ---- GainNode (GainNode.cs:48-58) ---------------------------------------------------------------------
@@ -1711,7 +1720,7 @@ __global__ __launch_bounds__(256) void gain_kernel(const GainJob* __restrict job
 void launch_gain(hipStream_t s, const GainJob* jobs_dev, int njobs, int64_t max_n) {
   if (njobs <= 0 || max_n <= 0) return;
   int gx = (int)std::min<int64_t>((max_n + 255) / 256, 1024);
-  hipLaunchKernelGGL(gain_kernel, dim3(gx, njobs), dim3(256), 0, s, jobs_dev);
+  GA_LAUNCH_JOBS(gain_kernel, gx, 256, jobs_dev, njobs);
 }
 
 // =====================================================================================================
@@ -2210,7 +2219,7 @@ void launch_param_curve(hipStream_t s, const ParamJob* jobs_dev, int njobs, cons
                         const double* block_times_dev, double delta_time, int64_t max_blocks) {
   if (njobs <= 0 || max_blocks <= 0) return;
   int gx = (int)std::min<int64_t>(max_blocks, 4096);
-  hipLaunchKernelGGL(param_curve_kernel, dim3(gx, njobs), dim3(128), 0, s, jobs_dev, events_dev, block_times_dev, delta_time);
+  GA_LAUNCH_JOBS(param_curve_kernel, gx, 128, jobs_dev, njobs, events_dev, block_times_dev, delta_time);
 }
 
 // ---- looping rate-1 source (AudioBufferSourceNode.cs:186-235) --------------------------------------------
@@ -2226,7 +2235,7 @@ __global__ __launch_bounds__(256) void loop_source_kernel(const LoopJob* __restr
 void launch_loop_source(hipStream_t s, const LoopJob* jobs_dev, int njobs, int64_t max_n) {
   if (njobs <= 0 || max_n <= 0) return;
   int gx = (int)std::min<int64_t>((max_n + 255) / 256, 1024);
-  hipLaunchKernelGGL(loop_source_kernel, dim3(gx, njobs), dim3(256), 0, s, jobs_dev);
+  GA_LAUNCH_JOBS(loop_source_kernel, gx, 256, jobs_dev, njobs);
 }
 
 // =====================================================================================================
@@ -2283,7 +2292,7 @@ __global__ __launch_bounds__(64) void resample_kernel(const ResampleJob* __restr
 void launch_resample(hipStream_t s, const ResampleJob* jobs_dev, int njobs, const ResampleBlock* traj_dev, int64_t max_blocks) {
   if (njobs <= 0 || max_blocks <= 0) return;
   int gx = (int)((max_blocks + 63) / 64);
-  hipLaunchKernelGGL(resample_kernel, dim3(gx, njobs), dim3(64), 0, s, jobs_dev, traj_dev);
+  GA_LAUNCH_JOBS(resample_kernel, gx, 64, jobs_dev, njobs, traj_dev);
 }
 
 
@@ -2344,7 +2353,7 @@ __global__ __launch_bounds__(64) void gsr_kernel(const GsrJob* __restrict jobs, 
 void launch_gsr(hipStream_t s, const GsrJob* jobs_dev, int njobs, const uint8_t* plan_base_dev, int64_t max_blocks) {
   if (njobs <= 0 || max_blocks <= 0) return;
   int gx = (int)((max_blocks + 63) / 64);
-  hipLaunchKernelGGL(gsr_kernel, dim3(gx, njobs), dim3(64), 0, s, jobs_dev, plan_base_dev);
+  GA_LAUNCH_JOBS(gsr_kernel, gx, 64, jobs_dev, njobs, plan_base_dev);
 }
 
 
@@ -2363,7 +2372,7 @@ __global__ __launch_bounds__(256) void const_source_kernel(const ConstJob* __res
 void launch_const_source(hipStream_t s, const ConstJob* jobs_dev, int njobs, int64_t max_n) {
   if (njobs <= 0 || max_n <= 0) return;
   int gx = (int)std::min<int64_t>((max_n + 255) / 256, 1024);
-  hipLaunchKernelGGL(const_source_kernel, dim3(gx, njobs), dim3(256), 0, s, jobs_dev);
+  GA_LAUNCH_JOBS(const_source_kernel, gx, 256, jobs_dev, njobs);
 }
 
 __device__ __forceinline__ float osc_sample(double ph, int type) {   // GenerateSample, OscillatorNode.cs:171-195
@@ -2451,11 +2460,8 @@ __global__ __launch_bounds__(64) void oscillator_kernel(const OscJob* __restrict
 void launch_oscillator(hipStream_t s, const OscJob* jobs_dev, int njobs, bool any_curve) {
   if (njobs <= 0) return;
   size_t lds = 64 * sizeof(double) + ((64 * (kBlock + 1) * sizeof(float) + 7) / 8) * 8 + (any_curve ? 64 * kBlock * sizeof(double) : 0);
-  static bool attr = false;
-  if (!attr) {
+  if (lds > 48 * 1024)   // (a per-device attribute: set whenever it is needed, a process may drive several devices)
     (void)hipFuncSetAttribute((const void*)oscillator_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    attr = true;
-  }
   hipLaunchKernelGGL(oscillator_kernel, dim3(njobs), dim3(64), lds, s, jobs_dev);
 }
 
@@ -2482,7 +2488,7 @@ __global__ __launch_bounds__(256) void stereo_panner_kernel(const PanJob* __rest
 void launch_stereo_panner(hipStream_t s, const PanJob* jobs_dev, int njobs, int64_t max_n) {
   if (njobs <= 0 || max_n <= 0) return;
   int gx = (int)std::min<int64_t>((max_n + 255) / 256, 1024);
-  hipLaunchKernelGGL(stereo_panner_kernel, dim3(gx, njobs), dim3(256), 0, s, jobs_dev);
+  GA_LAUNCH_JOBS(stereo_panner_kernel, gx, 256, jobs_dev, njobs);
 }
 
 
@@ -2499,7 +2505,7 @@ __global__ __launch_bounds__(256) void delay_kernel(const DelayJob* __restrict j
 void launch_delay(hipStream_t s, const DelayJob* jobs_dev, int njobs, int64_t max_n) {
   if (njobs <= 0 || max_n <= 0) return;
   int gx = (int)std::min<int64_t>((max_n + 255) / 256, 1024);
-  hipLaunchKernelGGL(delay_kernel, dim3(gx, njobs), dim3(256), 0, s, jobs_dev);
+  GA_LAUNCH_JOBS(delay_kernel, gx, 256, jobs_dev, njobs);
 }
 
 
@@ -2615,7 +2621,7 @@ __global__ __launch_bounds__(256) void param_mod_kernel(const ParamModJob* __res
 void launch_param_mod(hipStream_t s, const ParamModJob* jobs_dev, int njobs, int64_t max_n) {
   if (njobs <= 0 || max_n <= 0) return;
   int gx = (int)std::min<int64_t>((max_n + 255) / 256, 1024);
-  hipLaunchKernelGGL(param_mod_kernel, dim3(gx, njobs), dim3(256), 0, s, jobs_dev);
+  GA_LAUNCH_JOBS(param_mod_kernel, gx, 256, jobs_dev, njobs);
 }
 
 }  // namespace ga

@@ -7,6 +7,10 @@
 
 namespace ga {
 
+// A launcher that cannot serve its arguments (a planner bug, e.g. an FFT length without a kernel) reports it as an error
+// code through the C ABI (GA_ERR_INVALID_OPERATION): the library never aborts the host process.  Defined in ga_engine.cpp.
+[[noreturn]] void launch_fail(const char* what);
+
 constexpr int kBlock = 128;  // AudioBuffer.FramesPerBlock (AudioBuffer.cs:10)
 constexpr int kBins = 129;   // complexCount for fftSize 256 (PartitionedConvolver.cs:40-41)
 

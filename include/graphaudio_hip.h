@@ -48,6 +48,12 @@ extern "C" {
 #define GA_ERR_DEVICE (-7)            /* HIP runtime error */
 #define GA_ERR_OUT_OF_MEMORY (-8)
 #define GA_ERR_NO_DEVICE (-9)         /* no gfx950 device / HIP code object missing: the product never falls back to a CPU path */
+/* Errors.  No entry point throws, aborts or exits the host process; a failure is a negative code plus ga_last_error().
+ * A render call (ga_render*, ga_process_blocks*) that fails while it validates its arguments or the graph (disposed context,
+ * GA_ERR_CYCLE, GA_ERR_UNSUPPORTED, argument checks) leaves the context exactly as it was.  A render that fails later --
+ * device out of memory, a rejected launch, a HIP error -- has already advanced control state it cannot take back
+ * (AudioContextBase.ProcessBlock has no rollback either): the context is then FAULTED and every further render on it returns
+ * GA_ERR_INVALID_OPERATION with the original message.  Destroy it and create a new one. */
 
 /* ---- enums (numeric values follow declaration order in the reference) ---- */
 enum { /* node types creatable through ga_node_create; the destination is always node id 0 */

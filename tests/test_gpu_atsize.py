@@ -1,0 +1,151 @@
+"""Parity against the CPU oracle AT THE SIZES BASELINE.json quotes (the 1 s short form of every configuration, SURVEY.md 8(d)
+"Parity check alongside timing"), not on scaled-down stand-ins:
+
+  * config 3: all 1024 voices -> per-voice ConvolverNode (shared 65,536-tap stereo IR) -> 2-channel destination, 375 blocks.
+    This is the measurement of the 1024-term destination sum (AudioNodeInput.cs:118-132,195-198) that the round-1 design
+    note only extrapolated from 4 voices.
+  * config 5: 16-channel 32,768-tap private IRs (P = 256, 16 columns per input; Nodes/ConvolverNode.cs:145-151).
+  * config 2 at 256 voices, config 4 at 512 voices (one GPU's shard of the 4096): the multi-workgroup indexing of the
+    single-section biquad, the 5-section pipeline and the resampler at the job counts they run with.
+  * a level with more than 65,535 jobs (gridDim.y windows of the job-table launchers).
+
+Tolerance (north_star): <= 1e-5 RMS per sample, absolute, float32; the bus-relative error is asserted as well.
+Oracle cost on the GPU box's host: ~45 s for config 3, seconds for the others.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from graphaudio_amd import (AudioBufferSourceNode, ConvolverNode, GainNode, InvalidOperationException, OfflineAudioContext,
+                            PlayableAudioBuffer)
+from tests import _graphs as G
+from tests._oracle import OracleContext
+
+SR = 48000
+TOL_RMS = 1e-5
+
+
+def both(builder, nrender, options=None, **kw):
+    outs = []
+    for mk in (OracleContext, OfflineAudioContext):
+        ctx = mk(SR)
+        if mk is OfflineAudioContext:
+            for k, v in (options or {}).items():
+                ctx.SetOption(k, v)
+        ch = builder(ctx, **kw)
+        outs.append(G.render(ctx, ch, nrender))
+        ctx.Dispose()
+    return outs
+
+
+def report(name, ref, got):
+    err, sig = G.rms(ref - got), G.rms(ref)
+    print(f"[atsize] {name}: bus rms {sig:.4e}  abs rms err {err:.3e}  relative {err / sig:.3e}")
+    return err, sig
+
+
+def test_config3_all_1024_voices_short_form():
+    frames = 375 * 128
+    ref, got = both(G.config3_convolver, frames, voices=1024, taps=65536, frames=frames)
+    err, sig = report("config 3, 1024 voices x 65,536-tap stereo IR, 375 blocks", ref, got)
+    assert sig > 0.5            # an incoherent bus of 1024 voices (sigma ~ 2.6 in steady state, less while the tail builds up)
+    assert err <= TOL_RMS, err
+    assert err / sig < 2e-6
+
+
+def _config5(ctx, sources, taps, frames, ir_channels=16):
+    ctx.Destination.SetChannelCount(ir_channels)
+    for v in range(sources):
+        s = AudioBufferSourceNode(ctx)
+        s.Buffer = PlayableAudioBuffer.FromMonoArray(G.voice(v, frames + 256), SR)
+        cv = ConvolverNode(ctx)
+        cv.Buffer = PlayableAudioBuffer.FromChannelArrays(
+            [G.synth_ir(c, taps, seed0=7 + 100 * v) for c in range(ir_channels)], SR)
+        s.Connect(cv).Connect(ctx.Destination)
+        s.Start()
+    return ir_channels
+
+
+def test_config5_16_channel_32768_tap_private_irs():
+    frames = 400 * 128          # > P = 256 blocks: every partition of every column is active at the end
+    ref, got = both(_config5, frames, sources=6, taps=32768, frames=frames)
+    assert ref.shape[0] == 16
+    err, sig = report("config 5, 6 sources x 16-channel 32,768-tap private IRs, 400 blocks", ref, got)
+    assert err <= TOL_RMS, err
+    assert err / sig < 2e-6
+    tail = slice(300 * 128, None)
+    assert G.rms(ref[:, tail] - got[:, tail]) / G.rms(ref[:, tail]) < 2e-6
+
+
+def test_config2_256_voices_bit_exact():
+    frames = 375 * 128
+    ref, got = both(G.config2_biquad, frames, voices=256, frames=frames)
+    report("config 2, 256 voices -> lowpass -> gain -> mono mix, 375 blocks", ref, got)
+    assert G.rms(ref) > 1e-3
+    assert np.array_equal(ref, got)
+
+
+def test_config4_512_voice_shard():
+    frames = 375 * 128
+    ref, got = both(G.config4_eq, frames, voices=512, frames=frames)
+    err, sig = report("config 4, 512 voices (resampler + 5-band EQ + gain automation), 375 blocks", ref, got)
+    assert sig > 1e-4
+    assert err <= 1e-6, err     # constant-coefficient cascades and the resampler are bit-exact; the gain curve is f64 on both sides
+
+
+def test_more_than_65535_jobs_in_one_level():
+    """4,200 voices, each starting in its own block of a 40-block chunk: the gain level of the chunk holds
+    voices x segments jobs, far beyond gridDim.y = 65,535 (launch_mix / gain / loop_source windows)."""
+    voices, blocks = 4200, 40
+    frames = blocks * 128
+
+    def build(ctx):
+        ctx.Destination.SetChannelCount(1)
+        bus = GainNode(ctx)
+        bus.Inputs[0].SetChannelCount(1)
+        bus.Gain.Value = 1.0 / 64
+        bus.Connect(ctx.Destination)
+        for v in range(voices):
+            s = AudioBufferSourceNode(ctx)
+            s.Buffer = PlayableAudioBuffer.FromMonoArray(G.voice(v % 64, 128 * 24), SR)
+            g = GainNode(ctx)
+            g.Inputs[0].SetChannelCount(1)
+            g.Gain.Value = 0.5 + 0.001 * (v % 100)
+            s.Connect(g).Connect(bus)
+            s.Start(((v % 32) * 128 + 1) / SR)
+        return 1
+
+    outs = []
+    for mk in (OracleContext, OfflineAudioContext):
+        ctx = mk(SR)
+        build(ctx)
+        outs.append(G.render(ctx, 1, frames))
+        if mk is OfflineAudioContext:
+            st = ctx.GetStats()
+            print("[atsize] many-jobs graph:", st["segments"], "segments,", st["kernel_launches"], "launches")
+        ctx.Dispose()
+    ref, got = outs
+    assert G.rms(ref) > 1e-3
+    assert np.array_equal(ref, got)
+
+
+def test_unsupported_fft_length_is_an_error_code_and_faults_the_context():
+    """A planner bug of the class fixed in round 1 (a block-axis FFT length without a kernel) must surface as an error code
+    through the C ABI -- never abort() the host -- and, since control state has moved, leave the context faulted."""
+    ctx = OfflineAudioContext(SR)
+    ctx.SetOption("coarse", 0)
+    G.config3_convolver(ctx, voices=2, taps=128 * 100, frames=128 * 64)
+    ctx.SetOption("debug_tconv_n2", 512)
+    out = np.zeros((2, 128 * 8), np.float32)
+    with pytest.raises(InvalidOperationException):
+        ctx.Render(out, 128 * 8)
+    ctx.SetOption("debug_tconv_n2", 0)
+    with pytest.raises(InvalidOperationException, match="faulted"):
+        ctx.Render(out, 128 * 8)
+    ctx.Dispose()
+    # the process and the device are fine: a new context renders
+    ctx = OfflineAudioContext(SR)
+    G.config3_convolver(ctx, voices=2, taps=128 * 100, frames=128 * 64)
+    assert G.rms(G.render(ctx, 2, 128 * 8)) > 0
+    ctx.Dispose()
