@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--direct", action="store_true", help="use the direct (matrix-core) partition sum instead of the block-axis FFT")
     ap.add_argument("--sync-steps", action="store_true", help="one blocking render per step (no host/device pipelining)")
+    ap.add_argument("--no-coarse", action="store_true", help="formulation C (block-axis FFT) instead of D (coarse partitions)")
     ap.add_argument("--force-dist", action="store_true", help="exercise the process-group / RCCL reduce path even with one rank")
     args = ap.parse_args()
 
@@ -131,6 +132,8 @@ def main():
     ctx.SetOption("max_chunk_blocks", 4096)
     if args.direct:
         ctx.SetOption("time_fft", 0)
+    if args.no_coarse:
+        ctx.SetOption("coarse", 0)
     build_graph(ctx, shard, v0, args.taps, frames, G)
 
     # the caller's output buffer is page-locked host memory (the D2H copy of the 3.8 MB bus is inside the timed region: a
@@ -257,6 +260,10 @@ def main():
                                    "other": d["other_ms_total"] / args.steps, "device_total": d["device_ms_total"] / args.steps,
                                    "launches": d["kernel_launches"] / args.steps},
             "device_bytes_in_use": st1["device_bytes_in_use"],
+            "stage_ms_per_step": {n: (st1["stage_ms"][i] - st0["stage_ms"][i]) / args.steps for i, n in enumerate(
+                ("other", "mix", "rfft_fwd", "mac", "rfft_inv", "coarse_fwd", "coarse_mac", "coarse_inv", "coarse_hist"))},
+            "stage_gb_per_step": {n: (st1["stage_bytes"][i] - st0["stage_bytes"][i]) / args.steps / 1e9 for i, n in enumerate(
+                ("other", "mix", "rfft_fwd", "mac", "rfft_inv", "coarse_fwd", "coarse_mac", "coarse_inv", "coarse_hist"))},
         }
         if not args.no_cpu_baseline and world == 1:
             rec["cpu_baseline"] = cpu_baseline(voices_total, args.taps, G)

@@ -75,10 +75,18 @@ class Stats(C.Structure):
         ("device_bytes_in_use", C.c_int64),
         ("n_nodes", C.c_int32),
         ("n_conv_rows", C.c_int32),
+        ("stage_ms", C.c_double * 16),
+        ("stage_launches", C.c_int64 * 16),
+        ("stage_bytes", C.c_double * 16),
     ]
+    STAGES = ("other", "mix", "rfft_fwd", "mac", "rfft_inv", "coarse_fwd", "coarse_mac", "coarse_inv", "coarse_hist")
 
     def as_dict(self):
-        return {name: getattr(self, name) for name, _ in self._fields_}
+        d = {}
+        for name, _ in self._fields_:
+            v = getattr(self, name)
+            d[name] = list(v) if hasattr(v, "__len__") else v
+        return d
 
 
 _vp, _i, _i64, _f, _d = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double

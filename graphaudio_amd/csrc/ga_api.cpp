@@ -96,7 +96,10 @@ int64_t Context::chunkLimit(int64_t) {
         for (auto& g : groups) convRowsMax = std::max(convRowsMax, (int)((g->rows.size() + 127) / 128 * 128));
         perBlock += (double)convRowsMax * kBins * 4.0 * 4.0;
         for (auto& np : nodes)   // private-IR convolvers (formulations B / C): y rows + x rows in both plane pairs
-          if (np->type == GA_NODE_CONVOLVER && np->ir && np->convPath != 1)
+          if (np->type == GA_NODE_CONVOLVER && np->ir && np->convPath == 4)
+            // formulation D: X frames of the input channels + (at worst, nothing fused) Y frames of the slots: 64 KB per 8192 samples
+            perBlock += (double)((np->isTrueStereo ? 2 : np->ir->nch) + (np->isTrueStereo ? 4 : np->ir->nch)) * 1024.0;
+          else if (np->type == GA_NODE_CONVOLVER && np->ir && np->convPath != 1)
             perBlock += (double)(np->ir->nch + 2 * (np->isTrueStereo ? 2 : np->ir->nch)) * kBins * 8.0;
         perBlock += ((double)nodes.size() * 2.0 + 64.0) * kBlock * 4.0;
         double budget = ((double)freeB + (double)slabBlocks.size() * (double)((size_t)1 << 30) * 0.0) * memBudgetFraction;
@@ -104,6 +107,7 @@ int64_t Context::chunkLimit(int64_t) {
         budget += (double)(planes[0].bytes + planes[1].bytes + planes[2].bytes + planes[3].bytes);
         budget += (double)(planesB[0].bytes + planesB[1].bytes + planesB[2].bytes + planesB[3].bytes + planesBalt[0].bytes + planesBalt[1].bytes);
         budget += (double)slabAll.size() * (double)slabFrames * 4.0;
+        budget += (double)(coarseX.bytes + coarseY.bytes);
         int64_t byMem = (int64_t)(budget / std::max(perBlock, 1.0));
         limit = std::max<int64_t>(1, std::min<int64_t>(limit, byMem));
       }

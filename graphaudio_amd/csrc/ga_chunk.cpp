@@ -26,6 +26,7 @@ struct Plan {
   struct L {
     std::function<void(uint8_t*)> fn;
     int kind;
+    double bytes;   // HBM bytes the launch has to move (inputs once + outputs once); 0 = not accounted
   };
   std::vector<L> launches;
   size_t put(const void* p, size_t bytes) {
@@ -38,7 +39,7 @@ struct Plan {
   size_t putv(const std::vector<T>& v) {
     return put(v.data(), v.size() * sizeof(T));
   }
-  void add(int kind, std::function<void(uint8_t*)> fn) { launches.push_back(L{std::move(fn), kind}); }
+  void add(int kind, std::function<void(uint8_t*)> fn, double bytes = 0.0) { launches.push_back(L{std::move(fn), kind, bytes}); }
 };
 
 // ======================================================================================================
@@ -887,6 +888,9 @@ struct Exec {
           for (int ch = 0; ch < dstCh; ch++) lists[ch].push_back(uv[0]);
       } else if (srcCh > 1 && dstCh == 1) {
         // (sum over channels) * 1/sqrt(N), AudioNodeInput.cs:214-228
+        bool anyCh = false;
+        for (int ch = 0; ch < srcCh; ch++) anyCh = anyCh || uv[ch] != nullptr;
+        if (!anyCh) continue;   // e.g. a convolver whose output is carried by the leader of its fused group
         DownmixJob dj;
         dj.out = getSlab(c);
         dj.term0 = (int)terms.size();
@@ -975,9 +979,11 @@ struct Exec {
       for (auto& j : mixJobs) mx = std::max(mx, j.n);
       bool v4 = mixAligned;
       hipStream_t st = c.stream;
-      plan.add(LK_OTHER, [=](uint8_t* base) {
+      double mixBytes = 0;
+      for (auto& j : mixJobs) mixBytes += 4.0 * (double)(j.nterms + 1) * (double)j.n;
+      plan.add(LK_MIX, [=](uint8_t* base) {
         launch_mix(st, (const MixJob*)(base + off), nj, (const float* const*)(base + termsOff), mx, v4);
-      });
+      }, mixBytes);
     }
     if (!pmodJobs.empty()) {   // after the mixes (the modulation inputs), before the nodes that read the parameter
       size_t off = plan.putv(pmodJobs);
@@ -1150,6 +1156,287 @@ void Context::ensureGroupState(ConvGroup& g) {
   g.overlap[1] = o1;
   g.ovCur = 0;
   g.rp = need;
+}
+
+// ======================================================================================================
+// formulation D (ga_coarse.hip): coarse partitions, consumer sums fused in the frequency domain
+// ======================================================================================================
+// Which convolver outputs may be summed as spectra?  A node whose single output feeds exactly ONE input (or parameter) of
+// one consumer, and is a term of that input in every segment of the chunk.  Every mixing rule of AudioNodeInput.MixBuffer
+// (equal counts, 1 -> N, N -> 1 down-mix, min(N, M), AudioNodeInput.cs:182-244) is linear in the term, so the consumer
+// may receive the sum of the group as ONE term -- the leader's output -- and nothing from the other members.  What changes
+// is only the association of the float32 additions (the reference adds the members one by one in connection order).
+void Context::planCoarseFusion(const std::vector<int>& topo, const std::vector<Segment>& segs) {
+  std::vector<int> cand;
+  for (int id : topo) {
+    NodeS& nd = *nodes[id];
+    if (nd.type != GA_NODE_CONVOLVER) continue;
+    nd.dLeader = -1;
+    if (!nd.ir || nd.convPath != 4) continue;
+    nd.dLeader = id;
+    if (nd.outputs[0].connectedInputs.size() == 1) cand.push_back(id);
+  }
+  if (cand.size() < 2) return;
+  std::unordered_map<int, int> seen;                 // candidate -> segments in which it is a term of its consumer's input
+  std::unordered_map<int, std::vector<int>> byConsumer;
+  for (int id : cand) {
+    seen[id] = 0;
+    byConsumer[nodes[id]->outputs[0].connectedInputs[0].node].push_back(id);
+  }
+  for (const Segment& sg : segs)
+    for (const NodeSeg& ns : sg.nodes) {
+      if (byConsumer.find(ns.id) == byConsumer.end()) continue;
+      auto scan = [&](const InSeg& is, int inputIdx) {
+        for (const TermS& t : is.terms) {
+          auto it = seen.find(t.node);
+          if (it == seen.end()) continue;
+          const InRef& r = nodes[t.node]->outputs[0].connectedInputs[0];
+          if (r.node == ns.id && r.input == inputIdx && t.out == 0) it->second++;
+        }
+      };
+      for (int i = 0; i < (int)ns.ins.size(); i++) scan(ns.ins[i], i);
+      for (int p = 0; p < (int)ns.pins.size(); p++) scan(ns.pins[p], -1 - p);
+    }
+  std::map<std::tuple<int, int, int, int, int>, int> leaderOf;   // (consumer, input, depth, output channels, partitions) -> leader
+  for (int id : cand) {   // topo order: the leader is the first member the traversal reaches
+    NodeS& nd = *nodes[id];
+    if (seen[id] != (int)segs.size()) continue;
+    const InRef& r = nd.outputs[0].connectedInputs[0];
+    auto key = std::make_tuple(r.node, r.input, nd.depth, nd.effectiveOutCh, nd.ir->coarseP);
+    auto it = leaderOf.find(key);
+    if (it == leaderOf.end()) leaderOf.emplace(key, id);
+    else nd.dLeader = it->second;
+  }
+}
+
+// chunk-long view of input channel `c` of a convolver: the segment views when they agree, else a materialised copy
+static const float* convChunkInput(Context& c, Exec& ex, const std::vector<std::vector<const float*>>& ci, int ch) {
+  const auto& segs = ex.segs;
+  const float* stable = nullptr;
+  bool same = true, first = true;
+  for (size_t si = 0; si < segs.size(); si++) {
+    const float* v = (ci[si].empty() || ch >= (int)ci[si].size()) ? nullptr : ci[si][ch];
+    if (first) { stable = v; first = false; } else if (v != stable) same = false;
+  }
+  if (same) return stable;
+  float* slab = getSlab(c);
+  for (size_t si = 0; si < segs.size(); si++) {
+    const float* v = (ci[si].empty() || ch >= (int)ci[si].size()) ? nullptr : ci[si][ch];
+    MixJob mj;
+    mj.out = slab;
+    mj.term0 = (int)ex.terms.size();
+    mj.nterms = v ? 1 : 0;
+    mj.f0 = segs[si].b0 * kBlock;
+    mj.n = (segs[si].b1 - segs[si].b0) * kBlock;
+    if (v) {
+      ex.terms.push_back(v);
+      ex.noteAlign(v, mj.f0);
+    }
+    ex.mixJobs.push_back(mj);
+  }
+  return slab;
+}
+
+static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes, int64_t n) {
+  const int64_t frames = n * kBlock;
+  const int nT = (int)((frames + kCoarseBlock - 1) / kCoarseBlock);
+  constexpr int kVoicesPerJob = 32;   // terms whose products one workgroup accumulates in registers
+  std::vector<CoarseXRow> xrows;
+  std::vector<CoarseHistJob> hjobs;
+  struct Piece {   // <= 4 columns of one signal: (impulse-response channel, output channel of the group)
+    int frame0, P;
+    IrSpectra* ir;
+    int leader;
+    int ncol;
+    int irCh[4], outCh[4];
+  };
+  std::vector<Piece> pieces;
+  int frameNext = 0;
+  int64_t maxHist = 0;
+  double fwdBytes = 0, histBytes = 0;
+  std::vector<const float*> chIn;
+  for (int id : dNodes) {
+    NodeS& nd = *c.nodes[id];
+    IrSpectra& ir = *nd.ir;
+    const int P = ir.coarseP;
+    if (P < 1 || P > kCoarseMaxP) fail(GA_ERR_INVALID_OPERATION, "internal: coarse partition count out of range");
+    const int64_t hl = nd.dHistLen;
+    auto& ci = ex.convIn[id];
+    chIn.assign(nd.bInCh, nullptr);
+    for (int ch = 0; ch < nd.bInCh; ch++) chIn[ch] = convChunkInput(c, ex, ci, ch);
+    bool allSame = true;
+    for (int ch = 1; ch < nd.bInCh; ch++) allSame = allSame && (chIn[ch] == chIn[0]);
+    if (nd.bShared && !allSame) {   // the channels start to differ: every channel inherits the (so far common) history
+      if (!nd.dHistZero)
+        for (int ch = 1; ch < nd.bInCh; ch++)
+          GA_HIP(hipMemcpyAsync(nd.dHist[nd.dHistCur] + (size_t)ch * hl, nd.dHist[nd.dHistCur], (size_t)hl * sizeof(float),
+                                hipMemcpyDeviceToDevice, c.stream));
+      nd.bShared = false;
+    }
+    const int nxr = nd.bShared ? 1 : nd.bInCh;
+    int xFrame[32];
+    for (int ch = 0; ch < nxr; ch++) {
+      CoarseXRow r;
+      r.hist = nd.dHistZero ? nullptr : nd.dHist[nd.dHistCur] + (size_t)ch * hl;
+      r.in = chIn[ch];
+      r.nvalid = frames;
+      r.frame0 = frameNext;
+      r.n_frames = nT + P - 1;
+      r.u0 = -(P - 1);
+      r.hist_len = (int)hl;
+      r.flags = 0;
+      r.scale = 1.0f;
+      xFrame[ch] = frameNext;
+      frameNext += r.n_frames;
+      xrows.push_back(r);
+      hjobs.push_back(CoarseHistJob{r.hist, r.in, nd.dHist[nd.dHistCur ^ 1] + (size_t)ch * hl, hl, frames});
+      maxHist = std::max(maxHist, hl);
+      fwdBytes += (double)(r.n_frames + 1) * kCoarseBlock * 4.0 + (double)r.n_frames * kCoarseBins * 8.0;
+      histBytes += 2.0 * (double)hl * 4.0;
+    }
+    nd.dHistCur ^= 1;
+    nd.dHistZero = false;
+    // columns: discrete -> slot c reads input c, IR channel c, output c ; true stereo -> (L,h0,outL) (L,h1,outR) (R,h2,outL)
+    // (R,h3,outR)  (ConvolverNode.cs:127-151)
+    const int leader = nd.dLeader >= 0 ? nd.dLeader : id;
+    for (int xc = 0; xc < nxr; xc++) {
+      int cols[32][2], ncols = 0;
+      for (int slot = 0; slot < nd.bSlots; slot++) {
+        const int inc = nd.isTrueStereo ? (slot >> 1) : slot;
+        if (!(nd.bShared || inc == xc)) continue;
+        cols[ncols][0] = slot;                               // slot index == IR channel index in both modes
+        cols[ncols][1] = nd.isTrueStereo ? (slot & 1) : slot;
+        ncols++;
+      }
+      for (int c0 = 0; c0 < ncols;) {   // pieces of 4, 2, 1 columns
+        const int left = ncols - c0;
+        const int w = left >= 4 ? 4 : (left >= 2 ? 2 : 1);
+        Piece pc{};
+        pc.frame0 = xFrame[xc];
+        pc.P = P;
+        pc.ir = &ir;
+        pc.leader = leader;
+        pc.ncol = w;
+        for (int j = 0; j < w; j++) {
+          pc.irCh[j] = cols[c0 + j][0];
+          pc.outCh[j] = cols[c0 + j][1];
+        }
+        pieces.push_back(pc);
+        c0 += w;
+      }
+    }
+    c.stats.mac_flops_total += 8.0 * ir.P * kBins * (double)nd.bSlots * (double)n;
+    c.stats.mac_bytes_total += ((double)ir.P * kBins * 8.0 + kBins * 8.0 + 512.0) * nd.bSlots * (double)n;
+  }
+  ex.flushLevel();   // (materialised inputs)
+
+  // ---- jobs: pieces with the same (leader, output channels, partitions) accumulate into the same Y rows ----
+  struct Key {
+    int leader, P, ncol, out[4];
+    bool operator<(const Key& o) const {
+      return std::tie(leader, P, ncol, out[0], out[1], out[2], out[3]) < std::tie(o.leader, o.P, o.ncol, o.out[0], o.out[1], o.out[2], o.out[3]);
+    }
+  };
+  std::map<Key, std::vector<const Piece*>> byKey;
+  for (const Piece& pc : pieces) {
+    Key k{pc.leader, pc.P, pc.ncol, {-1, -1, -1, -1}};
+    for (int j = 0; j < pc.ncol; j++) k.out[j] = pc.outCh[j];
+    byKey[k].push_back(&pc);
+  }
+  std::vector<CoarseTerm> terms;
+  std::vector<CoarseJob> jobs[3];          // by column count 1, 2, 4
+  int maxT[3] = {0, 0, 0}, maxP[3] = {0, 0, 0};
+  bool anyPrivate[3] = {false, false, false};
+  double macBytes[3] = {0, 0, 0};
+  std::map<std::pair<int, int>, std::vector<int>> outRows;   // (leader, channel) -> Y rows to sum
+  int yNext = 0;
+  for (auto& kv : byKey) {
+    const Key& k = kv.first;
+    const int cw = k.ncol, ci = cw == 1 ? 0 : (cw == 2 ? 1 : 2);
+    const auto& pv = kv.second;
+    for (size_t p0 = 0; p0 < pv.size(); p0 += kVoicesPerJob) {
+      const size_t p1 = std::min(pv.size(), p0 + kVoicesPerJob);
+      const int term0 = (int)terms.size();
+      bool shared = true;
+      for (size_t i = p0; i < p1; i++) {
+        const Piece& pc = *pv[i];
+        CoarseTerm t{};
+        t.frame0 = pc.frame0;
+        for (int j = 0; j < 4; j++) t.h[j] = nullptr;
+        for (int j = 0; j < cw; j++) t.h[j] = pc.ir->coarse + (size_t)pc.irCh[j] * pc.P * kCoarseBins;
+        if (i > p0)
+          for (int j = 0; j < cw; j++) shared = shared && (t.h[j] == terms[term0].h[j]);
+        terms.push_back(t);
+      }
+      const int yrow0 = yNext;
+      yNext += cw;
+      for (int j = 0; j < cw; j++) outRows[{k.leader, k.out[j]}].push_back(yrow0 + j);
+      const int jb = kCoarseJobBlocks(cw);
+      for (int t0 = 0; t0 < nT; t0 += jb) {
+        CoarseJob jb_{};
+        jb_.term0 = term0;
+        jb_.n_terms = (int)(p1 - p0);
+        jb_.P = k.P;
+        jb_.t0 = t0;
+        jb_.n_t = std::min(jb, nT - t0);
+        jb_.yrow0 = yrow0;
+        jb_.shared_h = shared ? 1 : 0;
+        jobs[ci].push_back(jb_);
+        maxT[ci] = std::max(maxT[ci], jb_.n_t);
+        maxP[ci] = std::max(maxP[ci], k.P);
+        anyPrivate[ci] = anyPrivate[ci] || !shared;
+        macBytes[ci] += (double)jb_.n_terms * (jb_.n_t + k.P - 1) * kCoarseBins * 8.0 +
+                        (double)(shared ? 1 : jb_.n_terms) * k.P * cw * kCoarseBins * 8.0 + (double)cw * jb_.n_t * kCoarseBins * 8.0;
+      }
+    }
+  }
+  std::vector<CoarseOut> outs;
+  std::vector<int> ylist;
+  double invBytes = 0;
+  for (auto& kv : outRows) {
+    CoarseOut o{};
+    o.out = ex.nodeOut(kv.first.first, kv.first.second);
+    o.nvalid = frames;
+    o.y0 = (int)ylist.size();
+    o.ny = (int)kv.second.size();
+    ylist.insert(ylist.end(), kv.second.begin(), kv.second.end());
+    outs.push_back(o);
+    invBytes += (double)o.ny * nT * kCoarseBins * 8.0 + (double)frames * 4.0;
+  }
+  if ((size_t)frameNext * kCoarseBins * sizeof(float2) > c.coarseX.bytes || (size_t)yNext * nT * kCoarseBins * sizeof(float2) > c.coarseY.bytes)
+    fail(GA_ERR_INVALID_OPERATION, "internal: coarse spectra arenas are too small for the plan");
+
+  const size_t xo = ex.plan.putv(xrows), ho = ex.plan.putv(hjobs), to = ex.plan.putv(terms), oo = ex.plan.putv(outs), yo = ex.plan.putv(ylist);
+  size_t jo[3];
+  for (int i = 0; i < 3; i++) jo[i] = ex.plan.putv(jobs[i]);
+  hipStream_t st = c.stream;
+  float2* X = (float2*)c.coarseX.p;
+  float2* Y = (float2*)c.coarseY.p;
+  const float2* tw16 = c.twiddles16(4096);
+  const float2* twab = c.coarseTwab();
+  const int nx = (int)xrows.size(), nh = (int)hjobs.size(), no = (int)outs.size();
+  int maxFrames = 0;
+  for (auto& r : xrows) maxFrames = std::max(maxFrames, r.n_frames);
+  // windows per workgroup: long runs fetch every input sample once; keep >= ~4 workgroups per CU's worth of parallelism
+  int run = 1;
+  while (run < 16 && (int64_t)nx * ((maxFrames + 2 * run - 1) / (2 * run)) >= 1024) run *= 2;
+  ex.plan.add(LK_CFWD, [=](uint8_t* base) { launch_coarse_fwd(st, (const CoarseXRow*)(base + xo), nx, maxFrames, run, X, tw16, twab); },
+              fwdBytes);
+  for (int i = 0; i < 3; i++) {
+    if (jobs[i].empty()) continue;
+    const int nj = (int)jobs[i].size(), cw = i == 0 ? 1 : (i == 1 ? 2 : 4), mt = maxT[i], mp = maxP[i];
+    const bool ap = anyPrivate[i];
+    const size_t off = jo[i];
+    ex.plan.add(LK_CMAC, [=](uint8_t* base) {
+      launch_coarse_mac(st, (const CoarseJob*)(base + off), nj, (const CoarseTerm*)(base + to), X, Y, nT, cw, mt, mp, ap);
+    }, macBytes[i]);
+    c.stats.mac_launches += 1;
+  }
+  ex.plan.add(LK_CINV, [=](uint8_t* base) {
+    launch_coarse_inv(st, (const CoarseOut*)(base + oo), no, nT, (const int*)(base + yo), Y, nT, tw16, twab);
+  }, invBytes);
+  const int64_t mh = maxHist;
+  ex.plan.add(LK_CHIST, [=](uint8_t* base) { launch_coarse_hist(st, (const CoarseHistJob*)(base + ho), nh, mh); }, histBytes);
 }
 
 // ======================================================================================================
@@ -1481,7 +1768,8 @@ void Context::runChunkImpl(int64_t n, float* const* /*unused*/) {
 
   // ---- convolver scratch planes are shared by all groups: size them for the largest group BEFORE any recorded
   //      launch captures their address ----
-  assignConvPaths(topo);
+  assignConvPaths(topo, n);
+  planCoarseFusion(topo, segs);
   int bHistMax = 0;
   {
     size_t xMax = 0, yMax = 0;
@@ -1489,7 +1777,7 @@ void Context::runChunkImpl(int64_t n, float* const* /*unused*/) {
     for (int id : topo) {
       NodeS& nd = *nodes[id];
       if (nd.type != GA_NODE_CONVOLVER || !nd.ir) continue;
-      if (nd.convPath >= 2) {
+      if (nd.convPath == 2 || nd.convPath == 3) {
         bx += nd.bInCh;
         by += nd.bSlots;
         bHistMax = std::max(bHistMax, nd.ir->P - 1);
@@ -1507,6 +1795,27 @@ void Context::runChunkImpl(int64_t n, float* const* /*unused*/) {
       ensure(planes[1], xMax);
       ensure(planes[2], yMax);
       ensure(planes[3], yMax);
+    }
+    {  // formulation D: the stages of a chunk run one after the other on the stream and share the two arenas
+      std::map<int, std::pair<size_t, size_t>> perDepth;   // depth -> (X frames, Y frames upper bound)
+      const int64_t nT = (n * kBlock + kCoarseBlock - 1) / kCoarseBlock;
+      for (int id : topo) {
+        NodeS& nd = *nodes[id];
+        if (nd.type != GA_NODE_CONVOLVER || !nd.ir || nd.convPath != 4) continue;
+        auto& pd = perDepth[nd.depth];
+        pd.first += (size_t)nd.bInCh * (size_t)(nT + nd.ir->coarseP - 1);
+        // Y rows: one per slot unless fused; fused groups need (members / 32 + 1) x channels rows, never more than the slots
+        pd.second += (size_t)nd.bSlots * (size_t)nT;
+      }
+      size_t xf = 0, yf = 0;
+      for (auto& kv : perDepth) {
+        xf = std::max(xf, kv.second.first);
+        yf = std::max(yf, kv.second.second);
+      }
+      if (xf) {
+        ensure(coarseX, xf * kCoarseBins * sizeof(float2));
+        ensure(coarseY, yf * kCoarseBins * sizeof(float2));
+      }
     }
     bRowX = bRowY = 0;
     if (bx) {  // formulation B scratch: [row][bin][block]; x planes alternate between two pairs (flushPlaneHistories)
@@ -1932,6 +2241,9 @@ void Context::runChunkImpl(int64_t n, float* const* /*unused*/) {
             auto& ci = ex.convIn[ns.id];
             if (ci.empty()) ci.assign(segs.size(), std::vector<const float*>());
             ci[si] = iv;
+            // formulation D: the outputs of a fused group are summed as spectra; the sum is the LEADER's output, the other
+            // members hand their consumer a null (= contributes nothing) view (Context::planCoarseFusion)
+            if (nd.convPath == 4 && nd.dLeader >= 0 && nd.dLeader != ns.id) break;
             for (int ch = 0; ch < ns.outCh; ch++) ov[ch] = ex.nodeOut(ns.id, ch);
             break;
           }
@@ -1960,11 +2272,16 @@ void Context::runChunkImpl(int64_t n, float* const* /*unused*/) {
     std::map<ConvGroup*, std::vector<std::pair<int, int>>, GroupLess> active;
     std::vector<const float*> prevIns;
     int prevP = -1, prevRp = -1, prevRows = -1;
-    std::vector<int> bNodes;  // formulation B nodes of this depth
+    std::vector<int> bNodes;  // formulation B / C nodes of this depth
+    std::vector<int> dNodes;  // formulation D nodes of this depth
     for (int id : topo) {
       NodeS& nd = *nodes[id];
       if (nd.type != GA_NODE_CONVOLVER || !nd.ir || nd.depth != d) continue;
       if (ex.convIn.find(id) == ex.convIn.end()) continue;
+      if (nd.convPath == 4) {
+        dNodes.push_back(id);
+        continue;
+      }
       if (nd.convPath >= 2) {
         bNodes.push_back(id);
         continue;
@@ -2075,6 +2392,8 @@ void Context::runChunkImpl(int64_t n, float* const* /*unused*/) {
                                (double)P * kBins * 8.0 * (double)n;
       stats.mac_launches += 1;
     }
+    // ---- formulation D: coarse partitions, consumer sums fused in the frequency domain ----
+    if (!dNodes.empty()) planCoarseStage(*this, ex, dNodes, n);
     // ---- formulation B: nodes with a private impulse response ----
     if (!bNodes.empty()) {
       const int hist = (int)roundup(bHistMax, 4);   // plane time origin, 16-byte aligned rows
@@ -2354,6 +2673,7 @@ void Context::runChunkImpl(int64_t n, float* const* /*unused*/) {
 
   std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
   std::vector<int> evKind;
+  std::vector<double> evBytes;
   hipEvent_t evBegin = nullptr, evEnd = nullptr;
   if (profile) {
     GA_HIP(hipEventCreate(&evBegin));
@@ -2372,13 +2692,14 @@ void Context::runChunkImpl(int64_t n, float* const* /*unused*/) {
       GA_HIP(hipEventRecord(e1, stream));
       evs.push_back({e0, e1});
       evKind.push_back(l.kind);
+      evBytes.push_back(l.bytes);
     }
     stats.kernel_launches++;
   }
   if (profile) GA_HIP(hipEventRecord(evEnd, stream));
   GA_HIP(hipGetLastError());
   tmLaunch = nowMs();
-  if (profile) pendingProf.push_back(ProfBatch{evBegin, evEnd, std::move(evs), std::move(evKind)});
+  if (profile) pendingProf.push_back(ProfBatch{evBegin, evEnd, std::move(evs), std::move(evKind), std::move(evBytes)});
   if (asyncMode) {
     if (!chunkDone[slot]) GA_HIP(hipEventCreateWithFlags(&chunkDone[slot], hipEventDisableTiming));
     GA_HIP(hipEventRecord(chunkDone[slot], stream));

@@ -80,12 +80,17 @@ Context::~Context() {
     if (np && np->bHistR) (void)hipFree(np->bHistR);
     if (np && np->bHistI) (void)hipFree(np->bHistI);
     if (np && np->bOverlap) (void)hipFree(np->bOverlap);
+    if (np && np->dHist[0]) (void)hipFree(np->dHist[0]);
+    if (np && np->dHist[1]) (void)hipFree(np->dHist[1]);
     if (np && np->delayHist) (void)hipFree(np->delayHist);
     if (np && np->delayLine) (void)hipFree(np->delayLine);
     if (np && np->oscPhase) (void)hipFree(np->oscPhase);
     if (np && np->panDev) (void)hipFree(np->panDev);
   }
   for (auto& kv : tw16) (void)hipFree(kv.second);
+  if (coarseTw) (void)hipFree(coarseTw);
+  if (coarseX.p) (void)hipFree(coarseX.p);
+  if (coarseY.p) (void)hipFree(coarseY.p);
   if (ilvDev) (void)hipFree(ilvDev);
   if (tables.p) (void)hipFree(tables.p);
   if (tablesHost) (void)hipHostFree(tablesHost);
@@ -202,9 +207,15 @@ void Context::harvestProfile(bool wait) {
     stats.device_ms_total += ms;
     for (size_t i = 0; i < b.evs.size(); i++) {
       GA_HIP(hipEventElapsedTime(&ms, b.evs[i].first, b.evs[i].second));
-      if (b.kinds[i] == LK_MAC) stats.mac_ms_total += ms;
-      else if (b.kinds[i] == LK_FFT) stats.fft_ms_total += ms;
+      const int k = b.kinds[i];
+      if (k == LK_MAC || k == LK_CMAC) stats.mac_ms_total += ms;
+      else if (k == LK_FFT || k == LK_IFFT || k == LK_CFWD || k == LK_CINV || k == LK_CHIST) stats.fft_ms_total += ms;
       else stats.other_ms_total += ms;
+      if (k >= 0 && k < 16) {
+        stats.stage_ms[k] += ms;
+        stats.stage_launches[k] += 1;
+        stats.stage_bytes[k] += i < b.bytes.size() ? b.bytes[i] : 0.0;
+      }
       (void)hipEventDestroy(b.evs[i].first);
       (void)hipEventDestroy(b.evs[i].second);
     }
@@ -327,6 +338,17 @@ void Context::releaseConvState(NodeS& n) {
     }
     dfree(n.bOverlap, (size_t)n.bSlots * 2 * kBlock * sizeof(float));
   }
+  if (n.dHist[0]) {
+    if (stream) (void)hipStreamSynchronize(stream);
+    const size_t hb = (size_t)n.bInCh * (size_t)n.dHistLen * sizeof(float);
+    dfree(n.dHist[0], hb);
+    dfree(n.dHist[1], hb);
+  }
+  n.dHist[0] = n.dHist[1] = nullptr;
+  n.dHistLen = 0;
+  n.dHistCur = 0;
+  n.dHistZero = true;
+  n.dLeader = -1;
   n.bHistR = n.bHistI = n.bOverlap = nullptr;
   n.bHistPlane = -1;
   n.convPath = 0;
@@ -399,7 +421,7 @@ ConvRowRef Context::addGroupRow(const std::shared_ptr<IrSpectra>& ir, int ch, in
 // Decide, for convolver nodes that do not have DSP state yet, which formulation serves them: nodes sharing an impulse
 // response with at least 7 others become rows of the shared-IR GEMM (A); nodes with a (nearly) private IR use the
 // per-node formulation (B), whose state is O(P) per input channel instead of O(P * 128 rows) per IR channel.
-void Context::assignConvPaths(const std::vector<int>& topo) {
+void Context::assignConvPaths(const std::vector<int>& topo, int64_t chunkBlocks) {
   std::map<IrSpectra*, int> users;
   std::map<IrSpectra*, bool> hasA;
   // a group is executed once per chunk at ONE convolver depth, for all of its rows; a graph edit that moved a node to another
@@ -449,8 +471,25 @@ void Context::assignConvPaths(const std::vector<int>& topo) {
     IrSpectra* ir = nd.ir.get();
     const int channels = ir->nch;
     const bool pathC = useTimeFft && ir->P > 64 && ir->P <= 1024;   // FFT along the block axis (N2 <= 4096)
-    const bool pathA = !pathC && (hasA[ir] || users[ir] >= 8);
-    if (pathA) {
+    // coarse partitions (formulation D): impulse responses of 8,193 .. 131,072 taps when the render comes in long chunks --
+    // a short chunk would pay the transforms of the whole input history for a few blocks of output (the node keeps the
+    // formulation it starts with: its state is formulation specific)
+    const int coarseParts = (int)(((int64_t)ir->P * kBlock + kCoarseBlock - 1) / kCoarseBlock);
+    const bool pathD = useCoarse && useTimeFft && ir->P > 64 && coarseParts <= kCoarseMaxP && chunkBlocks >= coarseMinBlocks;
+    const bool pathA = !pathC && !pathD && (hasA[ir] || users[ir] >= 8);
+    if (pathD) {
+      nd.bInCh = nd.isTrueStereo ? 2 : channels;
+      nd.bSlots = nd.isTrueStereo ? 4 : channels;
+      ensureCoarseSpectra(*ir);
+      nd.dHistLen = (int64_t)ir->coarseP * kCoarseBlock;
+      const size_t hb = (size_t)nd.bInCh * (size_t)nd.dHistLen * sizeof(float);
+      nd.dHist[0] = (float*)dalloc(hb);
+      nd.dHist[1] = (float*)dalloc(hb);
+      nd.dHistCur = 0;
+      nd.dHistZero = true;   // (never read while the flag is set)
+      nd.bShared = true;
+      nd.convPath = 4;
+    } else if (pathA) {
       for (int ch = 0; ch < channels; ch++) nd.convRows.push_back(addGroupRow(nd.ir, ch, nd.depth, id));
       nd.convPath = 1;
     } else {
@@ -615,7 +654,9 @@ std::shared_ptr<IrSpectra> Context::irSpectra(int bufId, bool normalize) {
   launch_extract_ir(stream, sp->hr, sp->hi, xr, xi, P, rp, P, nch);
   GA_HIP(hipStreamSynchronize(stream));
   GA_HIP(hipGetLastError());
-  dfree(dIn, scaled.size() * sizeof(float));
+  sp->taps = dIn;   // kept: formulation D transforms the scaled taps with its own partition size (ensureCoarseSpectra)
+  sp->tapsStride = padded;
+  sp->tapsBytes = scaled.size() * sizeof(float);
   dfree(xr, planeBytes);
   dfree(xi, planeBytes);
   dfree(rowsDev, sizeof(ConvRowIO) * nch);
@@ -637,6 +678,50 @@ const float2* Context::twiddles16(int N2) {
   GA_HIP(hipMemcpy(d, t.data(), sizeof(float2) * t.size(), hipMemcpyHostToDevice));
   tw16[N2] = d;
   return d;
+}
+
+// ---- formulation D (ga_coarse.hip) ----
+const float2* Context::coarseTwab() {
+  if (coarseTw) return coarseTw;
+  const double pi = 3.14159265358979323846264338327950288;
+  std::vector<float2> t(2 * 2049);
+  for (int k = 0; k <= 2048; k++) {
+    t[k] = make_float2((float)std::cos(2.0 * pi * k / 8192), (float)-std::sin(2.0 * pi * k / 8192));
+    t[2049 + k] = make_float2((float)std::cos(2.0 * pi * k / 16384), (float)-std::sin(2.0 * pi * k / 16384));
+  }
+  coarseTw = (float2*)dalloc(sizeof(float2) * t.size());
+  GA_HIP(hipMemcpy(coarseTw, t.data(), sizeof(float2) * t.size(), hipMemcpyHostToDevice));
+  return coarseTw;
+}
+// packed 16,384-point spectra of the coarse partitions [h_p | 0] of every channel, with the power-of-two factors of the
+// transform chain folded in: the forward / inverse kernels skip the 1/2 of their even / odd splits (x 2 on X, x 2 on H, x 4
+// in the inverse) and the 1 / 4096 of the inverse complex transform, so H carries 1 / (2 * 2 * 4 * 4096) = 2^-16 -- exact.
+void Context::ensureCoarseSpectra(IrSpectra& ir) {
+  if (ir.coarse) return;
+  if (!ir.taps) fail(GA_ERR_INVALID_OPERATION, "internal: impulse response without device taps");
+  const int P = (int)((ir.tapsStride + kCoarseBlock - 1) / kCoarseBlock);
+  ir.coarseP = P;
+  ir.coarseBytes = (size_t)ir.nch * P * kCoarseBins * sizeof(float2);
+  ir.coarse = (float2*)dalloc(ir.coarseBytes);
+  std::vector<CoarseXRow> rows(ir.nch);
+  for (int c = 0; c < ir.nch; c++) {
+    CoarseXRow& r = rows[c];
+    r.hist = nullptr;
+    r.in = ir.taps + (size_t)c * ir.tapsStride;
+    r.nvalid = ir.tapsStride;
+    r.frame0 = c * P;
+    r.n_frames = P;
+    r.u0 = 1;            // window p + 1 starts at partition p; its second half is forced to zero
+    r.hist_len = 0;
+    r.flags = 1;
+    r.scale = 1.0f / 65536.0f;
+  }
+  CoarseXRow* rd = (CoarseXRow*)dalloc(sizeof(CoarseXRow) * rows.size());
+  GA_HIP(hipMemcpy(rd, rows.data(), sizeof(CoarseXRow) * rows.size(), hipMemcpyHostToDevice));
+  launch_coarse_fwd(stream, rd, ir.nch, P, P, ir.coarse, twiddles16(4096), coarseTwab());
+  GA_HIP(hipGetLastError());
+  GA_HIP(hipStreamSynchronize(stream));
+  dfree(rd, sizeof(CoarseXRow) * rows.size());
 }
 
 const float2* Context::twiddlesC(int N2) {

@@ -101,6 +101,14 @@ struct IrSpectra {  // P zero-padded 256-point spectra per IR channel (Partition
   float2* hspecN[3] = {nullptr, nullptr, nullptr};
   static int n2Index(int N2) { return N2 == 1024 ? 0 : N2 == 2048 ? 1 : 2; }
   size_t hBytes = 0, hspecBytes = 0;
+  // formulation D: the scaled taps [nch][tapsStride] (kept for the coarse spectra, built on first use) and the packed
+  // 16,384-point spectra of the coarse partitions [nch][coarseP][kCoarseBins]
+  float* taps = nullptr;
+  int64_t tapsStride = 0;
+  size_t tapsBytes = 0;
+  int coarseP = 0;
+  float2* coarse = nullptr;
+  size_t coarseBytes = 0;
   int64_t* devBytesRef = nullptr;   // the owning context's byte counter
   IrSpectra() = default;
   IrSpectra(const IrSpectra&) = delete;
@@ -110,7 +118,9 @@ struct IrSpectra {  // P zero-padded 256-point spectra per IR channel (Partition
     if (hi) (void)hipFree(hi);
     for (float2* h : hspecN)
       if (h) (void)hipFree(h);
-    if (devBytesRef) *devBytesRef -= (int64_t)(2 * hBytes + hspecBytes);
+    if (taps) (void)hipFree(taps);
+    if (coarse) (void)hipFree(coarse);
+    if (devBytesRef) *devBytesRef -= (int64_t)(2 * hBytes + hspecBytes + tapsBytes + coarseBytes);
   }
 };
 
@@ -219,6 +229,15 @@ struct NodeS {
   int bHistPlane = -1;
   int bHistRow = 0, bHistNx = 1, bHistOff = 0, bHistTxb = 0;
   bool bHistZero = true;
+  // formulation D (convPath 4): the state of a node is the last coarseP x 8192 INPUT samples of every input channel (time
+  // domain, double buffered: a chunk reads one copy and writes the other); overlap-save keeps nothing on the output side
+  float* dHist[2] = {nullptr, nullptr};   // [bInCh][dHistLen]
+  int64_t dHistLen = 0;
+  int dHistCur = 0;
+  bool dHistZero = true;
+  // per chunk: convolver outputs that one summing input consumes are summed as spectra (Context::planCoarseFusion);
+  // the leader's output slabs carry the sum, the other members contribute no time-domain signal of their own
+  int dLeader = -1;
 };
 
 // one evaluated control state of a node within a segment
@@ -277,7 +296,10 @@ inline int tapFftSize(int P) {
   return std::max(1024, 4 * n);
 }
 
-enum LaunchKind { LK_OTHER = 0, LK_FFT = 1, LK_MAC = 2 };   // which statistics bucket a recorded launch belongs to
+// which statistics bucket a recorded launch belongs to: the GA_STAGE_* indices of ga_stats
+enum LaunchKind { LK_OTHER = GA_STAGE_OTHER, LK_MIX = GA_STAGE_MIX, LK_FFT = GA_STAGE_RFFT_FWD, LK_MAC = GA_STAGE_MAC,
+                  LK_IFFT = GA_STAGE_RFFT_INV, LK_CFWD = GA_STAGE_COARSE_FWD, LK_CMAC = GA_STAGE_COARSE_MAC,
+                  LK_CINV = GA_STAGE_COARSE_INV, LK_CHIST = GA_STAGE_COARSE_HIST };
 
 struct DevArena {  // grow-only device scratch
   void* p = nullptr;
@@ -347,6 +369,7 @@ struct Context {
     hipEvent_t begin, end;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
     std::vector<int> kinds;
+    std::vector<double> bytes;   // necessary HBM bytes of each launch (0 = not accounted)
   };
   std::deque<ProfBatch> pendingProf;
   void harvestProfile(bool wait);   // folds finished event batches into `stats`
@@ -391,7 +414,13 @@ struct Context {
 
   std::shared_ptr<IrSpectra> irSpectra(int bufId, bool normalize);
   void releaseConvState(NodeS& n);
-  void assignConvPaths(const std::vector<int>& topo);
+  void assignConvPaths(const std::vector<int>& topo, int64_t chunkBlocks);
+  // formulation D
+  DevArena coarseX, coarseY;        // spectra frames of a convolver stage (shared by the stages of a chunk, which run in order)
+  float2* coarseTw = nullptr;       // combine-pass twiddles [2][2049]: W_8192^k, W_16384^k
+  const float2* coarseTwab();
+  void ensureCoarseSpectra(IrSpectra& ir);
+  void planCoarseFusion(const std::vector<int>& topo, const std::vector<Segment>& segs);
   ConvRowRef addGroupRow(const std::shared_ptr<IrSpectra>& ir, int ch, int depth, int nodeId);
   void ensureGroupState(ConvGroup& g);
   const float2* twiddlesC(int N2);

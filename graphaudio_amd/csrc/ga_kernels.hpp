@@ -109,6 +109,55 @@ void launch_tconv(hipStream_t s, const ConvSetC* sets_dev, int nsets, int nblock
 void launch_tconv16(hipStream_t s, const ConvSetC* sets_dev, int nsets, int nblocks, int hist, ConvPlanesB pl, int N2, const float2* tw16,
                     int nseg, int tbase);
 
+// ---- convolver pipeline, formulation D: coarse partitions, consumer sum fused in the frequency domain (ga_coarse.hip) ----
+constexpr int kCoarseBlock = 8192;   // samples per coarse partition / output block
+constexpr int kCoarseMaxP = 16;      // partitions a job can slide over (impulse responses up to 131,072 taps)
+constexpr int kCoarseJobBlocks(int columns) { return columns <= 2 ? 64 : 32; }   // coarse blocks one multiply-accumulate job covers
+constexpr int kCoarseBins = 8192;    // packed complex bins of one 16,384-point real spectrum (bin 0 = (X[0], X[8192]))
+struct CoarseXRow {        // one transformed signal: a convolver input channel, or an impulse-response channel
+  const float* hist;       // the hist_len samples in front of the chunk (nullptr = zeros)
+  const float* in;         // chunk-frame indexed input (nullptr = zeros)
+  int64_t nvalid;          // samples of `in` (whole 128-frame blocks); zeros beyond
+  int frame0;              // index of the row's first frame in the X buffer
+  int n_frames;            // windows to transform
+  int u0;                  // window index of frame 0: window u covers samples [(u - 1) CB, (u + 1) CB) of the chunk
+  int hist_len;            // multiple of CB
+  int flags;               // bit 0: second half of every window is zero (impulse-response partitions [h_p | 0])
+  float scale;             // applied to every sample (impulse responses: normalisation and transform scale factors)
+};
+struct CoarseTerm {        // one (signal, impulse response) product feeding a job's accumulators
+  int frame0;              // frame of window u = -(P - 1) of the signal
+  int pad_;
+  const float2* h[4];      // per column: packed spectra [P][kCoarseBins] of the column's impulse-response channel
+};
+struct CoarseJob {         // accumulators Y[yrow0 + c][t] = sum over terms sum_p X[t - p] H_c[p],  c < columns of the launch
+  int term0, n_terms;
+  int P;                   // coarse partitions (all terms of a job)
+  int t0, n_t;             // coarse blocks [t0, t0 + n_t) of the chunk, n_t <= kCoarseJobBlocks(columns)
+  int yrow0;
+  int shared_h;            // every term uses the same spectra (loaded once)
+  int pad_;
+};
+struct CoarseOut {         // one time-domain output: the sum of `ny` Y rows
+  float* out;              // chunk-frame indexed
+  int64_t nvalid;          // chunk frames
+  int y0, ny;              // ylist[y0 .. y0 + ny)
+};
+struct CoarseHistJob {
+  const float* old_hist;   // nullptr = zeros
+  const float* in;         // nullptr = zeros
+  float* new_hist;
+  int64_t hist_len, n;
+};
+// tw16 = Context::twiddles16(4096); twab = [2][2049]: W_8192^k, W_16384^k
+void launch_coarse_fwd(hipStream_t s, const CoarseXRow* rows_dev, int nrows, int max_frames, int run, float2* X, const float2* tw16,
+                       const float2* twab);
+void launch_coarse_mac(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
+                       int y_frames, int cw, int max_t, int maxP, bool any_private);
+void launch_coarse_inv(hipStream_t s, const CoarseOut* outs_dev, int nouts, int n_t, const int* ylist_dev, const float2* Y, int y_frames,
+                       const float2* tw16, const float2* twab);
+void launch_coarse_hist(hipStream_t s, const CoarseHistJob* jobs_dev, int njobs, int64_t max_len);
+
 // ---- graph plumbing kernels ------------------------------------------------------------------------
 // out[f0 + i] = ((0 + t0[f0+i]) + t1[f0+i]) + ...  in term order (AudioNodeInput.cs:118-132,182-244)
 struct MixJob {

@@ -95,7 +95,25 @@ typedef struct ga_stats {
   int64_t device_bytes_in_use;
   int32_t n_nodes;
   int32_t n_conv_rows;          /* convolver channel-instances resident on the device */
+  /* per-stage device time (HIP events on the context's stream, option "profile"), launches and the HBM bytes each stage HAS TO
+     move in the formulation that was executed (inputs read once + outputs written once, from the plan) -- what bench.py prices
+     against the HBM roofline.  Index = GA_STAGE_*. */
+  double  stage_ms[16];
+  int64_t stage_launches[16];
+  double  stage_bytes[16];
 } ga_stats;
+enum {
+  GA_STAGE_OTHER = 0,        /* sources, biquads, gains, parameter curves, ... */
+  GA_STAGE_MIX = 1,          /* AudioNodeInput.MixBuffer sums (incl. the destination bus) */
+  GA_STAGE_RFFT_FWD = 2,     /* formulations A/B/C: 256-point forward transforms (+ history copy) */
+  GA_STAGE_MAC = 3,          /* formulations A/B/C: partition sum */
+  GA_STAGE_RFFT_INV = 4,     /* formulations A/B/C: 256-point inverse transforms + overlap-add */
+  GA_STAGE_COARSE_FWD = 5,   /* formulation D: 16,384-point forward transforms */
+  GA_STAGE_COARSE_MAC = 6,   /* formulation D: partition sum + frequency-domain mix */
+  GA_STAGE_COARSE_INV = 7,   /* formulation D: inverse transforms */
+  GA_STAGE_COARSE_HIST = 8,  /* formulation D: input history of the next chunk */
+  GA_STAGE_COUNT = 9
+};
 
 /* ---- library ---- */
 GA_EXPORT const char* GA_FN(strerror)(int code);              /* cf. sf_strerror, GraphAudio.IO/Libsndfile.cs:48-56 */
