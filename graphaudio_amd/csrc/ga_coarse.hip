@@ -30,6 +30,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 namespace ga {
 
@@ -60,7 +62,7 @@ struct HalfRegs {
   f2 v[8];
 };
 // the 8 (re, im) points this thread owns in half-window `j` of the row: x[4 (t + 256 q) + g], x[.. + g + 2]
-__device__ __forceinline__ void coarse_issue_half(const CoarseXRow& R, int j, int g, int t, float4 (&raw)[8]) {
+__device__ __forceinline__ void coarse_issue_half(const CoarseXRow& R, int j, int g, int t, v4f (&raw)[8]) {
   const float* src = nullptr;
   int64_t lim = 0;   // samples of this half that exist (the rest is zero)
   if (j < 0) {
@@ -78,24 +80,24 @@ __device__ __forceinline__ void coarse_issue_half(const CoarseXRow& R, int j, in
 #pragma unroll
   for (int q = 0; q < 8; q++) {
     const int o = 4 * (t + 256 * q);
-    raw[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    raw[q] = v4f{0.f, 0.f, 0.f, 0.f};
     if (src && o < lim) {   // lim is a multiple of 4 (chunks are whole 128-frame blocks, histories whole coarse blocks)
       if (aligned) {
-        raw[q] = *reinterpret_cast<const float4*>(src + o);
+        raw[q] = ldg4(src + o);
       } else {
-        raw[q] = make_float4(src[o], src[o + 1], src[o + 2], src[o + 3]);
+        raw[q] = v4f{ldg1(src + o), ldg1(src + o + 1), ldg1(src + o + 2), ldg1(src + o + 3)};
       }
     }
   }
   (void)g;
 }
-__device__ __forceinline__ void coarse_pick_half(const float4 (&raw)[8], int g, float scale, HalfRegs& h) {
+__device__ __forceinline__ void coarse_pick_half(const v4f (&raw)[8], int g, float scale, HalfRegs& h) {
 #pragma unroll
   for (int q = 0; q < 8; q++) h.v[q] = g ? f2{raw[q].y * scale, raw[q].w * scale} : f2{raw[q].x * scale, raw[q].z * scale};
 }
 
 __global__ __launch_bounds__(512) void coarse_fwd_kernel(const CoarseXRow* __restrict rows, int run, float2* __restrict X,
-                                                         const float2* __restrict twg, const float2* __restrict twab) {
+                                                         const float2* __restrict twg, const float2* __restrict twab, int exp) {
   using PL = R16Plan<CM>;
   extern __shared__ f2 clds[];
   f2* tw2 = clds;
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(512) void coarse_fwd_kernel(const CoarseXRow* __res
   const bool zero2 = (R.flags & 1) != 0;   // impulse-response partitions: [h_p | 0]
   HalfRegs cur, nxt;
   {
-    float4 raw[8];
+    v4f raw[8];
     coarse_issue_half(R, R.u0 + w0 - 1, g, t, raw);
     coarse_pick_half(raw, g, R.scale, cur);
     if (zero2) {
@@ -133,20 +135,30 @@ __global__ __launch_bounds__(512) void coarse_fwd_kernel(const CoarseXRow* __res
   __syncthreads();
   for (int w = w0; w < w1; w++) {
     const int u = R.u0 + w;
-    float4 raw[8];
+    v4f raw[8];
     const bool more = w + 1 < w1;
-    if (more) coarse_issue_half(R, zero2 ? u : u + 1, g, t, raw);   // in flight behind this window's transforms
+    if (more && !(exp & 8)) coarse_issue_half(R, zero2 ? u : u + 1, g, t, raw);   // in flight behind this window's transforms
     f2 own[16];
 #pragma unroll
     for (int m = 0; m < 8; m++) {
       own[m] = cur.v[m];
       own[8 + m] = nxt.v[m];
     }
-    fft16_own<CM>(own, buf, tw2, tw3, t);
+    if (!(exp & 4)) fft16_own<CM>(own, buf, tw2, tw3, t);
     __syncthreads();   // the last pass has read the buffer: store Z_g in natural order
 #pragma unroll
     for (int m = 0; m < 16; m++) buf[cpad(t + 256 * m)] = own[m];
     __syncthreads();
+    // the prefetched half is consumed BEFORE the combine pass issues its stores: vmcnt counts loads and stores in issue
+    // order, so waiting for these loads later would wait for this window's stores to complete as well
+    if (more) {
+      if (zero2) {
+        coarse_pick_half(raw, g, R.scale, cur);
+      } else {
+        cur = nxt;
+        coarse_pick_half(raw, g, R.scale, nxt);
+      }
+    }
     float2* __restrict F = X + (size_t)(R.frame0 + w) * kCoarseBins;
     auto quad = [&](int k, f2 a, f2 b) {
       const int km = (CM - k) & (CM - 1);
@@ -162,7 +174,9 @@ __global__ __launch_bounds__(512) void coarse_fwd_kernel(const CoarseXRow* __res
       const f2 T = cmulc(mul_mi(cj(b)), Omk);
       const f2 Xk = Ek + S, Xnk = cj(Ek - S);
       const f2 Xmk = Emk + T, Xpk = cj(Emk - T);
-      if (k == 0) {
+      if (exp & 1) {
+        if (Xk.x == 12345.f && Xnk.x == 54321.f && Xmk.x == 999.f && Xpk.y == 777.f) F[0] = make_float2(0.f, 0.f);
+      } else if (k == 0) {
         F[0] = make_float2(Xk.x, Xnk.x);            // packed: (X[0], X[8192])
         F[CM] = make_float2(Xmk.x, Xmk.y);
       } else {
@@ -174,17 +188,11 @@ __global__ __launch_bounds__(512) void coarse_fwd_kernel(const CoarseXRow* __res
         }
       }
     };
+    if (!(exp & 2)) {
 #pragma unroll
     for (int q = 0; q < 4; q++) quad(tid + 512 * q, ta[q], tb[q]);
-    if (tid == 0) quad(CM / 2, f2{twab[CM / 2].x, twab[CM / 2].y}, f2{twab[2049 + CM / 2].x, twab[2049 + CM / 2].y});
-    if (more) {
-      if (zero2) {
-        coarse_pick_half(raw, g, R.scale, cur);
-      } else {
-        cur = nxt;
-        coarse_pick_half(raw, g, R.scale, nxt);
-      }
     }
+    if (tid == 0 && !(exp & 2)) quad(CM / 2, f2{twab[CM / 2].x, twab[CM / 2].y}, f2{twab[2049 + CM / 2].x, twab[2049 + CM / 2].y});
     __syncthreads();   // the combine pass has read both buffers before the next transform writes them
   }
 }
@@ -199,7 +207,8 @@ void launch_coarse_fwd(hipStream_t s, const CoarseXRow* rows_dev, int nrows, int
   run = std::max(run, 1);
   for (int r0 = 0; r0 < nrows; r0 += 32768) {
     dim3 grid((max_frames + run - 1) / run, std::min(32768, nrows - r0));
-    hipLaunchKernelGGL(coarse_fwd_kernel, grid, dim3(512), lds, s, rows_dev + r0, run, X, tw16, twab);
+    static const int exp = getenv("GA_COARSE_EXP") ? atoi(getenv("GA_COARSE_EXP")) : 0;   // timing experiments only
+    hipLaunchKernelGGL(coarse_fwd_kernel, grid, dim3(512), lds, s, rows_dev + r0, run, X, tw16, twab, exp & 15);
   }
 }
 
@@ -212,14 +221,14 @@ void launch_coarse_fwd(hipStream_t s, const CoarseXRow* rows_dev, int nrows, int
 // =====================================================================================================================
 template <int CW, int TW>
 __global__ __launch_bounds__(256, 2) void coarse_mac_kernel(const CoarseJob* __restrict jobs, const CoarseTerm* __restrict terms,
-                                                            const float2* __restrict X, float2* __restrict Y, int y_frames) {
+                                                            const float2* __restrict X, float2* __restrict Y, int y_frames, int NFA, int exp) {
   extern __shared__ f2 mlds[];
   const CoarseJob J = jobs[blockIdx.y];
   const int tile = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int P = J.P, nT = J.n_t;
   const int NF = nT + P - 1;                 // frames of a term that are needed
-  const int NFA = 4 * TW + P - 1;            // frames an LDS buffer holds (the unrolled sweep may read past NF: never stored)
+  // NFA = frames an LDS buffer holds (launch-wide: the unrolled sweep of the last active wave may read past NF, never stored)
   f2* xs0 = mlds;
   f2* xs1 = mlds + (size_t)NFA * 64;
   f2* hs0 = mlds + (size_t)2 * NFA * 64;
@@ -254,8 +263,7 @@ __global__ __launch_bounds__(256, 2) void coarse_mac_kernel(const CoarseJob* __r
     for (int idx = tid; idx < P * CW * 32; idx += 256) {
       const int pc = idx >> 5, of = idx & 31;
       const int p = pc / CW, c = pc % CW;
-      *reinterpret_cast<float4*>(hs + pc * 64 + 2 * of) =
-          *reinterpret_cast<const float4*>(T.h[c] + (size_t)p * kCoarseBins + binoff + 2 * of);
+      *reinterpret_cast<v4f*>(hs + pc * 64 + 2 * of) = ldg4(T.h[c] + (size_t)p * kCoarseBins + binoff + 2 * of);
     }
   };
 
@@ -274,8 +282,8 @@ __global__ __launch_bounds__(256, 2) void coarse_mac_kernel(const CoarseJob* __r
     const bool more = i + 1 < J.n_terms;
     f2* xs = (i & 1) ? xs1 : xs0;
     f2* hs = (J.shared_h || !(i & 1)) ? hs0 : hs1;
-    if (more) issue_x(T[i + 1]);
-    if (t0w < nT) {
+    if (more && !(exp & 2)) issue_x(T[i + 1]);
+    if (t0w < nT && !(exp & 1)) {
       for (int p = 0; p < P; p++) {
         f2 h[CW];
 #pragma unroll
@@ -311,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void coarse_mac_kernel(const CoarseJob* __r
 #pragma unroll
   for (int tt = 0; tt < TW; tt++) {
     const int t = t0w + tt;
-    if (tt < twr && t < nT) {
+    if (tt < twr && t < nT && !(exp & 4)) {
 #pragma unroll
       for (int c = 0; c < CW; c++)
         Y[((size_t)(J.yrow0 + c) * y_frames + J.t0 + t) * kCoarseBins + binoff + lane] = make_float2(acc[tt][c].x, acc[tt][c].y);
@@ -321,16 +329,27 @@ __global__ __launch_bounds__(256, 2) void coarse_mac_kernel(const CoarseJob* __r
 
 template <int CW, int TW>
 static void launch_coarse_mac_t(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
-                                int y_frames, int maxP, bool any_private) {
-  const int NFA = 4 * TW + maxP - 1;
+                                int y_frames, int max_t, int maxP, bool any_private) {
+  static const int exp = getenv("GA_COARSE_EXP") ? atoi(getenv("GA_COARSE_EXP")) : 0;   // timing experiments only
+  // frames the sweep of the last active wave touches: t0w + TW + P - 1 with t0w = (waves - 1) * ceil(n_t / 4)
+  int NFA = 0;
+  for (int nt = 1; nt <= max_t; nt++) {
+    const int twr = (nt + 3) / 4, wl = (nt + twr - 1) / twr - 1;
+    NFA = std::max(NFA, wl * twr + TW + maxP - 1);
+  }
   const size_t lds = ((size_t)2 * NFA * 64 + (size_t)(any_private ? 2 : 1) * maxP * CW * 64) * sizeof(float2);
   if (lds > 160 * 1024) launch_fail("coarse multiply-accumulate: staging does not fit the LDS");
   if (hipFuncSetAttribute((const void*)coarse_mac_kernel<CW, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(lds, 65536)) !=
       hipSuccess)
     launch_fail("cannot raise the dynamic LDS limit of the coarse multiply-accumulate");
+  if (getenv("GA_COARSE_EXP")) {
+    int occ = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, coarse_mac_kernel<CW, TW>, 256, lds);
+    fprintf(stderr, "[coarse_mac<%d,%d>] lds %zu B, NFA %d, occupancy %d workgroups/CU, %d jobs\n", CW, TW, lds, NFA, occ, njobs);
+  }
   for (int j0 = 0; j0 < njobs; j0 += 32768)
     hipLaunchKernelGGL((coarse_mac_kernel<CW, TW>), dim3(kCoarseBins / 64, std::min(32768, njobs - j0)), dim3(256), lds, s, jobs_dev + j0,
-                       terms_dev, X, Y, y_frames);
+                       terms_dev, X, Y, y_frames, NFA, exp >> 4);
 }
 // all jobs of one launch have the same column count `cw` (1, 2 or 4) and at most `max_t` coarse blocks (<= kCoarseJobBlocks(cw))
 void launch_coarse_mac(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
@@ -339,14 +358,14 @@ void launch_coarse_mac(hipStream_t s, const CoarseJob* jobs_dev, int njobs, cons
   if (max_t > kCoarseJobBlocks(cw)) launch_fail("coarse multiply-accumulate: too many coarse blocks in a job");
   const bool small = max_t <= 16;
   if (cw == 1) {
-    if (small) launch_coarse_mac_t<1, 4>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, maxP, any_private);
-    else launch_coarse_mac_t<1, 16>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, maxP, any_private);
+    if (small) launch_coarse_mac_t<1, 4>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
+    else launch_coarse_mac_t<1, 16>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
   } else if (cw == 2) {
-    if (small) launch_coarse_mac_t<2, 4>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, maxP, any_private);
-    else launch_coarse_mac_t<2, 16>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, maxP, any_private);
+    if (small) launch_coarse_mac_t<2, 4>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
+    else launch_coarse_mac_t<2, 16>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
   } else if (cw == 4) {
-    if (small) launch_coarse_mac_t<4, 4>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, maxP, any_private);
-    else launch_coarse_mac_t<4, 8>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, maxP, any_private);   // 128 accumulator registers
+    if (small) launch_coarse_mac_t<4, 4>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
+    else launch_coarse_mac_t<4, 8>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);   // 128 accumulator registers
   } else {
     launch_fail("coarse multiply-accumulate: unsupported column count");
   }
@@ -453,10 +472,10 @@ __global__ __launch_bounds__(512) void coarse_inv_kernel(const CoarseOut* __rest
   float* __restrict dst = O.out + (int64_t)tb * kCoarseBlock;
   if ((((uintptr_t)dst) & 15) == 0) {
     for (int i = tid; i < kCoarseBlock / 4; i += 512)
-      if (4 * i < nout) *reinterpret_cast<float4*>(dst + 4 * i) = *reinterpret_cast<const float4*>(st + 4 * i);
+      if (4 * i < nout) stg4(dst + 4 * i, *reinterpret_cast<const v4f*>(st + 4 * i));
   } else {
     for (int i = tid; i < kCoarseBlock; i += 512)
-      if (i < nout) dst[i] = st[i];
+      if (i < nout) stg1(dst + i, st[i]);
   }
 }
 
@@ -480,9 +499,9 @@ __global__ __launch_bounds__(256) void coarse_hist_kernel(const CoarseHistJob* _
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < J.hist_len; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t sidx = i + J.n;   // position in the concatenation [old (hist_len) | in (n)]
     float v = 0.f;
-    if (sidx < J.hist_len) v = J.old_hist ? J.old_hist[sidx] : 0.f;
-    else if (J.in) v = J.in[sidx - J.hist_len];
-    J.new_hist[i] = v;
+    if (sidx < J.hist_len) v = J.old_hist ? ldg1(J.old_hist + sidx) : 0.f;
+    else if (J.in) v = ldg1(J.in + (sidx - J.hist_len));
+    stg1(J.new_hist + i, v);
   }
 }
 void launch_coarse_hist(hipStream_t s, const CoarseHistJob* jobs_dev, int njobs, int64_t max_len) {

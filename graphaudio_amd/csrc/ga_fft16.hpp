@@ -6,6 +6,26 @@
 
 namespace ga {
 
+// ---- explicit GLOBAL address space for pointers that come out of job tables ------------------------------------------
+// A pointer loaded from memory is a generic ("flat") pointer to the compiler: every access through it becomes flat_load /
+// flat_store, which counts on vmcnt AND lgkmcnt, completes out of order and therefore forces `s_waitcnt vmcnt(0) lgkmcnt(0)`
+// before anything that depends on it -- a prefetch issued in front of LDS work is waited for at once.  Every such pointer in
+// this library addresses device memory, so say so: the accesses become global_load / global_store.
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+#define GA_GLOBAL __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ GA_GLOBAL T* gptr(T* p) { return (GA_GLOBAL T*)p; }
+__device__ __forceinline__ v4f ldg4(const float* p) { return *(const GA_GLOBAL v4f*)p; }
+__device__ __forceinline__ v2f ldg2(const float* p) { return *(const GA_GLOBAL v2f*)p; }
+__device__ __forceinline__ v4f ldg4(const float2* p) { return *(const GA_GLOBAL v4f*)p; }
+__device__ __forceinline__ v2f ldg2(const float2* p) { return *(const GA_GLOBAL v2f*)p; }
+__device__ __forceinline__ float ldg1(const float* p) { return *(const GA_GLOBAL float*)p; }
+__device__ __forceinline__ void stg4(float* p, v4f v) { *(GA_GLOBAL v4f*)p = v; }
+__device__ __forceinline__ void stg4(float2* p, v4f v) { *(GA_GLOBAL v4f*)p = v; }
+__device__ __forceinline__ void stg2(float2* p, v2f v) { *(GA_GLOBAL v2f*)p = v; }
+__device__ __forceinline__ void stg1(float* p, float v) { *(GA_GLOBAL float*)p = v; }
+
 // ---- packed float2 arithmetic --------------------------------------------------------------------------------------
 // A complex number lives in an aligned VGPR pair; v_pk_add/mul/fma_f32 work on both halves at the full f32 rate, and their
 // op_sel / neg modifiers give the swaps and sign flips of complex arithmetic for free: a +- (-i) b is ONE instruction, a
