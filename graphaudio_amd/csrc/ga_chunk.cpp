@@ -1345,7 +1345,7 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
   }
   std::vector<CoarseTerm> terms;
   std::vector<CoarseJob> jobs[3];          // by column count 1, 2, 4
-  int maxT[3] = {0, 0, 0}, maxP[3] = {0, 0, 0};
+  int maxT[3] = {0, 0, 0}, maxP[3] = {0, 0, 0}, pbOf[3] = {4, 4, 4};   // pbOf: largest of 4, 2, 1 dividing every job's partition count
   bool anyPrivate[3] = {false, false, false};
   double macBytes[3] = {0, 0, 0};
   std::map<std::pair<int, int>, std::vector<int>> outRows;   // (leader, channel) -> Y rows to sum
@@ -1384,6 +1384,7 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
         jobs[ci].push_back(jb_);
         maxT[ci] = std::max(maxT[ci], jb_.n_t);
         maxP[ci] = std::max(maxP[ci], k.P);
+        while (k.P % pbOf[ci]) pbOf[ci] >>= 1;
         anyPrivate[ci] = anyPrivate[ci] || !shared;
         macBytes[ci] += (double)jb_.n_terms * (jb_.n_t + k.P - 1) * kCoarseBins * 8.0 +
                         (double)(shared ? 1 : jb_.n_terms) * k.P * cw * kCoarseBins * 8.0 + (double)cw * jb_.n_t * kCoarseBins * 8.0;
@@ -1427,8 +1428,9 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
     const int nj = (int)jobs[i].size(), cw = i == 0 ? 1 : (i == 1 ? 2 : 4), mt = maxT[i], mp = maxP[i];
     const bool ap = anyPrivate[i];
     const size_t off = jo[i];
+    const int pb = pbOf[i];
     ex.plan.add(LK_CMAC, [=](uint8_t* base) {
-      launch_coarse_mac(st, (const CoarseJob*)(base + off), nj, (const CoarseTerm*)(base + to), X, Y, nT, cw, mt, mp, ap);
+      launch_coarse_mac(st, (const CoarseJob*)(base + off), nj, (const CoarseTerm*)(base + to), X, Y, nT, cw, mt, mp, ap, pb);
     }, macBytes[i]);
     c.stats.mac_launches += 1;
   }

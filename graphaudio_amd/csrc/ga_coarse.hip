@@ -20,9 +20,10 @@
 // out + in, bus out -- ~11 GB against ~35 GB for formulation C.
 //
 // Real transform of N = 16,384 points through TWO complex transforms of 4,096 points (the radix-16 register / LDS
-// transform of ga_fft16.hpp) on z_a[m] = x[4m] + i x[4m+2], z_b[m] = x[4m+1] + i x[4m+3], and one combine pass
+// transform of ga_fft16.hpp) on z_a[m] = x[4m] + i x[4m+1], z_b[m] = x[4m+2] + i x[4m+3], and one combine pass
 // (tools/proto/coarse_math.py is the numpy statement of the index arithmetic).  Spectra are "packed": 8192 complex values per
-// frame, bin 0 holding the two real bins (X[0], X[8192]).  All power-of-two scale factors (the 1/2 of the even/odd
+// frame, bin 0 holding the two real bins (X[0], X[8192]), stored with the two halves of the spectrum interleaved (position
+// 2 j = bin j, 2 j + 1 = bin 4096 + j: what the combine pass produces per thread is then two aligned 16-byte words).  All power-of-two scale factors (the 1/2 of the even/odd
 // splits, 1/4096 of the inverse) are folded into the impulse-response spectra: exact.
 #include "ga_kernels.hpp"
 #include "ga_fft16.hpp"
@@ -30,6 +31,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdio>
 #include <cstdlib>
 
@@ -54,146 +56,159 @@ __device__ __forceinline__ f2 cfmap(f2 a, f2 b, f2 acc) {
 }
 
 // =====================================================================================================================
-//  forward: one workgroup of 512 threads = the two complex transforms (g = tid / 256) of one window, side by side; it walks a
-//  run of consecutive windows of one row so that a window's second half is the next window's first half (each input sample
-//  is fetched once per run) and the next half is in flight while the current window is transformed.
+//  forward: one workgroup of 256 threads per window, two workgroups per CU (66 KB of LDS each: while one waits for its stores or
+//  at a barrier the other one transforms).  Thread t owns the points j = t + 256 m (m < 16) of BOTH complex transforms
+//      z_a[j] = x[4j] + i x[4j+1],   z_b[j] = x[4j+2] + i x[4j+3]
+//  so it fetches x[4j .. 4j+3] as ONE 16-byte word and no sample is fetched twice; the transforms run one after the other
+//  through the same LDS buffer.  The combine pass needs Z[k] and Z[4096 - k]: a thread keeps Z[t + 256 m] for m < 8 in
+//  registers and gets the mirrored values (held by thread 256 - t as its m >= 8 half) through the buffer.  The workgroup walks a
+//  run of consecutive windows of one row: a window's second half is the next window's first half, and the half after that is
+//  in flight while the current window is transformed.
 // =====================================================================================================================
-struct HalfRegs {
-  f2 v[8];
-};
-// the 8 (re, im) points this thread owns in half-window `j` of the row: x[4 (t + 256 q) + g], x[.. + g + 2]
-__device__ __forceinline__ void coarse_issue_half(const CoarseXRow& R, int j, int g, int t, v4f (&raw)[8]) {
-  const float* src = nullptr;
-  int64_t lim = 0;   // samples of this half that exist (the rest is zero)
-  if (j < 0) {
-    const int64_t off = (int64_t)R.hist_len + (int64_t)j * kCoarseBlock;
-    if (R.hist && off >= 0) {
-      src = R.hist + off;
-      lim = kCoarseBlock;
-    }
-  } else if (R.in) {
-    const int64_t off = (int64_t)j * kCoarseBlock;
-    src = R.in + off;
-    lim = std::min<int64_t>(kCoarseBlock, R.nvalid - off);
-  }
-  const bool aligned = ((uintptr_t)src & 15) == 0;
+// the 16 points of transform `ab` (0: z_a[j] = x[4j] + i x[4j+1], 1: z_b[j] = x[4j+2] + i x[4j+3]) this thread owns in window u
+// of the row: j = t + 256 m, m < 8 in half-window u - 1, m >= 8 in half-window u (zero2: that half is zero)
+__device__ __forceinline__ void coarse_issue_points(const CoarseXRow& R, int u, int ab, int t, bool zero2, v2f (&pre)[16]) {
 #pragma unroll
-  for (int q = 0; q < 8; q++) {
-    const int o = 4 * (t + 256 * q);
-    raw[q] = v4f{0.f, 0.f, 0.f, 0.f};
-    if (src && o < lim) {   // lim is a multiple of 4 (chunks are whole 128-frame blocks, histories whole coarse blocks)
-      if (aligned) {
-        raw[q] = ldg4(src + o);
-      } else {
-        raw[q] = v4f{ldg1(src + o), ldg1(src + o + 1), ldg1(src + o + 2), ldg1(src + o + 3)};
+  for (int hh = 0; hh < 2; hh++) {
+    const int hw = u - 1 + hh;
+    const float* src = nullptr;
+    int64_t lim = 0;   // samples of this half that exist (the rest is zero)
+    if (hh == 1 && zero2) {
+    } else if (hw < 0) {
+      const int64_t off = (int64_t)R.hist_len + (int64_t)hw * kCoarseBlock;
+      if (R.hist && off >= 0) {
+        src = R.hist + off;
+        lim = kCoarseBlock;
+      }
+    } else if (R.in) {
+      const int64_t off = (int64_t)hw * kCoarseBlock;
+      src = R.in + off;
+      lim = std::min<int64_t>(kCoarseBlock, R.nvalid - off);
+    }
+    const bool aligned = ((uintptr_t)src & 7) == 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int o = 4 * (t + 256 * q) + 2 * ab;
+      pre[8 * hh + q] = v2f{0.f, 0.f};
+      if (src && o < lim) {   // lim is a multiple of 4 (chunks are whole 128-frame blocks, histories whole coarse blocks)
+        if (aligned) pre[8 * hh + q] = ldg2(src + o);
+        else pre[8 * hh + q] = v2f{ldg1(src + o), ldg1(src + o + 1)};
       }
     }
   }
-  (void)g;
-}
-__device__ __forceinline__ void coarse_pick_half(const v4f (&raw)[8], int g, float scale, HalfRegs& h) {
-#pragma unroll
-  for (int q = 0; q < 8; q++) h.v[q] = g ? f2{raw[q].y * scale, raw[q].w * scale} : f2{raw[q].x * scale, raw[q].z * scale};
 }
 
-__global__ __launch_bounds__(512) void coarse_fwd_kernel(const CoarseXRow* __restrict rows, int run, float2* __restrict X,
-                                                         const float2* __restrict twg, const float2* __restrict twab, int exp) {
+__global__ __launch_bounds__(256, 2) void coarse_fwd_kernel(const CoarseXRow* __restrict rows, int run, float2* __restrict X,
+                                                            const float2* __restrict twg, const float2* __restrict twab, int exp) {
   using PL = R16Plan<CM>;
   extern __shared__ f2 clds[];
   f2* tw2 = clds;
   f2* tw3 = clds + PL::T2;
-  f2* zb0 = clds + PL::T2 + PL::T3;
-  const int tid = threadIdx.x;
-  const int g = __builtin_amdgcn_readfirstlane(tid >> 8), t = tid & 255;
-  f2* buf = zb0 + g * CPAD;
-  for (int i = tid; i < PL::T2 + PL::T3; i += 512) clds[i] = f2{twg[i].x, twg[i].y};
+  f2* buf = clds + PL::T2 + PL::T3;
+  const int t_ = threadIdx.x;
+  for (int i = t_; i < PL::T2 + PL::T3; i += 256) clds[i] = f2{twg[i].x, twg[i].y};
   const CoarseXRow R = rows[blockIdx.y];
   const int w0 = blockIdx.x * run;
   const int w1 = min(R.n_frames, w0 + run);
   if (w0 >= w1) return;   // (uniform)
-  // combine-pass twiddles of this thread's bins k = tid + 512 q: a = W_8192^k, b = W_16384^k
-  f2 ta[4], tb[4];
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    ta[q] = f2{twab[tid + 512 * q].x, twab[tid + 512 * q].y};
-    tb[q] = f2{twab[2049 + tid + 512 * q].x, twab[2049 + tid + 512 * q].y};
-  }
+  // combine-pass twiddles of this thread's bins k = t + 256 m: b = W_16384^k = W_16384^t W_64^m (and W_8192^k = b^2); only
+  // W_16384^t lives in registers, the eight W_64^m are literals
+  const f2 tb0 = f2{twab[2049 + t_].x, twab[2049 + t_].y};
   const bool zero2 = (R.flags & 1) != 0;   // impulse-response partitions: [h_p | 0]
-  HalfRegs cur, nxt;
-  {
-    v4f raw[8];
-    coarse_issue_half(R, R.u0 + w0 - 1, g, t, raw);
-    coarse_pick_half(raw, g, R.scale, cur);
-    if (zero2) {
-#pragma unroll
-      for (int q = 0; q < 8; q++) nxt.v[q] = f2{0.f, 0.f};
-    } else {
-      coarse_issue_half(R, R.u0 + w0, g, t, raw);
-      coarse_pick_half(raw, g, R.scale, nxt);
-    }
-  }
+  const float scale = R.scale;
+  // Inputs are fetched per TRANSFORM, one transform ahead: 16 eight-byte words (32 registers) are in flight behind each
+  // transform instead of whole half-windows (96 registers) -- the register file is what limits this kernel to two
+  // workgroups per CU.  A sample is requested four times (two windows x two transforms); after the first the L1 / L2 serve it.
+  v2f pre[16];
+  coarse_issue_points(R, R.u0 + w0, 0, t_, zero2, pre);
   __syncthreads();
   for (int w = w0; w < w1; w++) {
+    // the thread index is made opaque per window: otherwise every loop-invariant address of the unrolled body (LDS slots,
+    // store offsets of the 32 output bins, prefetch offsets) is hoisted out of the loop and held in ~100 registers
+    int t = t_;
+    asm volatile("" : "+v"(t));
     const int u = R.u0 + w;
-    v4f raw[8];
     const bool more = w + 1 < w1;
-    if (more && !(exp & 8)) coarse_issue_half(R, zero2 ? u : u + 1, g, t, raw);   // in flight behind this window's transforms
     f2 own[16];
+    // ---- transform a ----
+#pragma unroll
+    for (int m = 0; m < 16; m++) own[m] = f2{pre[m].x * scale, pre[m].y * scale};
+    if (!(exp & 8)) coarse_issue_points(R, u, 1, t, zero2, pre);       // transform b's points: in flight behind transform a
+    if (!(exp & 4)) fft16_own<CM>(own, buf, tw2, tw3, t);
+    f2 za[8], pa[8];
+    const f2 za8 = own[8];   // Z_a[2048] (thread 0)
+    __syncthreads();          // the last pass has read the buffer
 #pragma unroll
     for (int m = 0; m < 8; m++) {
-      own[m] = cur.v[m];
-      own[8 + m] = nxt.v[m];
+      za[m] = own[m];
+      buf[cpad(t + 256 * m)] = own[8 + m];   // Z[j], j >= 2048, at slot j - 2048
     }
-    if (!(exp & 4)) fft16_own<CM>(own, buf, tw2, tw3, t);
-    __syncthreads();   // the last pass has read the buffer: store Z_g in natural order
-#pragma unroll
-    for (int m = 0; m < 16; m++) buf[cpad(t + 256 * m)] = own[m];
     __syncthreads();
-    // the prefetched half is consumed BEFORE the combine pass issues its stores: vmcnt counts loads and stores in issue
-    // order, so waiting for these loads later would wait for this window's stores to complete as well
-    if (more) {
-      if (zero2) {
-        coarse_pick_half(raw, g, R.scale, cur);
-      } else {
-        cur = nxt;
-        coarse_pick_half(raw, g, R.scale, nxt);
-      }
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const int k = t + 256 * m;             // mirror 4096 - k >= 2049 sits at slot 2048 - k  (k = 0: Z[4096] = Z[0], own)
+      pa[m] = k == 0 ? za[0] : buf[cpad(2048 - k)];
     }
+    __syncthreads();          // mirrors fetched before transform b writes the buffer
+    // ---- transform b ----
+#pragma unroll
+    for (int m = 0; m < 16; m++) own[m] = f2{pre[m].x * scale, pre[m].y * scale};
+    if (more && !(exp & 8)) coarse_issue_points(R, u + 1, 0, t, zero2, pre);   // the next window's transform a
+    if (!(exp & 4)) fft16_own<CM>(own, buf, tw2, tw3, t);
+    f2 pb[8];
+    const f2 zb8 = own[8];
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 8; m++) buf[cpad(t + 256 * m)] = own[8 + m];
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const int k = t + 256 * m;
+      pb[m] = k == 0 ? own[0] : buf[cpad(2048 - k)];
+    }
+    // ---- combine: W = A + a B (8192-point complex spectrum of x[2n] + i x[2n+1]), then the real-input split.
+    //      All values carry a factor 2 (the 1/2 of the split is folded into the impulse-response scale).
     float2* __restrict F = X + (size_t)(R.frame0 + w) * kCoarseBins;
-    auto quad = [&](int k, f2 a, f2 b) {
-      const int km = (CM - k) & (CM - 1);
-      const f2 zak = zb0[cpad(k)], zam = cj(zb0[cpad(km)]);
-      const f2 zbk = zb0[CPAD + cpad(k)], zbm = cj(zb0[CPAD + cpad(km)]);
-      // (all values carry a factor 2 -- folded into the impulse-response scale)
-      const f2 fea = zak + zam, foa = mul_mi(zak - zam);
-      const f2 feb = zbk + zbm, fob = mul_mi(zbk - zbm);
-      const f2 afa = cmulc(a, foa), afb = cmulc(a, fob);
-      const f2 Ek = fea + afa, Emk = cj(fea - afa);
-      const f2 Ok = feb + afb, Omk = cj(feb - afb);
-      const f2 S = cmulc(b, Ok);
-      const f2 T = cmulc(mul_mi(cj(b)), Omk);
-      const f2 Xk = Ek + S, Xnk = cj(Ek - S);
-      const f2 Xmk = Emk + T, Xpk = cj(Emk - T);
+    auto quad = [&](int k, f2 Ak, f2 Am, f2 Bk, f2 Bm, f2 b) {
+      const f2 a = cmulc(b, b);
+      const f2 aB = cmulc(a, Bk), caBm = cmulc(cj(a), Bm);
+      const f2 Wk = Ak + aB, Wp = Ak - aB;          // W[k], W[4096 + k]
+      const f2 Wm = Am - caBm, Wn = Am + caBm;      // W[4096 - k], W[8192 - k]
+      const f2 fe = Wk + cj(Wn), bfo = cmulc(b, mul_mi(Wk - cj(Wn)));
+      const f2 Xk = fe + bfo, Xn = cj(fe - bfo);
+      const f2 fe2 = Wm + cj(Wp), wfo2 = cmulc(mul_mi(cj(b)), mul_mi(Wm - cj(Wp)));
+      const f2 Xm = fe2 + wfo2, Xp = cj(fe2 - wfo2);
+      // frame layout: position 2 j = bin j, position 2 j + 1 = bin 4096 + j (j < 4096): the two pairs of a quad are two
+      // aligned 16-byte words, consecutive in k across the lanes (1 KB per wave and store instruction)
       if (exp & 1) {
-        if (Xk.x == 12345.f && Xnk.x == 54321.f && Xmk.x == 999.f && Xpk.y == 777.f) F[0] = make_float2(0.f, 0.f);
+        if (Xk.x == 12345.f && Xn.x == 54321.f && Xm.x == 999.f && Xp.y == 777.f) F[0] = make_float2(0.f, 0.f);
       } else if (k == 0) {
-        F[0] = make_float2(Xk.x, Xnk.x);            // packed: (X[0], X[8192])
-        F[CM] = make_float2(Xmk.x, Xmk.y);
+        stg4(F, v4f{Xk.x, Xn.x, Xm.x, Xm.y});                  // bin 0 packed (X[0], X[8192]) ; bin 4096
+      } else if (k == CM / 2) {
+        stg4(F + 2 * k, v4f{Xk.x, Xk.y, Xn.x, Xn.y});          // bins 2048, 6144
       } else {
-        F[k] = make_float2(Xk.x, Xk.y);
-        F[2 * CM - k] = make_float2(Xnk.x, Xnk.y);
-        if (k != CM / 2) {
-          F[CM - k] = make_float2(Xmk.x, Xmk.y);
-          F[CM + k] = make_float2(Xpk.x, Xpk.y);
-        }
+        stg4(F + 2 * k, v4f{Xk.x, Xk.y, Xp.x, Xp.y});          // bins k, 4096 + k
+        stg4(F + 2 * (CM - k), v4f{Xm.x, Xm.y, Xn.x, Xn.y});   // bins 4096 - k, 8192 - k
       }
     };
     if (!(exp & 2)) {
+      constexpr float w64[8][2] = {{1.f, 0.f},
+                                   {0.99518472667219688624f, -0.09801714032956060199f},
+                                   {0.98078528040323044913f, -0.19509032201612826785f},
+                                   {0.95694033573220886494f, -0.29028467725446236764f},
+                                   {0.92387953251128675613f, -0.38268343236508977173f},
+                                   {0.88192126434835502971f, -0.47139673682599764856f},
+                                   {0.83146961230254523708f, -0.55557023301960222474f},
+                                   {0.77301045336273696081f, -0.63439328416364549822f}};
 #pragma unroll
-    for (int q = 0; q < 4; q++) quad(tid + 512 * q, ta[q], tb[q]);
+      for (int m = 0; m < 8; m++) {
+        const f2 b = m == 0 ? tb0 : cmulc(tb0, f2{w64[m][0], w64[m][1]});
+        quad(t + 256 * m, za[m], pa[m], own[m], pb[m], b);
+        __builtin_amdgcn_sched_barrier(0);   // one quad at a time: the unrolled pass would otherwise keep all eight in flight
+      }
+      if (t == 0) quad(CM / 2, za8, za8, zb8, zb8, f2{twab[2049 + CM / 2].x, twab[2049 + CM / 2].y});
     }
-    if (tid == 0 && !(exp & 2)) quad(CM / 2, f2{twab[CM / 2].x, twab[CM / 2].y}, f2{twab[2049 + CM / 2].x, twab[2049 + CM / 2].y});
-    __syncthreads();   // the combine pass has read both buffers before the next transform writes them
+    __syncthreads();   // mirrors of transform b fetched before the next window's transform a writes the buffer
   }
 }
 
@@ -201,14 +216,14 @@ void launch_coarse_fwd(hipStream_t s, const CoarseXRow* rows_dev, int nrows, int
                        const float2* twab) {
   if (nrows <= 0 || max_frames <= 0) return;
   using PL = R16Plan<CM>;
-  const size_t lds = (size_t)(PL::T2 + PL::T3 + 2 * CPAD) * sizeof(float2);
+  const size_t lds = (size_t)(PL::T2 + PL::T3 + CPAD) * sizeof(float2);
   if (hipFuncSetAttribute((const void*)coarse_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     launch_fail("cannot raise the dynamic LDS limit of the coarse forward transform");
+  static const int exp = getenv("GA_COARSE_EXP") ? atoi(getenv("GA_COARSE_EXP")) : 0;   // timing experiments only
   run = std::max(run, 1);
   for (int r0 = 0; r0 < nrows; r0 += 32768) {
     dim3 grid((max_frames + run - 1) / run, std::min(32768, nrows - r0));
-    static const int exp = getenv("GA_COARSE_EXP") ? atoi(getenv("GA_COARSE_EXP")) : 0;   // timing experiments only
-    hipLaunchKernelGGL(coarse_fwd_kernel, grid, dim3(512), lds, s, rows_dev + r0, run, X, tw16, twab, exp & 15);
+    hipLaunchKernelGGL(coarse_fwd_kernel, grid, dim3(256), lds, s, rows_dev + r0, run, X, tw16, twab, exp & 15);
   }
 }
 
@@ -219,9 +234,12 @@ void launch_coarse_fwd(hipStream_t s, const CoarseXRow* rows_dev, int nrows, int
 //      acc[t][c] += X[t - p] . H_c[p]          p < P', c < CW columns, t in the wave's range
 //  with the accumulators of ALL terms of the job in registers: the sum over the job's voices costs no memory traffic.
 // =====================================================================================================================
-template <int CW, int TW>
-__global__ __launch_bounds__(256, 2) void coarse_mac_kernel(const CoarseJob* __restrict jobs, const CoarseTerm* __restrict terms,
-                                                            const float2* __restrict X, float2* __restrict Y, int y_frames, int NFA, int exp) {
+constexpr int kMacWaves = 8;                 // waves per workgroup: each takes an eighth of the job's coarse blocks
+constexpr int kMacThreads = 64 * kMacWaves;
+template <int CW, int TW, int PB>
+__global__ __launch_bounds__(kMacThreads, 4) void coarse_mac_kernel(const CoarseJob* __restrict jobs, const CoarseTerm* __restrict terms,
+                                                                    const float2* __restrict X, float2* __restrict Y, int y_frames, int NFA,
+                                                                    int exp) {
   extern __shared__ f2 mlds[];
   const CoarseJob J = jobs[blockIdx.y];
   const int tile = blockIdx.x;
@@ -233,34 +251,34 @@ __global__ __launch_bounds__(256, 2) void coarse_mac_kernel(const CoarseJob* __r
   f2* xs1 = mlds + (size_t)NFA * 64;
   f2* hs0 = mlds + (size_t)2 * NFA * 64;
   f2* hs1 = hs0 + (size_t)P * CW * 64;       // only when the job's terms have different impulse responses
-  const int twr = (nT + 3) / 4;              // coarse blocks per wave (<= TW)
+  const int twr = (nT + kMacWaves - 1) / kMacWaves;   // coarse blocks per wave (<= TW)
   const int t0w = wv * twr;
   const bool special = tile == 0;            // bin 0 of tile 0 is the packed pair of real bins
   const bool lane0 = special && lane == 0;
   const size_t binoff = (size_t)tile * 64;
 
   // staging of one term: NF x 32 float4 of X (+ P x CW x 32 float4 of H)
-  constexpr int XR = (4 * TW + 16 + 7) / 8;  // float4 per thread that cover NF <= 4 TW + 15 frames
-  float4 xr[XR];
+  constexpr int XR = (kMacWaves * TW + kCoarseMaxP + 15) / 16;  // float4 per thread that cover NF <= kMacWaves TW + P - 1 frames
+  v4f xr[XR];
   auto issue_x = [&](const CoarseTerm& T) {
 #pragma unroll
     for (int r = 0; r < XR; r++) {
-      const int idx = tid + 256 * r;
+      const int idx = tid + kMacThreads * r;
       const int fr = idx >> 5, of = idx & 31;
-      xr[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (fr < NF) xr[r] = *reinterpret_cast<const float4*>(X + (size_t)(T.frame0 + J.t0 + fr) * kCoarseBins + binoff + 2 * of);
+      xr[r] = v4f{0.f, 0.f, 0.f, 0.f};
+      if (fr < NF) xr[r] = ldg4(X + (size_t)(T.frame0 + J.t0 + fr) * kCoarseBins + binoff + 2 * of);
     }
   };
   auto commit_x = [&](f2* xs) {
 #pragma unroll
     for (int r = 0; r < XR; r++) {
-      const int idx = tid + 256 * r;
+      const int idx = tid + kMacThreads * r;
       const int fr = idx >> 5, of = idx & 31;
-      if (fr < NF) *reinterpret_cast<float4*>(xs + fr * 64 + 2 * of) = xr[r];
+      if (fr < NF) *reinterpret_cast<v4f*>(xs + fr * 64 + 2 * of) = xr[r];
     }
   };
   auto load_h = [&](const CoarseTerm& T, f2* hs) {   // straight to LDS (small: P x CW x 512 bytes)
-    for (int idx = tid; idx < P * CW * 32; idx += 256) {
+    for (int idx = tid; idx < P * CW * 32; idx += kMacThreads) {
       const int pc = idx >> 5, of = idx & 31;
       const int p = pc / CW, c = pc % CW;
       *reinterpret_cast<v4f*>(hs + pc * 64 + 2 * of) = ldg4(T.h[c] + (size_t)p * kCoarseBins + binoff + 2 * of);
@@ -284,31 +302,42 @@ __global__ __launch_bounds__(256, 2) void coarse_mac_kernel(const CoarseJob* __r
     f2* hs = (J.shared_h || !(i & 1)) ? hs0 : hs1;
     if (more && !(exp & 2)) issue_x(T[i + 1]);
     if (t0w < nT && !(exp & 1)) {
-      for (int p = 0; p < P; p++) {
-        f2 h[CW];
+      // blocks of PB partitions (P is a multiple of PB): their spectra sit in registers, and the frames b - (PB - 1) .. b +
+      // TW - 1 of the sweep (b = frame of (tt = 0, j = 0); (tt, j) uses frame b + tt - j) are requested up front: one LDS
+      // latency per block of partitions, then the block is pure VALU with j outermost, so that consecutive fmas belong to
+      // different accumulators.  `SP` (tile 0: lane 0 holds two real bins) is a compile-time copy of the loop: as a run-time
+      // flag inside the unrolled body the compiler evaluates both products for every tile.
+      auto sweep = [&](auto sp) {
+        constexpr bool SP = decltype(sp)::value;
+        for (int pb = 0; pb < P; pb += PB) {
+          f2 h[PB][CW];
 #pragma unroll
-        for (int c = 0; c < CW; c++) h[c] = hs[(p * CW + c) * 64 + lane];
-        const f2* __restrict xb = xs + (t0w + (P - 1) - p) * 64 + lane;
-        if (!special) {
+          for (int j = 0; j < PB; j++)
 #pragma unroll
-          for (int tt = 0; tt < TW; tt++) {
-            const f2 x = xb[tt * 64];
+            for (int c = 0; c < CW; c++) h[j][c] = hs[((pb + j) * CW + c) * 64 + lane];
+          const f2* __restrict xb = xs + (t0w + (P - 1) - pb - (PB - 1)) * 64 + lane;   // (pb + PB - 1 <= P - 1: inside the buffer)
+          f2 xv[TW + PB - 1];
 #pragma unroll
-            for (int c = 0; c < CW; c++) acc[tt][c] = cfmap(x, h[c], acc[tt][c]);
-          }
-        } else {
+          for (int q = 0; q < TW + PB - 1; q++) xv[q] = xb[q * 64];
 #pragma unroll
-          for (int tt = 0; tt < TW; tt++) {
-            const f2 x = xb[tt * 64];
+          for (int j = 0; j < PB; j++)
 #pragma unroll
-            for (int c = 0; c < CW; c++) {
-              const f2 gen = cfmap(x, h[c], acc[tt][c]);
-              const f2 pk = __builtin_elementwise_fma(x, h[c], acc[tt][c]);   // two real bins side by side
-              acc[tt][c] = lane0 ? pk : gen;
-            }
-          }
+            for (int tt = 0; tt < TW; tt++)
+#pragma unroll
+              for (int c = 0; c < CW; c++) {
+                const f2 x = xv[tt - j + (PB - 1)];
+                if constexpr (!SP) {
+                  acc[tt][c] = cfmap(x, h[j][c], acc[tt][c]);
+                } else {
+                  const f2 gen = cfmap(x, h[j][c], acc[tt][c]);
+                  const f2 pk = __builtin_elementwise_fma(x, h[j][c], acc[tt][c]);   // two real bins side by side
+                  acc[tt][c] = lane0 ? pk : gen;
+                }
+              }
         }
-      }
+      };
+      if (special) sweep(std::true_type{});
+      else sweep(std::false_type{});
     }
     if (more) {
       commit_x((i & 1) ? xs0 : xs1);
@@ -322,53 +351,56 @@ __global__ __launch_bounds__(256, 2) void coarse_mac_kernel(const CoarseJob* __r
     if (tt < twr && t < nT && !(exp & 4)) {
 #pragma unroll
       for (int c = 0; c < CW; c++)
-        Y[((size_t)(J.yrow0 + c) * y_frames + J.t0 + t) * kCoarseBins + binoff + lane] = make_float2(acc[tt][c].x, acc[tt][c].y);
+        stg2(Y + ((size_t)(J.yrow0 + c) * y_frames + J.t0 + t) * kCoarseBins + binoff + lane, v2f{acc[tt][c].x, acc[tt][c].y});
     }
   }
 }
 
-template <int CW, int TW>
+template <int CW, int TW, int PB>
 static void launch_coarse_mac_t(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
                                 int y_frames, int max_t, int maxP, bool any_private) {
   static const int exp = getenv("GA_COARSE_EXP") ? atoi(getenv("GA_COARSE_EXP")) : 0;   // timing experiments only
-  // frames the sweep of the last active wave touches: t0w + TW + P - 1 with t0w = (waves - 1) * ceil(n_t / 4)
+  // frames the sweep of the last active wave touches: t0w + TW + P - 1 with t0w = (active waves - 1) * ceil(n_t / waves)
   int NFA = 0;
   for (int nt = 1; nt <= max_t; nt++) {
-    const int twr = (nt + 3) / 4, wl = (nt + twr - 1) / twr - 1;
+    const int twr = (nt + kMacWaves - 1) / kMacWaves, wl = (nt + twr - 1) / twr - 1;
     NFA = std::max(NFA, wl * twr + TW + maxP - 1);
   }
   const size_t lds = ((size_t)2 * NFA * 64 + (size_t)(any_private ? 2 : 1) * maxP * CW * 64) * sizeof(float2);
   if (lds > 160 * 1024) launch_fail("coarse multiply-accumulate: staging does not fit the LDS");
-  if (hipFuncSetAttribute((const void*)coarse_mac_kernel<CW, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(lds, 65536)) !=
-      hipSuccess)
+  if (hipFuncSetAttribute((const void*)coarse_mac_kernel<CW, TW, PB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)std::max<size_t>(lds, 65536)) != hipSuccess)
     launch_fail("cannot raise the dynamic LDS limit of the coarse multiply-accumulate");
   if (getenv("GA_COARSE_EXP")) {
     int occ = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, coarse_mac_kernel<CW, TW>, 256, lds);
-    fprintf(stderr, "[coarse_mac<%d,%d>] lds %zu B, NFA %d, occupancy %d workgroups/CU, %d jobs\n", CW, TW, lds, NFA, occ, njobs);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, coarse_mac_kernel<CW, TW, PB>, kMacThreads, lds);
+    fprintf(stderr, "[coarse_mac<%d,%d,%d>] lds %zu B, NFA %d, occupancy %d workgroups/CU, %d jobs\n", CW, TW, PB, lds, NFA, occ, njobs);
   }
   for (int j0 = 0; j0 < njobs; j0 += 32768)
-    hipLaunchKernelGGL((coarse_mac_kernel<CW, TW>), dim3(kCoarseBins / 64, std::min(32768, njobs - j0)), dim3(256), lds, s, jobs_dev + j0,
-                       terms_dev, X, Y, y_frames, NFA, exp >> 4);
+    hipLaunchKernelGGL((coarse_mac_kernel<CW, TW, PB>), dim3(kCoarseBins / 64, std::min(32768, njobs - j0)), dim3(kMacThreads), lds, s,
+                       jobs_dev + j0, terms_dev, X, Y, y_frames, NFA, exp >> 4);
 }
-// all jobs of one launch have the same column count `cw` (1, 2 or 4) and at most `max_t` coarse blocks (<= kCoarseJobBlocks(cw))
+// all jobs of one launch have the same column count `cw` (1, 2 or 4), at most `max_t` coarse blocks (<= kCoarseJobBlocks(cw))
+// and partition counts that are multiples of `pb` (1, 2 or 4: the register block of the sweep)
+template <int CW>
+static void launch_coarse_mac_cw(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
+                                 int y_frames, int max_t, int maxP, bool any_private, int pb) {
+  constexpr int TWL = CW <= 2 ? 8 : 4;   // accumulators: TW x CW complex values per lane (128 VGPRs per wave at 4 waves per SIMD)
+  if (max_t <= 2 * kMacWaves) launch_coarse_mac_t<CW, 2, 1>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
+  else if (pb == 4 && CW == 1) launch_coarse_mac_t<CW, TWL, 4>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
+  else if (pb >= 2) launch_coarse_mac_t<CW, TWL, 2>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
+  else launch_coarse_mac_t<CW, TWL, 1>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
+}
 void launch_coarse_mac(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
-                       int y_frames, int cw, int max_t, int maxP, bool any_private) {
+                       int y_frames, int cw, int max_t, int maxP, bool any_private, int pb) {
   if (njobs <= 0) return;
   if (max_t > kCoarseJobBlocks(cw)) launch_fail("coarse multiply-accumulate: too many coarse blocks in a job");
-  const bool small = max_t <= 16;
-  if (cw == 1) {
-    if (small) launch_coarse_mac_t<1, 4>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
-    else launch_coarse_mac_t<1, 16>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
-  } else if (cw == 2) {
-    if (small) launch_coarse_mac_t<2, 4>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
-    else launch_coarse_mac_t<2, 16>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
-  } else if (cw == 4) {
-    if (small) launch_coarse_mac_t<4, 4>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
-    else launch_coarse_mac_t<4, 8>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);   // 128 accumulator registers
-  } else {
-    launch_fail("coarse multiply-accumulate: unsupported column count");
-  }
+  if (const char* e = getenv("GA_COARSE_PB")) pb = std::min(pb, std::max(1, atoi(e)));   // measurements only
+  if (pb != 1 && pb != 2 && pb != 4) launch_fail("coarse multiply-accumulate: unsupported partition block");
+  if (cw == 1) launch_coarse_mac_cw<1>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private, pb);
+  else if (cw == 2) launch_coarse_mac_cw<2>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private, pb);
+  else if (cw == 4) launch_coarse_mac_cw<4>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private, pb);
+  else launch_fail("coarse multiply-accumulate: unsupported column count");
 }
 
 // =====================================================================================================================
@@ -391,7 +423,7 @@ __global__ __launch_bounds__(512) void coarse_inv_kernel(const CoarseOut* __rest
   const int64_t nout = std::min<int64_t>(kCoarseBlock, O.nvalid - (int64_t)tb * kCoarseBlock);
   if (nout <= 0 || !O.out) return;   // (uniform)
   for (int i = tid; i < PL::T2 + PL::T3; i += 512) clds[i] = f2{twg[i].x, twg[i].y};
-  // ---- frequency-domain mix: bins (2 i, 2 i + 1), i = tid + 512 r ----
+  // ---- frequency-domain mix: word i = tid + 512 r of a frame holds bins (i, 4096 + i)  (layout: coarse_fwd_kernel) ----
   {
     float4 sum[8];
 #pragma unroll
@@ -408,9 +440,9 @@ __global__ __launch_bounds__(512) void coarse_inv_kernel(const CoarseOut* __rest
     }
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-      const int b0 = 2 * (tid + 512 * r);
+      const int b0 = tid + 512 * r;
       zb0[cslot(b0)] = f2{sum[r].x, sum[r].y};
-      zb0[cslot(b0 + 1)] = f2{sum[r].z, sum[r].w};
+      zb0[cslot(CM + b0)] = f2{sum[r].z, sum[r].w};
     }
   }
   __syncthreads();

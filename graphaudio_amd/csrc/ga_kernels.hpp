@@ -112,7 +112,7 @@ void launch_tconv16(hipStream_t s, const ConvSetC* sets_dev, int nsets, int nblo
 // ---- convolver pipeline, formulation D: coarse partitions, consumer sum fused in the frequency domain (ga_coarse.hip) ----
 constexpr int kCoarseBlock = 8192;   // samples per coarse partition / output block
 constexpr int kCoarseMaxP = 16;      // partitions a job can slide over (impulse responses up to 131,072 taps)
-constexpr int kCoarseJobBlocks(int columns) { return columns <= 2 ? 64 : 32; }   // coarse blocks one multiply-accumulate job covers
+constexpr int kCoarseJobBlocks(int columns) { return columns <= 2 ? 64 : 32; }   // coarse blocks one multiply-accumulate job covers: 8 waves x 8 (x 4)
 constexpr int kCoarseBins = 8192;    // packed complex bins of one 16,384-point real spectrum (bin 0 = (X[0], X[8192]))
 struct CoarseXRow {        // one transformed signal: a convolver input channel, or an impulse-response channel
   const float* hist;       // the hist_len samples in front of the chunk (nullptr = zeros)
@@ -153,7 +153,7 @@ struct CoarseHistJob {
 void launch_coarse_fwd(hipStream_t s, const CoarseXRow* rows_dev, int nrows, int max_frames, int run, float2* X, const float2* tw16,
                        const float2* twab);
 void launch_coarse_mac(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
-                       int y_frames, int cw, int max_t, int maxP, bool any_private);
+                       int y_frames, int cw, int max_t, int maxP, bool any_private, int pb);
 void launch_coarse_inv(hipStream_t s, const CoarseOut* outs_dev, int nouts, int n_t, const int* ylist_dev, const float2* Y, int y_frames,
                        const float2* tw16, const float2* twab);
 void launch_coarse_hist(hipStream_t s, const CoarseHistJob* jobs_dev, int njobs, int64_t max_len);
