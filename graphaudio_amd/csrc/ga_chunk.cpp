@@ -2697,6 +2697,10 @@ void Context::runChunkImpl(int64_t n, float* const* /*unused*/) {
       evBytes.push_back(l.bytes);
     }
     stats.kernel_launches++;
+    if (l.kind >= 0 && l.kind < 16) {
+      stats.stage_launches[l.kind]++;
+      stats.stage_bytes[l.kind] += l.bytes;
+    }
   }
   if (profile) GA_HIP(hipEventRecord(evEnd, stream));
   GA_HIP(hipGetLastError());

@@ -211,11 +211,7 @@ void Context::harvestProfile(bool wait) {
       if (k == LK_MAC || k == LK_CMAC) stats.mac_ms_total += ms;
       else if (k == LK_FFT || k == LK_IFFT || k == LK_CFWD || k == LK_CINV || k == LK_CHIST) stats.fft_ms_total += ms;
       else stats.other_ms_total += ms;
-      if (k >= 0 && k < 16) {
-        stats.stage_ms[k] += ms;
-        stats.stage_launches[k] += 1;
-        stats.stage_bytes[k] += i < b.bytes.size() ? b.bytes[i] : 0.0;
-      }
+      if (k >= 0 && k < 16) stats.stage_ms[k] += ms;   // (launches and bytes are counted when the launch is enqueued)
       (void)hipEventDestroy(b.evs[i].first);
       (void)hipEventDestroy(b.evs[i].second);
     }

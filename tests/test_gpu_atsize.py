@@ -45,10 +45,31 @@ def report(name, ref, got):
     return err, sig
 
 
-def test_config3_all_1024_voices_short_form():
+_cfg3_ref = {}
+
+
+def _config3_reference(frames):
+    """the oracle's 1024-voice render (~45 s of host CPU) is shared by the formulations checked against it"""
+    if frames not in _cfg3_ref:
+        o = OracleContext(SR)
+        G.config3_convolver(o, voices=1024, taps=65536, frames=frames)
+        _cfg3_ref[frames] = G.render(o, 2, frames)
+        o.Dispose()
+    return _cfg3_ref[frames]
+
+
+@pytest.mark.parametrize("formulation", ["coarse partitions (D, default)", "block-axis FFT (C)"])
+def test_config3_all_1024_voices_short_form(formulation):
     frames = 375 * 128
-    ref, got = both(G.config3_convolver, frames, voices=1024, taps=65536, frames=frames)
-    err, sig = report("config 3, 1024 voices x 65,536-tap stereo IR, 375 blocks", ref, got)
+    ref = _config3_reference(frames)
+    h = OfflineAudioContext(SR)
+    h.SetOption("coarse", 1 if formulation.startswith("coarse") else 0)
+    G.config3_convolver(h, voices=1024, taps=65536, frames=frames)
+    got = G.render(h, 2, frames)
+    st = h.GetStats()
+    h.Dispose()
+    assert (st["stage_launches"][5] > 0) == formulation.startswith("coarse")
+    err, sig = report(f"config 3, 1024 voices x 65,536-tap stereo IR, 375 blocks, {formulation}", ref, got)
     assert sig > 0.5            # an incoherent bus of 1024 voices (sigma ~ 2.6 in steady state, less while the tail builds up)
     assert err <= TOL_RMS, err
     assert err / sig < 2e-6
@@ -67,11 +88,12 @@ def _config5(ctx, sources, taps, frames, ir_channels=16):
     return ir_channels
 
 
-def test_config5_16_channel_32768_tap_private_irs():
+@pytest.mark.parametrize("coarse", [1, 0])
+def test_config5_16_channel_32768_tap_private_irs(coarse):
     frames = 400 * 128          # > P = 256 blocks: every partition of every column is active at the end
-    ref, got = both(_config5, frames, sources=6, taps=32768, frames=frames)
+    ref, got = both(_config5, frames, options={"coarse": coarse}, sources=6, taps=32768, frames=frames)
     assert ref.shape[0] == 16
-    err, sig = report("config 5, 6 sources x 16-channel 32,768-tap private IRs, 400 blocks", ref, got)
+    err, sig = report(f"config 5, 6 sources x 16-channel 32,768-tap private IRs, 400 blocks, coarse={coarse}", ref, got)
     assert err <= TOL_RMS, err
     assert err / sig < 2e-6
     tail = slice(300 * 128, None)

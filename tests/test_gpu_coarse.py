@@ -1,0 +1,375 @@
+"""Formulation D of the convolver (coarse partitions of 8192 samples, consumer sums fused in the frequency domain,
+graphaudio_amd/csrc/ga_coarse.hip) against the CPU oracle.  By default a convolver takes formulation D only when its first
+chunk is long (option coarse_min_blocks = 256); these tests force it (coarse_min_blocks = 1) so that short renders, uneven
+pieces and graph edits exercise its state handling: the state of a node is the last P' x 8192 input samples per channel.
+
+Tolerance: north_star's 1e-5 RMS absolute, plus a bus-relative bound (float32 transforms of 4096 complex points: ~4e-7).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from graphaudio_amd import (AudioBufferSourceNode, BiQuadFilterNode, ChannelCountMode, ConvolverNode, FilterType, GainNode,
+                            OfflineAudioContext, PlayableAudioBuffer)
+from tests import _graphs as G
+from tests._oracle import OracleContext
+
+SR = 48000
+TOL_RMS = 1e-5
+REL = 2e-6
+
+
+def hip(**opts):
+    ctx = OfflineAudioContext(SR)
+    ctx.SetOption("coarse_min_blocks", 1)
+    for k, v in opts.items():
+        ctx.SetOption(k, v)
+    return ctx
+
+
+def check(ref, got, rel=REL):
+    err, sig = G.rms(ref - got), G.rms(ref)
+    assert sig > 1e-5
+    assert err <= TOL_RMS, err
+    assert err <= rel * sig, (err, sig, err / sig)
+
+
+def pair(builder, frames, pieces=None, **opts):
+    o = OracleContext(SR)
+    ch = builder(o)
+    ref = G.render(o, ch, frames)
+    h = hip(**opts)
+    builder(h)
+    got = np.zeros_like(ref)
+    pos = 0
+    for n in (pieces or [frames]):
+        n = min(n, frames - pos)
+        if n > 0:
+            h.Render(got, n, pos)
+            pos += n
+    if pos < frames:
+        h.Render(got, frames - pos, pos)
+    st = h.GetStats()
+    h.Dispose()
+    o.Dispose()
+    return ref, got, st
+
+
+def used_coarse(st):
+    return st["stage_launches"][5] > 0 and st["stage_launches"][3] == 0   # coarse_fwd ran, no A/B/C partition sum
+
+
+@pytest.mark.parametrize("taps", [8193, 8200, 16384, 20000, 40000, 65536])
+def test_tap_counts(taps):
+    """P' = 2 .. 8 coarse partitions, last partition short; 3 voices fused into one sum per channel."""
+    frames = 128 * 600
+    ref, got, st = pair(lambda c: G.config3_convolver(c, voices=3, taps=taps, frames=frames), frames)
+    assert used_coarse(st)
+    check(ref, got)
+
+
+def test_131072_taps_sixteen_partitions():
+    frames = 128 * 1100
+    ref, got, st = pair(lambda c: G.config3_convolver(c, voices=2, taps=131072, frames=frames), frames)
+    assert used_coarse(st)
+    check(ref, got)
+    tail = slice(128 * 1030, None)   # every partition populated
+    assert G.rms(ref[:, tail] - got[:, tail]) <= REL * G.rms(ref[:, tail])
+
+
+def test_state_across_uneven_pieces():
+    """Partial blocks (leftover cache), one-block chunks, chunks shorter and longer than the history, many chunks."""
+    frames = 128 * 500
+    pieces = [100, 128 * 3 + 7, 1, 128 * 70, 128, 128 * 200 - 5, 77]
+    ref, got, st = pair(lambda c: G.config3_convolver(c, voices=4, taps=30000, frames=frames), frames, pieces, max_chunk_blocks=96)
+    assert used_coarse(st) and st["chunks"] > 8
+    check(ref, got)
+
+
+def test_more_than_64_coarse_blocks_in_one_chunk():
+    """A chunk of 9,000 blocks is 141 coarse blocks: the multiply-accumulate jobs are split along time (<= 64 blocks each)."""
+    frames = 128 * 9000
+    ref, got, st = pair(lambda c: G.config3_convolver(c, voices=1, taps=9000, frames=frames), frames, max_chunk_blocks=32768)
+    assert used_coarse(st) and st["chunks"] == 1
+    check(ref, got)
+
+
+def test_unique_ir_per_voice():
+    frames = 128 * 400
+    ref, got, st = pair(lambda c: G.config3_convolver(c, voices=5, taps=20000, frames=frames, shared=False), frames)
+    assert used_coarse(st)
+    check(ref, got)
+
+
+def _true_stereo(ctx, frames):
+    irs = [G.synth_ir(c, 17000) for c in range(4)]
+    s = AudioBufferSourceNode(ctx)
+    s.Buffer = PlayableAudioBuffer.FromStereoArrays(G.voice(50, frames + 256), G.voice(51, frames + 256), SR)
+    cv = ConvolverNode(ctx)
+    cv.Buffer = PlayableAudioBuffer.FromChannelArrays(irs, SR)
+    s.Connect(cv).Connect(ctx.Destination)
+    s.Start()
+    return 2
+
+
+def test_true_stereo_four_channel_ir():
+    """outL = L * h0 + R * h2, outR = L * h1 + R * h3 (ConvolverNode.cs:127-151): four terms, two accumulators."""
+    frames = 128 * 400
+    ref, got, st = pair(lambda c: _true_stereo(c, frames), frames, [128 * 150, 128 * 250])
+    assert used_coarse(st)
+    check(ref, got)
+
+
+def _stereo_discrete(ctx, frames):
+    s = AudioBufferSourceNode(ctx)
+    s.Buffer = PlayableAudioBuffer.FromStereoArrays(G.voice(60, frames + 256), G.voice(61, frames + 256), SR)
+    cv = ConvolverNode(ctx)
+    cv.EnableTrueStereo = False
+    cv.Buffer = PlayableAudioBuffer.FromChannelArrays([G.synth_ir(c, 12000) for c in range(2)], SR)
+    s.Connect(cv).Connect(ctx.Destination)
+    s.Start()
+    return 2
+
+
+def test_stereo_input_discrete_channels():
+    """Two different input channels, each against its own IR channel: two signals, one column each."""
+    frames = 128 * 300
+    ref, got, st = pair(lambda c: _stereo_discrete(c, frames), frames)
+    assert used_coarse(st)
+    check(ref, got)
+
+
+def _sixteen(ctx, frames, sources=3):
+    ctx.Destination.SetChannelCount(16)
+    for v in range(sources):
+        s = AudioBufferSourceNode(ctx)
+        s.Buffer = PlayableAudioBuffer.FromMonoArray(G.voice(v, frames + 256), SR)
+        cv = ConvolverNode(ctx)
+        cv.Buffer = PlayableAudioBuffer.FromChannelArrays([G.synth_ir(c, 10000, seed0=7 + 100 * v) for c in range(16)], SR)
+        s.Connect(cv).Connect(ctx.Destination)
+        s.Start()
+    return 16
+
+
+def test_sixteen_channel_ir_long_chunk():
+    """16 columns per input = four jobs of 4 columns; 40 coarse blocks > 32: the 4-column jobs are split along time."""
+    frames = 128 * 2560
+    ref, got, st = pair(lambda c: _sixteen(c, frames), frames)
+    assert used_coarse(st)
+    check(ref, got)
+
+
+def _not_fused(ctx, frames):
+    """conv -> gain -> destination, and a second convolver whose output feeds TWO inputs: nothing to fuse."""
+    ir = PlayableAudioBuffer.FromChannelArrays([G.synth_ir(c, 9000) for c in range(2)], SR)
+    for v in range(2):
+        s = AudioBufferSourceNode(ctx)
+        s.Buffer = PlayableAudioBuffer.FromMonoArray(G.voice(v, frames + 256), SR)
+        cv = ConvolverNode(ctx)
+        cv.Buffer = ir
+        g = GainNode(ctx)
+        g.Gain.Value = 0.5 + 0.25 * v
+        s.Connect(cv)
+        cv.Connect(g)
+        g.Connect(ctx.Destination)
+        if v == 1:
+            g2 = GainNode(ctx)
+            g2.Gain.Value = -0.3
+            cv.Connect(g2)
+            g2.Connect(ctx.Destination)
+        s.Start()
+    return 2
+
+
+def test_outputs_that_cannot_be_fused():
+    frames = 128 * 300
+    ref, got, st = pair(lambda c: _not_fused(c, frames), frames)
+    assert used_coarse(st)
+    check(ref, got)
+
+
+def _fused_with_other_terms(ctx, frames):
+    """The destination sums a fused group of convolvers AND plain voices AND a convolver of another length (second group)."""
+    ir = PlayableAudioBuffer.FromChannelArrays([G.synth_ir(c, 20000) for c in range(2)], SR)
+    ir2 = PlayableAudioBuffer.FromChannelArrays([G.synth_ir(c, 9000, seed0=40) for c in range(2)], SR)
+    for v in range(6):
+        s = AudioBufferSourceNode(ctx)
+        s.Buffer = PlayableAudioBuffer.FromMonoArray(G.voice(v, frames + 256), SR)
+        if v == 2:
+            g = GainNode(ctx)
+            g.Gain.Value = 0.01
+            s.Connect(g).Connect(ctx.Destination)
+        else:
+            cv = ConvolverNode(ctx)
+            cv.Buffer = ir2 if v == 4 else ir
+            s.Connect(cv).Connect(ctx.Destination)
+        s.Start()
+    return 2
+
+
+def test_fused_group_next_to_other_terms():
+    frames = 128 * 300
+    ref, got, st = pair(lambda c: _fused_with_other_terms(c, frames), frames)
+    assert used_coarse(st)
+    check(ref, got)
+
+
+def _mono_ir_into_stereo_destination(ctx, frames):
+    """A 1-channel IR: the convolver's output is mono and the destination (2 channels) copies it to both (1 -> N rule)."""
+    ir = PlayableAudioBuffer.FromChannelArrays([G.synth_ir(0, 9000)], SR)
+    for v in range(3):
+        s = AudioBufferSourceNode(ctx)
+        s.Buffer = PlayableAudioBuffer.FromMonoArray(G.voice(v, frames + 256), SR)
+        cv = ConvolverNode(ctx)
+        cv.Buffer = ir
+        s.Connect(cv).Connect(ctx.Destination)
+        s.Start()
+    return 2
+
+
+def test_fused_mono_outputs_upmixed_by_the_consumer():
+    frames = 128 * 200
+    ref, got, st = pair(lambda c: _mono_ir_into_stereo_destination(c, frames), frames)
+    assert used_coarse(st)
+    check(ref, got)
+    assert np.array_equal(got[0], got[1])
+
+
+def _downmixed(ctx, frames):
+    """Stereo convolver outputs into a mono (explicit) input: the N -> 1 rule (sum of channels / sqrt N) applied to the group sum."""
+    ctx.Destination.SetChannelCount(1)
+    bus = GainNode(ctx)
+    bus.Inputs[0].SetChannelCount(1)
+    bus.Inputs[0].SetChannelCountMode(ChannelCountMode.Explicit)
+    bus.Connect(ctx.Destination)
+    ir = PlayableAudioBuffer.FromChannelArrays([G.synth_ir(c, 9000) for c in range(2)], SR)
+    for v in range(3):
+        s = AudioBufferSourceNode(ctx)
+        s.Buffer = PlayableAudioBuffer.FromMonoArray(G.voice(v, frames + 256), SR)
+        cv = ConvolverNode(ctx)
+        cv.Buffer = ir
+        s.Connect(cv).Connect(bus)
+        s.Start()
+    return 1
+
+
+def test_fused_group_downmixed_by_the_consumer():
+    frames = 128 * 200
+    ref, got, st = pair(lambda c: _downmixed(c, frames), frames)
+    assert used_coarse(st)
+    check(ref, got)
+
+
+def _chain(ctx, frames):
+    """Two convolvers in series (convolver depth 0 and 1) with a biquad in between."""
+    s = AudioBufferSourceNode(ctx)
+    s.Buffer = PlayableAudioBuffer.FromMonoArray(G.voice(3, frames + 256), SR)
+    a = ConvolverNode(ctx)
+    a.Buffer = PlayableAudioBuffer.FromChannelArrays([G.synth_ir(0, 9000)], SR)
+    bq = BiQuadFilterNode(ctx)
+    bq.Type = FilterType.Highpass
+    bq.Frequency.Value = 900.0
+    b = ConvolverNode(ctx)
+    b.Buffer = PlayableAudioBuffer.FromChannelArrays([G.synth_ir(c, 12000, seed0=90) for c in range(2)], SR)
+    s.Connect(a).Connect(bq).Connect(b).Connect(ctx.Destination)
+    s.Start()
+    return 2
+
+
+def test_convolvers_in_series():
+    frames = 128 * 300
+    ref, got, st = pair(lambda c: _chain(c, frames), frames, [128 * 100, 128 * 200])
+    assert used_coarse(st)
+    check(ref, got, rel=2e-5)   # the high-pass recursion amplifies the 4e-7 of the first convolver
+
+
+def _scheduled(ctx, frames):
+    """Voices that start late, stop early and end inside the chunk: segments; the convolver keeps ringing on silent input."""
+    ir = PlayableAudioBuffer.FromChannelArrays([G.synth_ir(c, 10000) for c in range(2)], SR)
+    for v in range(4):
+        s = AudioBufferSourceNode(ctx)
+        s.Buffer = PlayableAudioBuffer.FromMonoArray(G.voice(v, 128 * (40 + 30 * v)), SR)
+        cv = ConvolverNode(ctx)
+        cv.Buffer = ir
+        s.Connect(cv).Connect(ctx.Destination)
+        s.Start(0.01 * v)
+        if v == 1:
+            s.Stop(0.2)
+    return 2
+
+
+def test_sources_ending_inside_the_chunk():
+    frames = 128 * 300
+    ref, got, st = pair(lambda c: _scheduled(c, frames), frames)
+    assert used_coarse(st) and st["segments"] > 2
+    check(ref, got)
+
+
+def test_unplugged_convolver_keeps_its_state():
+    """A convolver disconnected from the destination for a while is not processed (pull model): its input history stays."""
+    frames = 128 * 360
+
+    def run(ctx):
+        ir = PlayableAudioBuffer.FromChannelArrays([G.synth_ir(c, 9000) for c in range(2)], SR)
+        cvs = []
+        for v in range(2):
+            s = AudioBufferSourceNode(ctx)
+            s.Buffer = PlayableAudioBuffer.FromMonoArray(G.voice(v, frames + 256), SR)
+            cv = ConvolverNode(ctx)
+            cv.Buffer = ir
+            s.Connect(cv).Connect(ctx.Destination)
+            s.Start()
+            cvs.append(cv)
+        out = np.zeros((2, frames), np.float32)
+        ctx.Render(out, 128 * 120, 0)
+        cvs[1].Disconnect()
+        ctx.Render(out, 128 * 100, 128 * 120)
+        cvs[1].Connect(ctx.Destination)
+        ctx.Render(out, 128 * 140, 128 * 220)
+        return out
+
+    ref = run(OracleContext(SR))
+    got = run(hip())
+    check(ref, got)
+
+
+def test_ir_swap_resets_the_state():
+    frames = 128 * 300
+
+    def run(ctx):
+        s = AudioBufferSourceNode(ctx)
+        s.Buffer = PlayableAudioBuffer.FromMonoArray(G.voice(7, frames + 256), SR)
+        cv = ConvolverNode(ctx)
+        cv.Buffer = PlayableAudioBuffer.FromChannelArrays([G.synth_ir(c, 9000) for c in range(2)], SR)
+        s.Connect(cv).Connect(ctx.Destination)
+        s.Start()
+        out = np.zeros((2, frames), np.float32)
+        ctx.Render(out, 128 * 150, 0)
+        cv.Buffer = PlayableAudioBuffer.FromChannelArrays([G.synth_ir(c, 14000, seed0=70) for c in range(2)], SR)
+        ctx.Render(out, 128 * 150, 128 * 150)
+        return out
+
+    ref = run(OracleContext(SR))
+    got = run(hip())
+    check(ref, got)
+
+
+def test_default_policy_long_first_chunk_takes_the_coarse_path():
+    frames = 128 * 300
+    o = OracleContext(SR)
+    G.config3_convolver(o, voices=2, taps=20000, frames=frames)
+    ref = G.render(o, 2, frames)
+    h = OfflineAudioContext(SR)   # defaults: coarse = 1, coarse_min_blocks = 256
+    G.config3_convolver(h, voices=2, taps=20000, frames=frames)
+    got = G.render(h, 2, frames)
+    assert used_coarse(h.GetStats())
+    check(ref, got)
+    h2 = OfflineAudioContext(SR)
+    G.config3_convolver(h2, voices=2, taps=20000, frames=frames)
+    got2 = np.zeros_like(ref)
+    h2.Render(got2, 128 * 100, 0)          # a short first chunk: the block-axis FFT formulation, kept for the node's life
+    h2.Render(got2, 128 * 200, 128 * 100)
+    st = h2.GetStats()
+    assert st["stage_launches"][5] == 0 and st["stage_launches"][3] > 0
+    check(ref, got2)

@@ -33,14 +33,24 @@ def build(ctx, voices, frames, delay_blocks=0, ir=None):
     return 2
 
 
-@pytest.mark.parametrize("time_fft", [0, 1])
-def test_steady_state_parity_at_full_tap_count(time_fft):
+# the three formulations that can serve this size: direct partition sum on the matrix cores (A/B), FFT along the block axis (C),
+# coarse partitions (D, the default for long chunks)
+PATHS = {"direct": {"time_fft": 0}, "block_axis_fft": {"time_fft": 1, "coarse": 0}, "coarse": {"time_fft": 1, "coarse": 1}}
+
+
+def set_path(ctx, path):
+    for k, v in PATHS[path].items():
+        ctx.SetOption(k, v)
+
+
+@pytest.mark.parametrize("path", list(PATHS))
+def test_steady_state_parity_at_full_tap_count(path):
     blocks = 640
     frames = blocks * 128
     outs = []
     for mk in (OracleContext, OfflineAudioContext):
         ctx = mk(SR)
-        ctx.SetOption("time_fft", time_fft)
+        set_path(ctx, path)
         build(ctx, range(3), frames)
         outs.append(G.render(ctx, 2, frames))
     ref, got = outs
@@ -58,15 +68,16 @@ def close(a, b, exact):
     return G.rms(a - b) <= 1e-6 * G.rms(a)
 
 
-@pytest.mark.parametrize("time_fft", [0, 1])
-def test_chunk_invariance(time_fft):
+@pytest.mark.parametrize("path", list(PATHS))
+def test_chunk_invariance(path):
     frames = 128 * 700
     a = OfflineAudioContext(SR)
-    a.SetOption("time_fft", time_fft)
+    set_path(a, path)
     build(a, range(48), frames)
     one = G.render(a, 2, frames)
     b = OfflineAudioContext(SR)
-    b.SetOption("time_fft", time_fft)
+    set_path(b, path)
+    b.SetOption("coarse_min_blocks", 1)
     b.SetOption("max_chunk_blocks", 96)
     build(b, range(48), frames)
     many = np.zeros_like(one)
@@ -77,26 +88,27 @@ def test_chunk_invariance(time_fft):
             b.Render(many, n, pos)
             pos += n
     assert b.GetStats()["chunks"] > 6
-    assert close(one, many, exact=not time_fft)
+    assert close(one, many, exact=path == "direct")
 
 
-@pytest.mark.parametrize("time_fft", [0, 1])
-def test_superposition_and_time_invariance(time_fft):
+@pytest.mark.parametrize("path", list(PATHS))
+def test_superposition_and_time_invariance(path):
+    time_fft = path != "direct"
     frames = 128 * 600
     full = OfflineAudioContext(SR)
-    full.SetOption("time_fft", time_fft)
+    set_path(full, path)
     build(full, range(32), frames)
     bus = G.render(full, 2, frames)
     parts = np.zeros_like(bus, dtype=np.float64)
     for half in (range(0, 16), range(16, 32)):
         c = OfflineAudioContext(SR)
-        c.SetOption("time_fft", time_fft)
+        set_path(c, path)
         build(c, half, frames)
         parts += G.render(c, 2, frames)
     assert G.rms(bus - parts) <= 4e-7 * G.rms(bus)   # float32 summation order only
     k = 7
     d = OfflineAudioContext(SR)
-    d.SetOption("time_fft", time_fft)
+    set_path(d, path)
     build(d, range(32), frames, delay_blocks=k)
     delayed = G.render(d, 2, frames)
     # FFT-based formulations leave ~1e-9 of circular-convolution rounding where the direct sum gives exact zeros
@@ -112,6 +124,7 @@ def test_mixed_segment_lengths_of_the_block_axis_fft(blocks):
     outs = []
     for mk in (OracleContext, OfflineAudioContext):
         ctx = mk(SR)
+        ctx.SetOption("coarse", 0)
         build(ctx, range(2), frames)
         outs.append(G.render(ctx, 2, frames))
     ref, got = outs

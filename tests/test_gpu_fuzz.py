@@ -17,8 +17,11 @@ from tests._oracle import OracleContext
 REGRESSION_SEEDS = [215, 219, 357, 430, 459, 749, 1232, 1273, 1476, 2550, 2577, 2916, 3371, 1186, 1763, 3027, 3639, 4787]
 
 
+# coarse = 1: convolvers with more than 64 partitions are forced onto formulation D (coarse partitions) even though the pieces are
+# short -- every piece re-transforms the input history, which is exactly the state handling to stress
+@pytest.mark.parametrize("coarse", [0, 1])
 @pytest.mark.parametrize("seed", list(range(120)) + REGRESSION_SEEDS)
-def test_random_graph_matches_oracle(seed):
+def test_random_graph_matches_oracle(seed, coarse):
     frames = 128 * 36
     o = OracleContext(48000)
     ch = build_random_graph(o, seed, frames)
@@ -33,6 +36,7 @@ def test_random_graph_matches_oracle(seed):
         return
     h = OfflineAudioContext(48000)
     h.SetOption("max_chunk_blocks", 11)
+    h.SetOption("coarse_min_blocks", 1 if coarse else 1 << 30)
     build_random_graph(h, seed, frames)
     got = np.zeros_like(ref)
     pos = 0
@@ -50,23 +54,25 @@ def test_random_graph_matches_oracle(seed):
     assert err <= 1e-5 and err <= 2e-5 * scale, (seed, err, scale)   # north_star: <= 1e-5 RMS per sample
 
 
-def _session_pair(seed, chunk=11):
+def _session_pair(seed, chunk=11, coarse=0):
     from tests._fuzz import run_random_session
     o = OracleContext(48000)
     ref, ref_log = run_random_session(o, seed)
     h = OfflineAudioContext(48000)
     h.SetOption("max_chunk_blocks", chunk)
+    h.SetOption("coarse_min_blocks", 1 if coarse else 1 << 30)
     got, got_log = run_random_session(h, seed)
     return ref, ref_log, got, got_log
 
 
 # 2850: a shared-IR convolver taken out of the graph for 17 blocks and plugged back (its delay line has to freeze)
+@pytest.mark.parametrize("coarse", [0, 1])
 @pytest.mark.parametrize("seed", list(range(60)) + [2850])
-def test_random_edit_session_matches_oracle(seed):
+def test_random_edit_session_matches_oracle(seed, coarse):
     """The graph is edited between render pieces (parameter writes, automation, stop, new voices, dispose, rewiring,
     impulse-response swaps, audio-rate modulation, channel settings): same output and the same exceptions."""
     try:
-        ref, ref_log, got, got_log = _session_pair(seed)
+        ref, ref_log, got, got_log = _session_pair(seed, coarse=coarse)
     except NotSupportedException as e:
         pytest.skip(f"session uses a feature outside the device path: {e}")
     assert ref_log == got_log
