@@ -142,6 +142,11 @@ SIGNATURES = {
     "process_blocks_interleaved": (_i, [_vp, C.POINTER(C.c_float), _i, _i64, _i]),
     "context_set_stream": (_i, [_vp, _vp]),
     "synchronize": (_i, [_vp]),
+    "comm_unique_id": (_i, [_vp]),
+    "comm_init": (_i, [_vp, _vp, _i, _i]),
+    "comm_destroy": (_i, [_vp]),
+    "shard_range": (_i, [_i64, _i, _i, C.POINTER(_i64), C.POINTER(_i64)]),
+    "render_reduce": (_i, [_vp, _pp, _i, _i64, _i64, _i]),
 }
 
 

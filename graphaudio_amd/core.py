@@ -503,6 +503,10 @@ class AudioContextBase:
 
     def SetOption(self, key: str, value: float):
         self._call("set_option", key.encode(), float(value))
+        if key == "async":
+            self._async = bool(value)   # asynchronous renders: output arrays are kept alive until Synchronize()
+            if not value:
+                self._pending_outputs = []
 
     def GetStats(self) -> dict:
         st = _capi.Stats()
@@ -568,6 +572,8 @@ class OfflineAudioContext(AudioContextBase):
             channels = self._api.destination_output_channels(self._h)
             out = np.zeros((channels, frameCount), dtype=np.float32)
             self.Render(out, frameCount)
+            if getattr(self, "_async", False):   # the copy into `out` may still be in flight: never hand back a half-written array
+                self._call("synchronize")
             return out
         if len(output) == 0:
             raise ArgumentException("Output buffer must have at least one channel.")
@@ -587,6 +593,10 @@ class OfflineAudioContext(AudioContextBase):
                     f"Channel {ch} buffer is too small. Required: {startIndex + frameCount}, Available: {row.shape[0]}")
             rows.append(row)
         ptrs = (C.c_void_p * len(rows))(*[r.ctypes.data for r in rows])
+        if getattr(self, "_async", False):
+            # the device writes these rows after the call has returned: the context holds a reference until the next
+            # Synchronize() / GetStats() so that a caller dropping its array cannot free memory a copy is still aimed at
+            self._pending_outputs = getattr(self, "_pending_outputs", [])[-3:] + [rows]
         self._call("render", ptrs, len(rows), int(frameCount), int(startIndex))
         self._raise_ended()
         return output
@@ -597,12 +607,45 @@ class OfflineAudioContext(AudioContextBase):
         self._call("render_device", ptrs, len(device_ptrs), int(frameCount), int(startIndex))
         self._raise_ended()
 
+    # ---- sharded render (include/graphaudio_hip.h "sharded render"): one context per GPU, one RCCL sum per Render ----
+    COMM_ID_BYTES = 128
+
+    def CommUniqueId(self) -> bytes:
+        """The 128-byte communicator id rank 0 creates and hands to every rank (any channel)."""
+        buf = C.create_string_buffer(self.COMM_ID_BYTES)
+        self._api.check(self._h, self._api.comm_unique_id(buf))
+        return buf.raw
+
+    def CommInit(self, comm_id: Optional[bytes], n_ranks: int, rank: int):
+        buf = C.create_string_buffer(bytes(comm_id), self.COMM_ID_BYTES) if comm_id is not None else None
+        self._call("comm_init", buf, int(n_ranks), int(rank))
+
+    def CommDestroy(self):
+        self._call("comm_destroy")
+
+    def RenderReduce(self, output, frameCount: int, startIndex: int = 0, root: int = 0):
+        """Render(output, frameCount, startIndex) of a voice-sharded graph: every rank renders its share, the destination
+        buses are summed on the device (RCCL), `output` (per-channel float32 arrays) is written on `root` only."""
+        n = len(output)
+        ptrs = (C.c_void_p * n)()
+        for ch in range(n):
+            row = output[ch]
+            if not (isinstance(row, np.ndarray) and row.dtype == np.float32 and row.flags["C_CONTIGUOUS"]):
+                raise ArgumentException(f"Channel {ch} buffer must be a contiguous float32 array.")
+            if row.shape[0] < startIndex + frameCount:
+                raise ArgumentException(f"Channel {ch} buffer is too small.")
+            ptrs[ch] = row.ctypes.data
+        self._pending_outputs = getattr(self, "_pending_outputs", [])[-3:] + [output]   # alive until Synchronize() (async contexts)
+        self._call("render_reduce", ptrs, n, int(frameCount), int(startIndex), int(root))
+        self._raise_ended()
+
     def SetStream(self, hip_stream: int):
         self._call("context_set_stream", C.c_void_p(int(hip_stream)))
 
     def Synchronize(self):
         """Wait for the renders enqueued under ``SetOption("async", 1)`` (include/graphaudio_hip.h, ga_synchronize)."""
         self._call("synchronize")
+        self._pending_outputs = []
 
 
 # The reference's class name for the stock CPU context is OfflineAudioContext; the drop-in replacement a C# user

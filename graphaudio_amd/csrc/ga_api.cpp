@@ -788,4 +788,33 @@ int ga_render_device(ga_context* ctx, float* const* out_planar_dev, int out_chan
   return guard(ctx, [&](Context& c) { c.render(out_planar_dev, out_channels, frame_count, start_index, true); });
 }
 
+// ---- sharded render (ga_comm.cpp) ----
+int ga_comm_unique_id(void* id_out) {
+  try {
+    ga::commUniqueId(id_out);
+    return GA_OK;
+  } catch (const Err& e) {
+    return e.code;
+  } catch (...) {
+    return GA_ERR_INVALID_OPERATION;
+  }
+}
+int ga_comm_init(ga_context* ctx, const void* id, int n_ranks, int rank) {
+  return guard(ctx, [&](Context& c) { c.commInit(id, n_ranks, rank); });
+}
+int ga_comm_destroy(ga_context* ctx) {
+  return guard(ctx, [&](Context& c) { c.commDestroy(); });
+}
+int ga_shard_range(int64_t n_voices, int n_ranks, int rank, int64_t* first, int64_t* count) {
+  if (!first || !count) return GA_ERR_INVALID_ARGUMENT;
+  if (n_voices < 0 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return GA_ERR_OUT_OF_RANGE;
+  const int64_t base = n_voices / n_ranks, extra = n_voices % n_ranks;
+  *first = rank * base + std::min<int64_t>(rank, extra);
+  *count = base + (rank < extra ? 1 : 0);
+  return GA_OK;
+}
+int ga_render_reduce(ga_context* ctx, float* const* out_planar, int out_channels, int64_t frame_count, int64_t start_index, int root) {
+  return guard(ctx, [&](Context& c) { c.renderReduce(out_planar, out_channels, frame_count, start_index, root); });
+}
+
 }  // extern "C"

@@ -62,6 +62,10 @@ void Context::init_device(int dev) {
 
 Context::~Context() {
   if (stream) (void)hipStreamSynchronize(stream);
+  try {
+    commDestroy();
+  } catch (...) {
+  }
   for (auto& b : buffers)
     if (b && b->dev) (void)hipFree(b->dev);
   for (auto& g : groups) {

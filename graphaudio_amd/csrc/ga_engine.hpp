@@ -444,6 +444,15 @@ struct Context {
   std::string faultMsg;
   int chunkPhase = 0;        // 0 = checks only (a failure leaves the context usable), 1 = state is moving
 
+  // sharded render (ga_comm_*, ga_render_reduce): the RCCL communicator of this rank and its device-side bus staging
+  void* comm = nullptr;          // ncclComm_t (RCCL is loaded with dlopen on first use: ga_comm.cpp)
+  int commRanks = 0, commRank = 0;
+  float* reduceBuf = nullptr;    // [channels][frames] contiguous
+  size_t reduceBytes = 0;
+  void commInit(const void* id, int nRanks, int rank);
+  void commDestroy();
+  void renderReduce(float* const* out, int channels, int64_t frames, int64_t start, int root);
+
   int64_t busCapFrames = 0;
   std::vector<float*> busSlabs;
   struct SegCh { int64_t b0, b1; int ch; };
@@ -465,5 +474,7 @@ struct Context {
   int chunkMinDestCh = 0;      // smallest destination channel count over the blocks of the last chunk
   int64_t chunkBlocksDone = 0; // blocks actually executed by the last runChunk
 };
+
+void commUniqueId(void* out);   // ga_comm.cpp: ncclGetUniqueId through the run-time loaded RCCL
 
 }  // namespace ga

@@ -224,6 +224,29 @@ GA_EXPORT int GA_FN(context_set_stream)(ga_context* ctx, void* hip_stream);
    ga_synchronize, or after any later work on the same stream.  The default is synchronous, as in the reference. */
 GA_EXPORT int GA_FN(synchronize)(ga_context* ctx);
 
+
+/* ---- sharded render: voices split over the GPUs of one node, ONE sum of the destination bus per render call ----------------
+ * The reference mixes every voice at the destination on one thread (AudioNodeInput.MixBuffer, AudioNodeInput.cs:118-132,
+ * 195-198).  Voice chains are independent up to that sum, so a host may build the same graph on N
+ * contexts -- one per GPU, each with a contiguous share of the voices (ga_shard_range) -- and let the library add the buses:
+ * ga_render_reduce renders this rank's share into device memory and sums the destination bus of all ranks with ONE RCCL
+ * reduce over xGMI, ordered on the context's stream (render -> reduce -> copy to the caller's arrays on the root rank).
+ * The ranks may be threads of one process or separate processes (one per GPU); the host only has to hand the 128-byte id
+ * that rank 0 obtains from ga_comm_unique_id to every rank (any channel: shared memory, a file, a socket).
+ * RCCL (librccl.so.1) is loaded on the first ga_comm_* call; single-GPU hosts never need it.  With n_ranks = 1 the calls work
+ * without RCCL and ga_render_reduce equals ga_render.  The float32 sum across ranks is associated differently from the
+ * reference's sequential order: rounding only. */
+#define GA_COMM_ID_BYTES 128
+GA_EXPORT int GA_FN(comm_unique_id)(void* id_out);   /* GA_COMM_ID_BYTES bytes; rank 0 calls it, every rank gets a copy */
+GA_EXPORT int GA_FN(comm_init)(ga_context* ctx, const void* id, int n_ranks, int rank);   /* collective over the ranks */
+GA_EXPORT int GA_FN(comm_destroy)(ga_context* ctx);
+/* voices [first, first + count) of n_voices for `rank` of n_ranks (contiguous, sizes differ by at most one) */
+GA_EXPORT int GA_FN(shard_range)(int64_t n_voices, int n_ranks, int rank, int64_t* first, int64_t* count);
+/* Render(output, frameCount, startIndex) of the sharded graph: collective; out_planar (host arrays, page-locked for
+   "async" contexts) is written on rank `root` only and may be null elsewhere.  out_channels must be the same on every rank. */
+GA_EXPORT int GA_FN(render_reduce)(ga_context* ctx, float* const* out_planar, int out_channels, int64_t frame_count,
+                                   int64_t start_index, int root);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1932,6 +1932,25 @@ int gao_render(ga_context* ctx, float* const* output, int channels, int64_t fram
   });
 }
 int gao_render_device(ga_context*, float* const*, int, int64_t, int64_t) { return GA_ERR_UNSUPPORTED; }
+// sharded render (include/graphaudio_hip.h): the CPU restatement is a single rank; shard_range is the same arithmetic
+int gao_comm_unique_id(void*) { return GA_ERR_UNSUPPORTED; }
+int gao_comm_init(ga_context* ctx, const void*, int n_ranks, int rank) {
+  if (!ctx) return GA_ERR_INVALID_ARGUMENT;
+  return (n_ranks == 1 && rank == 0) ? GA_OK : GA_ERR_UNSUPPORTED;
+}
+int gao_comm_destroy(ga_context* ctx) { return ctx ? GA_OK : GA_ERR_INVALID_ARGUMENT; }
+int gao_shard_range(int64_t n_voices, int n_ranks, int rank, int64_t* first, int64_t* count) {
+  if (!first || !count) return GA_ERR_INVALID_ARGUMENT;
+  if (n_voices < 0 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return GA_ERR_OUT_OF_RANGE;
+  const int64_t base = n_voices / n_ranks, extra = n_voices % n_ranks;
+  *first = rank * base + (rank < extra ? rank : extra);
+  *count = base + (rank < extra ? 1 : 0);
+  return GA_OK;
+}
+int gao_render_reduce(ga_context* ctx, float* const* out, int channels, int64_t frames, int64_t start, int root) {
+  if (root != 0) return GA_ERR_OUT_OF_RANGE;
+  return gao_render(ctx, out, channels, frames, start);
+}
 
 // AudioContextBase.ProcessBlocks, AudioContextBase.cs:163-186
 int gao_process_blocks(ga_context* ctx, float* const* outputBuffers, int nOut, int64_t blockCount, int onDevice) {

@@ -1,5 +1,7 @@
-"""N>1 path on CPU: two gloo ranks each render their voice shard (with the oracle standing in for the device) and the
-destination buses are summed with torch.distributed -- the same sharding + reduce code path bench.py uses with RCCL."""
+"""N>1 path on CPU: two gloo ranks run the host side of the sharded render -- ga_shard_range from the product library (pure host
+code, loads without a GPU), the communicator-id exchange of graphaudio_amd.distributed -- render their voice shard with the
+oracle standing in for the device, and sum the destination buses with a gloo reduce standing in for the RCCL reduce that
+ga_render_reduce issues on the GPU box (tests/test_gpu_device_out.py covers that call on the device)."""
 import os
 import subprocess
 import sys
@@ -13,7 +15,7 @@ import os, sys
 import numpy as np
 import torch, torch.distributed as dist
 sys.path.insert(0, os.environ["GA_ROOT"])
-from graphaudio_amd.distributed import shard_range, reduce_bus
+from graphaudio_amd.distributed import shard_range, exchange_comm_id
 from graphaudio_amd import AudioBufferSourceNode, ConvolverNode, PlayableAudioBuffer
 from tests import _graphs as G
 from tests._oracle import OracleContext
@@ -21,6 +23,9 @@ dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 V, frames, taps = 6, 128 * 12, 900
 b, e = shard_range(V, world, rank)
+class FakeRank0:                      # the id exchange only needs CommUniqueId() on rank 0
+    def CommUniqueId(self): return bytes(range(128))
+assert exchange_comm_id(FakeRank0(), rank, world) == bytes(range(128))
 ctx = OracleContext(48000)
 irbuf = PlayableAudioBuffer.FromChannelArrays([G.synth_ir(c, taps) for c in range(2)], 48000)
 for v in range(b, e):
@@ -30,7 +35,7 @@ for v in range(b, e):
 out = np.zeros((2, frames), np.float32)
 ctx.Render(out, frames)
 bus = torch.from_numpy(out)
-reduce_bus(bus, 0)
+dist.reduce(bus, dst=0, op=dist.ReduceOp.SUM)
 if rank == 0:
     np.save(os.environ["GA_OUT"], bus.numpy())
 dist.destroy_process_group()
@@ -64,3 +69,5 @@ def test_shard_range_partitions():
             spans = [shard_range(total, world, r) for r in range(world)]
             assert spans[0][0] == 0 and spans[-1][1] == total
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1

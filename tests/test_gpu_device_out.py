@@ -104,3 +104,55 @@ def test_async_renders_match_synchronous_ones():
     a, b = run(False), run(True)
     assert G.rms(a) > 1e-3
     assert np.array_equal(a, b)
+
+
+# ---- sharded render (include/graphaudio_hip.h "sharded render"): ga_comm_* + ga_render_reduce on the HIP path ----
+def _reduce_matches_render(n_ranks_id):
+    ref_ctx, ch = _ctx()
+    frames = 128 * 32
+    ref = G.render(ref_ctx, ch, frames)
+    ctx, _ = _ctx()
+    ctx.CommInit(n_ranks_id, 1, 0)
+    got = np.zeros((ch, frames), np.float32)
+    ctx.RenderReduce(got, 128 * 20 + 5, 0)               # uneven pieces: the leftover-frame cache behind the reduce
+    ctx.RenderReduce(got, 128 * 12 - 5, 128 * 20 + 5)
+    assert np.array_equal(ref, got)
+    ctx.CommDestroy()
+    ctx.Dispose()
+
+
+def test_render_reduce_single_rank_equals_render():
+    """n_ranks = 1 needs no RCCL: render into device memory, copy to the caller -- bit-identical to ga_render."""
+    _reduce_matches_render(None)
+
+
+def test_render_reduce_requires_comm_init():
+    from graphaudio_amd import InvalidOperationException
+    ctx, ch = _ctx()
+    with pytest.raises(InvalidOperationException):
+        ctx.RenderReduce(np.zeros((ch, 256), np.float32), 256)
+
+
+def test_comm_unique_id_loads_rccl():
+    """ga_comm_unique_id loads librccl.so.1 at run time (the product library itself links the HIP runtime only)."""
+    ctx, _ = _ctx()
+    a, b = ctx.CommUniqueId(), ctx.CommUniqueId()
+    assert len(a) == 128 and a != b
+
+
+def test_render_reduce_pipelined_steps():
+    """async contexts: consecutive sharded renders are enqueued back to back (host planning overlaps the device), results after
+    Synchronize()."""
+    ref_ctx, ch = _ctx()
+    frames = 128 * 16
+    ref = [G.render(ref_ctx, ch, frames) for _ in range(3)]
+    ctx, _ = _ctx()
+    ctx.CommInit(None, 1, 0)
+    ctx.SetOption("async", 1)
+    torch = _torch()
+    outs = [torch.zeros((ch, frames), dtype=torch.float32).pin_memory().numpy() for _ in range(3)]
+    for o in outs:
+        ctx.RenderReduce(o, frames)
+    ctx.Synchronize()
+    for r, o in zip(ref, outs):
+        assert np.array_equal(r, o)

@@ -6,6 +6,6 @@ for e in "$@"; do
   GA_COARSE_EXP=$e python bench.py --no-cpu-baseline --steps 5 --warmup 2 2>gpurun_out/exp_err.log | python -c "
 import json,sys
 r=json.loads(sys.stdin.read())
-print('ms/step %.3f' % r['ms_per_step'], {k: round(v,3) for k,v in r['stage_ms_per_step'].items() if v>0})"
+print('ms/step %.3f' % r['ms_per_step'], {k: round(v,3) for k,v in {n: s["ms_per_step"] for n, s in r["stages"].items()}.items()})"
 grep coarse_mac gpurun_out/exp_err.log | sort | uniq -c | head -3
 done
