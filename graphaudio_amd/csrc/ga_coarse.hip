@@ -65,35 +65,29 @@ __device__ __forceinline__ f2 cfmap(f2 a, f2 b, f2 acc) {
 //  run of consecutive windows of one row: a window's second half is the next window's first half, and the half after that is
 //  in flight while the current window is transformed.
 // =====================================================================================================================
-// the 16 points of transform `ab` (0: z_a[j] = x[4j] + i x[4j+1], 1: z_b[j] = x[4j+2] + i x[4j+3]) this thread owns in window u
-// of the row: j = t + 256 m, m < 8 in half-window u - 1, m >= 8 in half-window u (zero2: that half is zero)
-__device__ __forceinline__ void coarse_issue_points(const CoarseXRow& R, int u, int ab, int t, bool zero2, v2f (&pre)[16]) {
-#pragma unroll
-  for (int hh = 0; hh < 2; hh++) {
-    const int hw = u - 1 + hh;
-    const float* src = nullptr;
-    int64_t lim = 0;   // samples of this half that exist (the rest is zero)
-    if (hh == 1 && zero2) {
-    } else if (hw < 0) {
-      const int64_t off = (int64_t)R.hist_len + (int64_t)hw * kCoarseBlock;
-      if (R.hist && off >= 0) {
-        src = R.hist + off;
-        lim = kCoarseBlock;
-      }
-    } else if (R.in) {
-      const int64_t off = (int64_t)hw * kCoarseBlock;
-      src = R.in + off;
-      lim = std::min<int64_t>(kCoarseBlock, R.nvalid - off);
+// the 8 words x[4j .. 4j+3] = (z_a[j], z_b[j]), j = t + 256 q, this thread owns in half-window `hw` of the row
+__device__ __forceinline__ void coarse_issue_half(const CoarseXRow& R, int hw, int t, v4f (&raw)[8]) {
+  const float* src = nullptr;
+  int64_t lim = 0;   // samples of this half that exist (the rest is zero)
+  if (hw < 0) {
+    const int64_t off = (int64_t)R.hist_len + (int64_t)hw * kCoarseBlock;
+    if (R.hist && off >= 0) {
+      src = R.hist + off;
+      lim = kCoarseBlock;
     }
-    const bool aligned = ((uintptr_t)src & 7) == 0;
+  } else if (R.in) {
+    const int64_t off = (int64_t)hw * kCoarseBlock;
+    src = R.in + off;
+    lim = std::min<int64_t>(kCoarseBlock, R.nvalid - off);
+  }
+  const bool aligned = ((uintptr_t)src & 15) == 0;
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
-      const int o = 4 * (t + 256 * q) + 2 * ab;
-      pre[8 * hh + q] = v2f{0.f, 0.f};
-      if (src && o < lim) {   // lim is a multiple of 4 (chunks are whole 128-frame blocks, histories whole coarse blocks)
-        if (aligned) pre[8 * hh + q] = ldg2(src + o);
-        else pre[8 * hh + q] = v2f{ldg1(src + o), ldg1(src + o + 1)};
-      }
+  for (int q = 0; q < 8; q++) {
+    const int o = 4 * (t + 256 * q);
+    raw[q] = v4f{0.f, 0.f, 0.f, 0.f};
+    if (src && o < lim) {   // lim is a multiple of 4 (chunks are whole 128-frame blocks, histories whole coarse blocks)
+      if (aligned) raw[q] = ldg4(src + o);
+      else raw[q] = v4f{ldg1(src + o), ldg1(src + o + 1), ldg1(src + o + 2), ldg1(src + o + 3)};
     }
   }
 }
@@ -116,11 +110,17 @@ __global__ __launch_bounds__(256, 2) void coarse_fwd_kernel(const CoarseXRow* __
   const f2 tb0 = f2{twab[2049 + t_].x, twab[2049 + t_].y};
   const bool zero2 = (R.flags & 1) != 0;   // impulse-response partitions: [h_p | 0]
   const float scale = R.scale;
-  // Inputs are fetched per TRANSFORM, one transform ahead: 16 eight-byte words (32 registers) are in flight behind each
-  // transform instead of whole half-windows (96 registers) -- the register file is what limits this kernel to two
-  // workgroups per CU.  A sample is requested four times (two windows x two transforms); after the first the L1 / L2 serve it.
-  v2f pre[16];
-  coarse_issue_points(R, R.u0 + w0, 0, t_, zero2, pre);
+  // Every input sample is fetched ONCE per run, as part of a 16-byte word that holds one point of each transform: a window's
+  // second half (held as 8 words) is the next window's first half, and the half after that is requested between the two
+  // transforms of the current window (not earlier: its 32 registers would be live during transform a as well)
+  v4f first[8], second[8];
+  coarse_issue_half(R, R.u0 + w0 - 1, t_, first);
+  if (zero2) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) second[q] = v4f{0.f, 0.f, 0.f, 0.f};
+  } else {
+    coarse_issue_half(R, R.u0 + w0, t_, second);
+  }
   __syncthreads();
   for (int w = w0; w < w1; w++) {
     // the thread index is made opaque per window: otherwise every loop-invariant address of the unrolled body (LDS slots,
@@ -132,8 +132,10 @@ __global__ __launch_bounds__(256, 2) void coarse_fwd_kernel(const CoarseXRow* __
     f2 own[16];
     // ---- transform a ----
 #pragma unroll
-    for (int m = 0; m < 16; m++) own[m] = f2{pre[m].x * scale, pre[m].y * scale};
-    if (!(exp & 8)) coarse_issue_points(R, u, 1, t, zero2, pre);       // transform b's points: in flight behind transform a
+    for (int m = 0; m < 8; m++) {
+      own[m] = f2{first[m].x * scale, first[m].y * scale};
+      own[8 + m] = f2{second[m].x * scale, second[m].y * scale};
+    }
     if (!(exp & 4)) fft16_own<CM>(own, buf, tw2, tw3, t);
     f2 za[8], pa[8];
     const f2 za8 = own[8];   // Z_a[2048] (thread 0)
@@ -152,8 +154,21 @@ __global__ __launch_bounds__(256, 2) void coarse_fwd_kernel(const CoarseXRow* __
     __syncthreads();          // mirrors fetched before transform b writes the buffer
     // ---- transform b ----
 #pragma unroll
-    for (int m = 0; m < 16; m++) own[m] = f2{pre[m].x * scale, pre[m].y * scale};
-    if (more && !(exp & 8)) coarse_issue_points(R, u + 1, 0, t, zero2, pre);   // the next window's transform a
+    for (int m = 0; m < 8; m++) {
+      own[m] = f2{first[m].z * scale, first[m].w * scale};
+      own[8 + m] = f2{second[m].z * scale, second[m].w * scale};
+    }
+    // the window moves on: `second` becomes the first half, the half after it is requested now and arrives behind
+    // transform b and the combine pass
+    if (more) {
+      if (zero2) {
+        if (!(exp & 8)) coarse_issue_half(R, u, t, first);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; q++) first[q] = second[q];
+        if (!(exp & 8)) coarse_issue_half(R, u + 1, t, second);
+      }
+    }
     if (!(exp & 4)) fft16_own<CM>(own, buf, tw2, tw3, t);
     f2 pb[8];
     const f2 zb8 = own[8];
