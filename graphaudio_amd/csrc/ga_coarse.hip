@@ -543,8 +543,23 @@ void launch_coarse_inv(hipStream_t s, const CoarseOut* outs_dev, int nouts, int 
 // =====================================================================================================================
 __global__ __launch_bounds__(256) void coarse_hist_kernel(const CoarseHistJob* __restrict jobs) {
   const CoarseHistJob J = jobs[blockIdx.y];
+  // hist_len and n are multiples of 4 (whole coarse blocks / whole 128-frame blocks): 16-byte words never straddle the seam
+  const bool wide = (((uintptr_t)J.old_hist | (uintptr_t)J.in | (uintptr_t)J.new_hist) & 15) == 0;
+  if (wide) {
+    for (int64_t i = 4 * ((int64_t)blockIdx.x * blockDim.x + threadIdx.x); i < J.hist_len; i += 4 * (int64_t)gridDim.x * blockDim.x) {
+      const int64_t sidx = i + J.n;   // position in the concatenation [old (hist_len) | in (n)]
+      v4f v = v4f{0.f, 0.f, 0.f, 0.f};
+      if (sidx < J.hist_len) {
+        if (J.old_hist) v = ldg4(J.old_hist + sidx);
+      } else if (J.in) {
+        v = ldg4(J.in + (sidx - J.hist_len));
+      }
+      stg4(J.new_hist + i, v);
+    }
+    return;
+  }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < J.hist_len; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t sidx = i + J.n;   // position in the concatenation [old (hist_len) | in (n)]
+    const int64_t sidx = i + J.n;
     float v = 0.f;
     if (sidx < J.hist_len) v = J.old_hist ? ldg1(J.old_hist + sidx) : 0.f;
     else if (J.in) v = ldg1(J.in + (sidx - J.hist_len));
@@ -553,7 +568,7 @@ __global__ __launch_bounds__(256) void coarse_hist_kernel(const CoarseHistJob* _
 }
 void launch_coarse_hist(hipStream_t s, const CoarseHistJob* jobs_dev, int njobs, int64_t max_len) {
   if (njobs <= 0 || max_len <= 0) return;
-  const int gx = (int)std::min<int64_t>((max_len + 255) / 256, 256);
+  const int gx = (int)std::min<int64_t>((max_len / 4 + 255) / 256, 64);
   for (int j0 = 0; j0 < njobs; j0 += 32768)
     hipLaunchKernelGGL(coarse_hist_kernel, dim3(gx, std::min(32768, njobs - j0)), dim3(256), 0, s, jobs_dev + j0);
 }

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void rfft_fwd_kernel(const ConvRowIO* __restri
       s0r[u] = 0.0;
       s0i[u] = 0.0;
       if (in) {
-        const float* p = in + (int64_t)t * kBlock + 2 * lane;
+        const GA_GLOBAL float* p = gptr(in) + (int64_t)t * kBlock + 2 * lane;
         s0r[u] = (double)p[0];     // float -> double, PartitionedConvolver.cs:106
         s0i[u] = (double)p[1];
       }
@@ -311,8 +311,7 @@ __global__ __launch_bounds__(256) void irfft_ola_kernel(const ConvRowIO* __restr
             float o0 = (float)h0 + tail[rl][2 * lane];        // (float)y[i] + overlap[i]  (:148)
             float o1 = (float)h1 + tail[rl][2 * lane + 1];
             if (out) {
-              float2* op = reinterpret_cast<float2*>(out + (int64_t)t * kBlock + 2 * lane);
-              *op = make_float2(o0, o1);
+              *reinterpret_cast<GA_GLOBAL v2f*>(gptr(out) + (int64_t)t * kBlock + 2 * lane) = v2f{o0, o1};
             }
           }
           tail[rl][2 * lane] = (float)g0;                      // overlap[i] = (float)y[i + 128]  (:149)
@@ -560,7 +559,7 @@ __global__ __launch_bounds__(256) void rfft_fwd_b_kernel(const ConvRowIO* __rest
   const int src0 = rev6((64 - m) & 63), src1 = 63 - lane;
   const T wk0x = (T)tw.w256[k0].x, wk0y = (T)tw.w256[k0].y;
   const T wk1x = (T)tw.w256[k1].x, wk1y = (T)tw.w256[k1].y;
-  const float* in = xrows[xrow].in;
+  const GA_GLOBAL float* in = gptr(xrows[xrow].in);
   GA_TL(0);
 
   // all eight input blocks of this wave are requested up front: their HBM latency overlaps the first batch of transforms
@@ -571,7 +570,7 @@ __global__ __launch_bounds__(256) void rfft_fwd_b_kernel(const ConvRowIO* __rest
     inr[q] = 0.f;
     ini[q] = 0.f;
     if (in && t < nblocks) {
-      const float* p = in + (int64_t)t * kBlock + 2 * lane;
+      const GA_GLOBAL float* p = in + (int64_t)t * kBlock + 2 * lane;
       inr[q] = p[0];
       ini[q] = p[1];
     }
@@ -909,20 +908,20 @@ __global__ __launch_bounds__(256) void irfft_ola_b_kernel(const ConvRowIO* __res
       }
     }
   }
-  if (ta == 0 && tid < kBlock) tail[tid] = overlap_in[row][tid];   // incoming overlap of the chunk's first block
+  if (ta == 0 && tid < kBlock) tail[tid] = ldg1(overlap_in[row] + tid);   // incoming overlap of the chunk's first block
   __syncthreads();
   GA_TL(5);
   float* out = yrows[row].out;
   if (out) {
-    float4* o4 = reinterpret_cast<float4*>(out + (int64_t)ta * kBlock);
+    float* o4 = out + (int64_t)ta * kBlock;
     for (int idx = tid; idx < nrun * (kBlock / 4); idx += 256) {
       const int c = idx / (kBlock / 4) + 1, s4 = (idx % (kBlock / 4)) * 4;
       const float4 h = *reinterpret_cast<const float4*>(&head[c * kBlock + s4]);
       const float4 t = *reinterpret_cast<const float4*>(&tail[(c - 1) * kBlock + s4]);
-      o4[idx] = make_float4(h.x + t.x, h.y + t.y, h.z + t.z, h.w + t.w);   // (float)y[i] + overlap[i]  (:148)
+      stg4(o4 + 4 * idx, v4f{h.x + t.x, h.y + t.y, h.z + t.z, h.w + t.w});   // (float)y[i] + overlap[i]  (:148)
     }
   }
-  if (tb == nblocks && tid < kBlock) overlap_out[row][tid] = tail[nrun * kBlock + tid];   // overlap[i] = (float)y[i+128]  (:149)
+  if (tb == nblocks && tid < kBlock) stg1(overlap_out[row] + tid, tail[nrun * kBlock + tid]);   // overlap[i] = (float)y[i+128]  (:149)
   GA_TL(6);
 }
 void launch_irfft_ola_b(hipStream_t s, const ConvRowIO* yrows_dev, int ny, int nblocks, ConvPlanesB pl,
@@ -940,9 +939,9 @@ __global__ __launch_bounds__(256) void hist_copy_b_kernel(const HistJobB* __rest
   const HistJobB j = jobs[blockIdx.y];
   const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (k >= kBins) return;
-  float* __restrict d = j.dst + (size_t)k * j.dst_stride;
+  GA_GLOBAL float* __restrict d = gptr(j.dst) + (size_t)k * j.dst_stride;
   if (j.src) {
-    const float* __restrict sp = j.src + (size_t)k * j.src_stride;
+    const GA_GLOBAL float* __restrict sp = gptr(j.src) + (size_t)k * j.src_stride;
     for (int i = lane; i < j.n; i += 64) d[i] = sp[i];
   } else {
     for (int i = lane; i < j.n; i += 64) d[i] = 0.f;
@@ -1339,7 +1338,7 @@ __global__ __launch_bounds__(256, 3) void tconv16_kernel(const ConvSetC* __restr
       const bool act = work && j < ncol;
       f2 y[16];
       if (act) {
-        const f2* __restrict hs = reinterpret_cast<const f2*>(S->hs[j] + (size_t)k * N2);
+        const GA_GLOBAL f2* __restrict hs = reinterpret_cast<const GA_GLOBAL f2*>(gptr(S->hs[j]) + (size_t)k * N2);
 #pragma unroll
         for (int m = 0; m < 16; m++) y[m] = cmulp_swap(xf[m], hs[ut + T * m]);   // ifft(v) = swap(fft(swap(v))) / N, 1/N inside hs
       } else {
@@ -1456,24 +1455,24 @@ __global__ __launch_bounds__(256) void mix_kernel(const MixJob* __restrict jobs,
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
       int j = 0;
       for (; j + 4 <= job.nterms; j += 4) {   // four loads in flight, adds strictly in term order
-        float4 v0 = *reinterpret_cast<const float4*>(tp[j] + f);
-        float4 v1 = *reinterpret_cast<const float4*>(tp[j + 1] + f);
-        float4 v2 = *reinterpret_cast<const float4*>(tp[j + 2] + f);
-        float4 v3 = *reinterpret_cast<const float4*>(tp[j + 3] + f);
+        v4f v0 = ldg4(tp[j] + f);
+        v4f v1 = ldg4(tp[j + 1] + f);
+        v4f v2 = ldg4(tp[j + 2] + f);
+        v4f v3 = ldg4(tp[j + 3] + f);
         acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
         acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
         acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
         acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
       }
       for (; j < job.nterms; j++) {
-        float4 v = *reinterpret_cast<const float4*>(tp[j] + f);
+        v4f v = ldg4(tp[j] + f);
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
       }
-      *reinterpret_cast<float4*>(job.out + f) = acc;
+      stg4(job.out + f, v4f{acc.x, acc.y, acc.z, acc.w});
     } else {
       float acc = 0.f;
-      for (int j = 0; j < job.nterms; j++) acc += tp[j][f];
-      job.out[f] = acc;
+      for (int j = 0; j < job.nterms; j++) acc += ldg1(tp[j] + f);
+      gptr(job.out)[f] = acc;
     }
   }
 }
@@ -1493,8 +1492,8 @@ __global__ __launch_bounds__(256) void downmix_kernel(const DownmixJob* __restri
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < job.n; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t f = job.f0 + i;
     float sum = 0.f;
-    for (int ch = 0; ch < job.nch; ch++) sum += tp[ch][f];   // AudioNodeInput.cs:221-226
-    job.out[f] = sum * job.scale;
+    for (int ch = 0; ch < job.nch; ch++) sum += ldg1(tp[ch] + f);   // AudioNodeInput.cs:221-226
+    gptr(job.out)[f] = sum * job.scale;
   }
 }
 void launch_downmix(hipStream_t s, const DownmixJob* jobs_dev, int njobs, const float* const* terms_dev, int64_t max_n) {
@@ -1508,12 +1507,12 @@ __global__ __launch_bounds__(256) void gain_kernel(const GainJob* __restrict job
   const GainJob job = jobs[blockIdx.y];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < job.n; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t f = job.f0 + i;
-    float g = job.curve ? job.curve[f] : job.gain;
+    float g = job.curve ? gptr(job.curve)[f] : job.gain;
     if (job.mod) {   // Math.Clamp(intrinsicValue + modulation, min, max), AudioParam.cs:129
-      g = g + job.mod[f];
+      g = g + gptr(job.mod)[f];
       g = g < job.vmin ? job.vmin : (g > job.vmax ? job.vmax : g);
     }
-    job.out[f] = job.in[f] * g;
+    gptr(job.out)[f] = gptr(job.in)[f] * g;
   }
 }
 void launch_gain(hipStream_t s, const GainJob* jobs_dev, int njobs, int64_t max_n) {
@@ -1561,8 +1560,8 @@ __global__ __launch_bounds__(64) void biquad_kernel(const BiquadJob* __restrict 
       const BiquadSection sc = secs[me.sec0 + q];
       b0[q] = sc.b0; b1[q] = sc.b1; b2[q] = sc.b2; a1[q] = sc.a1; a2[q] = sc.a2;
       st[q] = sc.state;
-      w1[q] = sc.state[0];
-      w2[q] = sc.state[1];
+      w1[q] = ldg1(sc.state);
+      w2[q] = ldg1(sc.state + 1);
     }
   }
   const int64_t n = have ? me.n : 0;
@@ -1580,7 +1579,7 @@ __global__ __launch_bounds__(64) void biquad_kernel(const BiquadJob* __restrict 
 #pragma unroll
       for (int u = 0; u < TM; u++) {
         int64_t fi = base + 64 * u + lane;
-        pre[r][u] = (r < jcount && fi < nr) ? p[fi] : 0.f;
+        pre[r][u] = (r < jcount && fi < nr) ? ldg1(p + fi) : 0.f;
       }
     }
   };
@@ -1700,7 +1699,7 @@ __global__ __launch_bounds__(64) void biquad_kernel(const BiquadJob* __restrict 
 #pragma unroll
         for (int u = 0; u < TM; u++) {
           int64_t fi = base + 64 * u + lane;
-          if (fi < nr) q[fi] = tile[r][64 * u + lane];
+          if (fi < nr) stg1(q + fi, tile[r][64 * u + lane]);
         }
       }
     }
@@ -1709,8 +1708,8 @@ __global__ __launch_bounds__(64) void biquad_kernel(const BiquadJob* __restrict 
   if (have) {
 #pragma unroll
     for (int q = 0; q < NSEC; q++) {
-      st[q][0] = w1[q];
-      st[q][1] = w2[q];
+      stg1(st[q], w1[q]);
+      stg1(st[q] + 1, w2[q]);
     }
   }
 }
@@ -1757,8 +1756,8 @@ __global__ __launch_bounds__(64) void biquad_pipe_kernel(const BiquadJob* __rest
     const BiquadSection sc = secs[me.sec0 + q];
     b0 = sc.b0; b1 = sc.b1; b2 = sc.b2; a1 = sc.a1; a2 = sc.a2;
     st = sc.state;
-    w1 = sc.state[0];
-    w2 = sc.state[1];
+    w1 = ldg1(sc.state);
+    w2 = ldg1(sc.state + 1);
   }
   const int64_t n = have ? me.n : 0;
   int64_t nmax = n;
@@ -1779,7 +1778,7 @@ __global__ __launch_bounds__(64) void biquad_pipe_kernel(const BiquadJob* __rest
 #pragma unroll
         for (int u = 0; u < TM; u++) {
           int64_t fi = base + 64 * u + lane;
-          if (fi < nr) pre[r][u] = p[fi];
+          if (fi < nr) pre[r][u] = ldg1(p + fi);
         }
       }
     }
@@ -1854,15 +1853,15 @@ __global__ __launch_bounds__(64) void biquad_pipe_kernel(const BiquadJob* __rest
 #pragma unroll
         for (int u = 0; u < TM; u++) {
           int64_t fi = base + 64 * u + lane;
-          if (fi < nr) o[fi] = tile[r][64 * u + lane];
+          if (fi < nr) stg1(o + fi, tile[r][64 * u + lane]);
         }
       }
     }
     __syncthreads();
   }
   if (have) {
-    st[0] = w1;
-    st[1] = w2;
+    stg1(st, w1);
+    stg1(st + 1, w2);
   }
 }
 template <int NSEC>
@@ -1953,7 +1952,7 @@ __global__ __launch_bounds__(64) void biquad_dynamic_kernel(const BiquadDynJob* 
   const int j = blockIdx.x * 64 + threadIdx.x;
   if (j >= njobs) return;
   const BiquadDynJob* __restrict job = &jobs[j];
-  BiquadDynState* st = job->state;
+  GA_GLOBAL BiquadDynState* st = gptr(job->state);
   float b0 = st->b0, b1 = st->b1, b2 = st->b2, a1 = st->a1, a2 = st->a2;
   bool dirty = st->dirty != 0;
   const int C = job->channels;
@@ -1961,17 +1960,17 @@ __global__ __launch_bounds__(64) void biquad_dynamic_kernel(const BiquadDynJob* 
   const float nyq = job->nyquist, sr = job->sample_rate;
   for (int64_t b = 0; b < job->nblocks; b++) {
     const int64_t f0 = (job->b0 + b) * kBlock;
-    const float gainDb = job->gcurve ? job->gcurve[f0] : job->gval;
+    const float gainDb = job->gcurve ? ldg1(job->gcurve + f0) : job->gval;
     float lb0 = b0, lb1 = b1, lb2 = b2, la1 = a1, la2 = a2;   // lastB0 ... (:110)
     float usedFreq = 1000.f, usedQ = 1.0f;                     // _lastFrequency / _lastQ never change (:13-14,111-112)
     for (int ch = 0; ch < C; ch++) {
-      const float* in = job->in[ch];
-      float* out = job->out[ch];
+      const GA_GLOBAL float* in = gptr(job->in[ch]);
+      GA_GLOBAL float* out = gptr(job->out[ch]);
       float w1 = st->w[2 * ch], w2 = st->w[2 * ch + 1];
       for (int i = 0; i < kBlock; i++) {
-        float f = job->fcurve ? job->fcurve[f0 + i] : job->fval;
+        float f = job->fcurve ? ldg1(job->fcurve + f0 + i) : job->fval;
         f = f < 1.f ? 1.f : (f > nyq ? nyq : f);
-        float q = job->qcurve ? job->qcurve[f0 + i] : job->qval;
+        float q = job->qcurve ? ldg1(job->qcurve + f0 + i) : job->qval;
         q = q > 0.001f ? q : 0.001f;
         if (dirty || fabsf(f - usedFreq) > 0.001f || fabsf(q - usedQ) > 0.0001f) {   // usedGain == gainDb always (:113,126)
           biquad_update_coefficients(type, f, q, gainDb, sr, b0, b1, b2, a1, a2);
@@ -2011,7 +2010,7 @@ __global__ __launch_bounds__(128) void param_curve_kernel(const ParamJob* __rest
     const int64_t blk = job.b0 + b;
     const double bt = block_times[blk];
     double st = job.arate ? bt + i * delta_time : bt;
-    job.out[blk * kBlock + i] = param_value_at(events + job.ev0, job.nev, job.value, st);
+    gptr(job.out)[blk * kBlock + i] = param_value_at(events + job.ev0, job.nev, job.value, st);
   }
 }
 void launch_param_curve(hipStream_t s, const ParamJob* jobs_dev, int njobs, const ParamEvent* events_dev,
@@ -2028,7 +2027,7 @@ __global__ __launch_bounds__(256) void loop_source_kernel(const LoopJob* __restr
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < job.n; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t u = job.pos0 + i;
     if (u >= job.loop_end) u = job.loop_start + (len > 0 ? (u - job.loop_end) % len : 0);
-    job.out[job.f0 + i] = job.buf[u];
+    gptr(job.out)[job.f0 + i] = gptr(job.buf)[u];
   }
 }
 void launch_loop_source(hipStream_t s, const LoopJob* jobs_dev, int njobs, int64_t max_n) {
@@ -2053,7 +2052,7 @@ __global__ __launch_bounds__(64) void resample_kernel(const ResampleJob* __restr
   const bool have = b < job.nblocks;
   if (have) {
     const ResampleBlock rb = traj[job.traj0 + b];
-    const float* __restrict in = job.buf + job.start_pos;
+    const GA_GLOBAL float* __restrict in = gptr(job.buf) + job.start_pos;
     int64_t ip = rb.consumed;           // next input index (relative)
     double Pos = rb.pos;
     int ready = rb.ready;
@@ -2082,7 +2081,7 @@ __global__ __launch_bounds__(64) void resample_kernel(const ResampleJob* __restr
   }
   __syncthreads();
   const int nb = (int)min<int64_t>(64, job.nblocks - bl0);
-  float* __restrict out = job.out + (job.b0 + bl0) * kBlock;
+  GA_GLOBAL float* __restrict out = gptr(job.out) + (job.b0 + bl0) * kBlock;
   for (int r = 0; r < nb; r++) {
     out[(int64_t)r * kBlock + lane] = tile[r][lane];
     out[(int64_t)r * kBlock + 64 + lane] = tile[r][64 + lane];
@@ -2108,8 +2107,8 @@ __global__ __launch_bounds__(64) void gsr_kernel(const GsrJob* __restrict jobs, 
   if (bl0 >= job.nblocks) return;
   const int64_t b = bl0 + lane;
   if (b < job.nblocks) {
-    const GsrBlock d = ((const GsrBlock*)(base + job.desc_off))[b];
-    const float* __restrict in = job.buf;
+    const GsrBlock d = ((const GsrBlock*)(base + job.desc_off))[b];   // (`base` is a kernel argument: global)
+    const GA_GLOBAL float* __restrict in = gptr(job.buf);
     int64_t ip = d.next;
     auto feed = [&]() {
       float v = in[ip++];
@@ -2143,7 +2142,7 @@ __global__ __launch_bounds__(64) void gsr_kernel(const GsrJob* __restrict jobs, 
   }
   __syncthreads();
   const int nb = (int)min<int64_t>(64, job.nblocks - bl0);
-  float* __restrict out = job.out + (job.b0 + bl0) * kBlock;
+  GA_GLOBAL float* __restrict out = gptr(job.out) + (job.b0 + bl0) * kBlock;
   for (int r = 0; r < nb; r++) {
     out[(int64_t)r * kBlock + lane] = tile[r][lane];
     out[(int64_t)r * kBlock + 64 + lane] = tile[r][64 + lane];
@@ -2164,8 +2163,8 @@ __global__ __launch_bounds__(256) void const_source_kernel(const ConstJob* __res
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < job.n; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t f = job.f0 + i;
     float v = 0.f;
-    if (f >= job.lo && f < job.hi) v = job.curve ? job.curve[f] : job.value;
-    job.out[f] = v;
+    if (f >= job.lo && f < job.hi) v = job.curve ? gptr(job.curve)[f] : job.value;
+    gptr(job.out)[f] = v;
   }
 }
 void launch_const_source(hipStream_t s, const ConstJob* jobs_dev, int njobs, int64_t max_n) {
@@ -2199,7 +2198,7 @@ __global__ __launch_bounds__(64) void oscillator_kernel(const OscJob* __restrict
   const double sr = (double)job.sample_rate;
   const bool curve = job.curve != nullptr;
   const double inc_const = (PI2 * (double)job.value) / sr;   // `(2.0 * Math.PI * freqValues[i]) / Context.SampleRate` (:140)
-  double ph = *job.phase;
+  double ph = *gptr(job.phase);
   const int64_t nblk = job.n / kBlock;
   for (int64_t g0 = 0; g0 < nblk; g0 += 64) {
     const int nb = (int)min<int64_t>(64, nblk - g0);
@@ -2207,8 +2206,8 @@ __global__ __launch_bounds__(64) void oscillator_kernel(const OscJob* __restrict
     if (curve) {   // the increments of the whole group, computed 64-wide (the division stays out of the serial chain)
       for (int r = 0; r < nb; r++) {
         const int64_t f = fg + (int64_t)r * kBlock;
-        incs[r * kBlock + lane] = (PI2 * (double)job.curve[f + lane]) / sr;
-        incs[r * kBlock + 64 + lane] = (PI2 * (double)job.curve[f + 64 + lane]) / sr;
+        incs[r * kBlock + lane] = (PI2 * (double)gptr(job.curve)[f + lane]) / sr;
+        incs[r * kBlock + 64 + lane] = (PI2 * (double)gptr(job.curve)[f + 64 + lane]) / sr;
       }
       __syncthreads();
     }
@@ -2247,14 +2246,14 @@ __global__ __launch_bounds__(64) void oscillator_kernel(const OscJob* __restrict
     }
     __syncthreads();
     for (int r = 0; r < nb; r++) {
-      float* o = job.out + fg + (int64_t)r * kBlock;
+      GA_GLOBAL float* o = gptr(job.out) + fg + (int64_t)r * kBlock;
       o[lane] = tile[r][lane];
       o[64 + lane] = tile[r][64 + lane];
     }
     __syncthreads();
     ph = __shfl(ph, 0);   // every lane carries the running phase (only lane 0 advanced it)
   }
-  if (lane == 0) *job.phase = ph;
+  if (lane == 0) *gptr(job.phase) = ph;
 }
 void launch_oscillator(hipStream_t s, const OscJob* jobs_dev, int njobs, bool any_curve) {
   if (njobs <= 0) return;
@@ -2269,17 +2268,17 @@ __global__ __launch_bounds__(256) void stereo_panner_kernel(const PanJob* __rest
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < job.n; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t f = job.f0 + i;
     if (!job.stereo) {   // ProcessMono, :103-105
-      const float x = job.in_l[f];
-      job.out_l[f] = x * job.gain_l;
-      job.out_r[f] = x * job.gain_r;
+      const float x = gptr(job.in_l)[f];
+      gptr(job.out_l)[f] = x * job.gain_l;
+      gptr(job.out_r)[f] = x * job.gain_r;
     } else {             // ProcessStereo, :135-145
-      const float inl = job.in_l[f], inr = job.in_r[f];
+      const float inl = gptr(job.in_l)[f], inr = gptr(job.in_r)[f];
       if (job.pan <= 0.0f) {
-        job.out_l[f] = inl + inr * job.gain_l;
-        job.out_r[f] = inr * job.gain_r;
+        gptr(job.out_l)[f] = inl + inr * job.gain_l;
+        gptr(job.out_r)[f] = inr * job.gain_r;
       } else {
-        job.out_l[f] = inl * job.gain_l;
-        job.out_r[f] = inr + inl * job.gain_r;
+        gptr(job.out_l)[f] = inl * job.gain_l;
+        gptr(job.out_r)[f] = inr + inl * job.gain_r;
       }
     }
   }
@@ -2295,10 +2294,10 @@ __global__ __launch_bounds__(256) void delay_kernel(const DelayJob* __restrict j
   const DelayJob job = jobs[blockIdx.y];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < job.n; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t f = job.f0 + i;
-    const float dt = job.curve ? job.curve[f] : job.value;
+    const float dt = job.curve ? gptr(job.curve)[f] : job.value;
     int d = (int)(dt * (float)job.sample_rate);   // float * int -> float, truncated (:68, :88)
     d = min(max(d, 0), job.max_delay);
-    job.out[f] = d > 0 ? job.line[f - d] : 0.f;
+    gptr(job.out)[f] = d > 0 ? gptr(job.line)[f - d] : 0.f;
   }
 }
 void launch_delay(hipStream_t s, const DelayJob* jobs_dev, int njobs, int64_t max_n) {
@@ -2320,9 +2319,10 @@ __global__ __launch_bounds__(64) void stereo_panner_dynamic_kernel(const PanDynJ
   __shared__ PanState carry[65];
   const PanDynJob job = jobs[blockIdx.x];
   const int lane = threadIdx.x;
-  PanState st = job.init ? job.init_state : *job.state;
+  const GA_GLOBAL float* psrc = (const GA_GLOBAL float*)job.state;   // {last_pan, gain_l, gain_r, pad}
+  PanState st = job.init ? job.init_state : PanState{psrc[0], psrc[1], psrc[2], psrc[3]};
   const int64_t nblk = job.n / kBlock;
-  auto panAt = [&](int64_t f) { return fminf(fmaxf(job.curve[f], -1.0f), 1.0f); };   // Math.Clamp(panValues[i], -1, 1)
+  auto panAt = [&](int64_t f) { return fminf(fmaxf(gptr(job.curve)[f], -1.0f), 1.0f); };   // Math.Clamp(panValues[i], -1, 1)
   for (int64_t g0 = 0; g0 < nblk; g0 += 64) {
     const int nb = (int)min<int64_t>(64, nblk - g0);
     const int64_t fb = job.f0 + (g0 + lane) * kBlock;
@@ -2364,17 +2364,17 @@ __global__ __launch_bounds__(64) void stereo_panner_dynamic_kernel(const PanDynJ
           lp = pan;
         }
         if (!job.stereo) {
-          const float x = job.in_l[f];
-          job.out_l[f] = x * gl;
-          job.out_r[f] = x * gr;
+          const float x = gptr(job.in_l)[f];
+          gptr(job.out_l)[f] = x * gl;
+          gptr(job.out_r)[f] = x * gr;
         } else {
-          const float inl = job.in_l[f], inr = job.in_r[f];
+          const float inl = gptr(job.in_l)[f], inr = gptr(job.in_r)[f];
           if (pan <= 0.0f) {
-            job.out_l[f] = inl + inr * gl;
-            job.out_r[f] = inr * gr;
+            gptr(job.out_l)[f] = inl + inr * gl;
+            gptr(job.out_r)[f] = inr * gr;
           } else {
-            job.out_l[f] = inl * gl;
-            job.out_r[f] = inr + inl * gr;
+            gptr(job.out_l)[f] = inl * gl;
+            gptr(job.out_r)[f] = inr + inl * gr;
           }
         }
       }
@@ -2383,7 +2383,10 @@ __global__ __launch_bounds__(64) void stereo_panner_dynamic_kernel(const PanDynJ
     st = carry[nb];
     __syncthreads();
   }
-  if (lane == 0) *job.state = st;
+  if (lane == 0) {
+    GA_GLOBAL float* pdst = (GA_GLOBAL float*)job.state;
+    pdst[0] = st.last_pan; pdst[1] = st.gain_l; pdst[2] = st.gain_r; pdst[3] = st.pad_;
+  }
 }
 void launch_stereo_panner_dynamic(hipStream_t s, const PanDynJob* jobs_dev, int njobs) {
   if (njobs <= 0) return;
@@ -2413,8 +2416,8 @@ __global__ __launch_bounds__(256) void param_mod_kernel(const ParamModJob* __res
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < job.n; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t f = job.f0 + i;
     const int64_t fs = job.krate ? f - (f % kBlock) : f;   // k-rate: `_input.Buffer.GetChannelSpan(0)[0]` and the block-start value
-    const float intr = job.intrinsic ? job.intrinsic[fs] : job.value;
-    job.out[f] = fminf(fmaxf(intr + job.mod[fs], job.vmin), job.vmax);   // Math.Clamp(intrinsicValue + modulation, min, max)
+    const float intr = job.intrinsic ? gptr(job.intrinsic)[fs] : job.value;
+    gptr(job.out)[f] = fminf(fmaxf(intr + gptr(job.mod)[fs], job.vmin), job.vmax);   // Math.Clamp(intrinsicValue + modulation, min, max)
   }
 }
 void launch_param_mod(hipStream_t s, const ParamModJob* jobs_dev, int njobs, int64_t max_n) {
