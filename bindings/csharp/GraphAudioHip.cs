@@ -127,6 +127,20 @@ internal static unsafe partial class GraphAudioHip
     [LibraryImport(Lib, EntryPoint = "ga_synchronize")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]
     public static partial int ga_synchronize(IntPtr ctx);   // with option "async": waits for the enqueued renders
 
+    // ---- sharded render: one context per GPU (threads of this process or one process per GPU), voices split with
+    //      ga_shard_range, ONE RCCL sum of the destination bus per Render inside the library (include/graphaudio_hip.h) ----
+    public const int GA_COMM_ID_BYTES = 128;
+    [LibraryImport(Lib, EntryPoint = "ga_comm_unique_id")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]
+    public static partial int ga_comm_unique_id(byte* idOut);                 // rank 0; hand the 128 bytes to every rank
+    [LibraryImport(Lib, EntryPoint = "ga_comm_init")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]
+    public static partial int ga_comm_init(IntPtr ctx, byte* id, int nRanks, int rank);   // collective
+    [LibraryImport(Lib, EntryPoint = "ga_comm_destroy")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]
+    public static partial int ga_comm_destroy(IntPtr ctx);
+    [LibraryImport(Lib, EntryPoint = "ga_shard_range")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]
+    public static partial int ga_shard_range(long nVoices, int nRanks, int rank, out long first, out long count);
+    [LibraryImport(Lib, EntryPoint = "ga_render_reduce")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]
+    public static partial int ga_render_reduce(IntPtr ctx, float** outPlanar, int outChannels, long frameCount, long startIndex, int root);
+
     /// <summary>Maps a negative result code to the exception the stock CPU context throws in the same situation.</summary>
     public static void Check(IntPtr ctx, int code)
     {

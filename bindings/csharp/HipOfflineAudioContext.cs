@@ -36,8 +36,17 @@ public sealed unsafe class HipOfflineAudioContext : AudioContextBase
         _nodeIds[Destination] = 0;
     }
 
+    /// <summary>The native context handle (ga_comm_init and other calls that have no managed wrapper).</summary>
+    public IntPtr Handle => _native;
+
+    /// <summary>Render of a voice-sharded graph (INTEGRATION.md section 4): this rank renders its share, the library sums the
+    /// destination buses of all ranks with one RCCL reduce; <paramref name="output"/> is written on <paramref name="root"/> only.</summary>
+    public void RenderReduce(float[][] output, int frameCount, int startIndex = 0, int root = 0) => RenderCore(output, frameCount, startIndex, root);
+
     /// <summary>Same contract as OfflineAudioContext.Render (OfflineAudioContext.cs:30-102).</summary>
-    public void Render(float[][] output, int frameCount, int startIndex = 0)
+    public void Render(float[][] output, int frameCount, int startIndex = 0) => RenderCore(output, frameCount, startIndex, -1);
+
+    private void RenderCore(float[][] output, int frameCount, int startIndex, int reduceRoot)
     {
         if (output.Length == 0) throw new ArgumentException("Output buffer must have at least one channel.", nameof(output));
         if (frameCount <= 0) throw new ArgumentOutOfRangeException(nameof(frameCount), "Frame count must be positive.");
@@ -58,7 +67,9 @@ public sealed unsafe class HipOfflineAudioContext : AudioContextBase
                 handles[ch] = System.Runtime.InteropServices.GCHandle.Alloc(output[ch], System.Runtime.InteropServices.GCHandleType.Pinned);
                 ptrs[ch] = (float*)handles[ch].AddrOfPinnedObject();
             }
-            GraphAudioHip.Check(_native, GraphAudioHip.ga_render(_native, ptrs, output.Length, frameCount, startIndex));
+            GraphAudioHip.Check(_native, reduceRoot < 0
+                ? GraphAudioHip.ga_render(_native, ptrs, output.Length, frameCount, startIndex)
+                : GraphAudioHip.ga_render_reduce(_native, ptrs, output.Length, frameCount, startIndex, reduceRoot));
         }
         finally
         {
