@@ -44,7 +44,7 @@ sys.path.insert(0, ROOT)
 SR = 48000
 PEAK_F32_TFLOPS = 157.3        # MI355X_MICROARCH.md: peak FP32 (vector = matrix)
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak (spec); ~6.3 TB/s is what a streaming copy reaches
-STAGES = ("other", "mix", "rfft_fwd", "mac", "rfft_inv", "coarse_fwd", "coarse_mac", "coarse_inv", "coarse_hist")
+STAGES = ("other", "mix", "rfft_fwd", "mac", "rfft_inv", "coarse_fwd", "coarse_mac", "coarse_inv", "coarse_hist", "coarse_section")
 STAGE_KERNELS = {
     "mix": "mix_kernel (AudioNodeInput.MixBuffer)",
     "rfft_fwd": "hist_copy_b_kernel + rfft_fwd_b_kernel (256-point forward transforms)",
@@ -188,6 +188,7 @@ def main():
     ap.add_argument("--baseline-cores", type=int, default=0)
     ap.add_argument("--direct", action="store_true", help="direct (matrix-core) partition sum, formulation A")
     ap.add_argument("--no-coarse", action="store_true", help="formulation C (block-axis FFT) instead of D (coarse partitions)")
+    ap.add_argument("--overlap", action="store_true", help="formulation D: forward and multiply-accumulate stages concurrently on two streams (measured slower)")
     ap.add_argument("--sync-steps", action="store_true", help="one blocking render per step (no host/device pipelining)")
     ap.add_argument("--force-dist", action="store_true", help="exercise the sharded-render path (ga_render_reduce) even with one rank")
     args = ap.parse_args()
@@ -228,6 +229,8 @@ def main():
         ctx.SetOption("time_fft", 0)
     if args.no_coarse:
         ctx.SetOption("coarse", 0)
+    if args.overlap:
+        ctx.SetOption("coarse_overlap", 1)
     build_graph(ctx, v1 - v0, v0, args.taps, frames, G)
     if use_reduce:
         init_sharded(ctx, rank, world)

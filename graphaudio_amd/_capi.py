@@ -79,7 +79,7 @@ class Stats(C.Structure):
         ("stage_launches", C.c_int64 * 16),
         ("stage_bytes", C.c_double * 16),
     ]
-    STAGES = ("other", "mix", "rfft_fwd", "mac", "rfft_inv", "coarse_fwd", "coarse_mac", "coarse_inv", "coarse_hist")
+    STAGES = ("other", "mix", "rfft_fwd", "mac", "rfft_inv", "coarse_fwd", "coarse_mac", "coarse_inv", "coarse_hist", "coarse_section")
 
     def as_dict(self):
         d = {}

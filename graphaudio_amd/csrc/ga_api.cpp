@@ -306,6 +306,7 @@ int ga_set_option(ga_context* ctx, const char* key, double value) {
       c.asyncMode = value != 0;
     }
     else if (k == "coarse") c.useCoarse = value != 0;
+    else if (k == "coarse_overlap") c.coarseOverlap = value != 0;
     else if (k == "coarse_min_blocks") c.coarseMinBlocks = std::max<int64_t>(1, (int64_t)value);
     else if (k == "debug_tconv_n2") c.debugTconvN2 = (int)value;   // tests only: plan the block-axis FFT with this (possibly unsupported) length
     else if (k == "mem_budget_fraction") c.memBudgetFraction = std::min(0.95, std::max(0.05, value));

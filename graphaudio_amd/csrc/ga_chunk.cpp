@@ -1244,7 +1244,7 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
   std::vector<CoarseXRow> xrows;
   std::vector<CoarseHistJob> hjobs;
   struct Piece {   // <= 4 columns of one signal: (impulse-response channel, output channel of the group)
-    int frame0, P;
+    int frame0, P, xrow;
     IrSpectra* ir;
     int leader;
     int ncol;
@@ -1253,7 +1253,7 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
   std::vector<Piece> pieces;
   int frameNext = 0;
   int64_t maxHist = 0;
-  double fwdBytes = 0, histBytes = 0;
+  double histBytes = 0;
   std::vector<const float*> chIn;
   for (int id : dNodes) {
     NodeS& nd = *c.nodes[id];
@@ -1274,7 +1274,7 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
       nd.bShared = false;
     }
     const int nxr = nd.bShared ? 1 : nd.bInCh;
-    int xFrame[32];
+    int xFrame[32], xIndex[32];
     for (int ch = 0; ch < nxr; ch++) {
       CoarseXRow r;
       r.hist = nd.dHistZero ? nullptr : nd.dHist[nd.dHistCur] + (size_t)ch * hl;
@@ -1287,11 +1287,11 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
       r.flags = 0;
       r.scale = 1.0f;
       xFrame[ch] = frameNext;
+      xIndex[ch] = (int)xrows.size();
       frameNext += r.n_frames;
       xrows.push_back(r);
       hjobs.push_back(CoarseHistJob{r.hist, r.in, nd.dHist[nd.dHistCur ^ 1] + (size_t)ch * hl, hl, frames});
       maxHist = std::max(maxHist, hl);
-      fwdBytes += (double)(r.n_frames + 1) * kCoarseBlock * 4.0 + (double)r.n_frames * kCoarseBins * 8.0;
       histBytes += 2.0 * (double)hl * 4.0;
     }
     nd.dHistCur ^= 1;
@@ -1313,6 +1313,7 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
         const int w = left >= 4 ? 4 : (left >= 2 ? 2 : 1);
         Piece pc{};
         pc.frame0 = xFrame[xc];
+        pc.xrow = xIndex[xc];
         pc.P = P;
         pc.ir = &ir;
         pc.leader = leader;
@@ -1343,11 +1344,19 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
     for (int j = 0; j < pc.ncol; j++) k.out[j] = pc.outCh[j];
     byKey[k].push_back(&pc);
   }
+  // groups of signals: the multiply-accumulate jobs of group g run (second stream) while group g + 1 is transformed
+  const int nxAll = (int)xrows.size();
+  const int G = !c.coarseOverlap ? 1 : (nxAll >= 256 ? 4 : (nxAll >= 64 ? 2 : 1));
+  auto groupOf = [&](int xrow) { return std::min(G - 1, (int)((int64_t)xrow * G / std::max(nxAll, 1))); };
+  int gBegin[9];
+  for (int g = 0; g <= G; g++) gBegin[g] = 0;
+  for (int x = 0; x < nxAll; x++) gBegin[groupOf(x) + 1] = x + 1;
+  for (int g = 1; g <= G; g++) gBegin[g] = std::max(gBegin[g], gBegin[g - 1]);
   std::vector<CoarseTerm> terms;
-  std::vector<CoarseJob> jobs[3];          // by column count 1, 2, 4
+  std::vector<CoarseJob> jobs[3][8];       // by column count 1, 2, 4 and by the group whose transforms complete the job's inputs
   int maxT[3] = {0, 0, 0}, maxP[3] = {0, 0, 0}, pbOf[3] = {4, 4, 4};   // pbOf: largest of 4, 2, 1 dividing every job's partition count
   bool anyPrivate[3] = {false, false, false};
-  double macBytes[3] = {0, 0, 0};
+  double macBytes[3][8] = {};
   std::map<std::pair<int, int>, std::vector<int>> outRows;   // (leader, channel) -> Y rows to sum
   int yNext = 0;
   for (auto& kv : byKey) {
@@ -1358,6 +1367,7 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
       const size_t p1 = std::min(pv.size(), p0 + kVoicesPerJob);
       const int term0 = (int)terms.size();
       bool shared = true;
+      int lastX = 0;
       for (size_t i = p0; i < p1; i++) {
         const Piece& pc = *pv[i];
         CoarseTerm t{};
@@ -1367,7 +1377,9 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
         if (i > p0)
           for (int j = 0; j < cw; j++) shared = shared && (t.h[j] == terms[term0].h[j]);
         terms.push_back(t);
+        lastX = std::max(lastX, pc.xrow);
       }
+      const int grp = groupOf(lastX);
       const int yrow0 = yNext;
       yNext += cw;
       for (int j = 0; j < cw; j++) outRows[{k.leader, k.out[j]}].push_back(yrow0 + j);
@@ -1381,13 +1393,13 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
         jb_.n_t = std::min(jb, nT - t0);
         jb_.yrow0 = yrow0;
         jb_.shared_h = shared ? 1 : 0;
-        jobs[ci].push_back(jb_);
+        jobs[ci][grp].push_back(jb_);
         maxT[ci] = std::max(maxT[ci], jb_.n_t);
         maxP[ci] = std::max(maxP[ci], k.P);
         while (k.P % pbOf[ci]) pbOf[ci] >>= 1;
         anyPrivate[ci] = anyPrivate[ci] || !shared;
-        macBytes[ci] += (double)jb_.n_terms * (jb_.n_t + k.P - 1) * kCoarseBins * 8.0 +
-                        (double)(shared ? 1 : jb_.n_terms) * k.P * cw * kCoarseBins * 8.0 + (double)cw * jb_.n_t * kCoarseBins * 8.0;
+        macBytes[ci][grp] += (double)jb_.n_terms * (jb_.n_t + k.P - 1) * kCoarseBins * 8.0 +
+                             (double)(shared ? 1 : jb_.n_terms) * k.P * cw * kCoarseBins * 8.0 + (double)cw * jb_.n_t * kCoarseBins * 8.0;
       }
     }
   }
@@ -1408,32 +1420,74 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
     fail(GA_ERR_INVALID_OPERATION, "internal: coarse spectra arenas are too small for the plan");
 
   const size_t xo = ex.plan.putv(xrows), ho = ex.plan.putv(hjobs), to = ex.plan.putv(terms), oo = ex.plan.putv(outs), yo = ex.plan.putv(ylist);
-  size_t jo[3];
-  for (int i = 0; i < 3; i++) jo[i] = ex.plan.putv(jobs[i]);
+  struct MacLaunch { size_t off; int nj, cw, mt, mp, pb, grp; bool ap; double bytes; };
+  std::vector<MacLaunch> macs;
+  for (int g = 0; g < G; g++)
+    for (int i = 0; i < 3; i++) {
+      if (jobs[i][g].empty()) continue;
+      macs.push_back(MacLaunch{ex.plan.putv(jobs[i][g]), (int)jobs[i][g].size(), i == 0 ? 1 : (i == 1 ? 2 : 4), maxT[i], maxP[i], pbOf[i], g,
+                               anyPrivate[i], macBytes[i][g]});
+      c.stats.mac_launches += 1;
+    }
   hipStream_t st = c.stream;
   float2* X = (float2*)c.coarseX.p;
   float2* Y = (float2*)c.coarseY.p;
   const float2* tw16 = c.twiddles16(4096);
   const float2* twab = c.coarseTwab();
-  const int nx = (int)xrows.size(), nh = (int)hjobs.size(), no = (int)outs.size();
-  int maxFrames = 0;
-  for (auto& r : xrows) maxFrames = std::max(maxFrames, r.n_frames);
-  // windows per workgroup: long runs fetch every input sample once; keep >= ~4 workgroups per CU's worth of parallelism
-  int run = 1;
-  while (run < 16 && (int64_t)nx * ((maxFrames + 2 * run - 1) / (2 * run)) >= 1024) run *= 2;
-  ex.plan.add(LK_CFWD, [=](uint8_t* base) { launch_coarse_fwd(st, (const CoarseXRow*)(base + xo), nx, maxFrames, run, X, tw16, twab); },
-              fwdBytes);
-  for (int i = 0; i < 3; i++) {
-    if (jobs[i].empty()) continue;
-    const int nj = (int)jobs[i].size(), cw = i == 0 ? 1 : (i == 1 ? 2 : 4), mt = maxT[i], mp = maxP[i];
-    const bool ap = anyPrivate[i];
-    const size_t off = jo[i];
-    const int pb = pbOf[i];
-    ex.plan.add(LK_CMAC, [=](uint8_t* base) {
-      launch_coarse_mac(st, (const CoarseJob*)(base + off), nj, (const CoarseTerm*)(base + to), X, Y, nT, cw, mt, mp, ap, pb);
-    }, macBytes[i]);
-    c.stats.mac_launches += 1;
+  const int nh = (int)hjobs.size(), no = (int)outs.size();
+  // per group: rows, longest row, bytes, windows per workgroup (long runs fetch every input sample once; keep >= ~4
+  // workgroups per CU's worth of parallelism)
+  struct FwdLaunch { int x0, nx, maxFrames, run; double bytes; };
+  std::vector<FwdLaunch> fwds;
+  for (int g = 0; g < G; g++) {
+    FwdLaunch f{gBegin[g], gBegin[g + 1] - gBegin[g], 0, 1, 0.0};
+    for (int x = f.x0; x < f.x0 + f.nx; x++) {
+      f.maxFrames = std::max(f.maxFrames, xrows[x].n_frames);
+      f.bytes += (double)(xrows[x].n_frames + 1) * kCoarseBlock * 4.0 + (double)xrows[x].n_frames * kCoarseBins * 8.0;
+    }
+    while (f.run < 16 && (int64_t)nxAll * ((f.maxFrames + 2 * f.run - 1) / (2 * f.run)) >= 1024) f.run *= 2;
+    fwds.push_back(f);
   }
+  if (G > 1) c.ensureOverlapStream();
+  Context* cp = &c;
+  ex.plan.add(GA_STAGE_COARSE_SECTION, [=](uint8_t* base) {
+    // one piece of the section: a launch with its own profile events (the two stages overlap on two streams)
+    auto timed = [&](hipStream_t sx, int kind, double bytes, const std::function<void()>& launch) {
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (cp->profile) {
+        GA_HIP(hipEventCreate(&e0));
+        GA_HIP(hipEventCreate(&e1));
+        GA_HIP(hipEventRecord(e0, sx));
+      }
+      launch();
+      if (cp->profile) {
+        GA_HIP(hipEventRecord(e1, sx));
+        cp->extraProf.push_back(Context::ExtraProf{e0, e1, kind, bytes});
+      }
+      cp->stats.kernel_launches++;
+      cp->stats.stage_launches[kind]++;
+      cp->stats.stage_bytes[kind] += bytes;
+    };
+    hipStream_t s2 = G > 1 ? cp->stream2 : st;
+    for (int g = 0; g < G; g++) {
+      const FwdLaunch& f = fwds[g];
+      if (f.nx > 0)
+        timed(st, LK_CFWD, f.bytes, [&] { launch_coarse_fwd(st, (const CoarseXRow*)(base + xo) + f.x0, f.nx, f.maxFrames, f.run, X, tw16, twab); });
+      if (G > 1) {
+        GA_HIP(hipEventRecord(cp->dGroupEv[g], st));
+        GA_HIP(hipStreamWaitEvent(s2, cp->dGroupEv[g], 0));
+      }
+      for (const MacLaunch& m : macs)
+        if (m.grp == g)
+          timed(s2, LK_CMAC, m.bytes, [&] {
+            launch_coarse_mac(s2, (const CoarseJob*)(base + m.off), m.nj, (const CoarseTerm*)(base + to), X, Y, nT, m.cw, m.mt, m.mp, m.ap, m.pb);
+          });
+    }
+    if (G > 1) {   // join: the inverse transforms (and the next chunk's forward transforms, which reuse X) wait for every job
+      GA_HIP(hipEventRecord(cp->dJoinEv, s2));
+      GA_HIP(hipStreamWaitEvent(st, cp->dJoinEv, 0));
+    }
+  });
   ex.plan.add(LK_CINV, [=](uint8_t* base) {
     launch_coarse_inv(st, (const CoarseOut*)(base + oo), no, nT, (const int*)(base + yo), Y, nT, tw16, twab);
   }, invBytes);
@@ -2696,12 +2750,19 @@ void Context::runChunkImpl(int64_t n, float* const* /*unused*/) {
       evKind.push_back(l.kind);
       evBytes.push_back(l.bytes);
     }
+    if (l.kind == GA_STAGE_COARSE_SECTION) continue;   // (a section counts its own launches, per kernel)
     stats.kernel_launches++;
     if (l.kind >= 0 && l.kind < 16) {
       stats.stage_launches[l.kind]++;
       stats.stage_bytes[l.kind] += l.bytes;
     }
   }
+  for (auto& x : extraProf) {   // pieces timed inside a launch (formulation D's overlapped section)
+    evs.push_back({x.e0, x.e1});
+    evKind.push_back(x.kind);
+    evBytes.push_back(x.bytes);
+  }
+  extraProf.clear();
   if (profile) GA_HIP(hipEventRecord(evEnd, stream));
   GA_HIP(hipGetLastError());
   tmLaunch = nowMs();

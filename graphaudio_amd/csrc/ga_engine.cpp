@@ -93,6 +93,14 @@ Context::~Context() {
   }
   for (auto& kv : tw16) (void)hipFree(kv.second);
   if (coarseTw) (void)hipFree(coarseTw);
+  if (stream2) {
+    (void)hipStreamSynchronize(stream2);
+    (void)hipStreamDestroy(stream2);
+    for (auto& e : dGroupEv)
+      if (e) (void)hipEventDestroy(e);
+    if (dJoinEv) (void)hipEventDestroy(dJoinEv);
+  }
+  for (auto& x : extraProf) { (void)hipEventDestroy(x.e0); (void)hipEventDestroy(x.e1); }
   if (coarseX.p) (void)hipFree(coarseX.p);
   if (coarseY.p) (void)hipFree(coarseY.p);
   if (ilvDev) (void)hipFree(ilvDev);
@@ -214,7 +222,7 @@ void Context::harvestProfile(bool wait) {
       const int k = b.kinds[i];
       if (k == LK_MAC || k == LK_CMAC) stats.mac_ms_total += ms;
       else if (k == LK_FFT || k == LK_IFFT || k == LK_CFWD || k == LK_CINV || k == LK_CHIST) stats.fft_ms_total += ms;
-      else stats.other_ms_total += ms;
+      else if (k != GA_STAGE_COARSE_SECTION) stats.other_ms_total += ms;
       if (k >= 0 && k < 16) stats.stage_ms[k] += ms;   // (launches and bytes are counted when the launch is enqueued)
       (void)hipEventDestroy(b.evs[i].first);
       (void)hipEventDestroy(b.evs[i].second);
@@ -681,6 +689,12 @@ const float2* Context::twiddles16(int N2) {
 }
 
 // ---- formulation D (ga_coarse.hip) ----
+void Context::ensureOverlapStream() {
+  if (stream2) return;
+  GA_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+  for (auto& e : dGroupEv) GA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  GA_HIP(hipEventCreateWithFlags(&dJoinEv, hipEventDisableTiming));
+}
 const float2* Context::coarseTwab() {
   if (coarseTw) return coarseTw;
   const double pi = 3.14159265358979323846264338327950288;

@@ -416,6 +416,19 @@ struct Context {
   void releaseConvState(NodeS& n);
   void assignConvPaths(const std::vector<int>& topo, int64_t chunkBlocks);
   // formulation D
+  // Option `coarse_overlap` (default 0): run the forward transforms and the multiply-accumulate CONCURRENTLY -- the signals
+  // are cut into groups, group g's multiply-accumulate jobs run on a second stream while the main stream transforms group
+  // g + 1, joined before the inverse transforms.  Measured on config 3: 3.37 ms of device time per step against 3.18 ms one
+  // after the other (both stages slow down by ~50 % when they share the chip: they are bound by the same memory system),
+  // so it stays off; kept as a switch for other shapes.
+  hipStream_t stream2 = nullptr;
+  hipEvent_t dGroupEv[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t dJoinEv = nullptr;
+  bool coarseOverlap = false;
+  void ensureOverlapStream();
+  // event pairs recorded by launches that time their own pieces (several kernels, two streams); folded into the chunk's profile batch
+  struct ExtraProf { hipEvent_t e0, e1; int kind; double bytes; };
+  std::vector<ExtraProf> extraProf;
   DevArena coarseX, coarseY;        // spectra frames of a convolver stage (shared by the stages of a chunk, which run in order)
   float2* coarseTw = nullptr;       // combine-pass twiddles [2][2049]: W_8192^k, W_16384^k
   const float2* coarseTwab();

@@ -112,7 +112,9 @@ enum {
   GA_STAGE_COARSE_MAC = 6,   /* formulation D: partition sum + frequency-domain mix */
   GA_STAGE_COARSE_INV = 7,   /* formulation D: inverse transforms */
   GA_STAGE_COARSE_HIST = 8,  /* formulation D: input history of the next chunk */
-  GA_STAGE_COUNT = 9
+  GA_STAGE_COARSE_SECTION = 9, /* formulation D: wall time of the forward || multiply-accumulate section (the two stages overlap
+                                  on two streams, so their own times add up to more than this) */
+  GA_STAGE_COUNT = 10
 };
 
 /* ---- library ---- */
