@@ -1527,19 +1527,35 @@ void Context::runChunk(int64_t n, float* const* bus) {
     throw;
   }
 }
-void Context::runChunkImpl(int64_t n, float* const* /*unused*/) {
-  static const bool timing = getenv("GA_TIMING") != nullptr;
-  const double tm0 = nowMs();
-  double tmSim = 0, tmPlan = 0, tmLaunch = 0;
-  GA_HIP(hipSetDevice(device));
-  if (disposed) fail(GA_ERR_DISPOSED, "context disposed");
-  drain();  // AudioContextBase.cs:57
-  if (!releasedPending.empty() || ++chunksSinceGc >= 64) collectGarbage();
-  latched = true;
+// Everything the passes of one chunk share.  runChunkImpl is the sequence of these passes; every pass is a member function of
+// Context so that its body reads the graph state directly.
+struct ChunkRun {
+  int64_t n = 0;                       // blocks of the chunk (the simulation may shorten it)
+  std::vector<int> topo;               // reachable nodes in processing (post) order
+  int maxDepth = 0, maxLevel = 0;
+  std::vector<double> bt;              // accumulated block clock
+  std::vector<int> srcIds;
+  std::vector<SrcPlanOut> srcPlans;
+  std::vector<Segment> segs;
+  std::unique_ptr<Exec> ex;
+  int bHistMax = 0;
+  double tm0 = 0, tmTopo = 0, tmSrc = 0, tmSim = 0, tmRes = 0, tmPre = 0, tmPlan = 0, tmLaunch = 0;
+};
 
+// pass 1: reachability, level and convolver depth of every node; state handed back by automated runs that ended
+void Context::chunkTopology(ChunkRun& r) {
+  Context& c_ = *this; (void)c_;
+  std::vector<int>& topo = r.topo;
+  int& maxDepth = r.maxDepth; int& maxLevel = r.maxLevel; (void)maxDepth; (void)maxLevel;
+  int64_t& n = r.n; (void)n;
+  std::vector<double>& bt = r.bt; (void)bt;
+  std::vector<int>& srcIds = r.srcIds; (void)srcIds;
+  std::vector<SrcPlanOut>& srcPlans = r.srcPlans; (void)srcPlans;
+  std::vector<Segment>& segs = r.segs; (void)segs;
+  const int64_t frames = r.n * kBlock; (void)frames;
+  int& bHistMax = r.bHistMax; (void)bHistMax;
   // ---- reachability, level, convolver depth on the graph as it stands after the queued commands ----
   // (cached while no connection, disposal or impulse response changed since the last chunk)
-  std::vector<int> topo;
   if (topoVersion == graphVersion && !topoCache.empty()) {
     topo = topoCache;
   } else {
@@ -1586,7 +1602,8 @@ void Context::runChunkImpl(int64_t n, float* const* /*unused*/) {
   topoCache = topo;
   topoVersion = graphVersion;
   }
-  int maxDepth = 0, maxLevel = 0;
+  maxDepth = 0;
+  maxLevel = 0;
   for (int id : topo) {
     maxDepth = std::max(maxDepth, nodes[id]->depth);
     maxLevel = std::max(maxLevel, nodes[id]->level);
@@ -1616,16 +1633,27 @@ void Context::runChunkImpl(int64_t n, float* const* /*unused*/) {
     }
   }
 
-  const double tmTopo = nowMs();
+}
+
+// pass 2: block clock, source timelines, control-plane simulation -> segments (from here on control state moves)
+void Context::chunkSimulate(ChunkRun& r) {
+  Context& c_ = *this; (void)c_;
+  std::vector<int>& topo = r.topo;
+  int& maxDepth = r.maxDepth; int& maxLevel = r.maxLevel; (void)maxDepth; (void)maxLevel;
+  int64_t& n = r.n; (void)n;
+  std::vector<double>& bt = r.bt; (void)bt;
+  std::vector<int>& srcIds = r.srcIds; (void)srcIds;
+  std::vector<SrcPlanOut>& srcPlans = r.srcPlans; (void)srcPlans;
+  std::vector<Segment>& segs = r.segs; (void)segs;
+  int& bHistMax = r.bHistMax; (void)bHistMax;
+  r.tmTopo = nowMs();
   // ---- block clock (accumulated, AudioContextBase.cs:78-79) ----
-  std::vector<double> bt(n + 1);
+  bt.assign(n + 1, 0.0);
   bt[0] = currentTime;
   const double increment = (double)kBlock / sampleRate;
   for (int64_t i = 0; i < n; i++) bt[i + 1] = bt[i] + increment;
 
   // ---- plan sources ----
-  std::vector<int> srcIds;
-  std::vector<SrcPlanOut> srcPlans;
   std::vector<int64_t> breaks;
   for (int id : topo) {
     NodeS& nd = *nodes[id];
@@ -1646,10 +1674,9 @@ void Context::runChunkImpl(int64_t n, float* const* /*unused*/) {
   for (size_t i = 0; i < srcIds.size(); i++)
     if (srcPlans[i].gone && srcPlans[i].goneAt < n) goneAt[srcPlans[i].goneAt].push_back(srcIds[i]);
 
-  const double tmSrc = nowMs();
+  r.tmSrc = nowMs();
   chunkPhase = 1;   // from here on persistent control state moves: a failure is sticky (see runChunk)
   // ---- simulate ----
-  std::vector<Segment> segs;
   Sim sim{*this, n};
   std::vector<int64_t> extraBreaks;
   sim.extraBreaks = &extraBreaks;
@@ -1704,9 +1731,22 @@ void Context::runChunkImpl(int64_t n, float* const* /*unused*/) {
     if (n < (int64_t)bt.size() - 1) bt.resize(n + 1);
   }
   chunkMinDestCh = minDestCh;
-  const int64_t frames = n * kBlock;
-  tmSim = nowMs();
+  r.tmSim = nowMs();
 
+}
+
+// pass 3: per-chunk device resources (delay lines, slabs, zero page, bus)
+void Context::chunkResources(ChunkRun& r) {
+  Context& c_ = *this; (void)c_;
+  std::vector<int>& topo = r.topo;
+  int& maxDepth = r.maxDepth; int& maxLevel = r.maxLevel; (void)maxDepth; (void)maxLevel;
+  int64_t& n = r.n; (void)n;
+  std::vector<double>& bt = r.bt; (void)bt;
+  std::vector<int>& srcIds = r.srcIds; (void)srcIds;
+  std::vector<SrcPlanOut>& srcPlans = r.srcPlans; (void)srcPlans;
+  std::vector<Segment>& segs = r.segs; (void)segs;
+  const int64_t frames = r.n * kBlock; (void)frames;
+  int& bHistMax = r.bHistMax; (void)bHistMax;
   // ---- DelayNode state: history [rings][maxDelay] (persistent) and the chunk's line [rings][maxDelay + frames] ----
   for (int id : topo) {
     NodeS& nd = *nodes[id];
@@ -1766,11 +1806,21 @@ void Context::runChunkImpl(int64_t n, float* const* /*unused*/) {
     while ((int)busSlabs.size() < mx) busSlabs.push_back((float*)dalloc((size_t)busCapFrames * 4));
   }
 
-  const double tmRes = nowMs();
-  Exec ex(*this, n, segs);
-  ex.outViews.resize(segs.size());
-  ex.plan.host.resize(16);  // reserved header
+}
 
+// pass 4: AudioParam timelines -> device curves
+void Context::chunkParamCurves(ChunkRun& r) {
+  Context& c_ = *this; (void)c_;
+  std::vector<int>& topo = r.topo;
+  int& maxDepth = r.maxDepth; int& maxLevel = r.maxLevel; (void)maxDepth; (void)maxLevel;
+  int64_t& n = r.n; (void)n;
+  std::vector<double>& bt = r.bt; (void)bt;
+  std::vector<int>& srcIds = r.srcIds; (void)srcIds;
+  std::vector<SrcPlanOut>& srcPlans = r.srcPlans; (void)srcPlans;
+  std::vector<Segment>& segs = r.segs; (void)segs;
+  const int64_t frames = r.n * kBlock; (void)frames;
+  int& bHistMax = r.bHistMax; (void)bHistMax;
+  Exec& ex = *r.ex;
   // ---- AudioParam curves (AudioParam.cs:93-166) for automated gain params: one launch for the whole chunk ----
   {
     std::vector<ParamJob> pjobs;
@@ -1819,6 +1869,20 @@ void Context::runChunkImpl(int64_t n, float* const* /*unused*/) {
     }
   }
 
+}
+
+// pass 5: convolver formulations of new nodes, fusion groups, scratch arenas (sized before any recorded launch captures them)
+void Context::chunkConvScratch(ChunkRun& r) {
+  Context& c_ = *this; (void)c_;
+  std::vector<int>& topo = r.topo;
+  int& maxDepth = r.maxDepth; int& maxLevel = r.maxLevel; (void)maxDepth; (void)maxLevel;
+  int64_t& n = r.n; (void)n;
+  std::vector<double>& bt = r.bt; (void)bt;
+  std::vector<int>& srcIds = r.srcIds; (void)srcIds;
+  std::vector<SrcPlanOut>& srcPlans = r.srcPlans; (void)srcPlans;
+  std::vector<Segment>& segs = r.segs; (void)segs;
+  const int64_t frames = r.n * kBlock; (void)frames;
+  int& bHistMax = r.bHistMax; (void)bHistMax;
   // resampler trajectories used in this chunk go into one device table
   for (auto& kv : resamplers) kv.second->devOffset = -1;
 
@@ -1826,7 +1890,7 @@ void Context::runChunkImpl(int64_t n, float* const* /*unused*/) {
   //      launch captures their address ----
   assignConvPaths(topo, n);
   planCoarseFusion(topo, segs);
-  int bHistMax = 0;
+  bHistMax = 0;
   {
     size_t xMax = 0, yMax = 0;
     size_t bx = 0, by = 0;
@@ -1897,7 +1961,9 @@ void Context::runChunkImpl(int64_t n, float* const* /*unused*/) {
     nd.oscPhase = (double*)dalloc(64);
     GA_HIP(hipMemsetAsync(nd.oscPhase, 0, 64, stream));
   }
-  auto ensureBiquadState = [&](NodeS& bn) {
+}
+
+void Context::ensureBiquadState(NodeS& bn) {
     if (bn.bqDyn) return;
     const size_t per = (sizeof(BiquadDynState) + 31) & ~(size_t)31;
     const size_t blk = (size_t)1 << 20;
@@ -1910,10 +1976,21 @@ void Context::runChunkImpl(int64_t n, float* const* /*unused*/) {
     bn.bqDyn = (BiquadDynState*)((char*)bqBlocks.back() + bqUsed);
     bn.bqState = (float*)((char*)bn.bqDyn + 24);
     bqUsed += per;
-  };
-  const double tmPre = nowMs();
-  // ---- stages: convolver depth d ; inside a stage every segment is executed level by level ----
-  for (int d = 0; d <= maxDepth; d++) {
+  }
+
+// pass 6 (per convolver depth d): every segment, level by level -- node launches are batched per (level, type)
+void Context::chunkPlanNodes(ChunkRun& r, int d) {
+  Context& c_ = *this; (void)c_;
+  std::vector<int>& topo = r.topo;
+  int& maxDepth = r.maxDepth; int& maxLevel = r.maxLevel; (void)maxDepth; (void)maxLevel;
+  int64_t& n = r.n; (void)n;
+  std::vector<double>& bt = r.bt; (void)bt;
+  std::vector<int>& srcIds = r.srcIds; (void)srcIds;
+  std::vector<SrcPlanOut>& srcPlans = r.srcPlans; (void)srcPlans;
+  std::vector<Segment>& segs = r.segs; (void)segs;
+  const int64_t frames = r.n * kBlock; (void)frames;
+  int& bHistMax = r.bHistMax; (void)bHistMax;
+  Exec& ex = *r.ex;
     for (size_t si = 0; si < segs.size(); si++) {
       Segment& sg = segs[si];
       if (ex.outViews[si].empty()) ex.outViews[si].resize(nodes.size());
@@ -2315,7 +2392,21 @@ void Context::runChunkImpl(int64_t n, float* const* /*unused*/) {
       }
       ex.flushLevel();
     }
+}
 
+// pass 7 (per convolver depth d): the convolvers whose inputs are complete, once per chunk over all blocks
+void Context::chunkPlanConvolvers(ChunkRun& r, int d) {
+  Context& c_ = *this; (void)c_;
+  std::vector<int>& topo = r.topo;
+  int& maxDepth = r.maxDepth; int& maxLevel = r.maxLevel; (void)maxDepth; (void)maxLevel;
+  int64_t& n = r.n; (void)n;
+  std::vector<double>& bt = r.bt; (void)bt;
+  std::vector<int>& srcIds = r.srcIds; (void)srcIds;
+  std::vector<SrcPlanOut>& srcPlans = r.srcPlans; (void)srcPlans;
+  std::vector<Segment>& segs = r.segs; (void)segs;
+  const int64_t frames = r.n * kBlock; (void)frames;
+  int& bHistMax = r.bHistMax; (void)bHistMax;
+  Exec& ex = *r.ex;
     // ---- convolvers whose inputs are complete (depth d): once per chunk over all blocks ----
     // group -> (node, slot); ordered by (IR buffer, IR channel) so groups fed by the same inputs are adjacent
     struct GroupLess {
@@ -2690,8 +2781,21 @@ void Context::runChunkImpl(int64_t n, float* const* /*unused*/) {
         if (a && b2) ex.plan.add(LK_OTHER, [=](uint8_t*) { launch_pair_sum(st, out, a, b2, fr); });
       }
     }
-  }
+}
 
+// pass 8: delay-line histories of the next chunk
+void Context::chunkDelayCommit(ChunkRun& r) {
+  Context& c_ = *this; (void)c_;
+  std::vector<int>& topo = r.topo;
+  int& maxDepth = r.maxDepth; int& maxLevel = r.maxLevel; (void)maxDepth; (void)maxLevel;
+  int64_t& n = r.n; (void)n;
+  std::vector<double>& bt = r.bt; (void)bt;
+  std::vector<int>& srcIds = r.srcIds; (void)srcIds;
+  std::vector<SrcPlanOut>& srcPlans = r.srcPlans; (void)srcPlans;
+  std::vector<Segment>& segs = r.segs; (void)segs;
+  const int64_t frames = r.n * kBlock; (void)frames;
+  int& bHistMax = r.bHistMax; (void)bHistMax;
+  Exec& ex = *r.ex;
   // DelayNode: the last maxDelay samples every ring has seen become the history of the next chunk
   for (int id : topo) {
     NodeS& nd = *nodes[id];
@@ -2706,7 +2810,23 @@ void Context::runChunkImpl(int64_t n, float* const* /*unused*/) {
     }
   }
 
-  tmPlan = nowMs();
+}
+
+// pass 9: upload the job tables, enqueue every recorded launch in order, profile events
+void Context::chunkExecute(ChunkRun& r) {
+  static const bool timing = getenv("GA_TIMING") != nullptr;
+  Context& c_ = *this; (void)c_;
+  std::vector<int>& topo = r.topo;
+  int& maxDepth = r.maxDepth; int& maxLevel = r.maxLevel; (void)maxDepth; (void)maxLevel;
+  int64_t& n = r.n; (void)n;
+  std::vector<double>& bt = r.bt; (void)bt;
+  std::vector<int>& srcIds = r.srcIds; (void)srcIds;
+  std::vector<SrcPlanOut>& srcPlans = r.srcPlans; (void)srcPlans;
+  std::vector<Segment>& segs = r.segs; (void)segs;
+  const int64_t frames = r.n * kBlock; (void)frames;
+  int& bHistMax = r.bHistMax; (void)bHistMax;
+  Exec& ex = *r.ex;
+  r.tmPlan = nowMs();
   // ---- upload tables, run ----
   ex.trajOffFinal = ex.plan.putv(ex.traj);
   size_t tbytes = ex.plan.host.size();
@@ -2765,7 +2885,7 @@ void Context::runChunkImpl(int64_t n, float* const* /*unused*/) {
   extraProf.clear();
   if (profile) GA_HIP(hipEventRecord(evEnd, stream));
   GA_HIP(hipGetLastError());
-  tmLaunch = nowMs();
+  r.tmLaunch = nowMs();
   if (profile) pendingProf.push_back(ProfBatch{evBegin, evEnd, std::move(evs), std::move(evKind), std::move(evBytes)});
   if (asyncMode) {
     if (!chunkDone[slot]) GA_HIP(hipEventCreateWithFlags(&chunkDone[slot], hipEventDisableTiming));
@@ -2777,12 +2897,26 @@ void Context::runChunkImpl(int64_t n, float* const* /*unused*/) {
   }
   chunkSeq++;
   if (timing)
-    fprintf(stderr, "[ga]   host detail: topo %.2f, sources %.2f, sim %.2f | resources %.2f, params %.2f, exec %.2f ms\n", tmTopo - tm0,
-            tmSrc - tmTopo, tmSim - tmSrc, tmRes - tmSim, tmPre - tmRes, tmPlan - tmPre);
+    fprintf(stderr, "[ga]   host detail: topo %.2f, sources %.2f, sim %.2f | resources %.2f, params %.2f, exec %.2f ms\n", r.tmTopo - r.tm0,
+            r.tmSrc - r.tmTopo, r.tmSim - r.tmSrc, r.tmRes - r.tmSim, r.tmPre - r.tmRes, r.tmPlan - r.tmPre);
   if (timing)
-    fprintf(stderr, "[ga] chunk %lld blocks: sim %.2f ms, plan %.2f ms, enqueue %.2f ms, wait %.2f ms\n", (long long)n, tmSim - tm0,
-            tmPlan - tmSim, tmLaunch - tmPlan, nowMs() - tmLaunch);
+    fprintf(stderr, "[ga] chunk %lld blocks: sim %.2f ms, plan %.2f ms, enqueue %.2f ms, wait %.2f ms\n", (long long)n, r.tmSim - r.tm0,
+            r.tmPlan - r.tmSim, r.tmLaunch - r.tmPlan, nowMs() - r.tmLaunch);
 
+}
+
+// pass 10: commit the control state (source positions, Ended / Dispose bookkeeping, block clock) to the end of the chunk
+void Context::chunkCommit(ChunkRun& r) {
+  Context& c_ = *this; (void)c_;
+  std::vector<int>& topo = r.topo;
+  int& maxDepth = r.maxDepth; int& maxLevel = r.maxLevel; (void)maxDepth; (void)maxLevel;
+  int64_t& n = r.n; (void)n;
+  std::vector<double>& bt = r.bt; (void)bt;
+  std::vector<int>& srcIds = r.srcIds; (void)srcIds;
+  std::vector<SrcPlanOut>& srcPlans = r.srcPlans; (void)srcPlans;
+  std::vector<Segment>& segs = r.segs; (void)segs;
+  const int64_t frames = r.n * kBlock; (void)frames;
+  int& bHistMax = r.bHistMax; (void)bHistMax;
   // ---- commit the control state to the end of the chunk ----
   for (size_t i = 0; i < srcIds.size(); i++) {
     NodeS& s = *nodes[srcIds[i]];
@@ -2844,6 +2978,34 @@ void Context::runChunkImpl(int64_t n, float* const* /*unused*/) {
   chunkBlocksDone = n;
   chunkSegCh.clear();
   for (const Segment& sg : segs) chunkSegCh.push_back(SegCh{sg.b0, sg.b1, sg.nodes.back().outCh});
+}
+
+void Context::runChunkImpl(int64_t nblocks, float* const* /*unused*/) {
+  ChunkRun r;
+  r.n = nblocks;
+  r.tm0 = nowMs();
+  GA_HIP(hipSetDevice(device));
+  if (disposed) fail(GA_ERR_DISPOSED, "context disposed");
+  drain();  // AudioContextBase.cs:57
+  if (!releasedPending.empty() || ++chunksSinceGc >= 64) collectGarbage();
+  latched = true;
+  chunkTopology(r);
+  chunkSimulate(r);
+  chunkResources(r);
+  r.tmRes = nowMs();
+  r.ex = std::make_unique<Exec>(*this, r.n, r.segs);
+  r.ex->outViews.resize(r.segs.size());
+  r.ex->plan.host.resize(16);  // reserved header
+  chunkParamCurves(r);
+  chunkConvScratch(r);
+  r.tmPre = nowMs();
+  for (int d = 0; d <= r.maxDepth; d++) {   // stages: convolver depth d
+    chunkPlanNodes(r, d);
+    chunkPlanConvolvers(r, d);
+  }
+  chunkDelayCommit(r);
+  chunkExecute(r);
+  chunkCommit(r);
 }
 
 }  // namespace ga

@@ -316,6 +316,8 @@ struct Resampler {  // host replay of CubicResampler's position recurrence (Cubi
   void extend(int64_t nblocks);
 };
 
+struct ChunkRun;   // ga_chunk.cpp
+
 struct Context {
   int sampleRate;
   int device = 0;
@@ -453,6 +455,18 @@ struct Context {
   void render(float* const* out, int channels, int64_t frames, int64_t start, bool deviceOut);
   void runChunk(int64_t nblocks, float* const* bus);
   void runChunkImpl(int64_t nblocks, float* const* bus);
+  // the passes of one chunk (ga_chunk.cpp; ChunkRun holds what they share)
+  void chunkTopology(ChunkRun& r);
+  void chunkSimulate(ChunkRun& r);
+  void chunkResources(ChunkRun& r);
+  void chunkParamCurves(ChunkRun& r);
+  void chunkConvScratch(ChunkRun& r);
+  void chunkPlanNodes(ChunkRun& r, int depth);
+  void chunkPlanConvolvers(ChunkRun& r, int depth);
+  void chunkDelayCommit(ChunkRun& r);
+  void chunkExecute(ChunkRun& r);
+  void chunkCommit(ChunkRun& r);
+  void ensureBiquadState(NodeS& bn);
   bool faulted = false;      // a render failed after control state had moved: the context refuses further renders
   std::string faultMsg;
   int chunkPhase = 0;        // 0 = checks only (a failure leaves the context usable), 1 = state is moving
