@@ -179,7 +179,8 @@ _product_api = None
 
 
 def library_path() -> str:
-    return os.path.join(_HERE, LIB_NAME)
+    # GA_LIBRARY: a differently built library for kernel-variant measurements (tools/); never set in tests or bench runs
+    return os.environ.get("GA_LIBRARY") or os.path.join(_HERE, LIB_NAME)
 
 
 def product_api() -> CApi:

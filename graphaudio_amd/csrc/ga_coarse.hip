@@ -249,10 +249,20 @@ void launch_coarse_fwd(hipStream_t s, const CoarseXRow* rows_dev, int nrows, int
 //      acc[t][c] += X[t - p] . H_c[p]          p < P', c < CW columns, t in the wave's range
 //  with the accumulators of ALL terms of the job in registers: the sum over the job's voices costs no memory traffic.
 // =====================================================================================================================
-constexpr int kMacWaves = 8;                 // waves per workgroup: each takes an eighth of the job's coarse blocks
+#ifndef GA_MAC_WAVES
+#define GA_MAC_WAVES 8
+#endif
+#ifndef GA_MAC_TW
+#define GA_MAC_TW 8
+#endif
+#ifndef GA_MAC_PB2
+#define GA_MAC_PB2 2      // partition block used for 2-column jobs whose partition count is a multiple of 4
+#endif
+constexpr int kMacWaves = GA_MAC_WAVES;      // waves per workgroup: each takes 1/kMacWaves of the job's coarse blocks
 constexpr int kMacThreads = 64 * kMacWaves;
+constexpr int kMacWavesPerSimd = kMacWaves / 2;   // two workgroups per CU (LDS), four SIMDs
 template <int CW, int TW, int PB>
-__global__ __launch_bounds__(kMacThreads, 4) void coarse_mac_kernel(const CoarseJob* __restrict jobs, const CoarseTerm* __restrict terms,
+__global__ __launch_bounds__(kMacThreads, kMacWavesPerSimd) void coarse_mac_kernel(const CoarseJob* __restrict jobs, const CoarseTerm* __restrict terms,
                                                                     const float2* __restrict X, float2* __restrict Y, int y_frames, int NFA,
                                                                     int exp) {
   extern __shared__ f2 mlds[];
@@ -273,7 +283,7 @@ __global__ __launch_bounds__(kMacThreads, 4) void coarse_mac_kernel(const Coarse
   const size_t binoff = (size_t)tile * 64;
 
   // staging of one term: NF x 32 float4 of X (+ P x CW x 32 float4 of H)
-  constexpr int XR = (kMacWaves * TW + kCoarseMaxP + 15) / 16;  // float4 per thread that cover NF <= kMacWaves TW + P - 1 frames
+  constexpr int XR = ((kMacWaves * TW + kCoarseMaxP) * 32 + kMacThreads - 1) / kMacThreads;  // float4 per thread that cover NF <= kMacWaves TW + P - 1 frames
   v4f xr[XR];
   auto issue_x = [&](const CoarseTerm& T) {
 #pragma unroll
@@ -400,9 +410,9 @@ static void launch_coarse_mac_t(hipStream_t s, const CoarseJob* jobs_dev, int nj
 template <int CW>
 static void launch_coarse_mac_cw(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
                                  int y_frames, int max_t, int maxP, bool any_private, int pb) {
-  constexpr int TWL = CW <= 2 ? 8 : 4;   // accumulators: TW x CW complex values per lane (128 VGPRs per wave at 4 waves per SIMD)
+  constexpr int TWL = CW <= 2 ? GA_MAC_TW : GA_MAC_TW / 2;   // accumulators: TW x CW complex values per lane
   if (max_t <= 2 * kMacWaves) launch_coarse_mac_t<CW, 2, 1>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
-  else if (pb == 4 && CW == 1) launch_coarse_mac_t<CW, TWL, 4>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
+  else if (pb == 4 && (CW == 1 || (CW == 2 && GA_MAC_PB2 == 4))) launch_coarse_mac_t<CW, TWL, 4>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
   else if (pb >= 2) launch_coarse_mac_t<CW, TWL, 2>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
   else launch_coarse_mac_t<CW, TWL, 1>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
 }

@@ -14,8 +14,10 @@ from tests._oracle import OracleContext
 SR = 48000
 
 
-def test_released_buffers_and_spectra_are_freed_but_playing_ones_stay():
+@pytest.mark.parametrize("coarse_min_blocks", [256, 1])   # 1: the 20,000-tap impulse responses take formulation D (history buffers, coarse spectra, kept taps)
+def test_released_buffers_and_spectra_are_freed_but_playing_ones_stay(coarse_min_blocks):
     ctx = OfflineAudioContext(SR)
+    ctx.SetOption("coarse_min_blocks", coarse_min_blocks)
     rng = np.random.default_rng(0)
     out = np.zeros((2, 128 * 4), np.float32)
     conv = ConvolverNode(ctx)

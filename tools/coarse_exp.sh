@@ -3,9 +3,6 @@
 # forward: 1 no stores, 2 no combine, 4 no FFT, 8 no input loads ; multiply-accumulate (x16): 1 no MAC, 2 no X loads, 4 no Y stores
 for e in "$@"; do
   echo "== GA_COARSE_EXP=$e"
-  GA_COARSE_EXP=$e python bench.py --no-cpu-baseline --steps 5 --warmup 2 2>gpurun_out/exp_err.log | python -c "
-import json,sys
-r=json.loads(sys.stdin.read())
-print('ms/step %.3f' % r['ms_per_step'], {k: round(v,3) for k,v in {n: s["ms_per_step"] for n, s in r["stages"].items()}.items()})"
-grep coarse_mac gpurun_out/exp_err.log | sort | uniq -c | head -3
+  GA_COARSE_EXP=$e python bench.py --no-cpu-baseline --steps 5 --warmup 2 2>gpurun_out/exp_err.log | python tools/bench_stages.py
+  grep coarse_mac gpurun_out/exp_err.log | sort | uniq -c | head -3
 done
