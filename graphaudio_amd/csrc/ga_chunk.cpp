@@ -1433,6 +1433,7 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
   float2* X = (float2*)c.coarseX.p;
   float2* Y = (float2*)c.coarseY.p;
   const float2* tw16 = c.twiddles16(4096);
+  const float2* twFwd = c.twiddles16pw();
   const float2* twab = c.coarseTwab();
   const int nh = (int)hjobs.size(), no = (int)outs.size();
   // per group: rows, longest row, bytes, windows per workgroup (long runs fetch every input sample once; keep >= ~4
@@ -1472,7 +1473,7 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
     for (int g = 0; g < G; g++) {
       const FwdLaunch& f = fwds[g];
       if (f.nx > 0)
-        timed(st, LK_CFWD, f.bytes, [&] { launch_coarse_fwd(st, (const CoarseXRow*)(base + xo) + f.x0, f.nx, f.maxFrames, f.run, X, tw16, twab); });
+        timed(st, LK_CFWD, f.bytes, [&] { launch_coarse_fwd(st, (const CoarseXRow*)(base + xo) + f.x0, f.nx, f.maxFrames, f.run, X, twFwd, twab); });
       if (G > 1) {
         GA_HIP(hipEventRecord(cp->dGroupEv[g], st));
         GA_HIP(hipStreamWaitEvent(s2, cp->dGroupEv[g], 0));

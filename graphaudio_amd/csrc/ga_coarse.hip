@@ -56,8 +56,8 @@ __device__ __forceinline__ f2 cfmap(f2 a, f2 b, f2 acc) {
 }
 
 // =====================================================================================================================
-//  forward: one workgroup of 256 threads per window, two workgroups per CU (66 KB of LDS each: while one waits for its stores or
-//  at a barrier the other one transforms).  Thread t owns the points j = t + 256 m (m < 16) of BOTH complex transforms
+//  forward: one workgroup of 256 threads per window, THREE workgroups per CU (44 KB of LDS and <= 168 VGPRs each: while one waits
+//  for its loads / stores or at a barrier the others transform).  Thread t owns the points j = t + 256 m (m < 16) of BOTH complex transforms
 //      z_a[j] = x[4j] + i x[4j+1],   z_b[j] = x[4j+2] + i x[4j+3]
 //  so it fetches x[4j .. 4j+3] as ONE 16-byte word and no sample is fetched twice; the transforms run one after the other
 //  through the same LDS buffer.  The combine pass needs Z[k] and Z[4096 - k]: a thread keeps Z[t + 256 m] for m < 8 in
@@ -92,15 +92,16 @@ __device__ __forceinline__ void coarse_issue_half(const CoarseXRow& R, int hw, i
   }
 }
 
-__global__ __launch_bounds__(256, 2) void coarse_fwd_kernel(const CoarseXRow* __restrict rows, int run, float2* __restrict X,
+constexpr int kFwdTw3 = 4 * 256;   // power twiddles of the last pass: W_4096^(j m), m = 1, 2, 4, 8 (ga_fft16.hpp, PW)
+__global__ __launch_bounds__(256, 3) void coarse_fwd_kernel(const CoarseXRow* __restrict rows, int run, float2* __restrict X,
                                                             const float2* __restrict twg, const float2* __restrict twab, int exp) {
   using PL = R16Plan<CM>;
   extern __shared__ f2 clds[];
   f2* tw2 = clds;
   f2* tw3 = clds + PL::T2;
-  f2* buf = clds + PL::T2 + PL::T3;
+  f2* buf = clds + PL::T2 + kFwdTw3;
   const int t_ = threadIdx.x;
-  for (int i = t_; i < PL::T2 + PL::T3; i += 256) clds[i] = f2{twg[i].x, twg[i].y};
+  for (int i = t_; i < PL::T2 + kFwdTw3; i += 256) clds[i] = f2{twg[i].x, twg[i].y};
   const CoarseXRow R = rows[blockIdx.y];
   const int w0 = blockIdx.x * run;
   const int w1 = min(R.n_frames, w0 + run);
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void coarse_fwd_kernel(const CoarseXRow* __
       own[m] = f2{first[m].x * scale, first[m].y * scale};
       own[8 + m] = f2{second[m].x * scale, second[m].y * scale};
     }
-    if (!(exp & 4)) fft16_own<CM>(own, buf, tw2, tw3, t);
+    if (!(exp & 4)) fft16_own<CM, true>(own, buf, tw2, tw3, t);
     f2 za[8], pa[8];
     const f2 za8 = own[8];   // Z_a[2048] (thread 0)
     __syncthreads();          // the last pass has read the buffer
@@ -158,18 +159,7 @@ __global__ __launch_bounds__(256, 2) void coarse_fwd_kernel(const CoarseXRow* __
       own[m] = f2{first[m].z * scale, first[m].w * scale};
       own[8 + m] = f2{second[m].z * scale, second[m].w * scale};
     }
-    // the window moves on: `second` becomes the first half, the half after it is requested now and arrives behind
-    // transform b and the combine pass
-    if (more) {
-      if (zero2) {
-        if (!(exp & 8)) coarse_issue_half(R, u, t, first);
-      } else {
-#pragma unroll
-        for (int q = 0; q < 8; q++) first[q] = second[q];
-        if (!(exp & 8)) coarse_issue_half(R, u + 1, t, second);
-      }
-    }
-    if (!(exp & 4)) fft16_own<CM>(own, buf, tw2, tw3, t);
+    if (!(exp & 4)) fft16_own<CM, true>(own, buf, tw2, tw3, t);
     f2 pb[8];
     const f2 zb8 = own[8];
     __syncthreads();
@@ -180,6 +170,17 @@ __global__ __launch_bounds__(256, 2) void coarse_fwd_kernel(const CoarseXRow* __
     for (int m = 0; m < 8; m++) {
       const int k = t + 256 * m;
       pb[m] = k == 0 ? own[0] : buf[cpad(2048 - k)];
+    }
+    // the window moves on: `second` becomes the first half, the half after it is requested now (not earlier: its 32 registers
+    // would be live during the transforms) and arrives behind the combine pass and the next window's first transform
+    if (more) {
+      if (zero2) {
+        if (!(exp & 8)) coarse_issue_half(R, u, t, first);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; q++) first[q] = second[q];
+        if (!(exp & 8)) coarse_issue_half(R, u + 1, t, second);
+      }
     }
     // ---- combine: W = A + a B (8192-point complex spectrum of x[2n] + i x[2n+1]), then the real-input split.
     //      All values carry a factor 2 (the 1/2 of the split is folded into the impulse-response scale).
@@ -231,7 +232,7 @@ void launch_coarse_fwd(hipStream_t s, const CoarseXRow* rows_dev, int nrows, int
                        const float2* twab) {
   if (nrows <= 0 || max_frames <= 0) return;
   using PL = R16Plan<CM>;
-  const size_t lds = (size_t)(PL::T2 + PL::T3 + CPAD) * sizeof(float2);
+  const size_t lds = (size_t)(PL::T2 + kFwdTw3 + CPAD) * sizeof(float2);
   if (hipFuncSetAttribute((const void*)coarse_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     launch_fail("cannot raise the dynamic LDS limit of the coarse forward transform");
   static const int exp = getenv("GA_COARSE_EXP") ? atoi(getenv("GA_COARSE_EXP")) : 0;   // timing experiments only

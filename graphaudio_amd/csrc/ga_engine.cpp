@@ -93,6 +93,7 @@ Context::~Context() {
   }
   for (auto& kv : tw16) (void)hipFree(kv.second);
   if (coarseTw) (void)hipFree(coarseTw);
+  if (tw16pw) (void)hipFree(tw16pw);
   if (stream2) {
     (void)hipStreamSynchronize(stream2);
     (void)hipStreamDestroy(stream2);
@@ -732,10 +733,25 @@ void Context::ensureCoarseSpectra(IrSpectra& ir) {
   }
   CoarseXRow* rd = (CoarseXRow*)dalloc(sizeof(CoarseXRow) * rows.size());
   GA_HIP(hipMemcpy(rd, rows.data(), sizeof(CoarseXRow) * rows.size(), hipMemcpyHostToDevice));
-  launch_coarse_fwd(stream, rd, ir.nch, P, P, ir.coarse, twiddles16(4096), coarseTwab());
+  launch_coarse_fwd(stream, rd, ir.nch, P, P, ir.coarse, twiddles16pw(), coarseTwab());
   GA_HIP(hipGetLastError());
   GA_HIP(hipStreamSynchronize(stream));
   dfree(rd, sizeof(CoarseXRow) * rows.size());
+}
+
+// forward transform of formulation D: the W_256 table of the second pass followed by the POWER twiddles of the last pass,
+// W_4096^(j m) for m = 1, 2, 4, 8 (ga_fft16.hpp, fft16_own<4096, true>)
+const float2* Context::twiddles16pw() {
+  if (tw16pw) return tw16pw;
+  const double pi = 3.14159265358979323846264338327950288;
+  std::vector<float2> t;
+  for (int m = 1; m < 16; m++)
+    for (int kk = 0; kk < 16; kk++) t.push_back(make_float2((float)std::cos(2.0 * pi * kk * m / 256), (float)-std::sin(2.0 * pi * kk * m / 256)));
+  for (int m : {1, 2, 4, 8})
+    for (int j = 0; j < 256; j++) t.push_back(make_float2((float)std::cos(2.0 * pi * j * m / 4096), (float)-std::sin(2.0 * pi * j * m / 4096)));
+  tw16pw = (float2*)dalloc(sizeof(float2) * t.size());
+  GA_HIP(hipMemcpy(tw16pw, t.data(), sizeof(float2) * t.size(), hipMemcpyHostToDevice));
+  return tw16pw;
 }
 
 const float2* Context::twiddlesC(int N2) {

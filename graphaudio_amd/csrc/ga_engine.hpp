@@ -434,6 +434,8 @@ struct Context {
   DevArena coarseX, coarseY;        // spectra frames of a convolver stage (shared by the stages of a chunk, which run in order)
   float2* coarseTw = nullptr;       // combine-pass twiddles [2][2049]: W_8192^k, W_16384^k
   const float2* coarseTwab();
+  float2* tw16pw = nullptr;
+  const float2* twiddles16pw();
   void ensureCoarseSpectra(IrSpectra& ir);
   void planCoarseFusion(const std::vector<int>& topo, const std::vector<Segment>& segs);
   ConvRowRef addGroupRow(const std::shared_ptr<IrSpectra>& ir, int ch, int depth, int nodeId);

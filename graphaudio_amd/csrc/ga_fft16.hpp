@@ -147,7 +147,10 @@ struct R16Plan {
 };
 // forward FFT of the 16 thread-owned points {t + T m}; `buf` is this transform's N-point LDS buffer.  Contains three
 // workgroup barriers; every thread of the workgroup must call it (threads of an idle transform pass live = false).
-template <int N>
+// PW ("power twiddles", N = 4096 only): `tw3` holds W_N^(j m) for m = 1, 2, 4, 8 only ([4][256], 8 KB instead of 30 KB) and the
+// other eleven twiddles of a butterfly are products of those (<= 3 roundings each) -- for kernels that are short of LDS,
+// not of VALU issue slots.
+template <int N, bool PW = false>
 __device__ __forceinline__ void fft16_own(f2 (&own)[16], f2* __restrict buf, const f2* __restrict tw2,
                                           const f2* __restrict tw3, int t) {
   using PL = R16Plan<N>;
@@ -186,12 +189,25 @@ __device__ __forceinline__ void fft16_own(f2 (&own)[16], f2* __restrict buf, con
       f2 v[R3];
 #pragma unroll
       for (int m = 0; m < R3; m++) v[m] = buf[b2 + (T + T / 32) * u + 264 * m];
+      if constexpr (PW) {
+        static_assert(!PW || R3 == 16, "power twiddles: 4096 points only");
+        const f2 w1 = tw3[j], w2 = tw3[256 + j], w4 = tw3[512 + j], w8 = tw3[768 + j];
+        const f2 w3 = cmulp(w1, w2), w5 = cmulp(w4, w1), w6 = cmulp(w4, w2), w7 = cmulp(w4, w3);
+        v[1] = cmulp(v[1], w1); v[2] = cmulp(v[2], w2); v[3] = cmulp(v[3], w3); v[4] = cmulp(v[4], w4);
+        v[5] = cmulp(v[5], w5); v[6] = cmulp(v[6], w6); v[7] = cmulp(v[7], w7); v[8] = cmulp(v[8], w8);
+        __builtin_amdgcn_sched_barrier(0);
+        v[9] = cmulp(v[9], cmulp(w8, w1)); v[10] = cmulp(v[10], cmulp(w8, w2)); v[11] = cmulp(v[11], cmulp(w8, w3));
+        v[12] = cmulp(v[12], cmulp(w8, w4)); v[13] = cmulp(v[13], cmulp(w8, w5)); v[14] = cmulp(v[14], cmulp(w8, w6));
+        v[15] = cmulp(v[15], cmulp(w8, w7));
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
 #pragma unroll
       for (int q = 0; q < R3 / 4; q++) {
 #pragma unroll
         for (int m = 4 * q; m < 4 * q + 4; m++)
           if (m > 0) v[m] = cmulp(v[m], tw3[(m - 1) * 256 + j]);
         __builtin_amdgcn_sched_barrier(0);
+      }
       }
       if constexpr (R3 == 16) pdft16(v);
       else if constexpr (R3 == 8) pdft8(v);

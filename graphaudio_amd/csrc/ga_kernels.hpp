@@ -149,7 +149,7 @@ struct CoarseHistJob {
   float* new_hist;
   int64_t hist_len, n;
 };
-// tw16 = Context::twiddles16(4096); twab = [2][2049]: W_8192^k, W_16384^k
+// forward: tw16 = Context::twiddles16pw() ; inverse: tw16 = Context::twiddles16(4096) ; twab = [2][2049]: W_8192^k, W_16384^k
 void launch_coarse_fwd(hipStream_t s, const CoarseXRow* rows_dev, int nrows, int max_frames, int run, float2* X, const float2* tw16,
                        const float2* twab);
 void launch_coarse_mac(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
