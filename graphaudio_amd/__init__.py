@@ -6,7 +6,7 @@ libgraphaudio_hip.so (include/graphaudio_hip.h).  No CPU fallback: the HIP libra
 from ._capi import (ArgumentException, ArgumentOutOfRangeException, DeviceException, GraphAudioLibraryError,
                     InvalidOperationException, NotSupportedException, ObjectDisposedException, library_path,
                     product_api)
-from .core import (AudioBufferSourceNode, AudioContextBase, AudioDestinationNode, AudioNode, AudioNodeInput,
+from .core import (AudioStreamSourceNode, StreamState, AudioBufferSourceNode, AudioContextBase, AudioDestinationNode, AudioNode, AudioNodeInput,
                    AudioParam, AutomationRate, BiQuadFilterNode, ChannelCountMode, ChannelInterpretation,
                    ChannelMergerNode, ChannelSplitterNode, ConstantSourceNode, ConvolverNode, DelayNode, FilterType,
                    FramesPerBlock, GainNode, HipOfflineAudioContext, OfflineAudioContext, OscillatorNode,

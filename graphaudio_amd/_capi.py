@@ -142,6 +142,11 @@ SIGNATURES = {
     "process_blocks_interleaved": (_i, [_vp, C.POINTER(C.c_float), _i, _i64, _i]),
     "context_set_stream": (_i, [_vp, _vp]),
     "synchronize": (_i, [_vp]),
+    "stream_queue_buffer": (_i, [_vp, _i, _i]),
+    "stream_set_state": (_i, [_vp, _i, _i]),
+    "stream_dequeue_processed": (_i, [_vp, _i, C.POINTER(_i)]),
+    "stream_queued_count": (_i, [_vp, _i]),
+    "stream_processed_count": (_i, [_vp, _i]),
     "comm_unique_id": (_i, [_vp]),
     "comm_init": (_i, [_vp, _vp, _i, _i]),
     "comm_destroy": (_i, [_vp]),

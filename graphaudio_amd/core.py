@@ -351,6 +351,59 @@ class AudioBufferSourceNode(AudioNode):  # Nodes/AudioBufferSourceNode.cs:13-415
         self.Context._call("source_stop", self._id, float(when))
 
 
+class StreamState(enum.IntEnum):  # GraphAudio.IO/AudioStreamSourceNodeBase.cs:12-17
+    Playing = 0
+    Paused = 1
+    Stopped = 2
+
+
+class AudioStreamSourceNode(AudioNode):
+    """AudioStreamNodeBase (GraphAudio.IO/AudioStreamSourceNodeBase.cs:19-329) with an explicit queue: the host calls
+    QueueBuffer (protected in the reference, where a decoder thread feeds it) so that renders are deterministic."""
+    _node_type = 11
+    _input_count = 0
+
+    def __init__(self, context):
+        super().__init__(context, "AudioStreamSource")
+        self.PlaybackRate = self._param("playbackRate", 1.0, 0.001, 1000.0, AutomationRate.KRate)
+        self._buffers = {}   # native id -> PlayableAudioBuffer (keeps queued buffers alive on the host side)
+
+    @property
+    def State(self) -> "StreamState":
+        return self._state if hasattr(self, "_state") else StreamState.Stopped
+
+    def _set(self, st):
+        self.Context._call("stream_set_state", self._id, int(st))
+        self._state = StreamState(st)
+
+    def Play(self):   # :70-73
+        self._set(StreamState.Playing)
+
+    def Pause(self):  # :78-81
+        self._set(StreamState.Paused)
+
+    def Stop(self):   # :86-89
+        self._set(StreamState.Stopped)
+
+    def QueueBuffer(self, buffer: "PlayableAudioBuffer"):  # :118-124
+        bid = buffer._native_id(self.Context)
+        self._buffers[bid] = buffer
+        self.Context._call("stream_queue_buffer", self._id, bid)
+
+    def TryDequeueProcessedBuffer(self):  # :126-129
+        out = C.c_int(-1)
+        got = self.Context._call("stream_dequeue_processed", self._id, C.byref(out))
+        return self._buffers.get(out.value) if got else None
+
+    @property
+    def QueuedBufferCount(self) -> int:
+        return self.Context._call("stream_queued_count", self._id)
+
+    @property
+    def ProcessedBufferCount(self) -> int:
+        return self.Context._call("stream_processed_count", self._id)
+
+
 class OscillatorType(enum.IntEnum):  # OscillatorNode.cs:207-213
     Sine = 0
     Square = 1

@@ -440,6 +440,10 @@ int ga_node_create_ex(ga_context* ctx, int node_type, double arg, int* out_id) {
         n->params.push_back(makeParam(0.f, 0.f, (float)arg, true));
         break;
       }
+      case GA_NODE_STREAM_SOURCE:      // AudioStreamSourceNodeBase.cs:59-67
+        n->outputs.resize(1);
+        n->params.push_back(makeParam(1.f, 0.001f, 1000.f, false));
+        break;
       default: fail(GA_ERR_INVALID_ARGUMENT, "unknown node type");
     }
     *out_id = n->id;
@@ -787,6 +791,47 @@ int ga_process_blocks_interleaved(ga_context* ctx, float* interleaved, int chann
 }
 int ga_render_device(ga_context* ctx, float* const* out_planar_dev, int out_channels, int64_t frame_count, int64_t start_index) {
   return guard(ctx, [&](Context& c) { c.render(out_planar_dev, out_channels, frame_count, start_index, true); });
+}
+
+// ---- AudioStreamNodeBase (GraphAudio.IO/AudioStreamSourceNodeBase.cs) ----
+int ga_stream_queue_buffer(ga_context* ctx, int node, int buffer_id) {
+  return guard(ctx, [&](Context& c) {
+    NodeS* n = typed(c, node, GA_NODE_STREAM_SOURCE);
+    PlayBuf* b = c.buffer(buffer_id);
+    if (b->channels < 1 || b->length < 1) fail(GA_ERR_INVALID_ARGUMENT, "Buffer must be initialized");
+    if (c.inRender) fail(GA_ERR_INVALID_OPERATION, "QueueBuffer during a render");
+    n->stQueued.push_back(buffer_id);
+  });
+}
+int ga_stream_set_state(ga_context* ctx, int node, int state) {
+  return guard(ctx, [&](Context& c) {
+    NodeS* n = typed(c, node, GA_NODE_STREAM_SOURCE);
+    if (state < GA_STREAM_PLAYING || state > GA_STREAM_STOPPED) fail(GA_ERR_OUT_OF_RANGE, "stream state");
+    const int old = n->stState;   // State setter (:37-49): immediate (Interlocked in the reference), not a posted command
+    n->stState = state;
+    if (state == GA_STREAM_STOPPED && old != GA_STREAM_STOPPED) c.streamFlushToProcessed(*n);
+  });
+}
+int ga_stream_dequeue_processed(ga_context* ctx, int node, int* buffer_id_out) {
+  int got = 0;
+  int rc = guard(ctx, [&](Context& c) {
+    NodeS* n = typed(c, node, GA_NODE_STREAM_SOURCE);
+    if (n->stProcessed.empty()) return;
+    if (buffer_id_out) *buffer_id_out = n->stProcessed.front();
+    n->stProcessed.pop_front();
+    got = 1;
+  });
+  return rc < 0 ? rc : got;
+}
+int ga_stream_queued_count(ga_context* ctx, int node) {
+  int v = 0;
+  int rc = guard(ctx, [&](Context& c) { v = (int)typed(c, node, GA_NODE_STREAM_SOURCE)->stQueued.size(); });
+  return rc < 0 ? rc : v;
+}
+int ga_stream_processed_count(ga_context* ctx, int node) {
+  int v = 0;
+  int rc = guard(ctx, [&](Context& c) { v = (int)typed(c, node, GA_NODE_STREAM_SOURCE)->stProcessed.size(); });
+  return rc < 0 ? rc : v;
 }
 
 // ---- sharded render (ga_comm.cpp) ----

@@ -696,6 +696,12 @@ struct Sim {
         n_.outputs[0].silent = !any;
         break;
       }
+      case GA_NODE_STREAM_SOURCE: {  // AudioStreamSourceNodeBase.cs:132-301: channel count / silence per block from the host replay
+        const NodeS::StreamBlockInfo bi = brel < (int64_t)n_.stInfo.size() ? n_.stInfo[brel] : NodeS::StreamBlockInfo{1, true};
+        n_.outputs[0].bufCh = bi.outCh;
+        n_.outputs[0].silent = bi.silent;
+        break;
+      }
       case GA_NODE_CONSTANT_SOURCE:
       case GA_NODE_OSCILLATOR: {  // always a 1-channel buffer; non-silent in every block that plays (:136, :151)
         const SrcSpan& sp = spanAt(n_, brel);
@@ -833,6 +839,7 @@ struct Exec {
   std::vector<LoopJob> loopJobs;
   std::vector<ResampleJob> rsJobs;
   std::vector<GsrJob> gsrJobs;
+  std::vector<StreamJob> streamJobs;
   std::vector<ConstJob> constJobs;
   std::vector<OscJob> oscJobs;
   std::vector<PanJob> panJobs;
@@ -1021,6 +1028,14 @@ struct Exec {
       hipStream_t st = c.stream;
       plan.add(LK_OTHER, [=](uint8_t* base) { launch_gsr(st, (const GsrJob*)(base + off), nj, base, mx); });
     }
+    if (!streamJobs.empty()) {
+      size_t off = plan.putv(streamJobs);
+      int nj = (int)streamJobs.size();
+      int64_t mx = 0;
+      for (auto& j : streamJobs) mx = std::max(mx, j.nblocks);
+      hipStream_t st = c.stream;
+      plan.add(LK_OTHER, [=](uint8_t* base) { launch_stream(st, (const StreamJob*)(base + off), nj, base, mx); });
+    }
     if (!constJobs.empty()) {
       size_t off = plan.putv(constJobs);
       int nj = (int)constJobs.size();
@@ -1099,6 +1114,7 @@ struct Exec {
     loopJobs.clear();
     rsJobs.clear();
     gsrJobs.clear();
+    streamJobs.clear();
     constJobs.clear();
     oscJobs.clear();
     panJobs.clear();
@@ -1156,6 +1172,175 @@ void Context::ensureGroupState(ConvGroup& g) {
   g.overlap[1] = o1;
   g.ovCur = 0;
   g.rp = need;
+}
+
+// ======================================================================================================
+// AudioStreamNodeBase.Process on indices (GraphAudio.IO/AudioStreamSourceNodeBase.cs:132-301)
+// ======================================================================================================
+void Context::streamReplay(NodeS& s, int64_t nblocks, const std::vector<double>& bt, bool commit) {
+  // working copy of the node's state
+  std::deque<int> queued = s.stQueued, processed = s.stProcessed;
+  int cur = s.stCurrent;
+  int64_t pos = s.stPos;
+  int lastRate = s.stLastRate;
+  int rsChannels = s.stChannels;
+  struct Rs { int64_t w[4]; int wseg[4]; double pos; int ready; } rs;
+  for (int k = 0; k < 4; k++) {
+    rs.w[k] = k;
+    rs.wseg[k] = s.stWinValid ? -2 : -1;   // -2: the value the slot holds on the device since the previous chunk
+  }
+  rs.pos = s.stRsPos;
+  rs.ready = s.stRsReady;
+  auto clearRs = [&]() {
+    for (int k = 0; k < 4; k++) { rs.w[k] = 0; rs.wseg[k] = -1; }
+    rs.pos = 0.0;
+    rs.ready = 0;
+  };
+  bool fed = false;
+  if (!commit) {
+    s.stInfo.assign(nblocks, NodeS::StreamBlockInfo{1, true});
+    s.stBlocks.assign(nblocks, StreamBlock{0, 0});
+    s.stPieces.clear();
+    s.stSegs.clear();
+    s.stUploaded = false;
+  }
+  std::unordered_map<int, int> segOf;   // buffer id -> segment index of this chunk
+  auto segment = [&](int bufId) {
+    auto it = segOf.find(bufId);
+    if (it != segOf.end()) return it->second;
+    PlayBuf& b = *buffers[bufId];
+    const int idx = (int)segOf.size();
+    segOf[bufId] = idx;
+    if (!commit) s.stSegs.push_back(StreamSeg{b.dev, b.stride});
+    return idx;
+  };
+  const bool hasTimeline = !s.params[0].events.empty();
+  for (int64_t blk = 0; blk < nblocks; blk++) {
+    if (s.stState != GA_STREAM_PLAYING) continue;   // ProduceSilence (:136-140)
+    if (cur < 0) {
+      if (queued.empty()) continue;                  // ProduceSilence (:144-148)
+      cur = queued.front();
+      queued.pop_front();
+      pos = 0;
+    }
+    const int channelCount = buffers[cur]->channels;
+    if (rsChannels != channelCount) {   // `_resamplers is null || Length != channelCount` (:164-171): new, cleared resamplers
+      clearRs();
+      rsChannels = channelCount;
+    }
+    // PlaybackRate.GetValues()[0]: k-rate value at the block start (the parameter is computed once per block)
+    const float playbackRate = hasTimeline ? param_value_at(s.params[0].events.data(), (int)s.params[0].events.size(), s.params[0].value, bt[blk])
+                                           : s.params[0].value;
+    int rendered = 0;
+    const int piece0 = commit ? 0 : (int)s.stPieces.size();
+    while (rendered < kBlock) {
+      if (cur < 0) {
+        if (queued.empty()) break;
+        cur = queued.front();
+        queued.pop_front();
+        pos = 0;
+        if (buffers[cur]->channels != channelCount) {   // :189-198: the buffer goes back to the END of the queue
+          queued.push_back(cur);
+          cur = -1;
+          break;
+        }
+      }
+      PlayBuf& b = *buffers[cur];
+      if (b.sampleRate != lastRate && lastRate != 0) clearRs();
+      lastRate = b.sampleRate;
+      const double effectiveRate = (b.sampleRate / (double)sampleRate) * playbackRate;
+      StreamPiece pc{};
+      pc.seg = segment(cur);
+      pc.next = pos;
+      pc.out0 = rendered;
+      pc.rate = effectiveRate;
+      if (effectiveRate == 1.0) {
+        const int remainingInBuffer = (int)b.length - (int)pos;
+        const int framesToCopy = std::min(remainingInBuffer, kBlock - rendered);
+        pc.copy = 1;
+        pc.produced = framesToCopy;
+        for (int k = 0; k < 4; k++) { pc.w[k] = 0; pc.wseg[k] = -1; }
+        if (!commit && framesToCopy > 0) s.stPieces.push_back(pc);
+        pos += framesToCopy;
+        rendered += framesToCopy;
+        if (pos >= b.length) {
+          processed.push_back(cur);
+          cur = -1;
+          pos = 0;
+        }
+      } else {
+        const int available = (int)b.length - (int)pos;
+        if (available <= 0) fail(GA_ERR_UNSUPPORTED, "stream buffer without samples behind the read position");
+        for (int k = 0; k < 4; k++) { pc.w[k] = rs.w[k]; pc.wseg[k] = rs.wseg[k]; }
+        pc.pos = rs.pos;
+        pc.ready = rs.ready;
+        // CubicResampler.Process (:26-63) on indices
+        int inPos = 0, outPos = 0;
+        const int outLen = kBlock - rendered;
+        auto feed = [&]() {
+          rs.w[0] = rs.w[1]; rs.wseg[0] = rs.wseg[1];
+          rs.w[1] = rs.w[2]; rs.wseg[1] = rs.wseg[2];
+          rs.w[2] = rs.w[3]; rs.wseg[2] = rs.wseg[3];
+          rs.w[3] = pos + inPos; rs.wseg[3] = pc.seg;
+          inPos++;
+          fed = true;
+        };
+        while (rs.ready < 4 && inPos < available) {
+          feed();
+          rs.ready++;
+        }
+        if (rs.ready == 4) {
+          while (outPos < outLen) {
+            const int consume = (int)rs.pos;
+            if (inPos + consume > available) break;
+            for (int i = 0; i < consume; i++) feed();
+            rs.pos -= consume;
+            outPos++;
+            rs.pos += effectiveRate;
+          }
+        }
+        pc.copy = 0;
+        pc.produced = outPos;
+        if (!commit && outPos > 0) s.stPieces.push_back(pc);
+        pos += inPos;
+        rendered += outPos;
+        if (pos >= b.length - 4) {
+          processed.push_back(cur);
+          cur = -1;
+          pos = 0;
+        }
+        if (inPos == 0) break;   // minInputConsumed == 0 (:285-292)
+      }
+    }
+    if (!commit) {
+      s.stInfo[blk] = NodeS::StreamBlockInfo{channelCount, rendered == 0};
+      s.stBlocks[blk] = StreamBlock{piece0, (int)s.stPieces.size() - piece0};
+    }
+  }
+  if (!commit) {
+    for (int k = 0; k < 4; k++) {
+      s.stWend[k] = rs.w[k];
+      s.stWendSeg[k] = rs.wseg[k];
+    }
+    s.stFed = fed;
+    return;
+  }
+  s.stQueued.swap(queued);
+  s.stProcessed.swap(processed);
+  s.stCurrent = cur;
+  s.stPos = pos;
+  s.stLastRate = lastRate;
+  s.stChannels = rsChannels;
+  s.stRsPos = rs.pos;
+  s.stRsReady = rs.ready;
+  bool any = false;
+  for (int k = 0; k < 4; k++) any = any || rs.wseg[k] != -1;
+  if (fed) {   // the device wrote the window at the end of these blocks into the other copy
+    s.stWinCur ^= 1;
+    s.stWinValid = any;
+  } else if (!any) {
+    s.stWinValid = false;   // cleared and not fed again
+  }
 }
 
 // ======================================================================================================
@@ -1537,6 +1722,7 @@ struct ChunkRun {
   std::vector<double> bt;              // accumulated block clock
   std::vector<int> srcIds;
   std::vector<SrcPlanOut> srcPlans;
+  std::vector<int> streamIds;          // AudioStreamSourceNodes of the chunk
   std::vector<Segment> segs;
   std::unique_ptr<Exec> ex;
   int bHistMax = 0;
@@ -1669,6 +1855,16 @@ void Context::chunkSimulate(ChunkRun& r) {
       if (srcPlans.back().partialBlock + 1 < n) breaks.push_back(srcPlans.back().partialBlock + 1);
     }
   }
+  for (int id : topo) {   // AudioStreamNodeBase: replay on indices; a change of channel count / silence is a segment break
+    NodeS& nd = *nodes[id];
+    if (nd.type != GA_NODE_STREAM_SOURCE) continue;
+    for (auto& p : nd.params)
+      if (!p.modulation.empty()) fail(GA_ERR_UNSUPPORTED, "audio-rate modulation of AudioStreamSourceNode.playbackRate is not on the device path");
+    streamReplay(nd, n, bt, false);
+    r.streamIds.push_back(id);
+    for (int64_t b = 1; b < n; b++)
+      if (nd.stInfo[b].outCh != nd.stInfo[b - 1].outCh || nd.stInfo[b].silent != nd.stInfo[b - 1].silent) breaks.push_back(b);
+  }
   std::sort(breaks.begin(), breaks.end());
   breaks.erase(std::unique(breaks.begin(), breaks.end()), breaks.end());
   std::unordered_map<int64_t, std::vector<int>> goneAt;
@@ -1729,7 +1925,11 @@ void Context::chunkSimulate(ChunkRun& r) {
       segs.push_back(std::move(sg));
     }
     lastHash = prevHash;
-    if (n < (int64_t)bt.size() - 1) bt.resize(n + 1);
+    if (n < (int64_t)bt.size() - 1) {
+      bt.resize(n + 1);
+      // the chunk was cut short: the stream tables (window at the END of the chunk, pieces) are rebuilt for the blocks that run
+      for (int id : r.streamIds) streamReplay(*nodes[id], n, bt, false);
+    }
   }
   chunkMinDestCh = minDestCh;
   r.tmSim = nowMs();
@@ -2271,6 +2471,40 @@ void Context::chunkPlanNodes(ChunkRun& r, int d) {
                 ex.rsJobs.push_back(rj);
                 ov[ch] = rj.out;
               }
+            }
+            break;
+          }
+          case GA_NODE_STREAM_SOURCE: {
+            if (ns.outSilent) break;   // ProduceSilence / nothing rendered: cleared buffer
+            if (!nd.stUploaded) {
+              nd.stBlocksOff = ex.plan.putv(nd.stBlocks);
+              nd.stPiecesOff = ex.plan.putv(nd.stPieces);
+              nd.stSegsOff = ex.plan.putv(nd.stSegs);
+              nd.stUploaded = true;
+            }
+            if (!nd.stWin[0]) {
+              nd.stWin[0] = (float*)dalloc(32 * 4 * sizeof(float));
+              nd.stWin[1] = (float*)dalloc(32 * 4 * sizeof(float));
+              GA_HIP(hipMemsetAsync(nd.stWin[0], 0, 32 * 4 * sizeof(float), stream));
+              GA_HIP(hipMemsetAsync(nd.stWin[1], 0, 32 * 4 * sizeof(float), stream));
+            }
+            for (int ch = 0; ch < ns.outCh && ch < 32; ch++) {
+              StreamJob sj{};
+              sj.out = ex.nodeOut(ns.id, ch);
+              sj.win_in = nd.stWin[nd.stWinCur] + 4 * ch;
+              sj.win_out = nd.stFed ? nd.stWin[nd.stWinCur ^ 1] + 4 * ch : nullptr;   // every job of the chunk writes the same end state
+              sj.blocks_off = nd.stBlocksOff;
+              sj.pieces_off = nd.stPiecesOff;
+              sj.segs_off = nd.stSegsOff;
+              sj.b0 = sg.b0;
+              sj.nblocks = nb;
+              for (int k = 0; k < 4; k++) {
+                sj.wend[k] = nd.stWend[k];
+                sj.wend_seg[k] = nd.stWendSeg[k];
+              }
+              sj.ch = ch;
+              ex.streamJobs.push_back(sj);
+              ov[ch] = sj.out;
             }
             break;
           }
@@ -2971,6 +3205,7 @@ void Context::chunkCommit(ChunkRun& r) {
       if (po.goneAt == n) pending.push_back([this, id = srcIds[i]]() { doDispose(id); });  // runs in the next block's drain
     }
   }
+  for (int id : r.streamIds) streamReplay(*nodes[id], n, bt, true);   // queue / resampler state at the end of the executed blocks
   currentBlock += n;
   currentTime = bt[n];
   stats.blocks_rendered = currentBlock;

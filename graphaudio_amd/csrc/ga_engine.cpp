@@ -86,6 +86,8 @@ Context::~Context() {
     if (np && np->bOverlap) (void)hipFree(np->bOverlap);
     if (np && np->dHist[0]) (void)hipFree(np->dHist[0]);
     if (np && np->dHist[1]) (void)hipFree(np->dHist[1]);
+    if (np && np->stWin[0]) (void)hipFree(np->stWin[0]);
+    if (np && np->stWin[1]) (void)hipFree(np->stWin[1]);
     if (np && np->delayHist) (void)hipFree(np->delayHist);
     if (np && np->delayLine) (void)hipFree(np->delayLine);
     if (np && np->oscPhase) (void)hipFree(np->oscPhase);
@@ -172,6 +174,11 @@ void Context::collectGarbage() {
       if (!np || np->disposed) continue;
       if (np->bufId >= 0 && np->bufId < (int)used.size()) used[np->bufId] = 1;
       if (np->irBuf >= 0 && np->irBuf < (int)used.size()) used[np->irBuf] = 1;
+      if (np->type == GA_NODE_STREAM_SOURCE) {   // queued, current and processed (not yet handed back) buffers of a stream
+        if (np->stCurrent >= 0 && np->stCurrent < (int)used.size()) used[np->stCurrent] = 1;
+        for (int id : np->stQueued) if (id >= 0 && id < (int)used.size()) used[id] = 1;
+        for (int id : np->stProcessed) if (id >= 0 && id < (int)used.size()) used[id] = 1;
+      }
     }
     std::vector<int> keep;
     bool synced = false;
@@ -322,6 +329,10 @@ void Context::doDispose(int id) {
     n.delayCap = 0;
   }
   if (n.type == GA_NODE_BUFFER_SOURCE) n.bufId = -1;  // AudioBufferSourceNode.cs:412
+  if (n.type == GA_NODE_STREAM_SOURCE && n.stState != GA_STREAM_STOPPED) {   // AudioStreamSourceNodeBase.cs:315-327
+    n.stState = GA_STREAM_STOPPED;
+    streamFlushToProcessed(n);
+  }
   if (n.type == GA_NODE_CONVOLVER) {                   // ConvolverNode.cs:166-175
     releaseConvState(n);   // while n.ir still tells the size of the private history (device byte accounting)
     n.ir.reset();
@@ -687,6 +698,23 @@ const float2* Context::twiddles16(int N2) {
   GA_HIP(hipMemcpy(d, t.data(), sizeof(float2) * t.size(), hipMemcpyHostToDevice));
   tw16[N2] = d;
   return d;
+}
+
+// AudioStreamNodeBase.FlushToProcessed (AudioStreamSourceNodeBase.cs:95-116)
+void Context::streamFlushToProcessed(NodeS& s) {
+  if (s.stCurrent >= 0) s.stProcessed.push_back(s.stCurrent);
+  s.stCurrent = -1;
+  while (!s.stQueued.empty()) {
+    s.stProcessed.push_back(s.stQueued.front());
+    s.stQueued.pop_front();
+  }
+  if (s.stChannels >= 0) {   // resamplers.Clear()
+    s.stRsPos = 0.0;
+    s.stRsReady = 0;
+    s.stWinValid = false;
+  }
+  s.stPos = 0;
+  s.stLastRate = 0;
 }
 
 // ---- formulation D (ga_coarse.hip) ----

@@ -235,6 +235,29 @@ struct NodeS {
   int64_t dHistLen = 0;
   int dHistCur = 0;
   bool dHistZero = true;
+  // AudioStreamNodeBase (GraphAudio.IO/AudioStreamSourceNodeBase.cs:21-28): queue state lives on the host (indices only), the
+  // resampler window of every channel lives on the device between chunks (stWin, double buffered), Pos / Ready on the host
+  std::deque<int> stQueued, stProcessed;   // buffer ids
+  int stCurrent = -1;
+  int64_t stPos = 0;
+  int stLastRate = 0;
+  int stState = GA_STREAM_STOPPED;
+  int stChannels = -1;                      // _resamplers.Length ; -1 = null
+  double stRsPos = 0.0;
+  int stRsReady = 0;
+  bool stWinValid = false;                  // false: every window slot is 0 (cleared / never fed)
+  float* stWin[2] = {nullptr, nullptr};     // [32 channels][4]
+  int stWinCur = 0;
+  struct StreamBlockInfo { int outCh; bool silent; };
+  std::vector<StreamBlockInfo> stInfo;      // per chunk: channel count / silence of every block
+  std::vector<StreamBlock> stBlocks;        // per chunk tables for stream_kernel
+  std::vector<StreamPiece> stPieces;
+  std::vector<StreamSeg> stSegs;
+  int64_t stWend[4] = {0, 0, 0, 0};
+  int stWendSeg[4] = {-1, -1, -1, -1};
+  bool stFed = false;                       // the chunk's pieces moved a resampler window
+  uint64_t stBlocksOff = 0, stPiecesOff = 0, stSegsOff = 0;
+  bool stUploaded = false;
   // per chunk: convolver outputs that one summing input consumes are summed as spectra (Context::planCoarseFusion);
   // the leader's output slabs carry the sum, the other members contribute no time-domain signal of their own
   int dLeader = -1;
@@ -469,6 +492,10 @@ struct Context {
   void chunkExecute(ChunkRun& r);
   void chunkCommit(ChunkRun& r);
   void ensureBiquadState(NodeS& bn);
+  // AudioStreamNodeBase.Process replayed on indices for `nblocks` blocks from the node's current state: fills the node's per-chunk
+  // tables (commit = false) or moves the node's state to the end of the replayed blocks (commit = true)
+  void streamReplay(NodeS& s, int64_t nblocks, const std::vector<double>& bt, bool commit);
+  void streamFlushToProcessed(NodeS& s);
   bool faulted = false;      // a render failed after control state had moved: the context refuses further renders
   std::string faultMsg;
   int chunkPhase = 0;        // 0 = checks only (a failure leaves the context usable), 1 = state is moving

@@ -2156,6 +2156,74 @@ void launch_gsr(hipStream_t s, const GsrJob* jobs_dev, int njobs, const uint8_t*
 
 
 // =====================================================================================================
+//  AudioStreamNodeBase.Process (see StreamPiece): one lane per block, pieces of a block in order; stores go through LDS like
+//  resample_kernel.  A rare path (streams are few): gathers are per lane.
+// =====================================================================================================
+__global__ __launch_bounds__(64) void stream_kernel(const StreamJob* __restrict jobs, const uint8_t* __restrict base) {
+  __shared__ float tile[64][kBlock + 1];
+  const StreamJob job = jobs[blockIdx.y];
+  const int lane = threadIdx.x;
+  const int64_t bl0 = (int64_t)blockIdx.x * 64;
+  if (bl0 >= job.nblocks) return;
+  const StreamSeg* __restrict segs = (const StreamSeg*)(base + job.segs_off);
+  const GA_GLOBAL float* win_in = gptr(job.win_in);
+  auto sample = [&](int seg, int64_t idx) -> float {
+    if (seg == -1) return 0.f;
+    if (seg == -2) return win_in[idx];
+    const StreamSeg sg = segs[seg];
+    return ldg1(sg.base + (int64_t)job.ch * sg.stride + idx);
+  };
+  const int64_t b = bl0 + lane;
+  if (b < job.nblocks) {
+    const StreamBlock blk = ((const StreamBlock*)(base + job.blocks_off))[job.b0 + b];
+    for (int i = 0; i < kBlock; i++) tile[lane][i] = 0.f;   // frames no piece covers are cleared
+    for (int q = 0; q < blk.npieces; q++) {
+      const StreamPiece d = ((const StreamPiece*)(base + job.pieces_off))[blk.piece0 + q];
+      const StreamSeg sg = segs[d.seg];
+      const GA_GLOBAL float* __restrict in = gptr(sg.base) + (int64_t)job.ch * sg.stride;
+      int64_t ip = d.next;
+      int outp = d.out0;
+      const int oend = d.out0 + d.produced;
+      if (d.copy) {
+        for (; outp < oend; outp++) tile[lane][outp] = in[ip++];
+      } else {
+        float S0 = sample(d.wseg[0], d.w[0]), S1 = sample(d.wseg[1], d.w[1]);
+        float S2 = sample(d.wseg[2], d.w[2]), S3 = sample(d.wseg[3], d.w[3]);
+        double Pos = d.pos;
+        int ready = d.ready;
+        if (d.produced > 0) {
+          while (ready < 4) {   // priming (CubicResampler.cs:31-35); the host has checked that the inputs exist
+            S0 = S1; S1 = S2; S2 = S3; S3 = in[ip++];
+            ready++;
+          }
+          for (; outp < oend; outp++) {
+            int consume = (int)Pos;
+            for (int i = 0; i < consume; i++) { S0 = S1; S1 = S2; S2 = S3; S3 = in[ip++]; }
+            Pos -= consume;
+            float t = (float)Pos;
+            tile[lane][outp] = S1 + t * (0.5f * (S2 - S0) + t * ((S0 - 2.5f * S1 + 2.f * S2 - 0.5f * S3) + t * (0.5f * (S3 - S0) + 1.5f * (S1 - S2))));
+            Pos += d.rate;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int nb = (int)min<int64_t>(64, job.nblocks - bl0);
+  GA_GLOBAL float* __restrict out = gptr(job.out) + (job.b0 + bl0) * kBlock;
+  for (int r = 0; r < nb; r++) {
+    out[(int64_t)r * kBlock + lane] = tile[r][lane];
+    out[(int64_t)r * kBlock + 64 + lane] = tile[r][64 + lane];
+  }
+  if (job.win_out && blockIdx.x == 0 && lane < 4) gptr(job.win_out)[lane] = sample(job.wend_seg[lane], job.wend[lane]);
+}
+void launch_stream(hipStream_t s, const StreamJob* jobs_dev, int njobs, const uint8_t* plan_base_dev, int64_t max_blocks) {
+  if (njobs <= 0 || max_blocks <= 0) return;
+  int gx = (int)((max_blocks + 63) / 64);
+  GA_LAUNCH_JOBS(stream_kernel, gx, 64, jobs_dev, njobs, plan_base_dev);
+}
+
+// =====================================================================================================
 //  ConstantSourceNode / OscillatorNode / StereoPannerNode (see ga_kernels.hpp)
 // =====================================================================================================
 __global__ __launch_bounds__(256) void const_source_kernel(const ConstJob* __restrict jobs) {

@@ -358,6 +358,42 @@ struct GsrJob {
 void launch_gsr(hipStream_t s, const GsrJob* jobs_dev, int njobs, const uint8_t* plan_base_dev, int64_t max_blocks);
 
 
+// ---- AudioStreamNodeBase.Process (GraphAudio.IO/AudioStreamSourceNodeBase.cs:132-301): a queue of buffers played back to back through
+// the CubicResampler.  The host replays Process block by block ON INDICES (which buffer and which samples every block feeds, the
+// resampler's position, the window as four sample references) and uploads, per block, the pieces the block is made of --
+// one per `while (framesRendered < framesToRender)` iteration of the reference, each fed from ONE buffer; the device does the
+// per-sample arithmetic.  A window reference is (segment, index): segment >= 0 = a buffer of the chunk's segment table, -1 =
+// never fed (0.0f), -2 = the value the window slot held at the start of the chunk (device state, per channel).
+struct StreamSeg {
+  const float* base;     // channel ch of the buffer at base + ch * stride
+  int64_t stride;
+};
+struct StreamPiece {
+  int64_t next;          // index (in the piece's buffer) of the first sample fed
+  int64_t w[4];          // window S0..S3 at the start of the piece
+  int wseg[4];
+  int seg;               // the buffer this piece feeds from
+  int out0, produced;    // output frames [out0, out0 + produced) of the block
+  int copy;              // 1: effective rate == 1.0 -> plain copy (:222-240), the resampler is not touched
+  int ready;             // CubicResampler.Ready
+  int pad_;
+  double pos, rate;      // CubicResampler.Pos, effective rate
+};
+struct StreamBlock {
+  int piece0, npieces;   // pieces of this block (index into the node's piece table); frames not covered are cleared
+};
+struct StreamJob {
+  float* out;            // chunk-frame indexed
+  const float* win_in;   // [4] window values of this channel at the start of the chunk
+  float* win_out;        // [4] window values at the end of the chunk (null: not written by this job)
+  uint64_t blocks_off, pieces_off, segs_off;   // byte offsets of the node's tables in the plan buffer
+  int64_t b0, nblocks;   // chunk-relative blocks of this job
+  int64_t wend[4];       // window at the end of the chunk
+  int wend_seg[4];
+  int ch, pad_;
+};
+void launch_stream(hipStream_t s, const StreamJob* jobs_dev, int njobs, const uint8_t* plan_base_dev, int64_t max_blocks);
+
 // ---- remaining pure-Core nodes ------------------------------------------------
 // ConstantSourceNode.Process (ConstantSourceNode.cs:76-141): out[f] = offset[f] for frames inside [lo, hi) of the chunk,
 // 0 outside (sample-accurate start / stop)

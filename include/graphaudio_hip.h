@@ -68,8 +68,11 @@ enum { /* node types creatable through ga_node_create; the destination is always
   GA_NODE_CONSTANT_SOURCE = 7,  /* Nodes/ConstantSourceNode.cs:15  ; params: 0 = offset (a-rate) ; scheduled source */
   GA_NODE_STEREO_PANNER = 8,    /* Nodes/StereoPannerNode.cs:9     ; params: 0 = pan (a-rate) */
   GA_NODE_OSCILLATOR = 9,       /* Nodes/OscillatorNode.cs:12      ; params: 0 = frequency (a-rate) ; scheduled source */
-  GA_NODE_DELAY = 10            /* Nodes/DelayNode.cs:9            ; params: 0 = delayTime (a-rate) ; create_ex arg = maxDelayTime */
+  GA_NODE_DELAY = 10,           /* Nodes/DelayNode.cs:9            ; params: 0 = delayTime (a-rate) ; create_ex arg = maxDelayTime */
+  /* the second call site of the resampler */
+  GA_NODE_STREAM_SOURCE = 11    /* GraphAudio.IO/AudioStreamSourceNodeBase.cs:19 (AudioStreamNodeBase) ; params: 0 = playbackRate (k-rate) */
 };
+enum { GA_STREAM_PLAYING = 0, GA_STREAM_PAUSED = 1, GA_STREAM_STOPPED = 2 };   /* StreamState, AudioStreamSourceNodeBase.cs:12-17 */
 enum { GA_FILTER_LOWPASS = 0, GA_FILTER_HIGHPASS, GA_FILTER_BANDPASS, GA_FILTER_NOTCH, GA_FILTER_ALLPASS,
        GA_FILTER_PEAKING, GA_FILTER_LOWSHELF, GA_FILTER_HIGHSHELF }; /* BiQuadFilterNode.cs:288-298 */
 enum { GA_OSC_SINE = 0, GA_OSC_SQUARE, GA_OSC_SAWTOOTH, GA_OSC_TRIANGLE };   /* OscillatorNode.cs:207-213 */
@@ -193,6 +196,21 @@ GA_EXPORT int GA_FN(biquad_set_type)(ga_context* ctx, int node, int filter_type)
 GA_EXPORT int GA_FN(convolver_set_normalize)(ga_context* ctx, int node, int normalize);
 GA_EXPORT int GA_FN(convolver_set_enable_true_stereo)(ga_context* ctx, int node, int enable);
 GA_EXPORT int GA_FN(convolver_set_buffer)(ga_context* ctx, int node, int buffer_id); /* buffer_id < 0 = null */
+
+/* ---- AudioStreamNodeBase (GraphAudio.IO/AudioStreamSourceNodeBase.cs:19-329): a queue of PlayableAudioBuffers played back to back
+ * through the CubicResampler.  The reference's concrete subclass (AudioDecoderStreamNode) fills the queue from a decoder
+ * thread, which makes its output depend on thread timing; here the HOST queues buffers explicitly (between renders), so the
+ * render is deterministic: same queue, same output as the reference's Process (:132-301).
+ *   ga_stream_queue_buffer       QueueBuffer (:118-124)
+ *   ga_stream_set_state          Play / Pause / Stop (:70-93); takes effect at once like the reference's Interlocked state; Stop
+ *                                flushes the current and the queued buffers to the processed list and clears the resamplers (:95-116)
+ *   ga_stream_dequeue_processed  TryDequeueProcessedBuffer (:126-129): 1 and the buffer id, or 0
+ *   ga_stream_queued_count / ga_stream_processed_count   QueuedBufferCount / ProcessedBufferCount (:52-57) */
+GA_EXPORT int GA_FN(stream_queue_buffer)(ga_context* ctx, int node, int buffer_id);
+GA_EXPORT int GA_FN(stream_set_state)(ga_context* ctx, int node, int state);
+GA_EXPORT int GA_FN(stream_dequeue_processed)(ga_context* ctx, int node, int* buffer_id_out);
+GA_EXPORT int GA_FN(stream_queued_count)(ga_context* ctx, int node);
+GA_EXPORT int GA_FN(stream_processed_count)(ga_context* ctx, int node);
 
 /* ---- OfflineAudioContext.Render(float[][] output, int frameCount, int startIndex = 0) (OfflineAudioContext.cs:30-102)
  * out_planar[ch] points at a host array of at least start_index + frame_count floats.  DSP state, the block clock

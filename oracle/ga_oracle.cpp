@@ -1339,6 +1339,142 @@ struct ScheduledNode : Node {
   void onDispose() override { out.reset(); }
 };
 
+// ---- AudioStreamNodeBase (GraphAudio.IO/AudioStreamSourceNodeBase.cs:19-329) with the queue filled by the host ----
+struct StreamNode : Node {
+  std::deque<PlayableBuffer*> queued, processed;   // _queuedBuffers / _processedBuffers (:21-22)
+  PlayableBuffer* current = nullptr;                // _currentBuffer
+  int64_t currentPos = 0;                           // _currentBufferPosition
+  int lastRate = 0;                                 // _lastBufferSampleRate
+  BufPtr out;
+  std::vector<CubicResampler> resamplers;
+  bool haveResamplers = false;                      // `_resamplers is null` until the first playing block
+  int state = GA_STREAM_STOPPED;
+
+  StreamNode(Context* c, int id) : Node(c, id, GA_NODE_STREAM_SOURCE, 0, 1) {
+    createParam(1.f, 0.001f, 1000.f, false);  // playbackRate, k-rate (:66)
+  }
+  void setState(int st) {  // State setter (:37-49): immediate, not a posted command
+    const int old = state;
+    state = st;
+    if (st == GA_STREAM_STOPPED && old != GA_STREAM_STOPPED) flushToProcessed();
+  }
+  void flushToProcessed() {  // :95-116
+    if (current) processed.push_back(current);
+    current = nullptr;
+    while (!queued.empty()) {
+      processed.push_back(queued.front());
+      queued.pop_front();
+    }
+    if (haveResamplers)
+      for (auto& r : resamplers) r.clear();
+    currentPos = 0;
+    lastRate = 0;
+  }
+  void produceSilence() {  // :303-313
+    if (!out || out->channelCount != 1) out = rent(1);
+    out->clear();
+    outputs[0]->buffer = out;
+  }
+  void process() override {  // :132-301
+    if (state != GA_STREAM_PLAYING) {
+      produceSilence();
+      return;
+    }
+    if (!current) {
+      if (queued.empty()) {
+        produceSilence();
+        return;
+      }
+      current = queued.front();
+      queued.pop_front();
+      currentPos = 0;
+    }
+    const int channelCount = current->channels;
+    if (!out || out->channelCount != channelCount) out = rent(channelCount);
+    const int framesToRender = kBlock;
+    int framesRendered = 0;
+    if (!haveResamplers || (int)resamplers.size() != channelCount) {
+      resamplers.assign(channelCount, CubicResampler());
+      haveResamplers = true;
+    }
+    auto clearRest = [&]() {
+      for (int ch = 0; ch < channelCount; ch++) std::fill(out->span(ch) + framesRendered, out->span(ch) + kBlock, 0.f);
+    };
+    while (framesRendered < framesToRender) {
+      if (!current) {
+        if (queued.empty()) {
+          clearRest();
+          break;
+        }
+        current = queued.front();
+        queued.pop_front();
+        currentPos = 0;
+        if (current->channels != channelCount) {  // :189-198: back to the END of the queue
+          clearRest();
+          queued.push_back(current);
+          current = nullptr;
+          break;
+        }
+      }
+      const int bufferSampleRate = current->sampleRate;
+      if (bufferSampleRate != lastRate && lastRate != 0 && haveResamplers)
+        for (auto& r : resamplers) r.clear();
+      lastRate = bufferSampleRate;
+      const float playbackRate = params[0]->computed[0];
+      const double sampleRateRatio = bufferSampleRate / (double)ctx->sampleRate;
+      const double effectiveRate = sampleRateRatio * playbackRate;
+      if (effectiveRate == 1.0) {
+        const int remainingInBuffer = (int)current->length - (int)currentPos;
+        const int remainingInOutput = framesToRender - framesRendered;
+        const int framesToCopy = std::min(remainingInBuffer, remainingInOutput);
+        for (int ch = 0; ch < channelCount; ch++)
+          std::copy(current->ch[ch].begin() + currentPos, current->ch[ch].begin() + currentPos + framesToCopy, out->span(ch) + framesRendered);
+        currentPos += framesToCopy;
+        framesRendered += framesToCopy;
+        if (currentPos >= current->length) {
+          processed.push_back(current);
+          current = nullptr;
+          currentPos = 0;
+        }
+      } else {
+        int64_t minInputConsumed = std::numeric_limits<int64_t>::max();
+        int outputProduced = 0;
+        for (int ch = 0; ch < channelCount; ch++) {
+          const int available = (int)current->length - (int)currentPos;
+          if (available <= 0) break;
+          int consumed = 0, produced = 0;
+          resamplers[ch].process(current->ch[ch].data() + currentPos, available, out->span(ch) + framesRendered, framesToRender - framesRendered,
+                                 effectiveRate, consumed, produced);
+          if (ch == 0) {
+            minInputConsumed = consumed;
+            outputProduced = produced;
+          } else {
+            minInputConsumed = std::min<int64_t>(minInputConsumed, consumed);
+          }
+        }
+        currentPos += minInputConsumed;
+        framesRendered += outputProduced;
+        if (currentPos >= current->length - 4) {
+          processed.push_back(current);
+          current = nullptr;
+          currentPos = 0;
+        }
+        if (minInputConsumed == 0) {
+          clearRest();
+          break;
+        }
+      }
+    }
+    if (framesRendered > 0) out->markNonSilent();
+    else out->clear();
+    outputs[0]->buffer = out;
+  }
+  void onDispose() override {  // :315-327
+    if (state != GA_STREAM_STOPPED) setState(GA_STREAM_STOPPED);
+    out.reset();
+  }
+};
+
 // ---- ConstantSourceNode (Nodes/ConstantSourceNode.cs:15-163) ----
 struct ConstantSourceNode : ScheduledNode {
   ConstantSourceNode(Context* c, int id) : ScheduledNode(c, id, GA_NODE_CONSTANT_SOURCE, 0, 1) {
@@ -1692,6 +1828,7 @@ int gao_node_create_ex(ga_context* ctx, int node_type, double arg, int* out_id) 
       case GA_NODE_STEREO_PANNER: c.nodes.push_back(std::make_unique<StereoPannerNode>(&c, id)); break;
       case GA_NODE_OSCILLATOR: c.nodes.push_back(std::make_unique<OscillatorNode>(&c, id)); break;
       case GA_NODE_DELAY: c.nodes.push_back(std::make_unique<DelayNode>(&c, id, arg)); break;
+      case GA_NODE_STREAM_SOURCE: c.nodes.push_back(std::make_unique<StreamNode>(&c, id)); break;
       default: fail(GA_ERR_INVALID_ARGUMENT, "unknown node type");
     }
     *out_id = id;
@@ -1864,6 +2001,45 @@ int gao_source_stop(ga_context* ctx, int node, double when) {
     if (n->type == GA_NODE_CONSTANT_SOURCE || n->type == GA_NODE_OSCILLATOR) static_cast<ScheduledNode*>(n)->stop(when);
     else as<SourceNode>(n, GA_NODE_BUFFER_SOURCE)->stop(when);
   });
+}
+int gao_stream_queue_buffer(ga_context* ctx, int node, int buffer_id) {
+  return guard(ctx, [&](Context& c) {
+    PlayableBuffer* b = getBuffer(c, buffer_id);
+    if (!b) fail(GA_ERR_INVALID_ARGUMENT, "Buffer must be initialized");
+    as<StreamNode>(getNode(c, node), GA_NODE_STREAM_SOURCE)->queued.push_back(b);
+  });
+}
+int gao_stream_set_state(ga_context* ctx, int node, int state) {
+  return guard(ctx, [&](Context& c) {
+    if (state < GA_STREAM_PLAYING || state > GA_STREAM_STOPPED) fail(GA_ERR_OUT_OF_RANGE, "stream state");
+    as<StreamNode>(getNode(c, node), GA_NODE_STREAM_SOURCE)->setState(state);
+  });
+}
+int gao_stream_dequeue_processed(ga_context* ctx, int node, int* buffer_id_out) {
+  int got = 0;
+  int rc = guard(ctx, [&](Context& c) {
+    auto* s = as<StreamNode>(getNode(c, node), GA_NODE_STREAM_SOURCE);
+    if (s->processed.empty()) return;
+    PlayableBuffer* b = s->processed.front();
+    s->processed.pop_front();
+    got = 1;
+    if (buffer_id_out) {
+      *buffer_id_out = -1;
+      for (size_t i = 0; i < c.buffers.size(); i++)
+        if (c.buffers[i].get() == b) *buffer_id_out = (int)i;
+    }
+  });
+  return rc < 0 ? rc : got;
+}
+int gao_stream_queued_count(ga_context* ctx, int node) {
+  int n = 0;
+  int rc = guard(ctx, [&](Context& c) { n = (int)as<StreamNode>(getNode(c, node), GA_NODE_STREAM_SOURCE)->queued.size(); });
+  return rc < 0 ? rc : n;
+}
+int gao_stream_processed_count(ga_context* ctx, int node) {
+  int n = 0;
+  int rc = guard(ctx, [&](Context& c) { n = (int)as<StreamNode>(getNode(c, node), GA_NODE_STREAM_SOURCE)->processed.size(); });
+  return rc < 0 ? rc : n;
 }
 int gao_oscillator_set_type(ga_context* ctx, int node, int oscillator_type) {
   return guard(ctx, [&](Context& c) {

@@ -95,3 +95,76 @@ def test_wav_impulse_response_and_voice_through_the_device_path():
     ref, got = outs
     assert G.rms(ref) > 1e-3
     assert G.rms(ref - got) <= 2e-6 * G.rms(ref)
+
+
+# ---- AIFF / AU containers (the other uncompressed formats libsndfile would decode) and the decoded stream feed ----
+class _KeepOpen(io.BytesIO):
+    """aifc / sunau close the file object they were given"""
+    def close(self):
+        pass
+
+
+def test_aiff_and_au_pcm16_decode_like_wav():
+    import aifc
+    import sunau
+    rng = np.random.default_rng(5)
+    data = rng.integers(-30000, 30000, size=(777, 2)).astype(np.int16)
+    a = _KeepOpen()
+    w = aifc.open(a, "wb")
+    w.setnchannels(2); w.setsampwidth(2); w.setframerate(44100)
+    w.writeframes(data.astype(">i2").tobytes())
+    w.close()
+    a = io.BytesIO(a.getvalue())
+    u = _KeepOpen()
+    w = sunau.open(u, "wb")
+    w.setcomptype("NONE", "not compressed")
+    w.setnchannels(2); w.setsampwidth(2); w.setframerate(44100)
+    w.writeframes(data.astype(">i2").tobytes())
+    w.close()
+    u = io.BytesIO(u.getvalue())
+    want = (data.astype(np.float32) / np.float32(32768.0)).T
+    for s in (a, u):
+        dec = AudioDecoder(s)
+        assert (dec.Channels, dec.SampleRate) == (2, 44100)
+        ch = [np.zeros(777, np.float32) for _ in range(2)]
+        assert dec.DecodePlanar(ch) == 777
+        assert np.array_equal(np.stack(ch), want)
+
+
+def test_aiff_24_bit_and_au_float():
+    import aifc
+    rng = np.random.default_rng(6)
+    v = rng.integers(-(1 << 23), 1 << 23, size=(300, 1)).astype(np.int32)
+    a = _KeepOpen()
+    w = aifc.open(a, "wb")
+    w.setnchannels(1); w.setsampwidth(3); w.setframerate(48000)
+    w.writeframes(v.astype(">i4").view(np.uint8).reshape(-1, 4)[:, 1:].tobytes())
+    w.close()
+    dec = AudioDecoder(io.BytesIO(a.getvalue()))
+    ch = [np.zeros(300, np.float32)]
+    assert dec.DecodePlanar(ch) == 300
+    assert np.array_equal(ch[0], (v[:, 0].astype(np.float32) / np.float32(8388608.0)))
+    x = rng.standard_normal((200, 2)).astype(np.float32)
+    au = struct.pack(">4sIIIII", b".snd", 24, x.size * 4, 6, 32000, 2) + x.astype(">f4").tobytes()
+    dec = AudioDecoder(io.BytesIO(au))
+    ch = [np.zeros(200, np.float32) for _ in range(2)]
+    assert dec.DecodePlanar(ch) == 200 and dec.SampleRate == 32000
+    assert np.array_equal(np.stack(ch), x.T)
+
+
+def test_decoded_stream_feed_plays_the_file_through_the_stream_node():
+    """queue_decoded_stream + AudioStreamSourceNode on the oracle: at the context's sample rate the stream node plays the file's
+    samples back to back (copy path, AudioStreamSourceNodeBase.cs:222-240)."""
+    from graphaudio_amd import AudioStreamSourceNode
+    from graphaudio_amd.io import queue_decoded_stream
+    rng = np.random.default_rng(7)
+    data = rng.integers(-20000, 20000, size=(10000, 1)).astype(np.int16)
+    ctx = OracleContext(48000)
+    s = AudioStreamSourceNode(ctx)
+    assert queue_decoded_stream(s, wav_pcm(data, 48000, 2), bufferSize=4096) == 3
+    s.Connect(ctx.Destination)
+    s.Play()
+    out = G.render(ctx, 2, 128 * 80)
+    want = data[:, 0].astype(np.float32) / np.float32(32768.0)
+    assert np.array_equal(out[0, :10000], want) and np.array_equal(out[1, :10000], want)
+    assert np.abs(out[:, 10000:]).max() == 0.0
