@@ -127,6 +127,18 @@ internal static unsafe partial class GraphAudioHip
     [LibraryImport(Lib, EntryPoint = "ga_synchronize")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]
     public static partial int ga_synchronize(IntPtr ctx);   // with option "async": waits for the enqueued renders
 
+    // ---- AudioStreamNodeBase with an explicit queue (GraphAudio.IO/AudioStreamSourceNodeBase.cs; node type 11) ----
+    [LibraryImport(Lib, EntryPoint = "ga_stream_queue_buffer")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]
+    public static partial int ga_stream_queue_buffer(IntPtr ctx, int node, int bufferId);          // QueueBuffer
+    [LibraryImport(Lib, EntryPoint = "ga_stream_set_state")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]
+    public static partial int ga_stream_set_state(IntPtr ctx, int node, int state);                // Play / Pause / Stop = 0 / 1 / 2
+    [LibraryImport(Lib, EntryPoint = "ga_stream_dequeue_processed")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]
+    public static partial int ga_stream_dequeue_processed(IntPtr ctx, int node, out int bufferId); // TryDequeueProcessedBuffer: 1 / 0
+    [LibraryImport(Lib, EntryPoint = "ga_stream_queued_count")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]
+    public static partial int ga_stream_queued_count(IntPtr ctx, int node);
+    [LibraryImport(Lib, EntryPoint = "ga_stream_processed_count")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]
+    public static partial int ga_stream_processed_count(IntPtr ctx, int node);
+
     // ---- sharded render: one context per GPU (threads of this process or one process per GPU), voices split with
     //      ga_shard_range, ONE RCCL sum of the destination bus per Render inside the library (include/graphaudio_hip.h) ----
     public const int GA_COMM_ID_BYTES = 128;
