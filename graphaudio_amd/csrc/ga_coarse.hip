@@ -92,6 +92,7 @@ __device__ __forceinline__ void coarse_issue_half(const CoarseXRow& R, int hw, i
   }
 }
 
+constexpr int kFwdPark = 4;         // values per thread parked in LDS across transform b (8 KB: what three workgroups per CU leave)
 constexpr int kFwdTw3 = 4 * 256;   // power twiddles of the last pass: W_4096^(j m), m = 1, 2, 4, 8 (ga_fft16.hpp, PW)
 __global__ __launch_bounds__(256, 3) void coarse_fwd_kernel(const CoarseXRow* __restrict rows, int run, float2* __restrict X,
                                                             const float2* __restrict twg, const float2* __restrict twab, int exp) {
@@ -100,6 +101,7 @@ __global__ __launch_bounds__(256, 3) void coarse_fwd_kernel(const CoarseXRow* __
   f2* tw2 = clds;
   f2* tw3 = clds + PL::T2;
   f2* buf = clds + PL::T2 + kFwdTw3;
+  f2* park = buf + CPAD;   // kFwdPark mirrored values of transform a per thread wait here while transform b runs (registers)
   const int t_ = threadIdx.x;
   for (int i = t_; i < PL::T2 + kFwdTw3; i += 256) clds[i] = f2{twg[i].x, twg[i].y};
   const CoarseXRow R = rows[blockIdx.y];
@@ -151,6 +153,7 @@ __global__ __launch_bounds__(256, 3) void coarse_fwd_kernel(const CoarseXRow* __
     for (int m = 0; m < 8; m++) {
       const int k = t + 256 * m;             // mirror 4096 - k >= 2049 sits at slot 2048 - k  (k = 0: Z[4096] = Z[0], own)
       pa[m] = k == 0 ? za[0] : buf[cpad(2048 - k)];
+      if (m >= 8 - kFwdPark) park[t + 256 * (m - (8 - kFwdPark))] = pa[m];
     }
     __syncthreads();          // mirrors fetched before transform b writes the buffer
     // ---- transform b ----
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(256, 3) void coarse_fwd_kernel(const CoarseXRow* __
 #pragma unroll
       for (int m = 0; m < 8; m++) {
         const f2 b = m == 0 ? tb0 : cmulc(tb0, f2{w64[m][0], w64[m][1]});
-        quad(t + 256 * m, za[m], pa[m], own[m], pb[m], b);
+        quad(t + 256 * m, za[m], m >= 8 - kFwdPark ? park[t + 256 * (m - (8 - kFwdPark))] : pa[m], own[m], pb[m], b);
         __builtin_amdgcn_sched_barrier(0);   // one quad at a time: the unrolled pass would otherwise keep all eight in flight
       }
       if (t == 0) quad(CM / 2, za8, za8, zb8, zb8, f2{twab[2049 + CM / 2].x, twab[2049 + CM / 2].y});
@@ -232,7 +235,7 @@ void launch_coarse_fwd(hipStream_t s, const CoarseXRow* rows_dev, int nrows, int
                        const float2* twab) {
   if (nrows <= 0 || max_frames <= 0) return;
   using PL = R16Plan<CM>;
-  const size_t lds = (size_t)(PL::T2 + kFwdTw3 + CPAD) * sizeof(float2);
+  const size_t lds = (size_t)(PL::T2 + kFwdTw3 + CPAD + kFwdPark * 256) * sizeof(float2);
   if (hipFuncSetAttribute((const void*)coarse_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     launch_fail("cannot raise the dynamic LDS limit of the coarse forward transform");
   static const int exp = getenv("GA_COARSE_EXP") ? atoi(getenv("GA_COARSE_EXP")) : 0;   // timing experiments only
