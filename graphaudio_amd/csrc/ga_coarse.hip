@@ -94,8 +94,11 @@ __device__ __forceinline__ void coarse_issue_half(const CoarseXRow& R, int hw, i
 
 constexpr int kFwdPark = 4;         // values per thread parked in LDS across transform b (8 KB: what three workgroups per CU leave)
 constexpr int kFwdTw3 = 4 * 256;   // power twiddles of the last pass: W_4096^(j m), m = 1, 2, 4, 8 (ga_fft16.hpp, PW)
+// EXPERIMENT: the phase-removal timing variants of tools/coarse_exp.sh (run-time flags `exp_`); the product kernel has none
+template <bool EXPERIMENT>
 __global__ __launch_bounds__(256, 3) void coarse_fwd_kernel(const CoarseXRow* __restrict rows, int run, float2* __restrict X,
-                                                            const float2* __restrict twg, const float2* __restrict twab, int exp) {
+                                                            const float2* __restrict twg, const float2* __restrict twab, int exp_) {
+  const int exp = EXPERIMENT ? exp_ : 0;
   using PL = R16Plan<CM>;
   extern __shared__ f2 clds[];
   f2* tw2 = clds;
@@ -110,12 +113,13 @@ __global__ __launch_bounds__(256, 3) void coarse_fwd_kernel(const CoarseXRow* __
   if (w0 >= w1) return;   // (uniform)
   // combine-pass twiddles of this thread's bins k = t + 256 m: b = W_16384^k = W_16384^t W_64^m (and W_8192^k = b^2); only
   // W_16384^t lives in registers, the eight W_64^m are literals
-  const f2 tb0 = f2{twab[2049 + t_].x, twab[2049 + t_].y};
+  // (fetched per window, next to the prefetch: held across the loop it is spilled to scratch and reloaded from there instead)
   const bool zero2 = (R.flags & 1) != 0;   // impulse-response partitions: [h_p | 0]
   const float scale = R.scale;
   // Every input sample is fetched ONCE per run, as part of a 16-byte word that holds one point of each transform: a window's
   // second half (held as 8 words) is the next window's first half, and the half after that is requested between the two
   // transforms of the current window (not earlier: its 32 registers would be live during transform a as well)
+  const int wave64 = __builtin_amdgcn_readfirstlane(t_ & ~63);
   v4f first[8], second[8];
   coarse_issue_half(R, R.u0 + w0 - 1, t_, first);
   if (zero2) {
@@ -128,7 +132,8 @@ __global__ __launch_bounds__(256, 3) void coarse_fwd_kernel(const CoarseXRow* __
   for (int w = w0; w < w1; w++) {
     // the thread index is made opaque per window: otherwise every loop-invariant address of the unrolled body (LDS slots,
     // store offsets of the 32 output bins, prefetch offsets) is hoisted out of the loop and held in ~100 registers
-    int t = t_;
+    // -- and it is rebuilt from the lane and wave numbers, or the allocator spills threadIdx.x itself and reloads it per window
+    int t = wave64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     asm volatile("" : "+v"(t));
     const int u = R.u0 + w;
     const bool more = w + 1 < w1;
@@ -139,20 +144,27 @@ __global__ __launch_bounds__(256, 3) void coarse_fwd_kernel(const CoarseXRow* __
       own[m] = f2{first[m].x * scale, first[m].y * scale};
       own[8 + m] = f2{second[m].x * scale, second[m].y * scale};
     }
-    if (!(exp & 4)) fft16_own<CM, true>(own, buf, tw2, tw3, t);
+    // each transform sits in its own basic block (a branch on an opaque, always-true scalar): as straight-line code the
+    // scheduler drags values of the neighbouring phases over the transform and the allocator spills them to scratch
+    int go = 1;
+    asm volatile("" : "+s"(go));
+    if (go && !(exp & 4)) fft16_own<CM, true>(own, buf, tw2, tw3, t);
     f2 za[8], pa[8];
     const f2 za8 = own[8];   // Z_a[2048] (thread 0)
     __syncthreads();          // the last pass has read the buffer
+    // LDS slots of the exchange: cpad(t + 256 m) = cpad(t) + 264 m and cpad(2048 - t - 256 m) = cpad(2048 - t) - 264 m (256 m is
+    // a multiple of 32), written as one base each plus immediates -- the compiler does not see it through the shifts
+    const int xw = cpad(t), xr = cpad(2048 - t) - 264 * 7;
 #pragma unroll
     for (int m = 0; m < 8; m++) {
       za[m] = own[m];
-      buf[cpad(t + 256 * m)] = own[8 + m];   // Z[j], j >= 2048, at slot j - 2048
+      buf[xw + 264 * m] = own[8 + m];   // Z[j], j >= 2048, at slot j - 2048
     }
     __syncthreads();
 #pragma unroll
     for (int m = 0; m < 8; m++) {
       const int k = t + 256 * m;             // mirror 4096 - k >= 2049 sits at slot 2048 - k  (k = 0: Z[4096] = Z[0], own)
-      pa[m] = k == 0 ? za[0] : buf[cpad(2048 - k)];
+      pa[m] = k == 0 ? za[0] : buf[xr + 264 * (7 - m)];
       if (m >= 8 - kFwdPark) park[t + 256 * (m - (8 - kFwdPark))] = pa[m];
     }
     __syncthreads();          // mirrors fetched before transform b writes the buffer
@@ -162,20 +174,23 @@ __global__ __launch_bounds__(256, 3) void coarse_fwd_kernel(const CoarseXRow* __
       own[m] = f2{first[m].z * scale, first[m].w * scale};
       own[8 + m] = f2{second[m].z * scale, second[m].w * scale};
     }
-    if (!(exp & 4)) fft16_own<CM, true>(own, buf, tw2, tw3, t);
+    asm volatile("" : "+s"(go));
+    if (go && !(exp & 4)) fft16_own<CM, true>(own, buf, tw2, tw3, t);
     f2 pb[8];
     const f2 zb8 = own[8];
     __syncthreads();
 #pragma unroll
-    for (int m = 0; m < 8; m++) buf[cpad(t + 256 * m)] = own[8 + m];
+    for (int m = 0; m < 8; m++) buf[xw + 264 * m] = own[8 + m];
     __syncthreads();
 #pragma unroll
     for (int m = 0; m < 8; m++) {
       const int k = t + 256 * m;
-      pb[m] = k == 0 ? own[0] : buf[cpad(2048 - k)];
+      pb[m] = k == 0 ? own[0] : buf[xr + 264 * (7 - m)];
     }
     // the window moves on: `second` becomes the first half, the half after it is requested now (not earlier: its 32 registers
     // would be live during the transforms) and arrives behind the combine pass and the next window's first transform
+    const float2 tb0g = twab[2049 + t];
+    const f2 tb0 = f2{tb0g.x, tb0g.y};
     if (more) {
       if (zero2) {
         if (!(exp & 8)) coarse_issue_half(R, u, t, first);
@@ -236,13 +251,14 @@ void launch_coarse_fwd(hipStream_t s, const CoarseXRow* rows_dev, int nrows, int
   if (nrows <= 0 || max_frames <= 0) return;
   using PL = R16Plan<CM>;
   const size_t lds = (size_t)(PL::T2 + kFwdTw3 + CPAD + kFwdPark * 256) * sizeof(float2);
-  if (hipFuncSetAttribute((const void*)coarse_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+  static const int exp = (getenv("GA_COARSE_EXP") ? atoi(getenv("GA_COARSE_EXP")) : 0) & 15;   // timing experiments only
+  auto kern = exp ? coarse_fwd_kernel<true> : coarse_fwd_kernel<false>;
+  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     launch_fail("cannot raise the dynamic LDS limit of the coarse forward transform");
-  static const int exp = getenv("GA_COARSE_EXP") ? atoi(getenv("GA_COARSE_EXP")) : 0;   // timing experiments only
   run = std::max(run, 1);
   for (int r0 = 0; r0 < nrows; r0 += 32768) {
     dim3 grid((max_frames + run - 1) / run, std::min(32768, nrows - r0));
-    hipLaunchKernelGGL(coarse_fwd_kernel, grid, dim3(256), lds, s, rows_dev + r0, run, X, tw16, twab, exp & 15);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, rows_dev + r0, run, X, tw16, twab, exp);
   }
 }
 

@@ -191,15 +191,21 @@ __device__ __forceinline__ void fft16_own(f2 (&own)[16], f2* __restrict buf, con
       for (int m = 0; m < R3; m++) v[m] = buf[b2 + (T + T / 32) * u + 264 * m];
       if constexpr (PW) {
         static_assert(!PW || R3 == 16, "power twiddles: 4096 points only");
-        const f2 w1 = tw3[j], w2 = tw3[256 + j], w4 = tw3[512 + j], w8 = tw3[768 + j];
-        const f2 w3 = cmulp(w1, w2), w5 = cmulp(w4, w1), w6 = cmulp(w4, w2), w7 = cmulp(w4, w3);
-        v[1] = cmulp(v[1], w1); v[2] = cmulp(v[2], w2); v[3] = cmulp(v[3], w3); v[4] = cmulp(v[4], w4);
-        v[5] = cmulp(v[5], w5); v[6] = cmulp(v[6], w6); v[7] = cmulp(v[7], w7); v[8] = cmulp(v[8], w8);
+        // W^(j m) = W^(j (m & 12)) W^(j (m & 3)): only W^j, W^2j, W^3j stay live; the group base (W^4j, W^8j, W^12j) comes and goes
+        const f2 w1 = tw3[j], w2 = tw3[256 + j];
+        const f2 w3 = cmulp(w1, w2);
+        v[1] = cmulp(v[1], w1); v[2] = cmulp(v[2], w2); v[3] = cmulp(v[3], w3);
         __builtin_amdgcn_sched_barrier(0);
-        v[9] = cmulp(v[9], cmulp(w8, w1)); v[10] = cmulp(v[10], cmulp(w8, w2)); v[11] = cmulp(v[11], cmulp(w8, w3));
-        v[12] = cmulp(v[12], cmulp(w8, w4)); v[13] = cmulp(v[13], cmulp(w8, w5)); v[14] = cmulp(v[14], cmulp(w8, w6));
-        v[15] = cmulp(v[15], cmulp(w8, w7));
-        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 1; g < 4; g++) {
+          const f2 w4 = tw3[512 + j];
+          const f2 b = g == 1 ? w4 : g == 2 ? tw3[768 + j] : cmulp(tw3[768 + j], w4);
+          v[4 * g] = cmulp(v[4 * g], b);
+          v[4 * g + 1] = cmulp(v[4 * g + 1], cmulp(b, w1));
+          v[4 * g + 2] = cmulp(v[4 * g + 2], cmulp(b, w2));
+          v[4 * g + 3] = cmulp(v[4 * g + 3], cmulp(b, w3));
+          __builtin_amdgcn_sched_barrier(0);
+        }
       } else {
 #pragma unroll
       for (int q = 0; q < R3 / 4; q++) {
