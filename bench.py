@@ -189,6 +189,7 @@ def main():
     ap.add_argument("--direct", action="store_true", help="direct (matrix-core) partition sum, formulation A")
     ap.add_argument("--no-coarse", action="store_true", help="formulation C (block-axis FFT) instead of D (coarse partitions)")
     ap.add_argument("--overlap", action="store_true", help="formulation D: forward and multiply-accumulate stages concurrently on two streams (measured slower)")
+    ap.add_argument("--copy-stream", action="store_true", help="hand the bus to the host on a copy stream of its own (measurement)")
     ap.add_argument("--sync-steps", action="store_true", help="one blocking render per step (no host/device pipelining)")
     ap.add_argument("--force-dist", action="store_true", help="exercise the sharded-render path (ga_render_reduce) even with one rank")
     args = ap.parse_args()
@@ -231,6 +232,8 @@ def main():
         ctx.SetOption("coarse", 0)
     if args.overlap:
         ctx.SetOption("coarse_overlap", 1)
+    if args.copy_stream:
+        ctx.SetOption("host_copy_stream", 1)
     build_graph(ctx, v1 - v0, v0, args.taps, frames, G)
     if use_reduce:
         init_sharded(ctx, rank, world)

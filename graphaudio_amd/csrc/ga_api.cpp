@@ -194,6 +194,7 @@ void Context::render(float* const* out, int channels, int64_t frameCount, int64_
     const bool blocking;
     ~Drain() {
       if (blocking && c.stream) (void)hipStreamSynchronize(c.stream);
+      if (blocking && c.copyStream) (void)hipStreamSynchronize(c.copyStream);
     }
   } drain{*this, !pipelined.callerAsync};
   int64_t written = 0;
@@ -219,8 +220,12 @@ void Context::render(float* const* out, int channels, int64_t frameCount, int64_
     if (channels > chunkMinDestCh) fail(GA_ERR_OUT_OF_RANGE, "channelIndex");
     const int64_t chunkFrames = done * kBlock;
     const int64_t toCopy = std::min(chunkFrames, need);
-    for (int ch = 0; ch < channels; ch++)
-      GA_HIP(hipMemcpyAsync(out[ch] + startIndex + written, busSlabs[ch], sizeof(float) * toCopy, kind, stream));
+    if (!deviceOut && ownStream && pipelined.callerAsync && hostCopyStream) {
+      handOverToHost(busSlabs.data(), out, channels, startIndex + written, toCopy);
+    } else {
+      for (int ch = 0; ch < channels; ch++)
+        GA_HIP(hipMemcpyAsync(out[ch] + startIndex + written, busSlabs[ch], sizeof(float) * toCopy, kind, stream));
+    }
     const int64_t excess = chunkFrames - toCopy;  // < 128: only the last block can be partial (:89-100)
     if (excess > 0) {
       cachedCh = chunkMinDestCh;
@@ -307,6 +312,7 @@ int ga_set_option(ga_context* ctx, const char* key, double value) {
     }
     else if (k == "coarse") c.useCoarse = value != 0;
     else if (k == "coarse_overlap") c.coarseOverlap = value != 0;
+    else if (k == "host_copy_stream") c.hostCopyStream = value != 0;
     else if (k == "coarse_min_blocks") c.coarseMinBlocks = std::max<int64_t>(1, (int64_t)value);
     else if (k == "debug_tconv_n2") c.debugTconvN2 = (int)value;   // tests only: plan the block-axis FFT with this (possibly unsupported) length
     else if (k == "mem_budget_fraction") c.memBudgetFraction = std::min(0.95, std::max(0.05, value));
@@ -331,6 +337,7 @@ int ga_synchronize(ga_context* ctx) {
 int ga_context_set_stream(ga_context* ctx, void* hip_stream) {
   return guard(ctx, [&](Context& c) {
     GA_HIP(hipStreamSynchronize(c.stream));
+    c.waitHostCopies();
     if (c.ownStream && c.stream) (void)hipStreamDestroy(c.stream);
     c.stream = (hipStream_t)hip_stream;
     c.ownStream = false;

@@ -1539,7 +1539,7 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
   for (int g = 1; g <= G; g++) gBegin[g] = std::max(gBegin[g], gBegin[g - 1]);
   std::vector<CoarseTerm> terms;
   std::vector<CoarseJob> jobs[3][8];       // by column count 1, 2, 4 and by the group whose transforms complete the job's inputs
-  int maxT[3] = {0, 0, 0}, maxP[3] = {0, 0, 0}, pbOf[3] = {4, 4, 4};   // pbOf: largest of 4, 2, 1 dividing every job's partition count
+  int maxT[3] = {0, 0, 0}, maxP[3] = {0, 0, 0}, pbOf[3] = {16, 16, 4};   // pbOf: largest of (16, 8,) 4, 2, 1 dividing every job's partition count
   bool anyPrivate[3] = {false, false, false};
   double macBytes[3][8] = {};
   std::map<std::pair<int, int>, std::vector<int>> outRows;   // (leader, channel) -> Y rows to sum

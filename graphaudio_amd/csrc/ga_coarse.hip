@@ -281,11 +281,13 @@ void launch_coarse_fwd(hipStream_t s, const CoarseXRow* rows_dev, int nrows, int
 constexpr int kMacWaves = GA_MAC_WAVES;      // waves per workgroup: each takes 1/kMacWaves of the job's coarse blocks
 constexpr int kMacThreads = 64 * kMacWaves;
 constexpr int kMacWavesPerSimd = kMacWaves / 2;   // two workgroups per CU (LDS), four SIMDs
-template <int CW, int TW, int PB>
+// HF: every job of the launch has exactly PB partitions and one impulse response for all its terms -- the PB x CW spectra of a
+// lane's bin then stay in registers for the whole job and the sweep reads only X frames from LDS, once per term.
+template <int CW, int TW, int PB, bool HF>
 __global__ __launch_bounds__(kMacThreads, kMacWavesPerSimd) void coarse_mac_kernel(const CoarseJob* __restrict jobs, const CoarseTerm* __restrict terms,
                                                                     const float2* __restrict X, float2* __restrict Y, int y_frames, int NFA,
                                                                     int exp) {
-  extern __shared__ f2 mlds[];
+  extern __shared__ f2 mlds[];   // (ALL of the kernel's LDS is this one array: a second object beside a direct-to-LDS target costs a vmcnt(0) per read)
   const CoarseJob J = jobs[blockIdx.y];
   const int tile = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -302,31 +304,27 @@ __global__ __launch_bounds__(kMacThreads, kMacWavesPerSimd) void coarse_mac_kern
   const bool lane0 = special && lane == 0;
   const size_t binoff = (size_t)tile * 64;
 
-  // staging of one term: NF x 32 float4 of X (+ P x CW x 32 float4 of H)
-  constexpr int XR = ((kMacWaves * TW + kCoarseMaxP) * 32 + kMacThreads - 1) / kMacThreads;  // float4 per thread that cover NF <= kMacWaves TW + P - 1 frames
-  v4f xr[XR];
-  auto issue_x = [&](const CoarseTerm& T) {
+  // staging of one term: NF x 32 float4 of X (+ P x CW x 32 float4 of H), global memory -> LDS directly (global_load_lds_dwordx4:
+  // no staging registers, no ds_write pass).  One wave instruction moves two consecutive 512-byte rows: the LDS image is
+  // linear in the lane (destination = wave-uniform base + 16 lane), the source address is per lane.
+  typedef __attribute__((address_space(3))) void* lds_t;
+  constexpr int XR = ((kMacWaves * TW + kCoarseMaxP) * 32 + kMacThreads - 1) / kMacThreads;  // instructions per wave that cover NF <= kMacWaves TW + P - 1 frames
+  auto issue_x = [&](const CoarseTerm& T, f2* xs) {
 #pragma unroll
     for (int r = 0; r < XR; r++) {
-      const int idx = tid + kMacThreads * r;
-      const int fr = idx >> 5, of = idx & 31;
-      xr[r] = v4f{0.f, 0.f, 0.f, 0.f};
-      if (fr < NF) xr[r] = ldg4(X + (size_t)(T.frame0 + J.t0 + fr) * kCoarseBins + binoff + 2 * of);
+      const int fr0 = (kMacThreads / 32) * r + 2 * wv;   // (uniform)
+      const int fr = fr0 + (lane >> 5), of = lane & 31;
+      if (fr < NF)
+        __builtin_amdgcn_global_load_lds(gptr(X + (size_t)(T.frame0 + J.t0 + fr) * kCoarseBins + binoff + 2 * of), (lds_t)(xs + fr0 * 64), 16, 0, 0);
     }
   };
-  auto commit_x = [&](f2* xs) {
-#pragma unroll
-    for (int r = 0; r < XR; r++) {
-      const int idx = tid + kMacThreads * r;
-      const int fr = idx >> 5, of = idx & 31;
-      if (fr < NF) *reinterpret_cast<v4f*>(xs + fr * 64 + 2 * of) = xr[r];
-    }
-  };
-  auto load_h = [&](const CoarseTerm& T, f2* hs) {   // straight to LDS (small: P x CW x 512 bytes)
-    for (int idx = tid; idx < P * CW * 32; idx += kMacThreads) {
-      const int pc = idx >> 5, of = idx & 31;
-      const int p = pc / CW, c = pc % CW;
-      *reinterpret_cast<v4f*>(hs + pc * 64 + 2 * of) = ldg4(T.h[c] + (size_t)p * kCoarseBins + binoff + 2 * of);
+  auto issue_h = [&](const CoarseTerm& T, f2* hs) {   // P x CW rows of 512 bytes
+    for (int pc0 = 2 * wv; pc0 < P * CW; pc0 += 2 * kMacWaves) {
+      const int pc = pc0 + (lane >> 5), of = lane & 31;
+      if (pc < P * CW) {
+        const int p = pc / CW, c = pc % CW;
+        __builtin_amdgcn_global_load_lds(gptr(T.h[c] + (size_t)p * kCoarseBins + binoff + 2 * of), (lds_t)(hs + pc0 * 64), 16, 0, 0);
+      }
     }
   };
 
@@ -337,56 +335,75 @@ __global__ __launch_bounds__(kMacThreads, kMacWavesPerSimd) void coarse_mac_kern
     for (int c = 0; c < CW; c++) acc[tt][c] = f2{0.f, 0.f};
 
   const CoarseTerm* __restrict T = terms + J.term0;
-  issue_x(T[0]);
-  load_h(T[0], hs0);
-  commit_x(xs0);
-  __syncthreads();
+  issue_x(T[0], xs0);
+  issue_h(T[0], hs0);
+  __syncthreads();   // (waits for the workgroup's direct-to-LDS loads: the barrier's fence includes vmcnt(0))
+  f2 hfix[HF ? PB : 1][CW];
+  if constexpr (HF) {
+#pragma unroll
+    for (int j = 0; j < PB; j++)
+#pragma unroll
+      for (int c = 0; c < CW; c++) hfix[j][c] = hs0[(j * CW + c) * 64 + lane];
+  }
   for (int i = 0; i < J.n_terms; i++) {
     const bool more = i + 1 < J.n_terms;
     f2* xs = (i & 1) ? xs1 : xs0;
     f2* hs = (J.shared_h || !(i & 1)) ? hs0 : hs1;
-    if (more && !(exp & 2)) issue_x(T[i + 1]);
+    // the next term lands in the other buffers while this one is accumulated (their last readers passed the barrier below)
+    if (more && !(exp & 2)) {
+      issue_x(T[i + 1], (i & 1) ? xs0 : xs1);
+      if (!J.shared_h) issue_h(T[i + 1], (i & 1) ? hs0 : hs1);
+    }
     if (t0w < nT && !(exp & 1)) {
       // blocks of PB partitions (P is a multiple of PB): their spectra sit in registers, and the frames b - (PB - 1) .. b +
       // TW - 1 of the sweep (b = frame of (tt = 0, j = 0); (tt, j) uses frame b + tt - j) are requested up front: one LDS
       // latency per block of partitions, then the block is pure VALU with j outermost, so that consecutive fmas belong to
       // different accumulators.  `SP` (tile 0: lane 0 holds two real bins) is a compile-time copy of the loop: as a run-time
       // flag inside the unrolled body the compiler evaluates both products for every tile.
-      auto sweep = [&](auto sp) {
-        constexpr bool SP = decltype(sp)::value;
-        for (int pb = 0; pb < P; pb += PB) {
-          f2 h[PB][CW];
+      auto sweep = [&](auto sp, auto hf, auto pbx) {
+        constexpr bool SP = decltype(sp)::value, HR = decltype(hf)::value;   // HR: spectra from the job-long registers
+        constexpr int PBX = decltype(pbx)::value;
+        for (int pb = 0; pb < (HR ? PBX : P); pb += PBX) {
+          f2 hl[HR ? 1 : PBX][CW];
+          if constexpr (!HR) {
 #pragma unroll
-          for (int j = 0; j < PB; j++)
+            for (int j = 0; j < PBX; j++)
 #pragma unroll
-            for (int c = 0; c < CW; c++) h[j][c] = hs[((pb + j) * CW + c) * 64 + lane];
-          const f2* __restrict xb = xs + (t0w + (P - 1) - pb - (PB - 1)) * 64 + lane;   // (pb + PB - 1 <= P - 1: inside the buffer)
-          f2 xv[TW + PB - 1];
+              for (int c = 0; c < CW; c++) hl[j][c] = hs[((pb + j) * CW + c) * 64 + lane];
+          }
+          const f2* __restrict xb = xs + (t0w + (P - 1) - pb - (PBX - 1)) * 64 + lane;   // (pb + PBX - 1 <= P - 1: inside the buffer)
+          f2 xv[TW + PBX - 1];
 #pragma unroll
-          for (int q = 0; q < TW + PB - 1; q++) xv[q] = xb[q * 64];
+          for (int q = 0; q < TW; q++) xv[q] = xb[q * 64];
+          // j runs from the oldest frames up: step j needs the frames (PBX - 1 - j) .. (PBX - 1 - j) + TW - 1, one more than the
+          // step before -- requested a step ahead, so that only TW + 1 frames are live (all TW + PBX - 1 at once spill)
 #pragma unroll
-          for (int j = 0; j < PB; j++)
+          for (int jj = 0; jj < PBX; jj++) {
+            const int j = PBX - 1 - jj;
+            if (jj + 1 < PBX) xv[TW + jj] = xb[(TW + jj) * 64];
 #pragma unroll
             for (int tt = 0; tt < TW; tt++)
 #pragma unroll
               for (int c = 0; c < CW; c++) {
-                const f2 x = xv[tt - j + (PB - 1)];
+                const f2 x = xv[tt - j + (PBX - 1)];
+                f2 h;
+                if constexpr (HR) h = hfix[j][c];
+                else h = hl[j][c];
                 if constexpr (!SP) {
-                  acc[tt][c] = cfmap(x, h[j][c], acc[tt][c]);
+                  acc[tt][c] = cfmap(x, h, acc[tt][c]);
                 } else {
-                  const f2 gen = cfmap(x, h[j][c], acc[tt][c]);
-                  const f2 pk = __builtin_elementwise_fma(x, h[j][c], acc[tt][c]);   // two real bins side by side
+                  const f2 gen = cfmap(x, h, acc[tt][c]);
+                  const f2 pk = __builtin_elementwise_fma(x, h, acc[tt][c]);   // two real bins side by side
                   acc[tt][c] = lane0 ? pk : gen;
                 }
               }
+            if constexpr (PBX > 2) __builtin_amdgcn_sched_barrier(0);
+          }
         }
       };
-      if (special) sweep(std::true_type{});
-      else sweep(std::false_type{});
-    }
-    if (more) {
-      commit_x((i & 1) ? xs0 : xs1);
-      if (!J.shared_h) load_h(T[i + 1], (i & 1) ? hs0 : hs1);
+      // tile 0 (one workgroup in 128) takes the plain one-partition-at-a-time loop when the others run on job-long registers
+      if (special) sweep(std::true_type{}, std::false_type{}, std::integral_constant<int, HF ? 1 : PB>{});
+      else sweep(std::false_type{}, std::integral_constant<bool, HF>{}, std::integral_constant<int, PB>{});
     }
     __syncthreads();
   }
@@ -401,7 +418,152 @@ __global__ __launch_bounds__(kMacThreads, kMacWavesPerSimd) void coarse_mac_kern
   }
 }
 
-template <int CW, int TW, int PB>
+// ---------------------------------------------------------------------------------------------------------------------
+//  The same multiply-accumulate for launches whose jobs all have exactly PB partitions and one impulse response for all
+//  terms (the common case: many voices through one room): ONE workgroup of 16 waves per CU and THREE X buffers.
+//    * the PB x CW spectra of a lane's bin are read once and stay in registers for the whole job;
+//    * two terms are always in flight: term i + 2 is requested before term i is accumulated and only term i + 1 is waited
+//      for at the end of the step (counted vmcnt, raw barrier: __syncthreads() would drain the queue) -- with two buffers
+//      the memory pipe ran empty once per term and the kernel's time was the SUM of its load and its VALU time;
+//    * a wave takes 4 coarse blocks (16 x 4 = the job's 64), slides over TW + PB - 1 frames and keeps TW + 1 of them live.
+//  Tile 0, lane 0 (the packed pair of real bins) accumulates the element-wise products beside the complex ones.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kMac16Waves = 16, kMac16Threads = 64 * kMac16Waves, kMac16TW = 4;
+constexpr int kMac16XR = ((kMac16Waves * kMac16TW + kCoarseMaxP) * 32 + kMac16Threads - 1) / kMac16Threads;   // load instructions per wave and term (3)
+template <int CW, int PB>
+__global__ __launch_bounds__(kMac16Threads) void coarse_mac16_kernel(const CoarseJob* __restrict jobs, const CoarseTerm* __restrict terms,
+                                                                    const float2* __restrict X, float2* __restrict Y, int y_frames, int NFA, int exp) {
+  constexpr int TW = kMac16TW, XR = kMac16XR;
+  static_assert(XR == 3, "the counted waits below are written for three load instructions per wave and term");
+  extern __shared__ f2 mlds[];   // (all of the kernel's LDS is this one array)
+  const CoarseJob J = jobs[blockIdx.y];
+  const int tile = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nT = J.n_t, NF = nT + PB - 1, nterms = J.n_terms;
+  const int twr = (nT + kMac16Waves - 1) / kMac16Waves, t0w = wv * twr;
+  const bool special = tile == 0, lane0 = special && lane == 0;
+  const size_t binoff = (size_t)tile * 64;
+  typedef __attribute__((address_space(3))) void* lds_t;
+  f2* b0 = mlds;
+  f2* b1 = mlds + (size_t)NFA * 64;
+  f2* b2 = mlds + (size_t)2 * NFA * 64;
+  int mine = 0;   // load instructions this wave issues per term (rows 32 r + 2 wv + {0, 1})
+#pragma unroll
+  for (int r = 0; r < XR; r++) mine += (32 * r + 2 * wv < NF) ? 1 : 0;
+  auto issue_x = [&](const CoarseTerm& T, f2* xs) {
+#pragma unroll
+    for (int r = 0; r < XR; r++) {
+      const int fr0 = 32 * r + 2 * wv;   // (uniform)
+      const int fr = fr0 + (lane >> 5), of = lane & 31;
+      if (fr < NF)
+        __builtin_amdgcn_global_load_lds(gptr(X + (size_t)(T.frame0 + J.t0 + fr) * kCoarseBins + binoff + 2 * of), (lds_t)(xs + fr0 * 64), 16, 0, 0);
+    }
+  };
+  const CoarseTerm* __restrict T = terms + J.term0;
+  {   // the impulse response's PB x CW rows pass through the third buffer
+    const int pc0 = 2 * wv, pc = pc0 + (lane >> 5), of = lane & 31;
+    if (pc < PB * CW)
+      __builtin_amdgcn_global_load_lds(gptr(T[0].h[pc % CW] + (size_t)(pc / CW) * kCoarseBins + binoff + 2 * of), (lds_t)(b2 + pc0 * 64), 16, 0, 0);
+    static_assert(PB * CW <= 2 * kMac16Waves, "one load instruction per wave covers the impulse response");
+  }
+  if (!(exp & 2)) {
+    issue_x(T[0], b0);
+    if (nterms > 1) issue_x(T[1], b1);
+  }
+  __syncthreads();   // (its fence waits for the direct-to-LDS loads: vmcnt(0))
+  f2 h[PB][CW];
+#pragma unroll
+  for (int j = 0; j < PB; j++)
+#pragma unroll
+    for (int c = 0; c < CW; c++) h[j][c] = b2[(j * CW + c) * 64 + lane];
+  __syncthreads();   // every wave holds its spectra: the buffer may take X frames
+  f2 acc[TW][CW], accS[TW][CW];
+#pragma unroll
+  for (int tt = 0; tt < TW; tt++)
+#pragma unroll
+    for (int c = 0; c < CW; c++) acc[tt][c] = accS[tt][c] = f2{0.f, 0.f};
+
+  for (int i = 0; i < nterms; i++) {
+    const bool ahead = i + 2 < nterms && !(exp & 2);
+    if (ahead) issue_x(T[i + 2], b2);   // (b2's last readers passed the barrier of step i - 1)
+    if (t0w < nT && !(exp & 1)) {
+      auto sweep = [&](auto sp) {
+        constexpr bool SP = decltype(sp)::value;
+        const f2* __restrict xb = b0 + t0w * 64 + lane;
+        f2 xv[TW + PB - 1];
+#pragma unroll
+        for (int q = 0; q < TW; q++) xv[q] = xb[q * 64];
+        // j runs from the oldest frames up; the one new frame of the next step is requested a step ahead
+#pragma unroll
+        for (int jj = 0; jj < PB; jj++) {
+          const int j = PB - 1 - jj;
+          if (jj + 1 < PB) xv[TW + jj] = xb[(TW + jj) * 64];
+#pragma unroll
+          for (int tt = 0; tt < TW; tt++)
+#pragma unroll
+            for (int c = 0; c < CW; c++) {
+              const f2 x = xv[tt - j + (PB - 1)];
+              acc[tt][c] = cfmap(x, h[j][c], acc[tt][c]);
+              if constexpr (SP) accS[tt][c] = __builtin_elementwise_fma(x, h[j][c], accS[tt][c]);   // two real bins side by side
+            }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      if (special) sweep(std::true_type{});
+      else sweep(std::false_type{});
+    }
+    // term i + 1 must have landed (and every wave must be done reading b0) before the next step; the loads just issued stay
+    // in flight across the barrier
+    const int keep = ahead ? mine : 0;
+    if (keep >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (keep == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (keep == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    f2* t = b0;
+    b0 = b1;
+    b1 = b2;
+    b2 = t;
+  }
+#pragma unroll
+  for (int tt = 0; tt < TW; tt++) {
+    const int t = t0w + tt;
+    if (tt < twr && t < nT && !(exp & 4)) {
+#pragma unroll
+      for (int c = 0; c < CW; c++) {
+        const f2 a = lane0 ? accS[tt][c] : acc[tt][c];
+        stg2(Y + ((size_t)(J.yrow0 + c) * y_frames + J.t0 + t) * kCoarseBins + binoff + lane, v2f{a.x, a.y});
+      }
+    }
+  }
+}
+
+template <int CW, int PB>
+static void launch_coarse_mac16(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
+                                int y_frames, int max_t) {
+  static const int exp = getenv("GA_COARSE_EXP") ? atoi(getenv("GA_COARSE_EXP")) : 0;   // timing experiments only
+  int NFA = PB * CW;   // (the impulse response passes through one buffer)
+  for (int nt = 1; nt <= max_t; nt++) {
+    const int twr = (nt + kMac16Waves - 1) / kMac16Waves, wl = (nt + twr - 1) / twr - 1;
+    NFA = std::max(NFA, wl * twr + kMac16TW + PB - 1);
+  }
+  const size_t lds = (size_t)3 * NFA * 64 * sizeof(float2);
+  if (lds > 160 * 1024) launch_fail("coarse multiply-accumulate: staging does not fit the LDS");
+  if (hipFuncSetAttribute((const void*)coarse_mac16_kernel<CW, PB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(lds, 65536)) !=
+      hipSuccess)
+    launch_fail("cannot raise the dynamic LDS limit of the coarse multiply-accumulate");
+  if (getenv("GA_COARSE_EXP")) {
+    int occ = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, coarse_mac16_kernel<CW, PB>, kMac16Threads, lds);
+    fprintf(stderr, "[coarse_mac16<%d,%d>] lds %zu B, NFA %d, occupancy %d workgroups/CU, %d jobs\n", CW, PB, lds, NFA, occ, njobs);
+  }
+  for (int j0 = 0; j0 < njobs; j0 += 32768)
+    hipLaunchKernelGGL((coarse_mac16_kernel<CW, PB>), dim3(kCoarseBins / 64, std::min(32768, njobs - j0)), dim3(kMac16Threads), lds, s, jobs_dev + j0,
+                       terms_dev, X, Y, y_frames, NFA, exp >> 4);
+}
+
+template <int CW, int TW, int PB, bool HF = false>
 static void launch_coarse_mac_t(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
                                 int y_frames, int max_t, int maxP, bool any_private) {
   static const int exp = getenv("GA_COARSE_EXP") ? atoi(getenv("GA_COARSE_EXP")) : 0;   // timing experiments only
@@ -413,16 +575,16 @@ static void launch_coarse_mac_t(hipStream_t s, const CoarseJob* jobs_dev, int nj
   }
   const size_t lds = ((size_t)2 * NFA * 64 + (size_t)(any_private ? 2 : 1) * maxP * CW * 64) * sizeof(float2);
   if (lds > 160 * 1024) launch_fail("coarse multiply-accumulate: staging does not fit the LDS");
-  if (hipFuncSetAttribute((const void*)coarse_mac_kernel<CW, TW, PB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  if (hipFuncSetAttribute((const void*)coarse_mac_kernel<CW, TW, PB, HF>, hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)std::max<size_t>(lds, 65536)) != hipSuccess)
     launch_fail("cannot raise the dynamic LDS limit of the coarse multiply-accumulate");
   if (getenv("GA_COARSE_EXP")) {
     int occ = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, coarse_mac_kernel<CW, TW, PB>, kMacThreads, lds);
-    fprintf(stderr, "[coarse_mac<%d,%d,%d>] lds %zu B, NFA %d, occupancy %d workgroups/CU, %d jobs\n", CW, TW, PB, lds, NFA, occ, njobs);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, coarse_mac_kernel<CW, TW, PB, HF>, kMacThreads, lds);
+    fprintf(stderr, "[coarse_mac<%d,%d,%d,%d>] lds %zu B, NFA %d, occupancy %d workgroups/CU, %d jobs\n", CW, TW, PB, (int)HF, lds, NFA, occ, njobs);
   }
   for (int j0 = 0; j0 < njobs; j0 += 32768)
-    hipLaunchKernelGGL((coarse_mac_kernel<CW, TW, PB>), dim3(kCoarseBins / 64, std::min(32768, njobs - j0)), dim3(kMacThreads), lds, s,
+    hipLaunchKernelGGL((coarse_mac_kernel<CW, TW, PB, HF>), dim3(kCoarseBins / 64, std::min(32768, njobs - j0)), dim3(kMacThreads), lds, s,
                        jobs_dev + j0, terms_dev, X, Y, y_frames, NFA, exp >> 4);
 }
 // all jobs of one launch have the same column count `cw` (1, 2 or 4), at most `max_t` coarse blocks (<= kCoarseJobBlocks(cw))
@@ -431,8 +593,18 @@ template <int CW>
 static void launch_coarse_mac_cw(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
                                  int y_frames, int max_t, int maxP, bool any_private, int pb) {
   constexpr int TWL = CW <= 2 ? GA_MAC_TW : GA_MAC_TW / 2;   // accumulators: TW x CW complex values per lane
+  static const bool no16 = getenv("GA_COARSE_NO16") != nullptr;   // measurements only
+  if constexpr (CW <= 2) {
+    if (!no16 && max_t > 2 * kMacWaves && !any_private && maxP == pb && max_t <= kMac16Waves * kMac16TW) {
+      if (pb == 4) return launch_coarse_mac16<CW, 4>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t);
+      if (pb == 8) return launch_coarse_mac16<CW, 8>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t);
+      if (pb == 16 && CW == 1) return launch_coarse_mac16<1, 16>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t);   // (2 x 16 spectra spill)
+    }
+  }
   if (max_t <= 2 * kMacWaves) launch_coarse_mac_t<CW, 2, 1>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
-  else if (pb == 4 && (CW == 1 || (CW == 2 && GA_MAC_PB2 == 4))) launch_coarse_mac_t<CW, TWL, 4>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
+  else if (pb == 8 && CW <= 2 && maxP == 8 && !any_private)   // (pb divides every partition count: all jobs have exactly 8)
+    launch_coarse_mac_t<CW <= 2 ? CW : 1, TWL, 8, true>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
+  else if (pb >= 4 && (CW == 1 || (CW == 2 && GA_MAC_PB2 == 4))) launch_coarse_mac_t<CW, TWL, 4>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
   else if (pb >= 2) launch_coarse_mac_t<CW, TWL, 2>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
   else launch_coarse_mac_t<CW, TWL, 1>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
 }
@@ -441,7 +613,7 @@ void launch_coarse_mac(hipStream_t s, const CoarseJob* jobs_dev, int njobs, cons
   if (njobs <= 0) return;
   if (max_t > kCoarseJobBlocks(cw)) launch_fail("coarse multiply-accumulate: too many coarse blocks in a job");
   if (const char* e = getenv("GA_COARSE_PB")) pb = std::min(pb, std::max(1, atoi(e)));   // measurements only
-  if (pb != 1 && pb != 2 && pb != 4) launch_fail("coarse multiply-accumulate: unsupported partition block");
+  if (pb != 1 && pb != 2 && pb != 4 && pb != 8 && pb != 16) launch_fail("coarse multiply-accumulate: unsupported partition block");
   if (cw == 1) launch_coarse_mac_cw<1>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private, pb);
   else if (cw == 2) launch_coarse_mac_cw<2>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private, pb);
   else if (cw == 4) launch_coarse_mac_cw<4>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private, pb);

@@ -131,9 +131,14 @@ void Context::renderReduce(float* const* out, int channels, int64_t frames, int6
       Rccl& r = rccl();
       check(r, r.Reduce(reduceBuf, reduceBuf, (size_t)channels * frames, /*ncclFloat32*/ 7, /*ncclSum*/ 0, root, comm, stream), "ncclReduce");
     }
-    if (isRoot)
-      for (int ch = 0; ch < channels; ch++)
-        GA_HIP(hipMemcpyAsync(out[ch] + start, rows[ch], (size_t)frames * sizeof(float), hipMemcpyDeviceToHost, stream));
+    if (isRoot) {
+      if (callerAsync && ownStream && hostCopyStream) {
+        handOverToHost(rows, out, channels, start, frames);   // (leaves on the copy stream: ga_engine.hpp)
+      } else {
+        for (int ch = 0; ch < channels; ch++)
+          GA_HIP(hipMemcpyAsync(out[ch] + start, rows[ch], (size_t)frames * sizeof(float), hipMemcpyDeviceToHost, stream));
+      }
+    }
   } catch (...) {
     asyncMode = callerAsync;
     throw;

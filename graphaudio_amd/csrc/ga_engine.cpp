@@ -96,6 +96,15 @@ Context::~Context() {
   for (auto& kv : tw16) (void)hipFree(kv.second);
   if (coarseTw) (void)hipFree(coarseTw);
   if (tw16pw) (void)hipFree(tw16pw);
+  if (copyStream) {
+    (void)hipStreamSynchronize(copyStream);
+    (void)hipStreamDestroy(copyStream);
+    for (int k = 0; k < 2; k++) {
+      if (outReady[k]) (void)hipEventDestroy(outReady[k]);
+      if (outCopied[k]) (void)hipEventDestroy(outCopied[k]);
+      if (outStage[k]) (void)hipFree(outStage[k]);
+    }
+  }
   if (stream2) {
     (void)hipStreamSynchronize(stream2);
     (void)hipStreamDestroy(stream2);
@@ -243,7 +252,47 @@ void Context::harvestProfile(bool wait) {
 void Context::synchronize() {
   GA_HIP(hipSetDevice(device));
   GA_HIP(hipStreamSynchronize(stream));
+  waitHostCopies();
   harvestProfile(true);
+}
+void Context::waitHostCopies() {
+  if (!copyStream) return;
+  GA_HIP(hipStreamSynchronize(copyStream));
+  outPending[0] = outPending[1] = false;
+}
+// device rows src[ch][0, frames) -> out[ch] + offset (host memory), off the context's stream (ga_engine.hpp)
+void Context::handOverToHost(const float* const* src, float* const* out, int channels, int64_t offset, int64_t frames) {
+  if (!copyStream) {
+    GA_HIP(hipStreamCreateWithFlags(&copyStream, hipStreamNonBlocking));
+    for (int k = 0; k < 2; k++) {
+      GA_HIP(hipEventCreateWithFlags(&outReady[k], hipEventDisableTiming));
+      GA_HIP(hipEventCreateWithFlags(&outCopied[k], hipEventDisableTiming));
+    }
+  }
+  const int k = outCur;
+  outCur ^= 1;
+  const size_t need = (size_t)channels * (size_t)frames * sizeof(float);
+  if (outStageBytes[k] < need) {
+    if (outPending[k]) GA_HIP(hipEventSynchronize(outCopied[k]));
+    outPending[k] = false;
+    if (outStage[k]) {
+      GA_HIP(hipStreamSynchronize(stream));   // (a device-to-device copy into it may still be queued)
+      dfree(outStage[k], outStageBytes[k]);
+      outStage[k] = nullptr;
+      outStageBytes[k] = 0;
+    }
+    outStage[k] = (float*)dalloc(need);
+    outStageBytes[k] = need;
+  }
+  if (outPending[k]) GA_HIP(hipStreamWaitEvent(stream, outCopied[k], 0));   // the buffer's previous contents have left
+  for (int ch = 0; ch < channels; ch++)
+    GA_HIP(hipMemcpyAsync(outStage[k] + (size_t)ch * frames, src[ch], sizeof(float) * (size_t)frames, hipMemcpyDeviceToDevice, stream));
+  GA_HIP(hipEventRecord(outReady[k], stream));
+  GA_HIP(hipStreamWaitEvent(copyStream, outReady[k], 0));
+  for (int ch = 0; ch < channels; ch++)
+    GA_HIP(hipMemcpyAsync(out[ch] + offset, outStage[k] + (size_t)ch * frames, sizeof(float) * (size_t)frames, hipMemcpyDeviceToHost, copyStream));
+  GA_HIP(hipEventRecord(outCopied[k], copyStream));
+  outPending[k] = true;
 }
 
 // ---- connections: AudioNodeOutput.ConnectTo / DisconnectFrom / DisconnectAll (AudioNodeOutput.cs:42-70) and

@@ -446,6 +446,21 @@ struct Context {
   // g + 1, joined before the inverse transforms.  Measured on config 3: 3.37 ms of device time per step against 3.18 ms one
   // after the other (both stages slow down by ~50 % when they share the chip: they are bound by the same memory system),
   // so it stays off; kept as a switch for other shapes.
+  // Output hand-over of an asynchronous render into host memory: the bus is copied (device to device, a few microseconds) into
+  // one of two staging buffers on the context's stream and leaves for the host on a copy stream of its own, so that the
+  // next chunk's kernels do not queue behind ~0.15 ms of PCIe transfer per 10 s of stereo bus.  Only with the context's own
+  // stream: a caller-supplied stream keeps the one-stream ordering its owner expects.  OFF by default (option
+  // "host_copy_stream"): measured on config 3 it LOSES 5 % (2.84-2.89 ms per step against 2.70-2.72): the copy's blit kernels
+  // start beside the next chunk's forward transforms and those run 0.1-0.3 ms longer for it (tools/trace_gaps.sh).
+  hipStream_t copyStream = nullptr;
+  bool hostCopyStream = false;   // option "host_copy_stream"
+  hipEvent_t outReady[2] = {nullptr, nullptr}, outCopied[2] = {nullptr, nullptr};
+  float* outStage[2] = {nullptr, nullptr};
+  size_t outStageBytes[2] = {0, 0};
+  bool outPending[2] = {false, false};
+  int outCur = 0;
+  void handOverToHost(const float* const* src, float* const* out, int channels, int64_t offset, int64_t frames);
+  void waitHostCopies();
   hipStream_t stream2 = nullptr;
   hipEvent_t dGroupEv[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t dJoinEv = nullptr;
