@@ -1425,7 +1425,7 @@ static const float* convChunkInput(Context& c, Exec& ex, const std::vector<std::
 static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes, int64_t n) {
   const int64_t frames = n * kBlock;
   const int nT = (int)((frames + kCoarseBlock - 1) / kCoarseBlock);
-  constexpr int kVoicesPerJob = 32;   // terms whose products one workgroup accumulates in registers
+  constexpr int kVoicesPerJob = kCoarseJobTerms;   // terms whose products one workgroup accumulates in registers
   std::vector<CoarseXRow> xrows;
   std::vector<CoarseHistJob> hjobs;
   struct Piece {   // <= 4 columns of one signal: (impulse-response channel, output channel of the group)

@@ -450,16 +450,21 @@ __global__ __launch_bounds__(kMac16Threads) void coarse_mac16_kernel(const Coars
   int mine = 0;   // load instructions this wave issues per term (rows 32 r + 2 wv + {0, 1})
 #pragma unroll
   for (int r = 0; r < XR; r++) mine += (32 * r + 2 * wv < NF) ? 1 : 0;
-  auto issue_x = [&](const CoarseTerm& T, f2* xs) {
+  const CoarseTerm* __restrict T = terms + J.term0;
+  // the terms' first frames, one per lane (a job has at most kCoarseJobTerms <= 64), read with v_readlane in the loop: a scalar
+  // load of the descriptor per term put a memory latency in front of every sweep (its lgkmcnt(0) also covers the first LDS reads)
+  static_assert(kCoarseJobTerms <= 64, "one lane per term");
+  const int f0v = lane < nterms ? T[lane].frame0 : 0;
+  auto issue_x = [&](int term, f2* xs) {
+    const int frame0 = __builtin_amdgcn_readlane(f0v, term & 63);
 #pragma unroll
     for (int r = 0; r < XR; r++) {
       const int fr0 = 32 * r + 2 * wv;   // (uniform)
       const int fr = fr0 + (lane >> 5), of = lane & 31;
       if (fr < NF)
-        __builtin_amdgcn_global_load_lds(gptr(X + (size_t)(T.frame0 + J.t0 + fr) * kCoarseBins + binoff + 2 * of), (lds_t)(xs + fr0 * 64), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(gptr(X + (size_t)(frame0 + J.t0 + fr) * kCoarseBins + binoff + 2 * of), (lds_t)(xs + fr0 * 64), 16, 0, 0);
     }
   };
-  const CoarseTerm* __restrict T = terms + J.term0;
   {   // the impulse response's PB x CW rows pass through the third buffer
     const int pc0 = 2 * wv, pc = pc0 + (lane >> 5), of = lane & 31;
     if (pc < PB * CW)
@@ -467,8 +472,8 @@ __global__ __launch_bounds__(kMac16Threads) void coarse_mac16_kernel(const Coars
     static_assert(PB * CW <= 2 * kMac16Waves, "one load instruction per wave covers the impulse response");
   }
   if (!(exp & 2)) {
-    issue_x(T[0], b0);
-    if (nterms > 1) issue_x(T[1], b1);
+    issue_x(0, b0);
+    if (nterms > 1) issue_x(1, b1);
   }
   __syncthreads();   // (its fence waits for the direct-to-LDS loads: vmcnt(0))
   f2 h[PB][CW];
@@ -485,7 +490,7 @@ __global__ __launch_bounds__(kMac16Threads) void coarse_mac16_kernel(const Coars
 
   for (int i = 0; i < nterms; i++) {
     const bool ahead = i + 2 < nterms && !(exp & 2);
-    if (ahead) issue_x(T[i + 2], b2);   // (b2's last readers passed the barrier of step i - 1)
+    if (ahead) issue_x(i + 2, b2);   // (b2's last readers passed the barrier of step i - 1)
     if (t0w < nT && !(exp & 1)) {
       auto sweep = [&](auto sp) {
         constexpr bool SP = decltype(sp)::value;

@@ -112,6 +112,7 @@ void launch_tconv16(hipStream_t s, const ConvSetC* sets_dev, int nsets, int nblo
 // ---- convolver pipeline, formulation D: coarse partitions, consumer sum fused in the frequency domain (ga_coarse.hip) ----
 constexpr int kCoarseBlock = 8192;   // samples per coarse partition / output block
 constexpr int kCoarseMaxP = 16;      // partitions a job can slide over (impulse responses up to 131,072 taps)
+constexpr int kCoarseJobTerms = 32;   // terms (signals) whose products one multiply-accumulate job sums in registers
 constexpr int kCoarseJobBlocks(int columns) { return columns <= 2 ? 64 : 32; }   // coarse blocks one multiply-accumulate job covers: 8 waves x 8 (x 4)
 constexpr int kCoarseBins = 8192;    // packed complex bins of one 16,384-point real spectrum (bin 0 = (X[0], X[8192]))
 struct CoarseXRow {        // one transformed signal: a convolver input channel, or an impulse-response channel
