@@ -7,9 +7,11 @@
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-template <int MODE>
-__global__ __launch_bounds__(256) void k(float* out, int iters, float seed, long long* cyc) {
+template <int MODE, int BLK = 256>
+__global__ __launch_bounds__(BLK) void k(float* out, int iters, float seed, long long* cyc) {
+  extern __shared__ float dyn_lds[];
   const int l = threadIdx.x;
+  if (iters < 0) dyn_lds[l] = seed;
   const long long c0 = clock64();
   if constexpr (MODE == 4) {
     // the sweep's shape: 4 x 2 accumulators, 8 partitions, sliding window of 11 frames, 16 spectra -- all in registers
@@ -35,7 +37,7 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed, long
     }
     f2 s = f2{0.f, 0.f};
     for (int i = 0; i < 8; i++) s += acc[i >> 1][i & 1];
-    out[blockIdx.x * 256 + l] = s.x + s.y;
+    out[blockIdx.x * blockDim.x + l] = s.x + s.y;
     if (l == 0 && blockIdx.x == 0) *cyc = clock64() - c0;
     return;
   }
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed, long
     }
     f2 s = f2{0.f, 0.f};
     for (int i = 0; i < 16; i++) s += acc[i];
-    out[blockIdx.x * 256 + l] = s.x + s.y;
+    out[blockIdx.x * blockDim.x + l] = s.x + s.y;
     if (l == 0 && blockIdx.x == 0) *cyc = clock64() - c0;
   } else {
     // MFMA 4x4x1 (16 blocks of 4x4 outer products): two instructions = 16 bins x 4 rows x 2 complex columns = 128 complex macs
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed, long
     }
     f4 s = f4{0.f, 0.f, 0.f, 0.f};
     for (int i = 0; i < 8; i++) s += acc[i];
-    out[blockIdx.x * 256 + l] = s.x + s.y + s.z + s.w;
+    out[blockIdx.x * blockDim.x + l] = s.x + s.y + s.z + s.w;
     if (l == 0 && blockIdx.x == 0) *cyc = clock64() - c0;
   }
 }
@@ -117,7 +119,35 @@ static void run(const char* name, double cmac_per_wave_iter, int wg_per_cu, doub
   hipFree(out);
 }
 
+template <int BLK>
+static void run_big(const char* name, size_t lds) {
+  const int iters = 4096, grid = 256;
+  float* out;
+  long long* cyc;
+  (void)hipMalloc(&out, sizeof(float) * grid * 1024);
+  (void)hipMalloc(&cyc, 8);
+  (void)hipFuncSetAttribute((const void*)k<4, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  const int nblk = 256 * (1024 / BLK);
+  k<4, BLK><<<nblk, BLK, lds>>>(out, 64, 0.5f, cyc);
+  (void)hipDeviceSynchronize();
+  (void)hipEventRecord(e0);
+  k<4, BLK><<<nblk, BLK, lds>>>(out, iters, 0.5f, cyc);
+  (void)hipEventRecord(e1);
+  (void)hipEventSynchronize(e1);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  long long hc = 0;
+  (void)hipMemcpy(&hc, cyc, 8, hipMemcpyDeviceToHost);
+  printf("%-50s %.3f ms  %.2f ns per pk_fma per SIMD (4 waves/SIMD), wave 0: %.2f ticks per instr\n", name, ms, ms * 1e6 / (256.0 * iters * 4), hc / (256.0 * iters));
+}
 int main() {
+  run_big<256>("sweep-shaped, 4 workgroups of 256 per CU", 0);
+  run_big<1024>("sweep-shaped, 1 workgroup of 1024 per CU", 0);
+  run_big<1024>("sweep-shaped, 1 workgroup of 1024 per CU, 100 KB LDS", 100 * 1024);
+  run_big<256>("sweep-shaped, 4 workgroups of 256 per CU", 0);
   for (int w : {1, 2, 4}) {
     run<0>("v_pk_fma_f32 plain", 64.0 * 64, w, 128);            // 64 pairs x 64 lanes
     run<1>("v_pk_fma_f32 complex pair (op_sel)", 64.0 * 64, w, 128);
