@@ -189,6 +189,9 @@ def main():
     ap.add_argument("--direct", action="store_true", help="direct (matrix-core) partition sum, formulation A")
     ap.add_argument("--no-coarse", action="store_true", help="formulation C (block-axis FFT) instead of D (coarse partitions)")
     ap.add_argument("--overlap", action="store_true", help="formulation D: forward and multiply-accumulate stages concurrently on two streams (measured slower)")
+    ap.add_argument("--profile-every", type=int, default=4, help="record the per-stage HIP events on every k-th chunk of the timed region")
+    ap.add_argument("--no-profile", action="store_true", help="no per-stage HIP events (measurement of their cost; the roofline object is then empty)")
+    ap.add_argument("--no-carry", action="store_true", help="formulation D: copy the input history with its own kernel instead of from the forward transforms (measurement)")
     ap.add_argument("--copy-stream", action="store_true", help="hand the bus to the host on a copy stream of its own (measurement)")
     ap.add_argument("--sync-steps", action="store_true", help="one blocking render per step (no host/device pipelining)")
     ap.add_argument("--force-dist", action="store_true", help="exercise the sharded-render path (ga_render_reduce) even with one rank")
@@ -224,7 +227,8 @@ def main():
     use_reduce = world > 1 or args.force_dist
 
     ctx = OfflineAudioContext(SR, device=local_rank)
-    ctx.SetOption("profile", 1)
+    ctx.SetOption("profile", 0 if args.no_profile else 1)
+    ctx.SetOption("profile_every", args.profile_every)   # the events cost device time: only every k-th chunk records them
     ctx.SetOption("max_chunk_blocks", 4096)
     if args.direct:
         ctx.SetOption("time_fft", 0)
@@ -232,6 +236,8 @@ def main():
         ctx.SetOption("coarse", 0)
     if args.overlap:
         ctx.SetOption("coarse_overlap", 1)
+    if args.no_carry:
+        ctx.SetOption("coarse_carry", 0)
     if args.copy_stream:
         ctx.SetOption("host_copy_stream", 1)
     build_graph(ctx, v1 - v0, v0, args.taps, frames, G)
@@ -283,8 +289,11 @@ def main():
         blocks = frames // 128
         stages = {}
         tot_ms = tot_b = 0.0
+        # stage times come from the chunks that recorded events (every --profile-every-th), scaled to a step
+        nprof = max(st1["profiled_chunks"] - st0["profiled_chunks"], 1)
+        per_step = (st1["chunks"] - st0["chunks"]) / args.steps / nprof
         for i, name in enumerate(STAGES):
-            ms = (st1["stage_ms"][i] - st0["stage_ms"][i]) / args.steps
+            ms = (st1["stage_ms"][i] - st0["stage_ms"][i]) * per_step
             nl = (st1["stage_launches"][i] - st0["stage_launches"][i]) / args.steps
             by = (st1["stage_bytes"][i] - st0["stage_bytes"][i]) / args.steps
             if nl <= 0:
@@ -296,6 +305,10 @@ def main():
             if by > 0:
                 tot_ms += ms
                 tot_b += by
+        if args.no_profile or not stages:   # --no-profile (measurement of the events' cost): nothing to price
+            print(json.dumps({"ms_per_step": dt / args.steps * 1e3, "value": value, "host_issue_ms_per_step": t_enq / args.steps * 1e3,
+                              "device_ms_per_step": 0.0, "stages": {}}))
+            return
         dom = max((n for n in stages if stages[n]["necessary_gb_per_step"]), key=lambda n: stages[n]["ms_per_step"])
         d = stages[dom]
         per_launch_ms = d["ms_per_step"] / d["launches_per_step"]
@@ -305,7 +318,7 @@ def main():
                 "frequency domain" if "coarse_fwd" in stages else
                 "formulation C: partition sum as an FFT convolution along the block axis" if not args.direct else
                 "formulation A: direct partition sum on the f32 matrix cores")
-        dev_ms = (st1["device_ms_total"] - st0["device_ms_total"]) / args.steps
+        dev_ms = (st1["device_ms_total"] - st0["device_ms_total"]) * per_step
         stream_bytes = (st1["mac_bytes_total"] - st0["mac_bytes_total"]) / args.steps
         rec = {
             "metric": "rendered frames/sec @48kHz, 1024-voice convolver graph",
@@ -320,6 +333,7 @@ def main():
             "realtime_factor": value / SR,
             "host_issue_ms_per_step": t_enq / args.steps * 1e3,
             "device_ms_per_step": dev_ms,
+            "profiled_chunks": nprof,
             "roofline": {"bound": "hbm", "achieved": per_launch_bytes / (per_launch_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": per_launch_bytes / (per_launch_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
                          "kernel": d["kernel"], "stage": dom, "avg_launch_ms": per_launch_ms, "launches_per_step": d["launches_per_step"],

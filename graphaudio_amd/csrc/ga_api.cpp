@@ -303,6 +303,7 @@ int ga_set_option(ga_context* ctx, const char* key, double value) {
     std::string k = key ? key : "";
     if (k == "max_chunk_blocks") c.maxChunkBlocks = std::max<int64_t>(1, std::min<int64_t>(32768, (int64_t)value));
     else if (k == "profile") c.profile = value != 0;
+    else if (k == "profile_every") c.profileEvery = (int)std::max<int64_t>(1, value);
     else if (k == "time_fft") c.useTimeFft = value != 0;
     else if (k == "fft64") c.fft64 = value != 0;
     else if (k == "tconv_radix16") c.useRadix16 = value != 0;
@@ -312,6 +313,7 @@ int ga_set_option(ga_context* ctx, const char* key, double value) {
     }
     else if (k == "coarse") c.useCoarse = value != 0;
     else if (k == "coarse_overlap") c.coarseOverlap = value != 0;
+    else if (k == "coarse_carry") c.coarseCarry = value != 0;
     else if (k == "host_copy_stream") c.hostCopyStream = value != 0;
     else if (k == "coarse_min_blocks") c.coarseMinBlocks = std::max<int64_t>(1, (int64_t)value);
     else if (k == "debug_tconv_n2") c.debugTconvN2 = (int)value;   // tests only: plan the block-axis FFT with this (possibly unsupported) length

@@ -1439,6 +1439,7 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
   int frameNext = 0;
   int64_t maxHist = 0;
   double histBytes = 0;
+  std::map<int, double> carryBytes;   // row -> bytes of next-chunk history its forward transform also writes
   std::vector<const float*> chIn;
   for (int id : dNodes) {
     NodeS& nd = *c.nodes[id];
@@ -1474,10 +1475,21 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
       xFrame[ch] = frameNext;
       xIndex[ch] = (int)xrows.size();
       frameNext += r.n_frames;
+      // the next chunk's history: the last hl samples of [history | input].  When they all come from this chunk's input the
+      // forward kernel writes them while it holds the samples (ga_kernels.hpp, CoarseXRow::carry); otherwise a copy job.
+      float* nextHist = nd.dHist[nd.dHistCur ^ 1] + (size_t)ch * hl;
+      r.carry = nullptr;
+      r.carry_from = 0;
+      if (c.coarseCarry && r.in && frames >= hl && (((uintptr_t)r.in | (uintptr_t)nextHist) & 15) == 0) {
+        r.carry = nextHist;
+        r.carry_from = frames - hl;
+        carryBytes[(int)xrows.size()] = (double)hl * 4.0;
+      } else {
+        hjobs.push_back(CoarseHistJob{r.hist, r.in, nextHist, hl, frames});
+        maxHist = std::max(maxHist, hl);
+        histBytes += 2.0 * (double)hl * 4.0;
+      }
       xrows.push_back(r);
-      hjobs.push_back(CoarseHistJob{r.hist, r.in, nd.dHist[nd.dHistCur ^ 1] + (size_t)ch * hl, hl, frames});
-      maxHist = std::max(maxHist, hl);
-      histBytes += 2.0 * (double)hl * 4.0;
     }
     nd.dHistCur ^= 1;
     nd.dHistZero = false;
@@ -1630,6 +1642,7 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
     for (int x = f.x0; x < f.x0 + f.nx; x++) {
       f.maxFrames = std::max(f.maxFrames, xrows[x].n_frames);
       f.bytes += (double)(xrows[x].n_frames + 1) * kCoarseBlock * 4.0 + (double)xrows[x].n_frames * kCoarseBins * 8.0;
+      if (auto it = carryBytes.find(x); it != carryBytes.end()) f.bytes += it->second;
     }
     while (f.run < 16 && (int64_t)nxAll * ((f.maxFrames + 2 * f.run - 1) / (2 * f.run)) >= 1024) f.run *= 2;
     fwds.push_back(f);
@@ -1640,13 +1653,13 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
     // one piece of the section: a launch with its own profile events (the two stages overlap on two streams)
     auto timed = [&](hipStream_t sx, int kind, double bytes, const std::function<void()>& launch) {
       hipEvent_t e0 = nullptr, e1 = nullptr;
-      if (cp->profile) {
+      if (cp->profileNow) {
         GA_HIP(hipEventCreate(&e0));
         GA_HIP(hipEventCreate(&e1));
         GA_HIP(hipEventRecord(e0, sx));
       }
       launch();
-      if (cp->profile) {
+      if (cp->profileNow) {
         GA_HIP(hipEventRecord(e1, sx));
         cp->extraProf.push_back(Context::ExtraProf{e0, e1, kind, bytes});
       }
@@ -1678,7 +1691,7 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
     launch_coarse_inv(st, (const CoarseOut*)(base + oo), no, nT, (const int*)(base + yo), Y, nT, tw16, twab);
   }, invBytes);
   const int64_t mh = maxHist;
-  ex.plan.add(LK_CHIST, [=](uint8_t* base) { launch_coarse_hist(st, (const CoarseHistJob*)(base + ho), nh, mh); }, histBytes);
+  if (nh > 0) ex.plan.add(LK_CHIST, [=](uint8_t* base) { launch_coarse_hist(st, (const CoarseHistJob*)(base + ho), nh, mh); }, histBytes);
 }
 
 // ======================================================================================================
@@ -3086,6 +3099,7 @@ void Context::chunkExecute(ChunkRun& r) {
   std::vector<int> evKind;
   std::vector<double> evBytes;
   hipEvent_t evBegin = nullptr, evEnd = nullptr;
+  const bool profile = profileNow;   // (this chunk is one of the sampled ones: option "profile_every")
   if (profile) {
     GA_HIP(hipEventCreate(&evBegin));
     GA_HIP(hipEventCreate(&evEnd));
@@ -3121,7 +3135,7 @@ void Context::chunkExecute(ChunkRun& r) {
   if (profile) GA_HIP(hipEventRecord(evEnd, stream));
   GA_HIP(hipGetLastError());
   r.tmLaunch = nowMs();
-  if (profile) pendingProf.push_back(ProfBatch{evBegin, evEnd, std::move(evs), std::move(evKind), std::move(evBytes)});
+  if (profileNow) pendingProf.push_back(ProfBatch{evBegin, evEnd, std::move(evs), std::move(evKind), std::move(evBytes)});
   if (asyncMode) {
     if (!chunkDone[slot]) GA_HIP(hipEventCreateWithFlags(&chunkDone[slot], hipEventDisableTiming));
     GA_HIP(hipEventRecord(chunkDone[slot], stream));
@@ -3225,6 +3239,7 @@ void Context::runChunkImpl(int64_t nblocks, float* const* /*unused*/) {
   drain();  // AudioContextBase.cs:57
   if (!releasedPending.empty() || ++chunksSinceGc >= 64) collectGarbage();
   latched = true;
+  profileNow = profile && (profileSeq++ % std::max(profileEvery, 1)) == 0;
   chunkTopology(r);
   chunkSimulate(r);
   chunkResources(r);

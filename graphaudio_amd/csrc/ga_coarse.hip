@@ -138,6 +138,15 @@ __global__ __launch_bounds__(256, 3) void coarse_fwd_kernel(const CoarseXRow* __
     const int u = R.u0 + w;
     const bool more = w + 1 < w1;
     f2 own[16];
+    // the samples of the window's second half that belong to the next chunk's history leave from here (every input half is
+    // the second half of exactly one window of the row)
+    if (R.carry && u >= 0 && (int64_t)(u + 1) * kCoarseBlock > R.carry_from) {
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int64_t sidx = (int64_t)u * kCoarseBlock + 4 * (t + 256 * q);
+        if (sidx >= R.carry_from && sidx < R.nvalid) stg4(R.carry + (sidx - R.carry_from), second[q]);
+      }
+    }
     // ---- transform a ----
 #pragma unroll
     for (int m = 0; m < 8; m++) {

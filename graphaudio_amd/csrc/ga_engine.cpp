@@ -234,6 +234,7 @@ void Context::harvestProfile(bool wait) {
     float ms = 0;
     GA_HIP(hipEventElapsedTime(&ms, b.begin, b.end));
     stats.device_ms_total += ms;
+    stats.profiled_chunks++;
     for (size_t i = 0; i < b.evs.size(); i++) {
       GA_HIP(hipEventElapsedTime(&ms, b.evs[i].first, b.evs[i].second));
       const int k = b.kinds[i];
@@ -807,6 +808,8 @@ void Context::ensureCoarseSpectra(IrSpectra& ir) {
     r.hist_len = 0;
     r.flags = 1;
     r.scale = 1.0f / 65536.0f;
+    r.carry = nullptr;
+    r.carry_from = 0;
   }
   CoarseXRow* rd = (CoarseXRow*)dalloc(sizeof(CoarseXRow) * rows.size());
   GA_HIP(hipMemcpy(rd, rows.data(), sizeof(CoarseXRow) * rows.size(), hipMemcpyHostToDevice));

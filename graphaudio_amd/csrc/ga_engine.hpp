@@ -364,6 +364,11 @@ struct Context {
   int64_t maxChunkBlocks = 4096;
   double memBudgetFraction = 0.7;
   bool profile = false;
+  // option "profile_every" = k: only every k-th chunk records its HIP events (they cost ~50 us of device time per chunk: 2 % of a
+  // 1024-voice step, 10 % of a 128-voice one); ga_stats.profiled_chunks counts the chunks the stage times come from
+  int profileEvery = 1;
+  int64_t profileSeq = 0;
+  bool profileNow = false;
   // device resources
   double2* w128 = nullptr;
   double2* w256 = nullptr;
@@ -465,6 +470,7 @@ struct Context {
   hipEvent_t dGroupEv[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t dJoinEv = nullptr;
   bool coarseOverlap = false;
+  bool coarseCarry = true;   // option "coarse_carry": the forward kernel writes the next chunk's history (0: always the copy kernel)
   void ensureOverlapStream();
   // event pairs recorded by launches that time their own pieces (several kernels, two streams); folded into the chunk's profile batch
   struct ExtraProf { hipEvent_t e0, e1; int kind; double bytes; };

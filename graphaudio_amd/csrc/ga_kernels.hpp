@@ -125,6 +125,11 @@ struct CoarseXRow {        // one transformed signal: a convolver input channel,
   int hist_len;            // multiple of CB
   int flags;               // bit 0: second half of every window is zero (impulse-response partitions [h_p | 0])
   float scale;             // applied to every sample (impulse responses: normalisation and transform scale factors)
+  // the next chunk's history, written by the forward kernel itself while it holds the samples (no separate copy pass):
+  // carry[s - carry_from] = in[s] for carry_from <= s < nvalid.  nullptr: the row's history is copied by coarse_hist_kernel
+  // (chunks shorter than the history, silent inputs, unaligned views).
+  float* carry;
+  int64_t carry_from;      // multiple of 4
 };
 struct CoarseTerm {        // one (signal, impulse response) product feeding a job's accumulators
   int frame0;              // frame of window u = -(P - 1) of the signal

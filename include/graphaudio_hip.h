@@ -104,6 +104,8 @@ typedef struct ga_stats {
   double  stage_ms[16];
   int64_t stage_launches[16];
   double  stage_bytes[16];
+  int64_t profiled_chunks;      /* chunks whose HIP events device_ms_total and stage_ms[] were read from (options "profile",
+                                   "profile_every"); stage_launches[] and stage_bytes[] count every chunk */
 } ga_stats;
 enum {
   GA_STAGE_OTHER = 0,        /* sources, biquads, gains, parameter curves, ... */
