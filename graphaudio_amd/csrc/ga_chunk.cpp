@@ -1550,10 +1550,12 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
   for (int x = 0; x < nxAll; x++) gBegin[groupOf(x) + 1] = x + 1;
   for (int g = 1; g <= G; g++) gBegin[g] = std::max(gBegin[g], gBegin[g - 1]);
   std::vector<CoarseTerm> terms;
-  std::vector<CoarseJob> jobs[3][8];       // by column count 1, 2, 4 and by the group whose transforms complete the job's inputs
-  int maxT[3] = {0, 0, 0}, maxP[3] = {0, 0, 0}, pbOf[3] = {16, 16, 4};   // pbOf: largest of (16, 8,) 4, 2, 1 dividing every job's partition count
-  bool anyPrivate[3] = {false, false, false};
-  double macBytes[3][8] = {};
+  // launches: by column count (1, 2, 4) x (terms with their own impulse responses | one impulse response for all terms), and
+  // by the group whose transforms complete the job's inputs.  Class index = 2 * column class + shared.
+  std::vector<CoarseJob> jobs[6][8];
+  int maxT[6] = {0, 0, 0, 0, 0, 0}, maxP[6] = {0, 0, 0, 0, 0, 0};
+  int pbOf[6] = {16, 16, 16, 16, 4, 4};   // largest of (16, 8,) 4, 2, 1 dividing every job's partition count
+  double macBytes[6][8] = {};
   std::map<std::pair<int, int>, std::vector<int>> outRows;   // (leader, channel) -> Y rows to sum
   int yNext = 0;
   for (auto& kv : byKey) {
@@ -1590,12 +1592,12 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
         jb_.n_t = std::min(jb, nT - t0);
         jb_.yrow0 = yrow0;
         jb_.shared_h = shared ? 1 : 0;
-        jobs[ci][grp].push_back(jb_);
-        maxT[ci] = std::max(maxT[ci], jb_.n_t);
-        maxP[ci] = std::max(maxP[ci], k.P);
-        while (k.P % pbOf[ci]) pbOf[ci] >>= 1;
-        anyPrivate[ci] = anyPrivate[ci] || !shared;
-        macBytes[ci][grp] += (double)jb_.n_terms * (jb_.n_t + k.P - 1) * kCoarseBins * 8.0 +
+        const int cj = 2 * ci + (shared ? 1 : 0);
+        jobs[cj][grp].push_back(jb_);
+        maxT[cj] = std::max(maxT[cj], jb_.n_t);
+        maxP[cj] = std::max(maxP[cj], k.P);
+        while (k.P % pbOf[cj]) pbOf[cj] >>= 1;
+        macBytes[cj][grp] += (double)jb_.n_terms * (jb_.n_t + k.P - 1) * kCoarseBins * 8.0 +
                              (double)(shared ? 1 : jb_.n_terms) * k.P * cw * kCoarseBins * 8.0 + (double)cw * jb_.n_t * kCoarseBins * 8.0;
       }
     }
@@ -1620,10 +1622,10 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
   struct MacLaunch { size_t off; int nj, cw, mt, mp, pb, grp; bool ap; double bytes; };
   std::vector<MacLaunch> macs;
   for (int g = 0; g < G; g++)
-    for (int i = 0; i < 3; i++) {
+    for (int i = 0; i < 6; i++) {
       if (jobs[i][g].empty()) continue;
-      macs.push_back(MacLaunch{ex.plan.putv(jobs[i][g]), (int)jobs[i][g].size(), i == 0 ? 1 : (i == 1 ? 2 : 4), maxT[i], maxP[i], pbOf[i], g,
-                               anyPrivate[i], macBytes[i][g]});
+      macs.push_back(MacLaunch{ex.plan.putv(jobs[i][g]), (int)jobs[i][g].size(), 1 << (i >> 1), maxT[i], maxP[i], pbOf[i], g, (i & 1) == 0,
+                               macBytes[i][g]});
       c.stats.mac_launches += 1;
     }
   hipStream_t st = c.stream;

@@ -577,6 +577,150 @@ static void launch_coarse_mac16(hipStream_t s, const CoarseJob* jobs_dev, int nj
                        terms_dev, X, Y, y_frames, NFA, exp >> 4);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+//  One impulse response for all terms of a job (many voices through one room: ConvolverNodes that hold the same buffer and
+//  feed the same sum): the spectral multiply commutes with the sum over the terms,
+//        sum_v sum_p X_v[t - p] H[p]  =  sum_p ( sum_v X_v[t - p] ) H[p],
+//  so the job first adds up its terms' X frames -- a pure streaming reduction, every thread owns a few 16-byte words of the
+//  (frames x 64 bins) tile and adds them straight from global memory into registers, four terms in flight, no LDS, no barrier
+//  -- and multiplies ONCE at the end (sum tile -> LDS, the usual sliding sweep).  The multiply-accumulate work per job drops
+//  from (terms x P x blocks) to (P x blocks) products per bin and the kernel runs at the rate it can read X.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kSumWaves = 8, kSumThreads = 64 * kSumWaves, kSumAhead = 4;
+template <int CW>
+__global__ __launch_bounds__(kSumThreads, 2) void coarse_sum_kernel(const CoarseJob* __restrict jobs, const CoarseTerm* __restrict terms,
+                                                                    const float2* __restrict X, float2* __restrict Y, int y_frames, int NFA, int exp) {
+  constexpr int TW = kCoarseJobBlocks(CW) / kSumWaves;                                   // coarse blocks per wave (8, 8, 4)
+  constexpr int XR = ((kCoarseJobBlocks(CW) + kCoarseMaxP) * 32 + kSumThreads - 1) / kSumThreads;   // 16-byte words per thread (5, 5, 3)
+  extern __shared__ f2 mlds[];   // (all of the kernel's LDS is this one array)
+  const CoarseJob J = jobs[blockIdx.y];
+  const int tile = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int P = J.P, nT = J.n_t, NF = nT + P - 1, nterms = J.n_terms;
+  const int twr = (nT + kSumWaves - 1) / kSumWaves, t0w = wv * twr;
+  const bool special = tile == 0, lane0 = special && lane == 0;
+  const size_t binoff = (size_t)tile * 64;
+  f2* S = mlds;                           // NFA frames x 64 bins: the summed spectra
+  f2* hs = mlds + (size_t)NFA * 64;       // P x CW rows of 64 bins
+  typedef __attribute__((address_space(3))) void* lds_t;
+  const CoarseTerm* __restrict T = terms + J.term0;
+  // the impulse response goes straight to LDS and is first needed after the reduction
+  for (int pc0 = 2 * wv; pc0 < P * CW; pc0 += 2 * kSumWaves) {
+    const int pc = pc0 + (lane >> 5), of = lane & 31;
+    if (pc < P * CW)
+      __builtin_amdgcn_global_load_lds(gptr(T[0].h[pc % CW] + (size_t)(pc / CW) * kCoarseBins + binoff + 2 * of), (lds_t)(hs + pc0 * 64), 16, 0, 0);
+  }
+  static_assert(kCoarseJobTerms <= 64, "one lane per term");
+  const int f0v = lane < nterms ? T[lane].frame0 : 0;   // the terms' first frames, read with v_readlane below
+  // word r of this thread: frame (tid + kSumThreads r) / 32 (clamped: the surplus words are loaded and never stored), bins 2 of, 2 of + 1
+  int64_t woff[XR];
+#pragma unroll
+  for (int r = 0; r < XR; r++) {
+    const int idx = tid + kSumThreads * r;
+    const int fr = min(idx >> 5, NF - 1), of = idx & 31;
+    woff[r] = (int64_t)(J.t0 + fr) * kCoarseBins + (int64_t)binoff + 2 * of;
+  }
+  v4f acc[XR];
+#pragma unroll
+  for (int r = 0; r < XR; r++) acc[r] = v4f{0.f, 0.f, 0.f, 0.f};
+  int i = 0;
+  if (!(exp & 2)) {
+    for (; i + kSumAhead <= nterms; i += kSumAhead) {
+      v4f ld[kSumAhead][XR];
+#pragma unroll
+      for (int u = 0; u < kSumAhead; u++) {
+        const float2* __restrict Xt = X + (int64_t)__builtin_amdgcn_readlane(f0v, i + u) * kCoarseBins;
+#pragma unroll
+        for (int r = 0; r < XR; r++) ld[u][r] = ldg4(Xt + woff[r]);
+      }
+#pragma unroll
+      for (int u = 0; u < kSumAhead; u++)
+#pragma unroll
+        for (int r = 0; r < XR; r++) acc[r] += ld[u][r];
+    }
+    for (; i < nterms; i++) {
+      const float2* __restrict Xt = X + (int64_t)__builtin_amdgcn_readlane(f0v, i) * kCoarseBins;
+#pragma unroll
+      for (int r = 0; r < XR; r++) acc[r] += ldg4(Xt + woff[r]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < XR; r++) {
+    const int idx = tid + kSumThreads * r;
+    const int fr = idx >> 5, of = idx & 31;
+    if (fr < NF) *reinterpret_cast<v4f*>(S + fr * 64 + 2 * of) = acc[r];
+  }
+  __syncthreads();   // (its fence also waits for the impulse response's direct-to-LDS loads)
+  // ---- one sweep: y[tt][c] = sum_p S[t0w + tt - p] H_c[p]; tile 0, lane 0 (two real bins) multiplies element-wise ----
+  f2 y[TW][CW], yS[TW][CW];
+#pragma unroll
+  for (int tt = 0; tt < TW; tt++)
+#pragma unroll
+    for (int c = 0; c < CW; c++) y[tt][c] = yS[tt][c] = f2{0.f, 0.f};
+  if (t0w < nT && !(exp & 1)) {
+    auto sweep = [&](auto sp) {
+      constexpr bool SP = decltype(sp)::value;
+      const f2* __restrict xb = S + (t0w + (P - 1)) * 64 + lane;   // frame of (tt = 0, p = 0)
+      f2 xv[TW];
+#pragma unroll
+      for (int q = 1; q < TW; q++) xv[q] = xb[q * 64];             // frames of tt = 1 .. TW - 1 at p = 0
+      for (int p = 0; p < P; p++) {
+        // window slides one frame back per partition: xv[tt] = frame (tt - p)
+#pragma unroll
+        for (int q = TW - 1; q > 0; q--) xv[q] = p == 0 ? xv[q] : xv[q - 1];
+        xv[0] = xb[-p * 64];
+        f2 h[CW];
+#pragma unroll
+        for (int c = 0; c < CW; c++) h[c] = hs[(p * CW + c) * 64 + lane];
+#pragma unroll
+        for (int tt = 0; tt < TW; tt++)
+#pragma unroll
+          for (int c = 0; c < CW; c++) {
+            y[tt][c] = cfmap(xv[tt], h[c], y[tt][c]);
+            if constexpr (SP) yS[tt][c] = __builtin_elementwise_fma(xv[tt], h[c], yS[tt][c]);
+          }
+      }
+    };
+    if (special) sweep(std::true_type{});
+    else sweep(std::false_type{});
+  }
+#pragma unroll
+  for (int tt = 0; tt < TW; tt++) {
+    const int t = t0w + tt;
+    if (tt < twr && t < nT && !(exp & 4)) {
+#pragma unroll
+      for (int c = 0; c < CW; c++) {
+        const f2 a = lane0 ? yS[tt][c] : y[tt][c];
+        stg2(Y + ((size_t)(J.yrow0 + c) * y_frames + J.t0 + t) * kCoarseBins + binoff + lane, v2f{a.x, a.y});
+      }
+    }
+  }
+}
+
+template <int CW>
+static void launch_coarse_sum(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
+                              int y_frames, int max_t, int maxP) {
+  static const int exp = getenv("GA_COARSE_EXP") ? atoi(getenv("GA_COARSE_EXP")) : 0;   // timing experiments only
+  constexpr int TW = kCoarseJobBlocks(CW) / kSumWaves;
+  int NFA = 0;   // frames the sweep of the last active wave touches
+  for (int nt = 1; nt <= max_t; nt++) {
+    const int twr = (nt + kSumWaves - 1) / kSumWaves, wl = (nt + twr - 1) / twr - 1;
+    NFA = std::max(NFA, wl * twr + TW + maxP - 1);
+  }
+  const size_t lds = ((size_t)NFA * 64 + (size_t)maxP * CW * 64) * sizeof(float2);
+  if (lds > 160 * 1024) launch_fail("coarse multiply-accumulate: staging does not fit the LDS");
+  if (hipFuncSetAttribute((const void*)coarse_sum_kernel<CW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(lds, 65536)) != hipSuccess)
+    launch_fail("cannot raise the dynamic LDS limit of the coarse multiply-accumulate");
+  if (getenv("GA_COARSE_EXP")) {
+    int occ = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, coarse_sum_kernel<CW>, kSumThreads, lds);
+    fprintf(stderr, "[coarse_sum<%d>] lds %zu B, NFA %d, occupancy %d workgroups/CU, %d jobs\n", CW, lds, NFA, occ, njobs);
+  }
+  for (int j0 = 0; j0 < njobs; j0 += 32768)
+    hipLaunchKernelGGL((coarse_sum_kernel<CW>), dim3(kCoarseBins / 64, std::min(32768, njobs - j0)), dim3(kSumThreads), lds, s, jobs_dev + j0, terms_dev, X,
+                       Y, y_frames, NFA, exp >> 4);
+}
+
 template <int CW, int TW, int PB, bool HF = false>
 static void launch_coarse_mac_t(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
                                 int y_frames, int max_t, int maxP, bool any_private) {
@@ -607,6 +751,8 @@ template <int CW>
 static void launch_coarse_mac_cw(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
                                  int y_frames, int max_t, int maxP, bool any_private, int pb) {
   constexpr int TWL = CW <= 2 ? GA_MAC_TW : GA_MAC_TW / 2;   // accumulators: TW x CW complex values per lane
+  static const bool nosum = getenv("GA_COARSE_NOSUM") != nullptr;   // measurements only
+  if (!nosum && !any_private) return launch_coarse_sum<CW>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP);
   static const bool no16 = getenv("GA_COARSE_NO16") != nullptr;   // measurements only
   if constexpr (CW <= 2) {
     if (!no16 && max_t > 2 * kMacWaves && !any_private && maxP == pb && max_t <= kMac16Waves * kMac16TW) {
