@@ -58,7 +58,7 @@ STAGE_KERNELS = {
 }
 
 
-def build_graph(ctx, voices, v0, taps, loop_frames, G, loop=True):
+def build_graph(ctx, voices, v0, taps, loop_frames, G, loop=True, private_ir=False):
     from graphaudio_amd import AudioBufferSourceNode, ConvolverNode, PlayableAudioBuffer
     irbuf = PlayableAudioBuffer.FromChannelArrays([G.synth_ir(c, taps) for c in range(2)], SR)
     ctx.Destination.SetChannelCount(2)
@@ -67,6 +67,8 @@ def build_graph(ctx, voices, v0, taps, loop_frames, G, loop=True):
         s.Buffer = PlayableAudioBuffer.FromMonoArray(G.voice(v, loop_frames), SR)
         s.Loop = loop
         cv = ConvolverNode(ctx)
+        if private_ir:   # --private-ir: every voice its own impulse response (the general multiply-accumulate path; not the headline)
+            irbuf = PlayableAudioBuffer.FromChannelArrays([np.roll(G.synth_ir(c, taps), 37 * v) for c in range(2)], SR)
         cv.Buffer = irbuf
         s.Connect(cv).Connect(ctx.Destination)
         s.Start()
@@ -191,6 +193,7 @@ def main():
     ap.add_argument("--overlap", action="store_true", help="formulation D: forward and multiply-accumulate stages concurrently on two streams (measured slower)")
     ap.add_argument("--profile-every", type=int, default=4, help="record the per-stage HIP events on every k-th chunk of the timed region")
     ap.add_argument("--no-profile", action="store_true", help="no per-stage HIP events (measurement of their cost; the roofline object is then empty)")
+    ap.add_argument("--private-ir", action="store_true", help="every voice convolves with its own impulse response (general path; measurement, not the headline config)")
     ap.add_argument("--no-carry", action="store_true", help="formulation D: copy the input history with its own kernel instead of from the forward transforms (measurement)")
     ap.add_argument("--copy-stream", action="store_true", help="hand the bus to the host on a copy stream of its own (measurement)")
     ap.add_argument("--sync-steps", action="store_true", help="one blocking render per step (no host/device pipelining)")
@@ -240,7 +243,7 @@ def main():
         ctx.SetOption("coarse_carry", 0)
     if args.copy_stream:
         ctx.SetOption("host_copy_stream", 1)
-    build_graph(ctx, v1 - v0, v0, args.taps, frames, G)
+    build_graph(ctx, v1 - v0, v0, args.taps, frames, G, private_ir=args.private_ir)
     if use_reduce:
         init_sharded(ctx, rank, world)
 
@@ -325,7 +328,7 @@ def main():
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{voices_total} voices -> PartitionedConvolver, {args.taps}-tap stereo IR shared by all voices "
+            "config": {"workload": f"{voices_total} voices -> PartitionedConvolver, {args.taps}-tap stereo IR {'of its own per voice' if args.private_ir else 'shared by all voices'} "
                                    f"(P={(args.taps + 127) // 128}), 128-sample blocks, 48 kHz, {blocks} blocks per step",
                        "voices": voices_total, "taps": args.taps, "frames_per_step": frames,
                        "parallelism": f"voice-shard x{world}, one RCCL reduce of the bus per step (ga_render_reduce)" if world > 1 else "single GPU",

@@ -1554,7 +1554,7 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
   // by the group whose transforms complete the job's inputs.  Class index = 2 * column class + shared.
   std::vector<CoarseJob> jobs[6][8];
   int maxT[6] = {0, 0, 0, 0, 0, 0}, maxP[6] = {0, 0, 0, 0, 0, 0};
-  int pbOf[6] = {16, 16, 16, 16, 4, 4};   // largest of (16, 8,) 4, 2, 1 dividing every job's partition count
+  int pbOf[6] = {4, 4, 4, 4, 4, 4};   // largest of 4, 2, 1 dividing every job's partition count (the sweep's register block)
   double macBytes[6][8] = {};
   std::map<std::pair<int, int>, std::vector<int>> outRows;   // (leader, channel) -> Y rows to sum
   int yNext = 0;

@@ -290,9 +290,8 @@ void launch_coarse_fwd(hipStream_t s, const CoarseXRow* rows_dev, int nrows, int
 constexpr int kMacWaves = GA_MAC_WAVES;      // waves per workgroup: each takes 1/kMacWaves of the job's coarse blocks
 constexpr int kMacThreads = 64 * kMacWaves;
 constexpr int kMacWavesPerSimd = kMacWaves / 2;   // two workgroups per CU (LDS), four SIMDs
-// HF: every job of the launch has exactly PB partitions and one impulse response for all its terms -- the PB x CW spectra of a
-// lane's bin then stay in registers for the whole job and the sweep reads only X frames from LDS, once per term.
-template <int CW, int TW, int PB, bool HF>
+// (launches whose terms all share one impulse response take coarse_sum_kernel below instead)
+template <int CW, int TW, int PB>
 __global__ __launch_bounds__(kMacThreads, kMacWavesPerSimd) void coarse_mac_kernel(const CoarseJob* __restrict jobs, const CoarseTerm* __restrict terms,
                                                                     const float2* __restrict X, float2* __restrict Y, int y_frames, int NFA,
                                                                     int exp) {
@@ -347,21 +346,14 @@ __global__ __launch_bounds__(kMacThreads, kMacWavesPerSimd) void coarse_mac_kern
   issue_x(T[0], xs0);
   issue_h(T[0], hs0);
   __syncthreads();   // (waits for the workgroup's direct-to-LDS loads: the barrier's fence includes vmcnt(0))
-  f2 hfix[HF ? PB : 1][CW];
-  if constexpr (HF) {
-#pragma unroll
-    for (int j = 0; j < PB; j++)
-#pragma unroll
-      for (int c = 0; c < CW; c++) hfix[j][c] = hs0[(j * CW + c) * 64 + lane];
-  }
   for (int i = 0; i < J.n_terms; i++) {
     const bool more = i + 1 < J.n_terms;
     f2* xs = (i & 1) ? xs1 : xs0;
     f2* hs = (J.shared_h || !(i & 1)) ? hs0 : hs1;
     // the next term lands in the other buffers while this one is accumulated (their last readers passed the barrier below)
     if (more && !(exp & 2)) {
+      if (!J.shared_h) issue_h(T[i + 1], (i & 1) ? hs0 : hs1);   // (first: anything its addressing waits for must not wait for the X loads)
       issue_x(T[i + 1], (i & 1) ? xs0 : xs1);
-      if (!J.shared_h) issue_h(T[i + 1], (i & 1) ? hs0 : hs1);
     }
     if (t0w < nT && !(exp & 1)) {
       // blocks of PB partitions (P is a multiple of PB): their spectra sit in registers, and the frames b - (PB - 1) .. b +
@@ -369,35 +361,31 @@ __global__ __launch_bounds__(kMacThreads, kMacWavesPerSimd) void coarse_mac_kern
       // latency per block of partitions, then the block is pure VALU with j outermost, so that consecutive fmas belong to
       // different accumulators.  `SP` (tile 0: lane 0 holds two real bins) is a compile-time copy of the loop: as a run-time
       // flag inside the unrolled body the compiler evaluates both products for every tile.
-      auto sweep = [&](auto sp, auto hf, auto pbx) {
-        constexpr bool SP = decltype(sp)::value, HR = decltype(hf)::value;   // HR: spectra from the job-long registers
-        constexpr int PBX = decltype(pbx)::value;
-        for (int pb = 0; pb < (HR ? PBX : P); pb += PBX) {
-          f2 hl[HR ? 1 : PBX][CW];
-          if constexpr (!HR) {
+      auto sweep = [&](auto sp) {
+        constexpr bool SP = decltype(sp)::value;
+        constexpr int PBX = PB;
+        for (int pb = 0; pb < P; pb += PBX) {
+          f2 hl[PBX][CW];
 #pragma unroll
-            for (int j = 0; j < PBX; j++)
+          for (int j = 0; j < PBX; j++)
 #pragma unroll
-              for (int c = 0; c < CW; c++) hl[j][c] = hs[((pb + j) * CW + c) * 64 + lane];
-          }
+            for (int c = 0; c < CW; c++) hl[j][c] = hs[((pb + j) * CW + c) * 64 + lane];
           const f2* __restrict xb = xs + (t0w + (P - 1) - pb - (PBX - 1)) * 64 + lane;   // (pb + PBX - 1 <= P - 1: inside the buffer)
           f2 xv[TW + PBX - 1];
 #pragma unroll
-          for (int q = 0; q < TW; q++) xv[q] = xb[q * 64];
+          for (int q = 0; q < (PBX > 2 ? TW : TW + PBX - 1); q++) xv[q] = xb[q * 64];
           // j runs from the oldest frames up: step j needs the frames (PBX - 1 - j) .. (PBX - 1 - j) + TW - 1, one more than the
-          // step before -- requested a step ahead, so that only TW + 1 frames are live (all TW + PBX - 1 at once spill)
+          // step before -- for blocks of 4 requested a step ahead, so that only TW + 1 frames are live
 #pragma unroll
           for (int jj = 0; jj < PBX; jj++) {
             const int j = PBX - 1 - jj;
-            if (jj + 1 < PBX) xv[TW + jj] = xb[(TW + jj) * 64];
+            if (PBX > 2 && jj + 1 < PBX) xv[TW + jj] = xb[(TW + jj) * 64];
 #pragma unroll
             for (int tt = 0; tt < TW; tt++)
 #pragma unroll
               for (int c = 0; c < CW; c++) {
                 const f2 x = xv[tt - j + (PBX - 1)];
-                f2 h;
-                if constexpr (HR) h = hfix[j][c];
-                else h = hl[j][c];
+                const f2 h = hl[j][c];
                 if constexpr (!SP) {
                   acc[tt][c] = cfmap(x, h, acc[tt][c]);
                 } else {
@@ -410,9 +398,8 @@ __global__ __launch_bounds__(kMacThreads, kMacWavesPerSimd) void coarse_mac_kern
           }
         }
       };
-      // tile 0 (one workgroup in 128) takes the plain one-partition-at-a-time loop when the others run on job-long registers
-      if (special) sweep(std::true_type{}, std::false_type{}, std::integral_constant<int, HF ? 1 : PB>{});
-      else sweep(std::false_type{}, std::integral_constant<bool, HF>{}, std::integral_constant<int, PB>{});
+      if (special) sweep(std::true_type{});
+      else sweep(std::false_type{});
     }
     __syncthreads();
   }
@@ -428,156 +415,6 @@ __global__ __launch_bounds__(kMacThreads, kMacWavesPerSimd) void coarse_mac_kern
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-//  The same multiply-accumulate for launches whose jobs all have exactly PB partitions and one impulse response for all
-//  terms (the common case: many voices through one room): ONE workgroup of 16 waves per CU and THREE X buffers.
-//    * the PB x CW spectra of a lane's bin are read once and stay in registers for the whole job;
-//    * two terms are always in flight: term i + 2 is requested before term i is accumulated and only term i + 1 is waited
-//      for at the end of the step (counted vmcnt, raw barrier: __syncthreads() would drain the queue) -- with two buffers
-//      the memory pipe ran empty once per term and the kernel's time was the SUM of its load and its VALU time;
-//    * a wave takes 4 coarse blocks (16 x 4 = the job's 64), slides over TW + PB - 1 frames and keeps TW + 1 of them live.
-//  Tile 0, lane 0 (the packed pair of real bins) accumulates the element-wise products beside the complex ones.
-// ---------------------------------------------------------------------------------------------------------------------
-constexpr int kMac16Waves = 16, kMac16Threads = 64 * kMac16Waves, kMac16TW = 4;
-constexpr int kMac16XR = ((kMac16Waves * kMac16TW + kCoarseMaxP) * 32 + kMac16Threads - 1) / kMac16Threads;   // load instructions per wave and term (3)
-template <int CW, int PB>
-__global__ __launch_bounds__(kMac16Threads) void coarse_mac16_kernel(const CoarseJob* __restrict jobs, const CoarseTerm* __restrict terms,
-                                                                    const float2* __restrict X, float2* __restrict Y, int y_frames, int NFA, int exp) {
-  constexpr int TW = kMac16TW, XR = kMac16XR;
-  static_assert(XR == 3, "the counted waits below are written for three load instructions per wave and term");
-  extern __shared__ f2 mlds[];   // (all of the kernel's LDS is this one array)
-  const CoarseJob J = jobs[blockIdx.y];
-  const int tile = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nT = J.n_t, NF = nT + PB - 1, nterms = J.n_terms;
-  const int twr = (nT + kMac16Waves - 1) / kMac16Waves, t0w = wv * twr;
-  const bool special = tile == 0, lane0 = special && lane == 0;
-  const size_t binoff = (size_t)tile * 64;
-  typedef __attribute__((address_space(3))) void* lds_t;
-  f2* b0 = mlds;
-  f2* b1 = mlds + (size_t)NFA * 64;
-  f2* b2 = mlds + (size_t)2 * NFA * 64;
-  int mine = 0;   // load instructions this wave issues per term (rows 32 r + 2 wv + {0, 1})
-#pragma unroll
-  for (int r = 0; r < XR; r++) mine += (32 * r + 2 * wv < NF) ? 1 : 0;
-  const CoarseTerm* __restrict T = terms + J.term0;
-  // the terms' first frames, one per lane (a job has at most kCoarseJobTerms <= 64), read with v_readlane in the loop: a scalar
-  // load of the descriptor per term put a memory latency in front of every sweep (its lgkmcnt(0) also covers the first LDS reads)
-  static_assert(kCoarseJobTerms <= 64, "one lane per term");
-  const int f0v = lane < nterms ? T[lane].frame0 : 0;
-  auto issue_x = [&](int term, f2* xs) {
-    const int frame0 = __builtin_amdgcn_readlane(f0v, term & 63);
-#pragma unroll
-    for (int r = 0; r < XR; r++) {
-      const int fr0 = 32 * r + 2 * wv;   // (uniform)
-      const int fr = fr0 + (lane >> 5), of = lane & 31;
-      if (fr < NF)
-        __builtin_amdgcn_global_load_lds(gptr(X + (size_t)(frame0 + J.t0 + fr) * kCoarseBins + binoff + 2 * of), (lds_t)(xs + fr0 * 64), 16, 0, 0);
-    }
-  };
-  {   // the impulse response's PB x CW rows pass through the third buffer
-    const int pc0 = 2 * wv, pc = pc0 + (lane >> 5), of = lane & 31;
-    if (pc < PB * CW)
-      __builtin_amdgcn_global_load_lds(gptr(T[0].h[pc % CW] + (size_t)(pc / CW) * kCoarseBins + binoff + 2 * of), (lds_t)(b2 + pc0 * 64), 16, 0, 0);
-    static_assert(PB * CW <= 2 * kMac16Waves, "one load instruction per wave covers the impulse response");
-  }
-  if (!(exp & 2)) {
-    issue_x(0, b0);
-    if (nterms > 1) issue_x(1, b1);
-  }
-  __syncthreads();   // (its fence waits for the direct-to-LDS loads: vmcnt(0))
-  f2 h[PB][CW];
-#pragma unroll
-  for (int j = 0; j < PB; j++)
-#pragma unroll
-    for (int c = 0; c < CW; c++) h[j][c] = b2[(j * CW + c) * 64 + lane];
-  __syncthreads();   // every wave holds its spectra: the buffer may take X frames
-  f2 acc[TW][CW], accS[TW][CW];
-#pragma unroll
-  for (int tt = 0; tt < TW; tt++)
-#pragma unroll
-    for (int c = 0; c < CW; c++) acc[tt][c] = accS[tt][c] = f2{0.f, 0.f};
-
-  for (int i = 0; i < nterms; i++) {
-    const bool ahead = i + 2 < nterms && !(exp & 2);
-    if (ahead) issue_x(i + 2, b2);   // (b2's last readers passed the barrier of step i - 1)
-    if (t0w < nT && !(exp & 1)) {
-      auto sweep = [&](auto sp) {
-        constexpr bool SP = decltype(sp)::value;
-        const f2* __restrict xb = b0 + t0w * 64 + lane;
-        f2 xv[TW + PB - 1];
-#pragma unroll
-        for (int q = 0; q < TW; q++) xv[q] = xb[q * 64];
-        // j runs from the oldest frames up; the one new frame of the next step is requested a step ahead
-#pragma unroll
-        for (int jj = 0; jj < PB; jj++) {
-          const int j = PB - 1 - jj;
-          if (jj + 1 < PB) xv[TW + jj] = xb[(TW + jj) * 64];
-#pragma unroll
-          for (int tt = 0; tt < TW; tt++)
-#pragma unroll
-            for (int c = 0; c < CW; c++) {
-              const f2 x = xv[tt - j + (PB - 1)];
-              acc[tt][c] = cfmap(x, h[j][c], acc[tt][c]);
-              if constexpr (SP) accS[tt][c] = __builtin_elementwise_fma(x, h[j][c], accS[tt][c]);   // two real bins side by side
-            }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      };
-      if (special) sweep(std::true_type{});
-      else sweep(std::false_type{});
-    }
-    // term i + 1 must have landed (and every wave must be done reading b0) before the next step; the loads just issued stay
-    // in flight across the barrier
-    const int keep = ahead ? mine : 0;
-    if (keep >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if (keep == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if (keep == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    f2* t = b0;
-    b0 = b1;
-    b1 = b2;
-    b2 = t;
-  }
-#pragma unroll
-  for (int tt = 0; tt < TW; tt++) {
-    const int t = t0w + tt;
-    if (tt < twr && t < nT && !(exp & 4)) {
-#pragma unroll
-      for (int c = 0; c < CW; c++) {
-        const f2 a = lane0 ? accS[tt][c] : acc[tt][c];
-        stg2(Y + ((size_t)(J.yrow0 + c) * y_frames + J.t0 + t) * kCoarseBins + binoff + lane, v2f{a.x, a.y});
-      }
-    }
-  }
-}
-
-template <int CW, int PB>
-static void launch_coarse_mac16(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
-                                int y_frames, int max_t) {
-  static const int exp = getenv("GA_COARSE_EXP") ? atoi(getenv("GA_COARSE_EXP")) : 0;   // timing experiments only
-  int NFA = PB * CW;   // (the impulse response passes through one buffer)
-  for (int nt = 1; nt <= max_t; nt++) {
-    const int twr = (nt + kMac16Waves - 1) / kMac16Waves, wl = (nt + twr - 1) / twr - 1;
-    NFA = std::max(NFA, wl * twr + kMac16TW + PB - 1);
-  }
-  const size_t lds = (size_t)3 * NFA * 64 * sizeof(float2);
-  if (lds > 160 * 1024) launch_fail("coarse multiply-accumulate: staging does not fit the LDS");
-  if (hipFuncSetAttribute((const void*)coarse_mac16_kernel<CW, PB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(lds, 65536)) !=
-      hipSuccess)
-    launch_fail("cannot raise the dynamic LDS limit of the coarse multiply-accumulate");
-  if (getenv("GA_COARSE_EXP")) {
-    int occ = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, coarse_mac16_kernel<CW, PB>, kMac16Threads, lds);
-    fprintf(stderr, "[coarse_mac16<%d,%d>] lds %zu B, NFA %d, occupancy %d workgroups/CU, %d jobs\n", CW, PB, lds, NFA, occ, njobs);
-  }
-  for (int j0 = 0; j0 < njobs; j0 += 32768)
-    hipLaunchKernelGGL((coarse_mac16_kernel<CW, PB>), dim3(kCoarseBins / 64, std::min(32768, njobs - j0)), dim3(kMac16Threads), lds, s, jobs_dev + j0,
-                       terms_dev, X, Y, y_frames, NFA, exp >> 4);
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
 //  One impulse response for all terms of a job (many voices through one room: ConvolverNodes that hold the same buffer and
 //  feed the same sum): the spectral multiply commutes with the sum over the terms,
 //        sum_v sum_p X_v[t - p] H[p]  =  sum_p ( sum_v X_v[t - p] ) H[p],
@@ -586,7 +423,10 @@ static void launch_coarse_mac16(hipStream_t s, const CoarseJob* jobs_dev, int nj
 //  -- and multiplies ONCE at the end (sum tile -> LDS, the usual sliding sweep).  The multiply-accumulate work per job drops
 //  from (terms x P x blocks) to (P x blocks) products per bin and the kernel runs at the rate it can read X.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kSumWaves = 8, kSumThreads = 64 * kSumWaves, kSumAhead = 4;
+#ifndef GA_SUM_AHEAD
+#define GA_SUM_AHEAD 4
+#endif
+constexpr int kSumWaves = 8, kSumThreads = 64 * kSumWaves, kSumAhead = GA_SUM_AHEAD;   // terms in flight per thread
 template <int CW>
 __global__ __launch_bounds__(kSumThreads, 2) void coarse_sum_kernel(const CoarseJob* __restrict jobs, const CoarseTerm* __restrict terms,
                                                                     const float2* __restrict X, float2* __restrict Y, int y_frames, int NFA, int exp) {
@@ -721,7 +561,7 @@ static void launch_coarse_sum(hipStream_t s, const CoarseJob* jobs_dev, int njob
                        Y, y_frames, NFA, exp >> 4);
 }
 
-template <int CW, int TW, int PB, bool HF = false>
+template <int CW, int TW, int PB>
 static void launch_coarse_mac_t(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
                                 int y_frames, int max_t, int maxP, bool any_private) {
   static const int exp = getenv("GA_COARSE_EXP") ? atoi(getenv("GA_COARSE_EXP")) : 0;   // timing experiments only
@@ -733,16 +573,16 @@ static void launch_coarse_mac_t(hipStream_t s, const CoarseJob* jobs_dev, int nj
   }
   const size_t lds = ((size_t)2 * NFA * 64 + (size_t)(any_private ? 2 : 1) * maxP * CW * 64) * sizeof(float2);
   if (lds > 160 * 1024) launch_fail("coarse multiply-accumulate: staging does not fit the LDS");
-  if (hipFuncSetAttribute((const void*)coarse_mac_kernel<CW, TW, PB, HF>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  if (hipFuncSetAttribute((const void*)coarse_mac_kernel<CW, TW, PB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)std::max<size_t>(lds, 65536)) != hipSuccess)
     launch_fail("cannot raise the dynamic LDS limit of the coarse multiply-accumulate");
   if (getenv("GA_COARSE_EXP")) {
     int occ = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, coarse_mac_kernel<CW, TW, PB, HF>, kMacThreads, lds);
-    fprintf(stderr, "[coarse_mac<%d,%d,%d,%d>] lds %zu B, NFA %d, occupancy %d workgroups/CU, %d jobs\n", CW, TW, PB, (int)HF, lds, NFA, occ, njobs);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, coarse_mac_kernel<CW, TW, PB>, kMacThreads, lds);
+    fprintf(stderr, "[coarse_mac<%d,%d,%d>] lds %zu B, NFA %d, occupancy %d workgroups/CU, %d jobs\n", CW, TW, PB, lds, NFA, occ, njobs);
   }
   for (int j0 = 0; j0 < njobs; j0 += 32768)
-    hipLaunchKernelGGL((coarse_mac_kernel<CW, TW, PB, HF>), dim3(kCoarseBins / 64, std::min(32768, njobs - j0)), dim3(kMacThreads), lds, s,
+    hipLaunchKernelGGL((coarse_mac_kernel<CW, TW, PB>), dim3(kCoarseBins / 64, std::min(32768, njobs - j0)), dim3(kMacThreads), lds, s,
                        jobs_dev + j0, terms_dev, X, Y, y_frames, NFA, exp >> 4);
 }
 // all jobs of one launch have the same column count `cw` (1, 2 or 4), at most `max_t` coarse blocks (<= kCoarseJobBlocks(cw))
@@ -753,17 +593,7 @@ static void launch_coarse_mac_cw(hipStream_t s, const CoarseJob* jobs_dev, int n
   constexpr int TWL = CW <= 2 ? GA_MAC_TW : GA_MAC_TW / 2;   // accumulators: TW x CW complex values per lane
   static const bool nosum = getenv("GA_COARSE_NOSUM") != nullptr;   // measurements only
   if (!nosum && !any_private) return launch_coarse_sum<CW>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP);
-  static const bool no16 = getenv("GA_COARSE_NO16") != nullptr;   // measurements only
-  if constexpr (CW <= 2) {
-    if (!no16 && max_t > 2 * kMacWaves && !any_private && maxP == pb && max_t <= kMac16Waves * kMac16TW) {
-      if (pb == 4) return launch_coarse_mac16<CW, 4>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t);
-      if (pb == 8) return launch_coarse_mac16<CW, 8>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t);
-      if (pb == 16 && CW == 1) return launch_coarse_mac16<1, 16>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t);   // (2 x 16 spectra spill)
-    }
-  }
   if (max_t <= 2 * kMacWaves) launch_coarse_mac_t<CW, 2, 1>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
-  else if (pb == 8 && CW <= 2 && maxP == 8 && !any_private)   // (pb divides every partition count: all jobs have exactly 8)
-    launch_coarse_mac_t<CW <= 2 ? CW : 1, TWL, 8, true>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
   else if (pb >= 4 && (CW == 1 || (CW == 2 && GA_MAC_PB2 == 4))) launch_coarse_mac_t<CW, TWL, 4>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
   else if (pb >= 2) launch_coarse_mac_t<CW, TWL, 2>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
   else launch_coarse_mac_t<CW, TWL, 1>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
