@@ -231,7 +231,8 @@ def main():
 
     ctx = OfflineAudioContext(SR, device=local_rank)
     ctx.SetOption("profile", 0 if args.no_profile else 1)
-    ctx.SetOption("profile_every", args.profile_every)   # the events cost device time: only every k-th chunk records them
+    # the events cost device time: only every k-th chunk records them (every chunk when the run is too short to sample)
+    ctx.SetOption("profile_every", args.profile_every if args.steps >= 2 * args.profile_every else 1)
     ctx.SetOption("max_chunk_blocks", 4096)
     if args.direct:
         ctx.SetOption("time_fft", 0)
