@@ -373,13 +373,9 @@ __global__ __launch_bounds__(kMacThreads, kMacWavesPerSimd) void coarse_mac_kern
           const f2* __restrict xb = xs + (t0w + (P - 1) - pb - (PBX - 1)) * 64 + lane;   // (pb + PBX - 1 <= P - 1: inside the buffer)
           f2 xv[TW + PBX - 1];
 #pragma unroll
-          for (int q = 0; q < (PBX > 2 ? TW : TW + PBX - 1); q++) xv[q] = xb[q * 64];
-          // j runs from the oldest frames up: step j needs the frames (PBX - 1 - j) .. (PBX - 1 - j) + TW - 1, one more than the
-          // step before -- for blocks of 4 requested a step ahead, so that only TW + 1 frames are live
+          for (int q = 0; q < TW + PBX - 1; q++) xv[q] = xb[q * 64];
 #pragma unroll
-          for (int jj = 0; jj < PBX; jj++) {
-            const int j = PBX - 1 - jj;
-            if (PBX > 2 && jj + 1 < PBX) xv[TW + jj] = xb[(TW + jj) * 64];
+          for (int j = 0; j < PBX; j++)
 #pragma unroll
             for (int tt = 0; tt < TW; tt++)
 #pragma unroll
@@ -394,8 +390,6 @@ __global__ __launch_bounds__(kMacThreads, kMacWavesPerSimd) void coarse_mac_kern
                   acc[tt][c] = lane0 ? pk : gen;
                 }
               }
-            if constexpr (PBX > 2) __builtin_amdgcn_sched_barrier(0);
-          }
         }
       };
       if (special) sweep(std::true_type{});
