@@ -373,3 +373,65 @@ def test_default_policy_long_first_chunk_takes_the_coarse_path():
     st = h2.GetStats()
     assert st["stage_launches"][5] == 0 and st["stage_launches"][3] > 0
     check(ref, got2)
+
+
+# ---- the two multiply-accumulate kernels: terms that share their impulse response are summed before the multiply
+#      (coarse_sum_kernel), terms with their own go through coarse_mac_kernel ----
+@pytest.mark.parametrize("voices", [1, 4, 5, 33, 70])
+def test_shared_ir_term_counts(voices):
+    """jobs of 32 terms + a rest; the reduction's four-terms-in-flight loop and its tail."""
+    frames = 128 * 300
+    ref, got, st = pair(lambda c: G.config3_convolver(c, voices=voices, taps=20000, frames=frames), frames, [128 * 130, 128 * 170])
+    assert used_coarse(st)
+    check(ref, got)
+
+
+@pytest.mark.parametrize("ir_channels", [1, 4])
+def test_shared_ir_one_and_four_columns(ir_channels):
+    """mono IR (1 column) and a 4-channel IR on mono voices (4 columns -> the 4-column instance of both kernels)"""
+    frames = 128 * 300
+    ref, got, st = pair(lambda c: G.config3_convolver(c, voices=6, taps=17000, frames=frames, ir_channels=ir_channels), frames)
+    assert used_coarse(st)
+    check(ref, got)
+
+
+def _shared_and_private(ctx, frames):
+    shared = PlayableAudioBuffer.FromChannelArrays([G.synth_ir(c, 25000) for c in range(2)], SR)
+    ctx.Destination.SetChannelCount(2)
+    for v in range(9):
+        s = AudioBufferSourceNode(ctx)
+        s.Buffer = PlayableAudioBuffer.FromMonoArray(G.voice(v, frames + 256), SR)
+        cv = ConvolverNode(ctx)
+        # voices 0-5 share one buffer, 6-8 have their own (same length: same partition count, same fused group)
+        cv.Buffer = shared if v < 6 else PlayableAudioBuffer.FromChannelArrays([G.synth_ir(c, 25000, seed0=900 + 10 * v) for c in range(2)], SR)
+        s.Connect(cv).Connect(ctx.Destination)
+        s.Start()
+    return 2
+
+
+def test_shared_and_private_impulse_responses_in_one_sum():
+    frames = 128 * 300
+    ref, got, st = pair(lambda c: _shared_and_private(c, frames), frames, [128 * 100, 128 * 200])
+    assert used_coarse(st)
+    check(ref, got)
+
+
+def test_history_carried_by_the_forward_kernel_equals_the_copy_kernel():
+    """option coarse_carry: the next chunk's history written by coarse_fwd_kernel or by coarse_hist_kernel -- same bits"""
+    frames = 128 * 700
+    pieces = [128 * 300, 128 * 50, 128 * 350]   # longer than the history (carried), shorter (copied), longer again
+    outs = []
+    for carry in (1, 0):
+        h = hip(coarse_carry=carry)
+        G.config3_convolver(h, voices=3, taps=30000, frames=frames)
+        got = np.zeros((2, frames), np.float32)
+        pos = 0
+        for n in pieces:
+            h.Render(got, n, pos)
+            pos += n
+        st = h.GetStats()
+        assert used_coarse(st)
+        assert (st["stage_launches"][8] > 0) if carry == 0 else True
+        outs.append(got)
+        h.Dispose()
+    assert np.array_equal(outs[0], outs[1])
