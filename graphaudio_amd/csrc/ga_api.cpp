@@ -213,14 +213,26 @@ void Context::render(float* const* out, int channels, int64_t frameCount, int64_
     int64_t nblk = (need + kBlock - 1) / kBlock;
     const int64_t limit = chunkLimit(nblk);
     nblk = std::min(nblk, limit);
+    // device output, whole blocks, 16-byte aligned rows: the destination mixes straight into the caller's memory
+    bool direct = deviceOut && need >= nblk * kBlock;
+    for (int ch = 0; ch < channels && direct; ch++) direct = (((uintptr_t)(out[ch] + startIndex + written)) & 15) == 0;
+    struct Target {   // (cleared on every way out of the chunk)
+      Context& c;
+      ~Target() { std::memset(c.busTarget, 0, sizeof(c.busTarget)); }
+    } target{*this};
+    if (direct)
+      for (int ch = 0; ch < channels; ch++) busTarget[ch] = out[ch] + startIndex + written;
     runChunk(nblk, nullptr);
+    std::memset(busTarget, 0, sizeof(busTarget));
     const int64_t done = chunkBlocksDone;
     if (done <= 0) fail(GA_ERR_INVALID_OPERATION, "render made no progress");
     // buffer.GetChannelSpan(ch) throws for ch >= destination channel count (:82-85)
     if (channels > chunkMinDestCh) fail(GA_ERR_OUT_OF_RANGE, "channelIndex");
     const int64_t chunkFrames = done * kBlock;
     const int64_t toCopy = std::min(chunkFrames, need);
-    if (!deviceOut && ownStream && pipelined.callerAsync && hostCopyStream) {
+    if (direct) {
+      // nothing to copy: the bus of these `done` blocks is where the caller wants it
+    } else if (!deviceOut && ownStream && pipelined.callerAsync && hostCopyStream) {
       handOverToHost(busSlabs.data(), out, channels, startIndex + written, toCopy);
     } else {
       for (int ch = 0; ch < channels; ch++)

@@ -2633,7 +2633,7 @@ void Context::chunkPlanNodes(ChunkRun& r, int d) {
           case GA_NODE_DESTINATION: {
             // the destination aliases its input buffer (AudioDestinationNode.cs:44-50): mix straight into the bus
             std::vector<float*> forced(std::max(ns.ins[0].bufCh, 1), nullptr);
-            for (int ch = 0; ch < ns.ins[0].bufCh && ch < (int)busSlabs.size(); ch++) forced[ch] = busSlabs[ch];
+            for (int ch = 0; ch < ns.ins[0].bufCh && ch < (int)busSlabs.size(); ch++) forced[ch] = busTarget[ch] ? busTarget[ch] : busSlabs[ch];
             ex.resolveInput((int)si, ns, 0, true, forced.data());
             break;
           }

@@ -532,6 +532,9 @@ struct Context {
 
   int64_t busCapFrames = 0;
   std::vector<float*> busSlabs;
+  // a render into device memory whose chunk covers whole blocks lets the destination mix straight into the caller's rows
+  // (no copy of the bus afterwards): set by Context::render around runChunk, consulted where the destination's input is resolved
+  float* busTarget[32] = {};
   struct SegCh { int64_t b0, b1; int ch; };
   std::vector<SegCh> chunkSegCh;   // destination buffer channel count of every segment of the last chunk
   float* ilvDev = nullptr;         // device staging for interleaved output
