@@ -194,6 +194,7 @@ def main():
     ap.add_argument("--profile-every", type=int, default=4, help="record the per-stage HIP events on every k-th chunk of the timed region")
     ap.add_argument("--no-profile", action="store_true", help="no per-stage HIP events (measurement of their cost; the roofline object is then empty)")
     ap.add_argument("--private-ir", action="store_true", help="every voice convolves with its own impulse response (general path; measurement, not the headline config)")
+    ap.add_argument("--no-tail", action="store_true", help="formulation D: no carried output tails, every chunk re-transforms the input history (measurement)")
     ap.add_argument("--no-carry", action="store_true", help="formulation D: copy the input history with its own kernel instead of from the forward transforms (measurement)")
     ap.add_argument("--copy-stream", action="store_true", help="hand the bus to the host on a copy stream of its own (measurement)")
     ap.add_argument("--sync-steps", action="store_true", help="one blocking render per step (no host/device pipelining)")
@@ -242,6 +243,8 @@ def main():
         ctx.SetOption("coarse_overlap", 1)
     if args.no_carry:
         ctx.SetOption("coarse_carry", 0)
+    if args.no_tail:
+        ctx.SetOption("coarse_tail", 0)
     if args.copy_stream:
         ctx.SetOption("host_copy_stream", 1)
     build_graph(ctx, v1 - v0, v0, args.taps, frames, G, private_ir=args.private_ir)

@@ -79,6 +79,7 @@ class Stats(C.Structure):
         ("stage_launches", C.c_int64 * 16),
         ("stage_bytes", C.c_double * 16),
         ("profiled_chunks", C.c_int64),
+        ("coarse_carried_outputs", C.c_int64),
     ]
     STAGES = ("other", "mix", "rfft_fwd", "mac", "rfft_inv", "coarse_fwd", "coarse_mac", "coarse_inv", "coarse_hist", "coarse_section")
 

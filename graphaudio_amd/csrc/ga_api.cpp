@@ -326,6 +326,7 @@ int ga_set_option(ga_context* ctx, const char* key, double value) {
     else if (k == "coarse") c.useCoarse = value != 0;
     else if (k == "coarse_overlap") c.coarseOverlap = value != 0;
     else if (k == "coarse_carry") c.coarseCarry = value != 0;
+    else if (k == "coarse_tail") c.coarseTail = value != 0;
     else if (k == "host_copy_stream") c.hostCopyStream = value != 0;
     else if (k == "coarse_min_blocks") c.coarseMinBlocks = std::max<int64_t>(1, (int64_t)value);
     else if (k == "debug_tconv_n2") c.debugTconvN2 = (int)value;   // tests only: plan the block-axis FFT with this (possibly unsupported) length

@@ -1429,13 +1429,38 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
   std::vector<CoarseXRow> xrows;
   std::vector<CoarseHistJob> hjobs;
   struct Piece {   // <= 4 columns of one signal: (impulse-response channel, output channel of the group)
-    int frame0, P, xrow;
+    int frame0, P, xrow, u0;
     IrSpectra* ir;
     int leader;
     int ncol;
     int irCh[4], outCh[4];
   };
   std::vector<Piece> pieces;
+  // ---- carried tails (option "coarse_tail"): every output of the stage keeps, from chunk to chunk, what the input so far adds to
+  // the samples behind the chunk's end.  While a group of fused convolvers is the same as in the previous chunk its members need
+  // no input history in front of the chunk: their windows start at the chunk (u = 0) and the previous chunk's tail is added to
+  // the output instead -- P' - 1 fewer transforms per signal and chunk.  Any change (member set, impulse responses, channel
+  // modes, a chunk in between that did not run this stage) falls back to the input histories, which are kept up to date either way.
+  struct GroupInfo { uint64_t sig = 1469598103934665603ull; int maxP = 0; bool carried = false; };
+  std::map<int, GroupInfo> groups;   // by leader
+  const bool tails = c.coarseTail;
+  {
+    auto mix = [](uint64_t& h, uint64_t v) { h = (h ^ v) * 1099511628211ull; };
+    for (int id : dNodes) {
+      NodeS& nd = *c.nodes[id];
+      GroupInfo& g = groups[nd.dLeader >= 0 ? nd.dLeader : id];
+      mix(g.sig, (uint64_t)id);
+      mix(g.sig, (uint64_t)(uintptr_t)nd.ir.get());
+      mix(g.sig, (uint64_t)nd.bInCh | ((uint64_t)nd.bSlots << 8) | ((uint64_t)nd.isTrueStereo << 16) | ((uint64_t)nd.bShared << 17) |
+                     ((uint64_t)nd.ir->coarseP << 24));
+      g.maxP = std::max(g.maxP, nd.ir->coarseP);
+    }
+    for (auto& kv : groups) {
+      NodeS& ld = *c.nodes[kv.first];
+      kv.second.carried = tails && ld.dTail[0] && ld.dTailSeq + 1 == c.chunkSeq && ld.dTailSig == kv.second.sig &&
+                          ld.dTailLen == (int64_t)(kv.second.maxP + 1) * kCoarseBlock;
+    }
+  }
   int frameNext = 0;
   int64_t maxHist = 0;
   double histBytes = 0;
@@ -1447,6 +1472,7 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
     const int P = ir.coarseP;
     if (P < 1 || P > kCoarseMaxP) fail(GA_ERR_INVALID_OPERATION, "internal: coarse partition count out of range");
     const int64_t hl = nd.dHistLen;
+    const bool carried = groups[nd.dLeader >= 0 ? nd.dLeader : id].carried;
     auto& ci = ex.convIn[id];
     chIn.assign(nd.bInCh, nullptr);
     for (int ch = 0; ch < nd.bInCh; ch++) chIn[ch] = convChunkInput(c, ex, ci, ch);
@@ -1463,12 +1489,15 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
     int xFrame[32], xIndex[32];
     for (int ch = 0; ch < nxr; ch++) {
       CoarseXRow r;
-      r.hist = nd.dHistZero ? nullptr : nd.dHist[nd.dHistCur] + (size_t)ch * hl;
+      const float* oldHist = nd.dHistZero ? nullptr : nd.dHist[nd.dHistCur] + (size_t)ch * hl;   // (kept up to date in every mode)
+      r.hist = carried ? nullptr : oldHist;
       r.in = chIn[ch];
       r.nvalid = frames;
       r.frame0 = frameNext;
-      r.n_frames = nT + P - 1;
-      r.u0 = -(P - 1);
+      // windows u0 .. u_last: with carried tails the last one is u = nT ([last block | nothing yet]: it feeds the outputs behind
+      // the chunk's end), and a group that continues needs none in front of the chunk
+      r.u0 = carried ? 0 : -(P - 1);
+      r.n_frames = (tails ? nT + 1 : nT) - r.u0;
       r.hist_len = (int)hl;
       r.flags = 0;
       r.scale = 1.0f;
@@ -1485,7 +1514,7 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
         r.carry_from = frames - hl;
         carryBytes[(int)xrows.size()] = (double)hl * 4.0;
       } else {
-        hjobs.push_back(CoarseHistJob{r.hist, r.in, nextHist, hl, frames});
+        hjobs.push_back(CoarseHistJob{oldHist, r.in, nextHist, hl, frames});
         maxHist = std::max(maxHist, hl);
         histBytes += 2.0 * (double)hl * 4.0;
       }
@@ -1511,6 +1540,7 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
         Piece pc{};
         pc.frame0 = xFrame[xc];
         pc.xrow = xIndex[xc];
+        pc.u0 = xrows[xIndex[xc]].u0;
         pc.P = P;
         pc.ir = &ir;
         pc.leader = leader;
@@ -1570,7 +1600,7 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
       for (size_t i = p0; i < p1; i++) {
         const Piece& pc = *pv[i];
         CoarseTerm t{};
-        t.frame0 = pc.frame0;
+        t.frame0 = pc.frame0 - (pc.u0 + (pc.P - 1));   // frame the window u = -(P - 1) would have (the kernels index from there)
         for (int j = 0; j < 4; j++) t.h[j] = nullptr;
         for (int j = 0; j < cw; j++) t.h[j] = pc.ir->coarse + (size_t)pc.irCh[j] * pc.P * kCoarseBins;
         if (i > p0)
@@ -1583,21 +1613,26 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
       yNext += cw;
       for (int j = 0; j < cw; j++) outRows[{k.leader, k.out[j]}].push_back(yrow0 + j);
       const int jb = kCoarseJobBlocks(cw);
-      for (int t0 = 0; t0 < nT; t0 += jb) {
+      const GroupInfo& gi = groups[k.leader];
+      const int nTo = tails ? nT + gi.maxP : nT;   // output blocks: the chunk's, and with tails those the chunk's input still reaches
+      for (int t0 = 0; t0 < nTo; t0 += jb) {
         CoarseJob jb_{};
         jb_.term0 = term0;
         jb_.n_terms = (int)(p1 - p0);
         jb_.P = k.P;
         jb_.t0 = t0;
-        jb_.n_t = std::min(jb, nT - t0);
+        jb_.n_t = std::min(jb, nTo - t0);
         jb_.yrow0 = yrow0;
         jb_.shared_h = shared ? 1 : 0;
+        jb_.u_lo = gi.carried ? 0 : -(k.P - 1);
+        jb_.u_hi = tails ? nT : nT - 1;
         const int cj = 2 * ci + (shared ? 1 : 0);
         jobs[cj][grp].push_back(jb_);
         maxT[cj] = std::max(maxT[cj], jb_.n_t);
         maxP[cj] = std::max(maxP[cj], k.P);
         while (k.P % pbOf[cj]) pbOf[cj] >>= 1;
-        macBytes[cj][grp] += (double)jb_.n_terms * (jb_.n_t + k.P - 1) * kCoarseBins * 8.0 +
+        const int fread = std::max(0, std::min(jb_.u_hi, t0 + jb_.n_t - 1) - std::max(jb_.u_lo, t0 - (k.P - 1)) + 1);   // frames that exist
+        macBytes[cj][grp] += (double)jb_.n_terms * fread * kCoarseBins * 8.0 +
                              (double)(shared ? 1 : jb_.n_terms) * k.P * cw * kCoarseBins * 8.0 + (double)cw * jb_.n_t * kCoarseBins * 8.0;
       }
     }
@@ -1605,17 +1640,62 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
   std::vector<CoarseOut> outs;
   std::vector<int> ylist;
   double invBytes = 0;
+  int maxPAll = 0;
+  for (auto& kv : groups) maxPAll = std::max(maxPAll, kv.second.maxP);
+  const int yFrames = tails ? nT + maxPAll : nT;   // coarse blocks per Y row (rows of shorter groups leave their end unused)
+  int invBlocks = nT;
+  if (tails) {   // tail buffers live with the group's leader: [2][channels][tail_len], read one, write the other
+    std::map<int, int> chOf;
+    for (auto& kv : outRows) chOf[kv.first.first] = std::max(chOf[kv.first.first], kv.first.second + 1);
+    for (auto& kv : groups) {
+      NodeS& ld = *c.nodes[kv.first];
+      const int64_t len = (int64_t)(kv.second.maxP + 1) * kCoarseBlock;
+      const int nch = chOf.count(kv.first) ? chOf[kv.first] : 0;
+      if (nch == 0) continue;
+      if (!ld.dTail[0] || ld.dTailLen != len || ld.dTailCh != nch) {
+        if (kv.second.carried) fail(GA_ERR_INVALID_OPERATION, "internal: a carried tail changed its shape");
+        GA_HIP(hipStreamSynchronize(c.stream));
+        for (int b = 0; b < 2; b++) {
+          if (ld.dTail[b]) c.dfree(ld.dTail[b], (size_t)ld.dTailLen * ld.dTailCh * sizeof(float));
+          ld.dTail[b] = (float*)c.dalloc((size_t)len * nch * sizeof(float));
+        }
+        ld.dTailLen = len;
+        ld.dTailCh = nch;
+        ld.dTailCur = 0;
+      }
+    }
+  }
   for (auto& kv : outRows) {
     CoarseOut o{};
     o.out = ex.nodeOut(kv.first.first, kv.first.second);
     o.nvalid = frames;
     o.y0 = (int)ylist.size();
     o.ny = (int)kv.second.size();
+    o.n_y = nT;
+    if (tails) {
+      NodeS& ld = *c.nodes[kv.first.first];
+      const GroupInfo& gi = groups[kv.first.first];
+      o.n_y = nT + gi.maxP;
+      o.tail_len = ld.dTailLen;
+      o.tail_in = gi.carried ? ld.dTail[ld.dTailCur] + (size_t)kv.first.second * ld.dTailLen : nullptr;
+      o.tail_out = ld.dTail[ld.dTailCur ^ 1] + (size_t)kv.first.second * ld.dTailLen;
+      invBlocks = std::max(invBlocks, (int)((frames + o.tail_len + kCoarseBlock - 1) / kCoarseBlock));
+      invBytes += (double)o.tail_len * 4.0 * (gi.carried ? 2.0 : 1.0);
+      if (gi.carried) c.stats.coarse_carried_outputs++;
+    }
     ylist.insert(ylist.end(), kv.second.begin(), kv.second.end());
     outs.push_back(o);
-    invBytes += (double)o.ny * nT * kCoarseBins * 8.0 + (double)frames * 4.0;
+    invBytes += (double)o.ny * o.n_y * kCoarseBins * 8.0 + (double)frames * 4.0;
   }
-  if ((size_t)frameNext * kCoarseBins * sizeof(float2) > c.coarseX.bytes || (size_t)yNext * nT * kCoarseBins * sizeof(float2) > c.coarseY.bytes)
+  if (tails)
+    for (auto& kv : groups) {   // this chunk's tails are the next chunk's, if the group is still the same then
+      NodeS& ld = *c.nodes[kv.first];
+      if (!ld.dTail[0]) continue;
+      ld.dTailCur ^= 1;
+      ld.dTailSig = kv.second.sig;
+      ld.dTailSeq = c.chunkSeq;
+    }
+  if ((size_t)frameNext * kCoarseBins * sizeof(float2) > c.coarseX.bytes || (size_t)yNext * yFrames * kCoarseBins * sizeof(float2) > c.coarseY.bytes)
     fail(GA_ERR_INVALID_OPERATION, "internal: coarse spectra arenas are too small for the plan");
 
   const size_t xo = ex.plan.putv(xrows), ho = ex.plan.putv(hjobs), to = ex.plan.putv(terms), oo = ex.plan.putv(outs), yo = ex.plan.putv(ylist);
@@ -1681,7 +1761,7 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
       for (const MacLaunch& m : macs)
         if (m.grp == g)
           timed(s2, LK_CMAC, m.bytes, [&] {
-            launch_coarse_mac(s2, (const CoarseJob*)(base + m.off), m.nj, (const CoarseTerm*)(base + to), X, Y, nT, m.cw, m.mt, m.mp, m.ap, m.pb);
+            launch_coarse_mac(s2, (const CoarseJob*)(base + m.off), m.nj, (const CoarseTerm*)(base + to), X, Y, yFrames, m.cw, m.mt, m.mp, m.ap, m.pb);
           });
     }
     if (G > 1) {   // join: the inverse transforms (and the next chunk's forward transforms, which reuse X) wait for every job
@@ -1690,7 +1770,7 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
     }
   });
   ex.plan.add(LK_CINV, [=](uint8_t* base) {
-    launch_coarse_inv(st, (const CoarseOut*)(base + oo), no, nT, (const int*)(base + yo), Y, nT, tw16, twab);
+    launch_coarse_inv(st, (const CoarseOut*)(base + oo), no, invBlocks, (const int*)(base + yo), Y, yFrames, tw16, twab);
   }, invBytes);
   const int64_t mh = maxHist;
   if (nh > 0) ex.plan.add(LK_CHIST, [=](uint8_t* base) { launch_coarse_hist(st, (const CoarseHistJob*)(base + ho), nh, mh); }, histBytes);
@@ -2139,9 +2219,9 @@ void Context::chunkConvScratch(ChunkRun& r) {
         NodeS& nd = *nodes[id];
         if (nd.type != GA_NODE_CONVOLVER || !nd.ir || nd.convPath != 4) continue;
         auto& pd = perDepth[nd.depth];
-        pd.first += (size_t)nd.bInCh * (size_t)(nT + nd.ir->coarseP - 1);
+        pd.first += (size_t)nd.bInCh * (size_t)(nT + nd.ir->coarseP);   // (+ the window behind the chunk's last block: carried tails)
         // Y rows: one per slot unless fused; fused groups need (members / 32 + 1) x channels rows, never more than the slots
-        pd.second += (size_t)nd.bSlots * (size_t)nT;
+        pd.second += (size_t)nd.bSlots * (size_t)(nT + kCoarseMaxP);
       }
       size_t xf = 0, yf = 0;
       for (auto& kv : perDepth) {

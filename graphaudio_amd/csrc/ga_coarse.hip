@@ -300,7 +300,8 @@ __global__ __launch_bounds__(kMacThreads, kMacWavesPerSimd) void coarse_mac_kern
   const int tile = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int P = J.P, nT = J.n_t;
-  const int NF = nT + P - 1;                 // frames of a term that are needed
+  const int NF = nT + P - 1;                 // frames of a term that are needed: frame fr = window J.t0 - (P - 1) + fr
+  const int fr_lo = max(0, J.u_lo - (J.t0 - (P - 1))), fr_hi = min(NF - 1, J.u_hi - (J.t0 - (P - 1)));   // those that exist (the others are zero)
   // NFA = frames an LDS buffer holds (launch-wide: the unrolled sweep of the last active wave may read past NF, never stored)
   f2* xs0 = mlds;
   f2* xs1 = mlds + (size_t)NFA * 64;
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(kMacThreads, kMacWavesPerSimd) void coarse_mac_kern
     for (int r = 0; r < XR; r++) {
       const int fr0 = (kMacThreads / 32) * r + 2 * wv;   // (uniform)
       const int fr = fr0 + (lane >> 5), of = lane & 31;
-      if (fr < NF)
+      if (fr >= fr_lo && fr <= fr_hi)
         __builtin_amdgcn_global_load_lds(gptr(X + (size_t)(T.frame0 + J.t0 + fr) * kCoarseBins + binoff + 2 * of), (lds_t)(xs + fr0 * 64), 16, 0, 0);
     }
   };
@@ -343,6 +344,14 @@ __global__ __launch_bounds__(kMacThreads, kMacWavesPerSimd) void coarse_mac_kern
     for (int c = 0; c < CW; c++) acc[tt][c] = f2{0.f, 0.f};
 
   const CoarseTerm* __restrict T = terms + J.term0;
+  // windows that do not exist are zero rows in both buffers (no term ever writes them)
+  for (int idx = tid; idx < NF * 32; idx += kMacThreads) {
+    const int fr = idx >> 5;
+    if (fr < fr_lo || fr > fr_hi) {
+      *reinterpret_cast<v4f*>(xs0 + fr * 64 + 2 * (idx & 31)) = v4f{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<v4f*>(xs1 + fr * 64 + 2 * (idx & 31)) = v4f{0.f, 0.f, 0.f, 0.f};
+    }
+  }
   issue_x(T[0], xs0);
   issue_h(T[0], hs0);
   __syncthreads();   // (waits for the workgroup's direct-to-LDS loads: the barrier's fence includes vmcnt(0))
@@ -422,7 +431,7 @@ __global__ __launch_bounds__(kMacThreads, kMacWavesPerSimd) void coarse_mac_kern
 #endif
 constexpr int kSumWaves = 8, kSumThreads = 64 * kSumWaves, kSumAhead = GA_SUM_AHEAD;   // terms in flight per thread
 template <int CW>
-__global__ __launch_bounds__(kSumThreads, 2) void coarse_sum_kernel(const CoarseJob* __restrict jobs, const CoarseTerm* __restrict terms,
+__global__ __launch_bounds__(kSumThreads, 4) void coarse_sum_kernel(const CoarseJob* __restrict jobs, const CoarseTerm* __restrict terms,
                                                                     const float2* __restrict X, float2* __restrict Y, int y_frames, int NFA, int exp) {
   constexpr int TW = kCoarseJobBlocks(CW) / kSumWaves;                                   // coarse blocks per wave (8, 8, 4)
   constexpr int XR = ((kCoarseJobBlocks(CW) + kCoarseMaxP) * 32 + kSumThreads - 1) / kSumThreads;   // 16-byte words per thread (5, 5, 3)
@@ -430,7 +439,10 @@ __global__ __launch_bounds__(kSumThreads, 2) void coarse_sum_kernel(const Coarse
   const CoarseJob J = jobs[blockIdx.y];
   const int tile = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int P = J.P, nT = J.n_t, NF = nT + P - 1, nterms = J.n_terms;
+  const int P = J.P, nT = J.n_t, NF = nT + P - 1, nterms = J.n_terms;   // frame fr = window J.t0 - (P - 1) + fr
+  const int fr_lo = max(0, J.u_lo - (J.t0 - (P - 1))), fr_hi = min(NF - 1, J.u_hi - (J.t0 - (P - 1)));   // the windows that exist
+  const int nvf = fr_hi - fr_lo + 1;                                         // (<= 0: nothing to add up)
+  const int nw = nvf > 0 ? (nvf * 32 + kSumThreads - 1) / kSumThreads : 0;   // 16-byte words per thread that cover them (uniform)
   const int twr = (nT + kSumWaves - 1) / kSumWaves, t0w = wv * twr;
   const bool special = tile == 0, lane0 = special && lane == 0;
   const size_t binoff = (size_t)tile * 64;
@@ -446,43 +458,62 @@ __global__ __launch_bounds__(kSumThreads, 2) void coarse_sum_kernel(const Coarse
   }
   static_assert(kCoarseJobTerms <= 64, "one lane per term");
   const int f0v = lane < nterms ? T[lane].frame0 : 0;   // the terms' first frames, read with v_readlane below
-  // word r of this thread: frame (tid + kSumThreads r) / 32 (clamped: the surplus words are loaded and never stored), bins 2 of, 2 of + 1
+  // word r of this thread: existing frame fr_lo + (tid + kSumThreads r) / 32 (clamped: the surplus words of the last round are
+  // loaded and never stored), bins 2 of, 2 of + 1
   int64_t woff[XR];
 #pragma unroll
   for (int r = 0; r < XR; r++) {
     const int idx = tid + kSumThreads * r;
-    const int fr = min(idx >> 5, NF - 1), of = idx & 31;
+    const int fr = fr_lo + min(idx >> 5, max(nvf - 1, 0)), of = idx & 31;
     woff[r] = (int64_t)(J.t0 + fr) * kCoarseBins + (int64_t)binoff + 2 * of;
   }
   v4f acc[XR];
 #pragma unroll
   for (int r = 0; r < XR; r++) acc[r] = v4f{0.f, 0.f, 0.f, 0.f};
-  int i = 0;
-  if (!(exp & 2)) {
+  // the reduction, compiled once per word count (a run-time count inside the unrolled body costs registers and spills)
+  auto stream = [&](auto nwc) {
+    constexpr int NW = decltype(nwc)::value;
+    int i = 0;
     for (; i + kSumAhead <= nterms; i += kSumAhead) {
-      v4f ld[kSumAhead][XR];
+      v4f ld[kSumAhead][NW];
 #pragma unroll
       for (int u = 0; u < kSumAhead; u++) {
         const float2* __restrict Xt = X + (int64_t)__builtin_amdgcn_readlane(f0v, i + u) * kCoarseBins;
 #pragma unroll
-        for (int r = 0; r < XR; r++) ld[u][r] = ldg4(Xt + woff[r]);
+        for (int r = 0; r < NW; r++) ld[u][r] = ldg4(Xt + woff[r]);
       }
 #pragma unroll
       for (int u = 0; u < kSumAhead; u++)
 #pragma unroll
-        for (int r = 0; r < XR; r++) acc[r] += ld[u][r];
+        for (int r = 0; r < NW; r++) acc[r] += ld[u][r];
     }
     for (; i < nterms; i++) {
       const float2* __restrict Xt = X + (int64_t)__builtin_amdgcn_readlane(f0v, i) * kCoarseBins;
 #pragma unroll
-      for (int r = 0; r < XR; r++) acc[r] += ldg4(Xt + woff[r]);
+      for (int r = 0; r < NW; r++) acc[r] += ldg4(Xt + woff[r]);
     }
+  };
+  if (!(exp & 2)) {
+    static_assert(XR <= 5, "one case per word count below");
+    switch (nw) {   // (uniform)
+      case 1: stream(std::integral_constant<int, 1>{}); break;
+      case 2: stream(std::integral_constant<int, 2>{}); break;
+      case 3: stream(std::integral_constant<int, XR >= 3 ? 3 : XR>{}); break;
+      case 4: stream(std::integral_constant<int, XR >= 4 ? 4 : XR>{}); break;
+      case 5: stream(std::integral_constant<int, XR >= 5 ? 5 : XR>{}); break;
+      default: break;
+    }
+  }
+  // the sum tile: zero rows for the windows that do not exist, the sums for the others
+  for (int idx = tid; idx < NF * 32; idx += kSumThreads) {
+    const int fr = idx >> 5;
+    if (fr < fr_lo || fr > fr_hi) *reinterpret_cast<v4f*>(S + fr * 64 + 2 * (idx & 31)) = v4f{0.f, 0.f, 0.f, 0.f};
   }
 #pragma unroll
   for (int r = 0; r < XR; r++) {
     const int idx = tid + kSumThreads * r;
-    const int fr = idx >> 5, of = idx & 31;
-    if (fr < NF) *reinterpret_cast<v4f*>(S + fr * 64 + 2 * of) = acc[r];
+    const int fv = idx >> 5, of = idx & 31;
+    if (fv < nvf) *reinterpret_cast<v4f*>(S + (fr_lo + fv) * 64 + 2 * of) = acc[r];
   }
   __syncthreads();   // (its fence also waits for the impulse response's direct-to-LDS loads)
   // ---- one sweep: y[tt][c] = sum_p S[t0w + tt - p] H_c[p]; tile 0, lane 0 (two real bins) multiplies element-wise ----
@@ -621,8 +652,28 @@ __global__ __launch_bounds__(512) void coarse_inv_kernel(const CoarseOut* __rest
   f2* buf = zb0 + g * CPAD;
   const CoarseOut O = outs[blockIdx.y];
   const int tb = blockIdx.x;
-  const int64_t nout = std::min<int64_t>(kCoarseBlock, O.nvalid - (int64_t)tb * kCoarseBlock);
-  if (nout <= 0 || !O.out) return;   // (uniform)
+  const int64_t s0 = (int64_t)tb * kCoarseBlock;   // first sample of this coarse block
+  const int64_t send = O.nvalid + (O.tail_out ? O.tail_len : 0);
+  if (s0 >= send || !O.out) return;   // (uniform)
+  float* st = reinterpret_cast<float*>(zb0);
+  const bool have_y = tb < O.n_y;
+  // where the block's samples go: the chunk's output up to nvalid, the carried tail behind it; the previous chunk's tail is added
+  auto route = [&](bool zero) {
+    __syncthreads();
+    for (int i = tid; i < kCoarseBlock / 4; i += 512) {
+      const int64_t si = s0 + 4 * i;
+      if (si >= send) continue;
+      v4f v = zero ? v4f{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const v4f*>(st + 4 * i);
+      if (O.tail_in && si < O.tail_len) v += ldg4(O.tail_in + si);
+      float* __restrict dst = si < O.nvalid ? O.out + si : O.tail_out + (si - O.nvalid);   // (nvalid, tail_len: multiples of 4)
+      if ((((uintptr_t)dst) & 15) == 0) stg4(dst, v);
+      else { stg1(dst, v.x); stg1(dst + 1, v.y); stg1(dst + 2, v.z); stg1(dst + 3, v.w); }
+    }
+  };
+  if (!have_y) {   // behind the last transformed block: only the older tail moves on
+    route(true);
+    return;
+  }
   for (int i = tid; i < PL::T2 + PL::T3; i += 512) clds[i] = f2{twg[i].x, twg[i].y};
   // ---- frequency-domain mix: word i = tid + 512 r of a frame holds bins (i, 4096 + i)  (layout: coarse_fwd_kernel) ----
   {
@@ -694,26 +745,19 @@ __global__ __launch_bounds__(512) void coarse_inv_kernel(const CoarseOut* __rest
   fft16_own<CM>(own, buf, tw2, tw3, t);
   __syncthreads();
   // ---- samples [CB, 2 CB): z_g[j], j = t + 256 m >= 2048, holds x[4 j + g] (re) and x[4 j + g + 2] (im) ----
-  float* st = reinterpret_cast<float*>(zb0);
 #pragma unroll
   for (int m = 8; m < 16; m++) {
     const int o = 4 * (t + 256 * (m - 8)) + g;
     st[o] = own[m].y;       // swapped back
     st[o + 2] = own[m].x;
   }
-  __syncthreads();
-  float* __restrict dst = O.out + (int64_t)tb * kCoarseBlock;
-  if ((((uintptr_t)dst) & 15) == 0) {
-    for (int i = tid; i < kCoarseBlock / 4; i += 512)
-      if (4 * i < nout) stg4(dst + 4 * i, *reinterpret_cast<const v4f*>(st + 4 * i));
-  } else {
-    for (int i = tid; i < kCoarseBlock; i += 512)
-      if (i < nout) stg1(dst + i, st[i]);
-  }
+  route(false);
 }
 
-void launch_coarse_inv(hipStream_t s, const CoarseOut* outs_dev, int nouts, int n_t, const int* ylist_dev, const float2* Y, int y_frames,
+// n_blocks: coarse blocks of the longest output, carried tail included (outputs return early behind their own end)
+void launch_coarse_inv(hipStream_t s, const CoarseOut* outs_dev, int nouts, int n_blocks, const int* ylist_dev, const float2* Y, int y_frames,
                        const float2* tw16, const float2* twab) {
+  const int n_t = n_blocks;
   if (nouts <= 0 || n_t <= 0) return;
   using PL = R16Plan<CM>;
   const size_t lds = (size_t)(PL::T2 + PL::T3 + 2 * CPAD) * sizeof(float2);

@@ -86,6 +86,8 @@ Context::~Context() {
     if (np && np->bOverlap) (void)hipFree(np->bOverlap);
     if (np && np->dHist[0]) (void)hipFree(np->dHist[0]);
     if (np && np->dHist[1]) (void)hipFree(np->dHist[1]);
+    if (np && np->dTail[0]) (void)hipFree(np->dTail[0]);
+    if (np && np->dTail[1]) (void)hipFree(np->dTail[1]);
     if (np && np->stWin[0]) (void)hipFree(np->stWin[0]);
     if (np && np->stWin[1]) (void)hipFree(np->stWin[1]);
     if (np && np->delayHist) (void)hipFree(np->delayHist);
@@ -414,6 +416,15 @@ void Context::releaseConvState(NodeS& n) {
     dfree(n.dHist[0], hb);
     dfree(n.dHist[1], hb);
   }
+  if (n.dTail[0]) {
+    if (stream) (void)hipStreamSynchronize(stream);
+    for (int b = 0; b < 2; b++) dfree(n.dTail[b], (size_t)n.dTailLen * n.dTailCh * sizeof(float));
+  }
+  n.dTail[0] = n.dTail[1] = nullptr;
+  n.dTailLen = 0;
+  n.dTailCh = n.dTailCur = 0;
+  n.dTailSig = 0;
+  n.dTailSeq = ~0ull - 1;
   n.dHist[0] = n.dHist[1] = nullptr;
   n.dHistLen = 0;
   n.dHistCur = 0;

@@ -235,6 +235,13 @@ struct NodeS {
   int64_t dHistLen = 0;
   int dHistCur = 0;
   bool dHistZero = true;
+  // ... and the LEADER of a fused group (or a convolver on its own) carries, per output channel, what the input so far adds to
+  // the samples behind the last chunk's end (ga_chunk.cpp, planCoarseStage): valid for the next chunk only, and only while the
+  // group's signature is the same; the input histories above stay the authoritative state
+  float* dTail[2] = {nullptr, nullptr};   // [dTailCh][dTailLen]
+  int64_t dTailLen = 0;
+  int dTailCh = 0, dTailCur = 0;
+  uint64_t dTailSig = 0, dTailSeq = ~0ull - 1;
   // AudioStreamNodeBase (GraphAudio.IO/AudioStreamSourceNodeBase.cs:21-28): queue state lives on the host (indices only), the
   // resampler window of every channel lives on the device between chunks (stWin, double buffered), Pos / Ready on the host
   std::deque<int> stQueued, stProcessed;   // buffer ids
@@ -470,6 +477,7 @@ struct Context {
   hipEvent_t dGroupEv[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t dJoinEv = nullptr;
   bool coarseOverlap = false;
+  bool coarseTail = true;    // option "coarse_tail": outputs carry their tails from chunk to chunk (0: input histories only)
   bool coarseCarry = true;   // option "coarse_carry": the forward kernel writes the next chunk's history (0: always the copy kernel)
   void ensureOverlapStream();
   // event pairs recorded by launches that time their own pieces (several kernels, two streams); folded into the chunk's profile batch

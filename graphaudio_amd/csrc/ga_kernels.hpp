@@ -142,12 +142,22 @@ struct CoarseJob {         // accumulators Y[yrow0 + c][t] = sum over terms sum_
   int t0, n_t;             // coarse blocks [t0, t0 + n_t) of the chunk, n_t <= kCoarseJobBlocks(columns)
   int yrow0;
   int shared_h;            // every term uses the same spectra (loaded once)
+  int u_lo, u_hi;          // windows of the terms that exist: X[u] = 0 for u outside [u_lo, u_hi] (no input history in front of the
+                           // chunk when the outputs carry their tails; nothing transformed behind the chunk's last window)
   int pad_;
 };
 struct CoarseOut {         // one time-domain output: the sum of `ny` Y rows
   float* out;              // chunk-frame indexed
   int64_t nvalid;          // chunk frames
   int y0, ny;              // ylist[y0 .. y0 + ny)
+  // Tail carried from chunk to chunk (what the input so far contributes to samples behind the chunk's end):
+  //   v[i] = y[i] (0 for coarse blocks >= n_y) + tail_in[i] (i < tail_len) ;  out[i] = v[i] for i < nvalid ;
+  //   tail_out[i - nvalid] = v[i] for nvalid <= i < nvalid + tail_len.   tail_in / tail_out may be nullptr.
+  const float* tail_in;
+  float* tail_out;
+  int64_t tail_len;        // multiple of 4
+  int n_y;                 // coarse blocks the Y rows hold for this output
+  int pad_;
 };
 struct CoarseHistJob {
   const float* old_hist;   // nullptr = zeros

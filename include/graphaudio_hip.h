@@ -106,6 +106,8 @@ typedef struct ga_stats {
   double  stage_bytes[16];
   int64_t profiled_chunks;      /* chunks whose HIP events device_ms_total and stage_ms[] were read from (options "profile",
                                    "profile_every"); stage_launches[] and stage_bytes[] count every chunk */
+  int64_t coarse_carried_outputs; /* formulation D: (output channel, chunk) pairs rendered from a carried tail instead of the
+                                     members' input histories */
 } ga_stats;
 enum {
   GA_STAGE_OTHER = 0,        /* sources, biquads, gains, parameter curves, ... */

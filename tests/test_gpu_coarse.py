@@ -435,3 +435,73 @@ def test_history_carried_by_the_forward_kernel_equals_the_copy_kernel():
         outs.append(got)
         h.Dispose()
     assert np.array_equal(outs[0], outs[1])
+
+
+# ---- carried output tails (option coarse_tail): a group that stays the same from chunk to chunk renders its first blocks from
+#      the tail the previous chunk left, not from the members' input histories; any change falls back to the histories ----
+def test_steady_chunks_render_from_carried_tails():
+    frames = 128 * 900
+    pieces = [128 * 300, 128 * 100, 128 * 37, 128 * 263, 128 * 200]   # longer and shorter than the 4-partition tail
+    ref, got, st = pair(lambda c: G.config3_convolver(c, voices=5, taps=30000, frames=frames), frames, pieces)
+    assert used_coarse(st)
+    assert st["coarse_carried_outputs"] >= 2 * (len(pieces) - 1)   # two output channels, every chunk but the first
+    check(ref, got)
+    ref2, got2, st2 = pair(lambda c: G.config3_convolver(c, voices=5, taps=30000, frames=frames), frames, pieces, coarse_tail=0)
+    assert st2["coarse_carried_outputs"] == 0
+    check(ref2, got2)
+    assert G.rms(got - got2) <= 4e-7 * G.rms(ref)   # the two routes differ by rounding only
+
+
+def test_group_changes_between_chunks_fall_back_to_the_histories():
+    """a voice joins the fused group, one leaves it, one comes back, one is disposed -- every time the tail of the old group is
+    dropped and the members' input histories take over (both kept up to date in every chunk)"""
+    def script(ctx, render):
+        shared = PlayableAudioBuffer.FromChannelArrays([G.synth_ir(c, 26000) for c in range(2)], SR)
+        ctx.Destination.SetChannelCount(2)
+        voices = []
+
+        def add(v):
+            s = AudioBufferSourceNode(ctx)
+            s.Buffer = PlayableAudioBuffer.FromMonoArray(G.voice(v, 128 * 1300), SR)
+            cv = ConvolverNode(ctx)
+            cv.Buffer = shared
+            s.Connect(cv).Connect(ctx.Destination)
+            s.Start()
+            voices.append((s, cv))
+        for v in range(3):
+            add(v)
+        render(128 * 200)
+        render(128 * 150)                       # same group: carried
+        add(3)                                  # a voice joins
+        render(128 * 150)
+        render(128 * 100)                       # carried again
+        voices[1][1].Disconnect()               # a member leaves the sum (its convolver stops being pulled)
+        render(128 * 120)
+        voices[1][1].Connect(ctx.Destination)   # ... and comes back with the state it had when it left
+        render(128 * 130)
+        voices[0][1].Dispose()                  # a member is disposed
+        render(128 * 150)
+        render(128 * 100)
+
+    total = 128 * 1100
+
+    def run(ctx):
+        out = np.zeros((2, total), np.float32)
+        pos = [0]
+
+        def render(n):
+            ctx.Render(out, n, pos[0])
+            pos[0] += n
+        script(ctx, render)
+        assert pos[0] == total
+        return out
+
+    o = OracleContext(SR)
+    ref = run(o)
+    h = hip()
+    got = run(h)
+    st = h.GetStats()
+    assert used_coarse(st) and st["coarse_carried_outputs"] >= 4
+    check(ref, got)
+    h.Dispose()
+    o.Dispose()
