@@ -1441,7 +1441,7 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
   // no input history in front of the chunk: their windows start at the chunk (u = 0) and the previous chunk's tail is added to
   // the output instead -- P' - 1 fewer transforms per signal and chunk.  Any change (member set, impulse responses, channel
   // modes, a chunk in between that did not run this stage) falls back to the input histories, which are kept up to date either way.
-  struct GroupInfo { uint64_t sig = 1469598103934665603ull; int maxP = 0; bool carried = false; };
+  struct GroupInfo { uint64_t sig = 1469598103934665603ull; int maxP = 0; bool carried = false, fresh = true, noHist = false; };
   std::map<int, GroupInfo> groups;   // by leader
   const bool tails = c.coarseTail;
   {
@@ -1454,11 +1454,13 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
       mix(g.sig, (uint64_t)nd.bInCh | ((uint64_t)nd.bSlots << 8) | ((uint64_t)nd.isTrueStereo << 16) | ((uint64_t)nd.bShared << 17) |
                      ((uint64_t)nd.ir->coarseP << 24));
       g.maxP = std::max(g.maxP, nd.ir->coarseP);
+      g.fresh = g.fresh && nd.dHistZero;   // no member has seen input yet: nothing in front of the chunk either
     }
     for (auto& kv : groups) {
       NodeS& ld = *c.nodes[kv.first];
       kv.second.carried = tails && ld.dTail[0] && ld.dTailSeq + 1 == c.chunkSeq && ld.dTailSig == kv.second.sig &&
                           ld.dTailLen == (int64_t)(kv.second.maxP + 1) * kCoarseBlock;
+      kv.second.noHist = kv.second.carried || (tails && kv.second.fresh);
     }
   }
   int frameNext = 0;
@@ -1472,7 +1474,7 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
     const int P = ir.coarseP;
     if (P < 1 || P > kCoarseMaxP) fail(GA_ERR_INVALID_OPERATION, "internal: coarse partition count out of range");
     const int64_t hl = nd.dHistLen;
-    const bool carried = groups[nd.dLeader >= 0 ? nd.dLeader : id].carried;
+    const bool carried = groups[nd.dLeader >= 0 ? nd.dLeader : id].noHist;   // no windows in front of the chunk
     auto& ci = ex.convIn[id];
     chIn.assign(nd.bInCh, nullptr);
     for (int ch = 0; ch < nd.bInCh; ch++) chIn[ch] = convChunkInput(c, ex, ci, ch);
@@ -1624,7 +1626,7 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
         jb_.n_t = std::min(jb, nTo - t0);
         jb_.yrow0 = yrow0;
         jb_.shared_h = shared ? 1 : 0;
-        jb_.u_lo = gi.carried ? 0 : -(k.P - 1);
+        jb_.u_lo = gi.noHist ? 0 : -(k.P - 1);
         jb_.u_hi = tails ? nT : nT - 1;
         const int cj = 2 * ci + (shared ? 1 : 0);
         jobs[cj][grp].push_back(jb_);
