@@ -137,15 +137,27 @@ def cpu_baseline_and_parity(voices, taps, G, args, all_cores):
     dt1 = time.perf_counter() - t0
     ctx.Dispose()
     fps1 = (frames - 128) / dt1
-    # the GPU path on the same graph, one render call (default options)
-    h = OfflineAudioContext(SR)
-    build_graph(h, voices, 0, taps, frames + 256, G, loop=False)
-    got = np.zeros((2, frames), np.float32)
-    h.Render(got, frames)
-    h.Dispose()
-    err, sig = G.rms(ref - got), G.rms(ref)
+    # the GPU path on the same graph (default options): as one render call, and as two (the second one renders from the tails
+    # the first one left -- the steady state of the timed steps)
+    sig = G.rms(ref)
+    errs, carried = [], 0
+    for pieces in ([frames], [min(frames, 256 * 128), frames - min(frames, 256 * 128)]):
+        h = OfflineAudioContext(SR)
+        build_graph(h, voices, 0, taps, frames + 256, G, loop=False)
+        got = np.zeros((2, frames), np.float32)
+        pos = 0
+        for n in pieces:
+            if n > 0:
+                h.Render(got, n, pos)
+                pos += n
+        carried = h.GetStats()["coarse_carried_outputs"]
+        h.Dispose()
+        errs.append(G.rms(ref - got))
+    err = max(errs)
     parity = {"rms_abs": err, "rms_relative_to_bus": err / sig, "bus_rms": sig, "tolerance_rms_abs": 1e-5,
-              "sample": f"{voices} voices x {blocks} blocks (1 s short form) of the bench graph, all voices, vs the CPU oracle"}
+              "rms_abs_one_call": errs[0], "rms_abs_two_calls": errs[1], "outputs_from_carried_tails_in_the_second_call": carried,
+              "sample": f"{voices} voices x {blocks} blocks (1 s short form) of the bench graph, all voices, vs the CPU oracle; "
+                        "rendered as one call and as 256 + the remaining blocks"}
     base = {
         "value": fps1, "unit": "frames/s", "cores": 1, "kind": "port",
         "sample": f"all {voices} voices x {blocks - 1} blocks of the bench graph ({taps}-tap stereo IR, 1 s short form), "
