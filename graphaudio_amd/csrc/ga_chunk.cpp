@@ -1441,7 +1441,7 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
   // no input history in front of the chunk: their windows start at the chunk (u = 0) and the previous chunk's tail is added to
   // the output instead -- P' - 1 fewer transforms per signal and chunk.  Any change (member set, impulse responses, channel
   // modes, a chunk in between that did not run this stage) falls back to the input histories, which are kept up to date either way.
-  struct GroupInfo { uint64_t sig = 1469598103934665603ull; int maxP = 0; bool carried = false, fresh = true, noHist = false; };
+  struct GroupInfo { uint64_t sig = 1469598103934665603ull; int maxP = 0, nIn = 0, nOut = 0; const void* ir0 = nullptr; bool oneIr = true, tail = false, carried = false, fresh = true, noHist = false; };
   std::map<int, GroupInfo> groups;   // by leader
   const bool tails = c.coarseTail;
   {
@@ -1455,12 +1455,20 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
                      ((uint64_t)nd.ir->coarseP << 24));
       g.maxP = std::max(g.maxP, nd.ir->coarseP);
       g.fresh = g.fresh && nd.dHistZero;   // no member has seen input yet: nothing in front of the chunk either
+      g.nIn += nd.bShared ? 1 : nd.bInCh;
+      if (!g.ir0) g.ir0 = nd.ir.get();
+      g.oneIr = g.oneIr && g.ir0 == nd.ir.get();
+      g.nOut = std::max(g.nOut, nd.isTrueStereo ? 2 : nd.bSlots);
     }
     for (auto& kv : groups) {
       NodeS& ld = *c.nodes[kv.first];
-      kv.second.carried = tails && ld.dTail[0] && ld.dTailSeq + 1 == c.chunkSeq && ld.dTailSig == kv.second.sig &&
+      // a tail costs P' more inverse transforms per output channel and chunk and saves P' - 2 forward transforms per input row:
+      // worth it for sums of many signals, not for a convolver on its own; and the P' more output blocks are nearly free only
+      // in the reduction kernel (one impulse response for the whole group) -- the general kernel would multiply through them
+      kv.second.tail = tails && kv.second.oneIr && (int64_t)kv.second.nIn * (kv.second.maxP - 2) >= (int64_t)kv.second.nOut * kv.second.maxP;
+      kv.second.carried = kv.second.tail && ld.dTail[0] && ld.dTailSeq + 1 == c.chunkSeq && ld.dTailSig == kv.second.sig &&
                           ld.dTailLen == (int64_t)(kv.second.maxP + 1) * kCoarseBlock;
-      kv.second.noHist = kv.second.carried || (tails && kv.second.fresh);
+      kv.second.noHist = kv.second.carried || (kv.second.tail && kv.second.fresh);
     }
   }
   int frameNext = 0;
@@ -1474,7 +1482,8 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
     const int P = ir.coarseP;
     if (P < 1 || P > kCoarseMaxP) fail(GA_ERR_INVALID_OPERATION, "internal: coarse partition count out of range");
     const int64_t hl = nd.dHistLen;
-    const bool carried = groups[nd.dLeader >= 0 ? nd.dLeader : id].noHist;   // no windows in front of the chunk
+    const GroupInfo& gi0 = groups[nd.dLeader >= 0 ? nd.dLeader : id];
+    const bool carried = gi0.noHist;   // no windows in front of the chunk
     auto& ci = ex.convIn[id];
     chIn.assign(nd.bInCh, nullptr);
     for (int ch = 0; ch < nd.bInCh; ch++) chIn[ch] = convChunkInput(c, ex, ci, ch);
@@ -1499,7 +1508,7 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
       // windows u0 .. u_last: with carried tails the last one is u = nT ([last block | nothing yet]: it feeds the outputs behind
       // the chunk's end), and a group that continues needs none in front of the chunk
       r.u0 = carried ? 0 : -(P - 1);
-      r.n_frames = (tails ? nT + 1 : nT) - r.u0;
+      r.n_frames = (gi0.tail ? nT + 1 : nT) - r.u0;
       r.hist_len = (int)hl;
       r.flags = 0;
       r.scale = 1.0f;
@@ -1616,7 +1625,7 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
       for (int j = 0; j < cw; j++) outRows[{k.leader, k.out[j]}].push_back(yrow0 + j);
       const int jb = kCoarseJobBlocks(cw);
       const GroupInfo& gi = groups[k.leader];
-      const int nTo = tails ? nT + gi.maxP : nT;   // output blocks: the chunk's, and with tails those the chunk's input still reaches
+      const int nTo = gi.tail ? nT + gi.maxP : nT;   // output blocks: the chunk's, and with a tail those the chunk's input still reaches
       for (int t0 = 0; t0 < nTo; t0 += jb) {
         CoarseJob jb_{};
         jb_.term0 = term0;
@@ -1627,7 +1636,7 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
         jb_.yrow0 = yrow0;
         jb_.shared_h = shared ? 1 : 0;
         jb_.u_lo = gi.noHist ? 0 : -(k.P - 1);
-        jb_.u_hi = tails ? nT : nT - 1;
+        jb_.u_hi = gi.tail ? nT : nT - 1;
         const int cj = 2 * ci + (shared ? 1 : 0);
         jobs[cj][grp].push_back(jb_);
         maxT[cj] = std::max(maxT[cj], jb_.n_t);
@@ -1643,13 +1652,15 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
   std::vector<int> ylist;
   double invBytes = 0;
   int maxPAll = 0;
-  for (auto& kv : groups) maxPAll = std::max(maxPAll, kv.second.maxP);
-  const int yFrames = tails ? nT + maxPAll : nT;   // coarse blocks per Y row (rows of shorter groups leave their end unused)
+  for (auto& kv : groups)
+    if (kv.second.tail) maxPAll = std::max(maxPAll, kv.second.maxP);
+  const int yFrames = nT + maxPAll;   // coarse blocks per Y row (rows of groups with a shorter or no tail leave their end unused)
   int invBlocks = nT;
   if (tails) {   // tail buffers live with the group's leader: [2][channels][tail_len], read one, write the other
     std::map<int, int> chOf;
     for (auto& kv : outRows) chOf[kv.first.first] = std::max(chOf[kv.first.first], kv.first.second + 1);
     for (auto& kv : groups) {
+      if (!kv.second.tail) continue;
       NodeS& ld = *c.nodes[kv.first];
       const int64_t len = (int64_t)(kv.second.maxP + 1) * kCoarseBlock;
       const int nch = chOf.count(kv.first) ? chOf[kv.first] : 0;
@@ -1674,7 +1685,7 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
     o.y0 = (int)ylist.size();
     o.ny = (int)kv.second.size();
     o.n_y = nT;
-    if (tails) {
+    if (groups[kv.first.first].tail) {
       NodeS& ld = *c.nodes[kv.first.first];
       const GroupInfo& gi = groups[kv.first.first];
       o.n_y = nT + gi.maxP;
@@ -1692,7 +1703,7 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
   if (tails)
     for (auto& kv : groups) {   // this chunk's tails are the next chunk's, if the group is still the same then
       NodeS& ld = *c.nodes[kv.first];
-      if (!ld.dTail[0]) continue;
+      if (!kv.second.tail || !ld.dTail[0]) continue;
       ld.dTailCur ^= 1;
       ld.dTailSig = kv.second.sig;
       ld.dTailSeq = c.chunkSeq;

@@ -439,6 +439,14 @@ def test_history_carried_by_the_forward_kernel_equals_the_copy_kernel():
 
 # ---- carried output tails (option coarse_tail): a group that stays the same from chunk to chunk renders its first blocks from
 #      the tail the previous chunk left, not from the members' input histories; any change falls back to the histories ----
+def test_a_convolver_on_its_own_keeps_to_its_input_history():
+    """a tail costs P' inverse transforms per output channel and saves P' - 2 forward transforms per input: no gain for one voice"""
+    frames = 128 * 600
+    ref, got, st = pair(lambda c: G.config3_convolver(c, voices=1, taps=65536, frames=frames), frames, [128 * 300, 128 * 300])
+    assert used_coarse(st) and st["coarse_carried_outputs"] == 0
+    check(ref, got)
+
+
 def test_steady_chunks_render_from_carried_tails():
     frames = 128 * 900
     pieces = [128 * 300, 128 * 100, 128 * 37, 128 * 263, 128 * 200]   # longer and shorter than the 4-partition tail
@@ -468,11 +476,11 @@ def test_group_changes_between_chunks_fall_back_to_the_histories():
             s.Connect(cv).Connect(ctx.Destination)
             s.Start()
             voices.append((s, cv))
-        for v in range(3):
+        for v in range(6):
             add(v)
         render(128 * 200)
         render(128 * 150)                       # same group: carried
-        add(3)                                  # a voice joins
+        add(6)                                  # a voice joins
         render(128 * 150)
         render(128 * 100)                       # carried again
         voices[1][1].Disconnect()               # a member leaves the sum (its convolver stops being pulled)
