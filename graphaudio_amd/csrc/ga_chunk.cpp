@@ -1623,7 +1623,7 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
       const int yrow0 = yNext;
       yNext += cw;
       for (int j = 0; j < cw; j++) outRows[{k.leader, k.out[j]}].push_back(yrow0 + j);
-      const int jb = kCoarseJobBlocks(cw);
+      const int jb = shared ? kCoarseSumJobBlocks(cw) : kCoarseJobBlocks(cw);   // (the two kernels' job sizes)
       const GroupInfo& gi = groups[k.leader];
       const int nTo = gi.tail ? nT + gi.maxP : nT;   // output blocks: the chunk's, and with a tail those the chunk's input still reaches
       for (int t0 = 0; t0 < nTo; t0 += jb) {

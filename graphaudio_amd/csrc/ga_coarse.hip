@@ -433,8 +433,8 @@ constexpr int kSumWaves = 8, kSumThreads = 64 * kSumWaves, kSumAhead = GA_SUM_AH
 template <int CW>
 __global__ __launch_bounds__(kSumThreads, 4) void coarse_sum_kernel(const CoarseJob* __restrict jobs, const CoarseTerm* __restrict terms,
                                                                     const float2* __restrict X, float2* __restrict Y, int y_frames, int NFA, int exp) {
-  constexpr int TW = kCoarseJobBlocks(CW) / kSumWaves;                                   // coarse blocks per wave (8, 8, 4)
-  constexpr int XR = ((kCoarseJobBlocks(CW) + kCoarseMaxP) * 32 + kSumThreads - 1) / kSumThreads;   // 16-byte words per thread (5, 5, 3)
+  constexpr int TW = kCoarseSumJobBlocks(CW) / kSumWaves;                                   // coarse blocks per wave (9, 9, 5)
+  constexpr int XR = ((kCoarseSumJobBlocks(CW) + kCoarseMaxP) * 32 + kSumThreads - 1) / kSumThreads;   // 16-byte words per thread (6, 6, 4)
   extern __shared__ f2 mlds[];   // (all of the kernel's LDS is this one array)
   const CoarseJob J = jobs[blockIdx.y];
   const int tile = blockIdx.x;
@@ -473,17 +473,18 @@ __global__ __launch_bounds__(kSumThreads, 4) void coarse_sum_kernel(const Coarse
   // the reduction, compiled once per word count (a run-time count inside the unrolled body costs registers and spills)
   auto stream = [&](auto nwc) {
     constexpr int NW = decltype(nwc)::value;
+    constexpr int AH = NW >= 6 ? 3 : kSumAhead;   // (6 words x 4 terms in flight would not fit the 128 registers of 4 waves per SIMD)
     int i = 0;
-    for (; i + kSumAhead <= nterms; i += kSumAhead) {
-      v4f ld[kSumAhead][NW];
+    for (; i + AH <= nterms; i += AH) {
+      v4f ld[AH][NW];
 #pragma unroll
-      for (int u = 0; u < kSumAhead; u++) {
+      for (int u = 0; u < AH; u++) {
         const float2* __restrict Xt = X + (int64_t)__builtin_amdgcn_readlane(f0v, i + u) * kCoarseBins;
 #pragma unroll
         for (int r = 0; r < NW; r++) ld[u][r] = ldg4(Xt + woff[r]);
       }
 #pragma unroll
-      for (int u = 0; u < kSumAhead; u++)
+      for (int u = 0; u < AH; u++)
 #pragma unroll
         for (int r = 0; r < NW; r++) acc[r] += ld[u][r];
     }
@@ -494,13 +495,14 @@ __global__ __launch_bounds__(kSumThreads, 4) void coarse_sum_kernel(const Coarse
     }
   };
   if (!(exp & 2)) {
-    static_assert(XR <= 5, "one case per word count below");
+    static_assert(XR <= 6, "one case per word count below");
     switch (nw) {   // (uniform)
       case 1: stream(std::integral_constant<int, 1>{}); break;
       case 2: stream(std::integral_constant<int, 2>{}); break;
       case 3: stream(std::integral_constant<int, XR >= 3 ? 3 : XR>{}); break;
       case 4: stream(std::integral_constant<int, XR >= 4 ? 4 : XR>{}); break;
       case 5: stream(std::integral_constant<int, XR >= 5 ? 5 : XR>{}); break;
+      case 6: stream(std::integral_constant<int, XR >= 6 ? 6 : XR>{}); break;
       default: break;
     }
   }
@@ -566,7 +568,7 @@ template <int CW>
 static void launch_coarse_sum(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
                               int y_frames, int max_t, int maxP) {
   static const int exp = getenv("GA_COARSE_EXP") ? atoi(getenv("GA_COARSE_EXP")) : 0;   // timing experiments only
-  constexpr int TW = kCoarseJobBlocks(CW) / kSumWaves;
+  constexpr int TW = kCoarseSumJobBlocks(CW) / kSumWaves;
   int NFA = 0;   // frames the sweep of the last active wave touches
   for (int nt = 1; nt <= max_t; nt++) {
     const int twr = (nt + kSumWaves - 1) / kSumWaves, wl = (nt + twr - 1) / twr - 1;
@@ -616,8 +618,7 @@ template <int CW>
 static void launch_coarse_mac_cw(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
                                  int y_frames, int max_t, int maxP, bool any_private, int pb) {
   constexpr int TWL = CW <= 2 ? GA_MAC_TW : GA_MAC_TW / 2;   // accumulators: TW x CW complex values per lane
-  static const bool nosum = getenv("GA_COARSE_NOSUM") != nullptr;   // measurements only
-  if (!nosum && !any_private) return launch_coarse_sum<CW>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP);
+  if (!any_private) return launch_coarse_sum<CW>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP);   // (the planner cut these jobs for it)
   if (max_t <= 2 * kMacWaves) launch_coarse_mac_t<CW, 2, 1>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
   else if (pb >= 4 && (CW == 1 || (CW == 2 && GA_MAC_PB2 == 4))) launch_coarse_mac_t<CW, TWL, 4>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
   else if (pb >= 2) launch_coarse_mac_t<CW, TWL, 2>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
@@ -626,7 +627,7 @@ static void launch_coarse_mac_cw(hipStream_t s, const CoarseJob* jobs_dev, int n
 void launch_coarse_mac(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
                        int y_frames, int cw, int max_t, int maxP, bool any_private, int pb) {
   if (njobs <= 0) return;
-  if (max_t > kCoarseJobBlocks(cw)) launch_fail("coarse multiply-accumulate: too many coarse blocks in a job");
+  if (max_t > (any_private ? kCoarseJobBlocks(cw) : kCoarseSumJobBlocks(cw))) launch_fail("coarse multiply-accumulate: too many coarse blocks in a job");
   if (const char* e = getenv("GA_COARSE_PB")) pb = std::min(pb, std::max(1, atoi(e)));   // measurements only
   if (pb != 1 && pb != 2 && pb != 4 && pb != 8 && pb != 16) launch_fail("coarse multiply-accumulate: unsupported partition block");
   if (cw == 1) launch_coarse_mac_cw<1>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private, pb);

@@ -113,6 +113,9 @@ void launch_tconv16(hipStream_t s, const ConvSetC* sets_dev, int nsets, int nblo
 constexpr int kCoarseBlock = 8192;   // samples per coarse partition / output block
 constexpr int kCoarseMaxP = 16;      // partitions a job can slide over (impulse responses up to 131,072 taps)
 constexpr int kCoarseJobTerms = 32;   // terms (signals) whose products one multiply-accumulate job sums in registers
+// ... and one reduction job (coarse_sum_kernel: the terms share their impulse response): 8 waves x 9 (x 5) -- a 10 s chunk with its
+// carried tail is 59 + 8 output blocks
+constexpr int kCoarseSumJobBlocks(int columns) { return columns <= 2 ? 72 : 40; }
 constexpr int kCoarseJobBlocks(int columns) { return columns <= 2 ? 64 : 32; }   // coarse blocks one multiply-accumulate job covers: 8 waves x 8 (x 4)
 constexpr int kCoarseBins = 8192;    // packed complex bins of one 16,384-point real spectrum (bin 0 = (X[0], X[8192]))
 struct CoarseXRow {        // one transformed signal: a convolver input channel, or an impulse-response channel
