@@ -206,6 +206,7 @@ def main():
     ap.add_argument("--profile-every", type=int, default=4, help="record the per-stage HIP events on every k-th chunk of the timed region")
     ap.add_argument("--no-profile", action="store_true", help="no per-stage HIP events (measurement of their cost; the roofline object is then empty)")
     ap.add_argument("--private-ir", action="store_true", help="every voice convolves with its own impulse response (general path; measurement, not the headline config)")
+    ap.add_argument("--no-host-direct", action="store_true", help="copy the bus to the host with copy kernels instead of writing it from the last kernel (measurement)")
     ap.add_argument("--no-tail", action="store_true", help="formulation D: no carried output tails, every chunk re-transforms the input history (measurement)")
     ap.add_argument("--no-carry", action="store_true", help="formulation D: copy the input history with its own kernel instead of from the forward transforms (measurement)")
     ap.add_argument("--copy-stream", action="store_true", help="hand the bus to the host on a copy stream of its own (measurement)")
@@ -257,6 +258,8 @@ def main():
         ctx.SetOption("coarse_carry", 0)
     if args.no_tail:
         ctx.SetOption("coarse_tail", 0)
+    if args.no_host_direct:
+        ctx.SetOption("host_direct", 0)
     if args.copy_stream:
         ctx.SetOption("host_copy_stream", 1)
     build_graph(ctx, v1 - v0, v0, args.taps, frames, G, private_ir=args.private_ir)

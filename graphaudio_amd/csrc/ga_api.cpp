@@ -214,14 +214,30 @@ void Context::render(float* const* out, int channels, int64_t frameCount, int64_
     const int64_t limit = chunkLimit(nblk);
     nblk = std::min(nblk, limit);
     // device output, whole blocks, 16-byte aligned rows: the destination mixes straight into the caller's memory
-    bool direct = deviceOut && need >= nblk * kBlock;
-    for (int ch = 0; ch < channels && direct; ch++) direct = (((uintptr_t)(out[ch] + startIndex + written)) & 15) == 0;
+    // ... and so does page-locked host memory the device can address (hipHostMalloc / hipHostRegister: what an asynchronous
+    // render needs anyway): the last kernel of the chunk writes the bus over PCIe itself instead of two copy kernels behind it
+    bool direct = (deviceOut || hostDirect) && need >= nblk * kBlock;
+    float* tgt[32];
+    for (int ch = 0; ch < channels && direct; ch++) {
+      float* p = out[ch] + startIndex + written;
+      if (!deviceOut) {
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, p) != hipSuccess || at.type != hipMemoryTypeHost || !at.devicePointer) {
+          (void)hipGetLastError();   // pageable memory: copies
+          direct = false;
+          break;
+        }
+        p = (float*)at.devicePointer;
+      }
+      tgt[ch] = p;
+      direct = (((uintptr_t)p) & 15) == 0;
+    }
     struct Target {   // (cleared on every way out of the chunk)
       Context& c;
       ~Target() { std::memset(c.busTarget, 0, sizeof(c.busTarget)); }
     } target{*this};
     if (direct)
-      for (int ch = 0; ch < channels; ch++) busTarget[ch] = out[ch] + startIndex + written;
+      for (int ch = 0; ch < channels; ch++) busTarget[ch] = tgt[ch];
     runChunk(nblk, nullptr);
     std::memset(busTarget, 0, sizeof(busTarget));
     const int64_t done = chunkBlocksDone;
@@ -327,6 +343,7 @@ int ga_set_option(ga_context* ctx, const char* key, double value) {
     else if (k == "coarse_overlap") c.coarseOverlap = value != 0;
     else if (k == "coarse_carry") c.coarseCarry = value != 0;
     else if (k == "coarse_tail") c.coarseTail = value != 0;
+    else if (k == "host_direct") c.hostDirect = value != 0;
     else if (k == "host_copy_stream") c.hostCopyStream = value != 0;
     else if (k == "coarse_min_blocks") c.coarseMinBlocks = std::max<int64_t>(1, (int64_t)value);
     else if (k == "debug_tconv_n2") c.debugTconvN2 = (int)value;   // tests only: plan the block-axis FFT with this (possibly unsupported) length

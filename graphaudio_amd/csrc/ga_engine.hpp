@@ -543,6 +543,7 @@ struct Context {
   // a render into device memory whose chunk covers whole blocks lets the destination mix straight into the caller's rows
   // (no copy of the bus afterwards): set by Context::render around runChunk, consulted where the destination's input is resolved
   float* busTarget[32] = {};
+  bool hostDirect = true;   // option "host_direct": page-locked host rows are such a target too (0: always the copy kernels)
   struct SegCh { int64_t b0, b1; int ch; };
   std::vector<SegCh> chunkSegCh;   // destination buffer channel count of every segment of the last chunk
   float* ilvDev = nullptr;         // device staging for interleaved output

@@ -156,3 +156,27 @@ def test_render_reduce_pipelined_steps():
     ctx.Synchronize()
     for r, o in zip(ref, outs):
         assert np.array_equal(r, o)
+
+
+def test_page_locked_host_rows_are_written_by_the_last_kernel():
+    """option host_direct (default): rows in page-locked host memory the device can address take the bus without copy kernels;
+    same bits as the copy path, at row offsets that are 16-byte aligned and at one that is not (falls back to copies)"""
+    import torch
+    from graphaudio_amd import OfflineAudioContext
+    from tests import _graphs as G
+    frames = 128 * 90
+    outs = []
+    for direct in (1, 0):
+        ctx = OfflineAudioContext(48000)
+        ctx.SetOption("host_direct", direct)
+        G.config3_convolver(ctx, voices=3, taps=3000, frames=frames)
+        pin = torch.zeros((2, frames + 8), dtype=torch.float32).pin_memory()
+        out = pin.numpy()
+        ctx.Render(out, 128 * 30, 0)
+        ctx.Render(out, 128 * 20, 128 * 30)          # aligned offset
+        ctx.Render(out, 128 * 40, 128 * 50 + 3)      # 12-byte offset: not a 16-byte aligned row
+        outs.append(out.copy())
+        ctx.Dispose()
+    assert np.abs(outs[0]).max() > 1e-3
+    assert np.array_equal(outs[0], outs[1])
+    assert np.all(outs[0][:, 128 * 50:128 * 50 + 3] == 0)
