@@ -1422,12 +1422,15 @@ static const float* convChunkInput(Context& c, Exec& ex, const std::vector<std::
   return slab;
 }
 
-static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes, int64_t n) {
-  const int64_t frames = n * kBlock;
-  const int nT = (int)((frames + kCoarseBlock - 1) / kCoarseBlock);
-  constexpr int kVoicesPerJob = kCoarseJobTerms;   // terms whose products one workgroup accumulates in registers
-  std::vector<CoarseXRow> xrows;
-  std::vector<CoarseHistJob> hjobs;
+// One convolver stage of a chunk in formulation D, planned in five passes (Context::chunkPlanConvolvers calls planCoarseStage).
+namespace {
+struct CoarseStage {
+  Context& c;
+  Exec& ex;
+  const std::vector<int>& dNodes;
+  const int64_t n, frames;
+  const int nT;
+  static constexpr int kVoicesPerJob = kCoarseJobTerms;   // terms whose products one workgroup accumulates in registers
   struct Piece {   // <= 4 columns of one signal: (impulse-response channel, output channel of the group)
     int frame0, P, xrow, u0;
     IrSpectra* ir;
@@ -1435,15 +1438,52 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
     int ncol;
     int irCh[4], outCh[4];
   };
+  struct GroupInfo {   // a fused group (by leader), or a convolver on its own
+    uint64_t sig = 1469598103934665603ull;
+    int maxP = 0, nIn = 0, nOut = 0;
+    const void* ir0 = nullptr;
+    bool oneIr = true, tail = false, carried = false, fresh = true, noHist = false;
+  };
+  std::vector<CoarseXRow> xrows;
+  std::vector<CoarseHistJob> hjobs;
   std::vector<Piece> pieces;
+  std::map<int, GroupInfo> groups;   // by leader
+  const bool tails;
+  int frameNext = 0;
+  int64_t maxHist = 0;
+  double histBytes = 0;
+  std::map<int, double> carryBytes;   // row -> bytes of next-chunk history its forward transform also writes
+  int nxAll = 0, G = 1;
+  int gBegin[9] = {};
+  std::vector<CoarseTerm> terms;
+  // launches: by column count (1, 2, 4) x (terms with their own impulse responses | one impulse response for all terms), and
+  // by the group whose transforms complete the job's inputs.  Class index = 2 * column class + shared.
+  std::vector<CoarseJob> jobs[6][8];
+  int maxT[6] = {0, 0, 0, 0, 0, 0}, maxP[6] = {0, 0, 0, 0, 0, 0};
+  int pbOf[6] = {4, 4, 4, 4, 4, 4};   // largest of 4, 2, 1 dividing every job's partition count (the sweep's register block)
+  double macBytes[6][8] = {};
+  std::map<std::pair<int, int>, std::vector<int>> outRows;   // (leader, channel) -> Y rows to sum
+  int yNext = 0;
+  std::vector<CoarseOut> outs;
+  std::vector<int> ylist;
+  double invBytes = 0;
+  int yFrames = 0, invBlocks = 0;
+
+  CoarseStage(Context& c_, Exec& ex_, const std::vector<int>& d, int64_t n_)
+      : c(c_), ex(ex_), dNodes(d), n(n_), frames(n_ * kBlock), nT((int)((n_ * kBlock + kCoarseBlock - 1) / kCoarseBlock)), tails(c_.coarseTail) {}
+  void classifyGroups();   // which groups carry a tail, which can use the one the previous chunk left
+  void buildRows();        // signals to transform, history hand-over, pieces (signal x columns)
+  void buildJobs();        // multiply-accumulate jobs and their terms
+  void buildOutputs();     // inverse-transform outputs, tail buffers
+  void enqueue();          // tables into the plan, launches
+};
+
+void CoarseStage::classifyGroups() {
   // ---- carried tails (option "coarse_tail"): every output of the stage keeps, from chunk to chunk, what the input so far adds to
   // the samples behind the chunk's end.  While a group of fused convolvers is the same as in the previous chunk its members need
   // no input history in front of the chunk: their windows start at the chunk (u = 0) and the previous chunk's tail is added to
   // the output instead -- P' - 1 fewer transforms per signal and chunk.  Any change (member set, impulse responses, channel
   // modes, a chunk in between that did not run this stage) falls back to the input histories, which are kept up to date either way.
-  struct GroupInfo { uint64_t sig = 1469598103934665603ull; int maxP = 0, nIn = 0, nOut = 0; const void* ir0 = nullptr; bool oneIr = true, tail = false, carried = false, fresh = true, noHist = false; };
-  std::map<int, GroupInfo> groups;   // by leader
-  const bool tails = c.coarseTail;
   {
     auto mix = [](uint64_t& h, uint64_t v) { h = (h ^ v) * 1099511628211ull; };
     for (int id : dNodes) {
@@ -1471,10 +1511,9 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
       kv.second.noHist = kv.second.carried || (kv.second.tail && kv.second.fresh);
     }
   }
-  int frameNext = 0;
-  int64_t maxHist = 0;
-  double histBytes = 0;
-  std::map<int, double> carryBytes;   // row -> bytes of next-chunk history its forward transform also writes
+}
+
+void CoarseStage::buildRows() {
   std::vector<const float*> chIn;
   for (int id : dNodes) {
     NodeS& nd = *c.nodes[id];
@@ -1569,6 +1608,9 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
   }
   ex.flushLevel();   // (materialised inputs)
 
+}
+
+void CoarseStage::buildJobs() {
   // ---- jobs: pieces with the same (leader, output channels, partitions) accumulate into the same Y rows ----
   struct Key {
     int leader, P, ncol, out[4];
@@ -1583,22 +1625,12 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
     byKey[k].push_back(&pc);
   }
   // groups of signals: the multiply-accumulate jobs of group g run (second stream) while group g + 1 is transformed
-  const int nxAll = (int)xrows.size();
-  const int G = !c.coarseOverlap ? 1 : (nxAll >= 256 ? 4 : (nxAll >= 64 ? 2 : 1));
+  nxAll = (int)xrows.size();
+  G = !c.coarseOverlap ? 1 : (nxAll >= 256 ? 4 : (nxAll >= 64 ? 2 : 1));
   auto groupOf = [&](int xrow) { return std::min(G - 1, (int)((int64_t)xrow * G / std::max(nxAll, 1))); };
-  int gBegin[9];
   for (int g = 0; g <= G; g++) gBegin[g] = 0;
   for (int x = 0; x < nxAll; x++) gBegin[groupOf(x) + 1] = x + 1;
   for (int g = 1; g <= G; g++) gBegin[g] = std::max(gBegin[g], gBegin[g - 1]);
-  std::vector<CoarseTerm> terms;
-  // launches: by column count (1, 2, 4) x (terms with their own impulse responses | one impulse response for all terms), and
-  // by the group whose transforms complete the job's inputs.  Class index = 2 * column class + shared.
-  std::vector<CoarseJob> jobs[6][8];
-  int maxT[6] = {0, 0, 0, 0, 0, 0}, maxP[6] = {0, 0, 0, 0, 0, 0};
-  int pbOf[6] = {4, 4, 4, 4, 4, 4};   // largest of 4, 2, 1 dividing every job's partition count (the sweep's register block)
-  double macBytes[6][8] = {};
-  std::map<std::pair<int, int>, std::vector<int>> outRows;   // (leader, channel) -> Y rows to sum
-  int yNext = 0;
   for (auto& kv : byKey) {
     const Key& k = kv.first;
     const int cw = k.ncol, ci = cw == 1 ? 0 : (cw == 2 ? 1 : 2);
@@ -1648,14 +1680,14 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
       }
     }
   }
-  std::vector<CoarseOut> outs;
-  std::vector<int> ylist;
-  double invBytes = 0;
+}
+
+void CoarseStage::buildOutputs() {
   int maxPAll = 0;
   for (auto& kv : groups)
     if (kv.second.tail) maxPAll = std::max(maxPAll, kv.second.maxP);
-  const int yFrames = nT + maxPAll;   // coarse blocks per Y row (rows of groups with a shorter or no tail leave their end unused)
-  int invBlocks = nT;
+  yFrames = nT + maxPAll;   // coarse blocks per Y row (rows of groups with a shorter or no tail leave their end unused)
+  invBlocks = nT;
   if (tails) {   // tail buffers live with the group's leader: [2][channels][tail_len], read one, write the other
     std::map<int, int> chOf;
     for (auto& kv : outRows) chOf[kv.first.first] = std::max(chOf[kv.first.first], kv.first.second + 1);
@@ -1711,6 +1743,12 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
   if ((size_t)frameNext * kCoarseBins * sizeof(float2) > c.coarseX.bytes || (size_t)yNext * yFrames * kCoarseBins * sizeof(float2) > c.coarseY.bytes)
     fail(GA_ERR_INVALID_OPERATION, "internal: coarse spectra arenas are too small for the plan");
 
+}
+
+void CoarseStage::enqueue() {
+  // (the launches below run after this object is gone: they capture locals, never members)
+  const int G = this->G, yFrames = this->yFrames, invBlocks = this->invBlocks, nxAll = this->nxAll;
+  const double invBytes = this->invBytes, histBytes = this->histBytes;
   const size_t xo = ex.plan.putv(xrows), ho = ex.plan.putv(hjobs), to = ex.plan.putv(terms), oo = ex.plan.putv(outs), yo = ex.plan.putv(ylist);
   struct MacLaunch { size_t off; int nj, cw, mt, mp, pb, grp; bool ap; double bytes; };
   std::vector<MacLaunch> macs;
@@ -1733,7 +1771,7 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
   struct FwdLaunch { int x0, nx, maxFrames, run; double bytes; };
   std::vector<FwdLaunch> fwds;
   for (int g = 0; g < G; g++) {
-    FwdLaunch f{gBegin[g], gBegin[g + 1] - gBegin[g], 0, 1, 0.0};
+    FwdLaunch f{this->gBegin[g], this->gBegin[g + 1] - this->gBegin[g], 0, 1, 0.0};
     for (int x = f.x0; x < f.x0 + f.nx; x++) {
       f.maxFrames = std::max(f.maxFrames, xrows[x].n_frames);
       f.bytes += (double)(xrows[x].n_frames + 1) * kCoarseBlock * 4.0 + (double)xrows[x].n_frames * kCoarseBins * 8.0;
@@ -1792,6 +1830,16 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
   }, invBytes);
   const int64_t mh = maxHist;
   if (nh > 0) ex.plan.add(LK_CHIST, [=](uint8_t* base) { launch_coarse_hist(st, (const CoarseHistJob*)(base + ho), nh, mh); }, histBytes);
+}
+}  // namespace
+
+static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes, int64_t n) {
+  CoarseStage s(c, ex, dNodes, n);
+  s.classifyGroups();
+  s.buildRows();
+  s.buildJobs();
+  s.buildOutputs();
+  s.enqueue();
 }
 
 // ======================================================================================================
