@@ -2343,7 +2343,6 @@ void Context::ensureBiquadState(NodeS& bn) {
 // pass 6 (per convolver depth d): every segment, level by level -- node launches are batched per (level, type)
 void Context::chunkPlanNodes(ChunkRun& r, int d) {
   Context& c_ = *this; (void)c_;
-  std::vector<int>& topo = r.topo;
   int& maxDepth = r.maxDepth; int& maxLevel = r.maxLevel; (void)maxDepth; (void)maxLevel;
   int64_t& n = r.n; (void)n;
   std::vector<double>& bt = r.bt; (void)bt;
@@ -3212,7 +3211,6 @@ void Context::chunkDelayCommit(ChunkRun& r) {
 void Context::chunkExecute(ChunkRun& r) {
   static const bool timing = getenv("GA_TIMING") != nullptr;
   Context& c_ = *this; (void)c_;
-  std::vector<int>& topo = r.topo;
   int& maxDepth = r.maxDepth; int& maxLevel = r.maxLevel; (void)maxDepth; (void)maxLevel;
   int64_t& n = r.n; (void)n;
   std::vector<double>& bt = r.bt; (void)bt;
@@ -3305,7 +3303,6 @@ void Context::chunkExecute(ChunkRun& r) {
 // pass 10: commit the control state (source positions, Ended / Dispose bookkeeping, block clock) to the end of the chunk
 void Context::chunkCommit(ChunkRun& r) {
   Context& c_ = *this; (void)c_;
-  std::vector<int>& topo = r.topo;
   int& maxDepth = r.maxDepth; int& maxLevel = r.maxLevel; (void)maxDepth; (void)maxLevel;
   int64_t& n = r.n; (void)n;
   std::vector<double>& bt = r.bt; (void)bt;
