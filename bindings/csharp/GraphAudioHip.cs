@@ -19,10 +19,11 @@ internal static unsafe partial class GraphAudioHip
                      GA_ERR_OUT_OF_MEMORY = -8, GA_ERR_NO_DEVICE = -9;
     public const int NodeBufferSource = 1, NodeGain = 2, NodeBiquad = 3, NodeConvolver = 4;
     public const int NodeChannelSplitter = 5, NodeChannelMerger = 6, NodeConstantSource = 7, NodeStereoPanner = 8,
-                     NodeOscillator = 9, NodeDelay = 10;
+                     NodeOscillator = 9, NodeDelay = 10, NodeStreamSource = 11;
 
+    // ga_stats (include/graphaudio_hip.h): the layout has to match field for field -- ga_get_stats writes the whole struct
     [StructLayout(LayoutKind.Sequential)]
-    public struct Stats
+    public unsafe struct Stats
     {
         public long blocks_rendered, chunks, segments, kernel_launches;
         public double device_ms_total;
@@ -30,6 +31,11 @@ internal static unsafe partial class GraphAudioHip
         public double mac_ms_total, mac_flops_total, mac_bytes_total, fft_ms_total, other_ms_total;
         public long device_bytes_in_use;
         public int n_nodes, n_conv_rows;
+        public fixed double stage_ms[16];        // index = GA_STAGE_*
+        public fixed long stage_launches[16];
+        public fixed double stage_bytes[16];
+        public long profiled_chunks;
+        public long coarse_carried_outputs;
     }
 
     [LibraryImport(Lib, EntryPoint = "ga_strerror")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]
@@ -126,6 +132,19 @@ internal static unsafe partial class GraphAudioHip
 
     [LibraryImport(Lib, EntryPoint = "ga_synchronize")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]
     public static partial int ga_synchronize(IntPtr ctx);   // with option "async": waits for the enqueued renders
+    [LibraryImport(Lib, EntryPoint = "ga_render_device")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]
+    public static unsafe partial int ga_render_device(IntPtr ctx, float** outPlanarDev, int outChannels, long frameCount, long startIndex);   // rows in device memory
+    [LibraryImport(Lib, EntryPoint = "ga_context_set_stream")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]
+    public static partial int ga_context_set_stream(IntPtr ctx, IntPtr hipStream);
+    [LibraryImport(Lib, EntryPoint = "ga_set_option", StringMarshalling = StringMarshalling.Utf8)] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]
+    public static partial int ga_set_option(IntPtr ctx, string key, double value);   // "async", "max_chunk_blocks", ... (DESIGN.md)
+    [LibraryImport(Lib, EntryPoint = "ga_version")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]
+    private static partial IntPtr ga_version();
+    public static string Version => Marshal.PtrToStringUTF8(ga_version()) ?? "";
+    [LibraryImport(Lib, EntryPoint = "ga_node_disconnect_param")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]
+    public static partial int ga_node_disconnect_param(IntPtr ctx, int src, int dstNode, int dstParam, int outputIndex);   // AudioNode.Disconnect(AudioParam, int)
+    [LibraryImport(Lib, EntryPoint = "ga_param_get_value")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]
+    public static partial int ga_param_get_value(IntPtr ctx, int node, int param, out float value);                        // AudioParam.Value getter
 
     // ---- AudioStreamNodeBase with an explicit queue (GraphAudio.IO/AudioStreamSourceNodeBase.cs; node type 11) ----
     [LibraryImport(Lib, EntryPoint = "ga_stream_queue_buffer")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]
