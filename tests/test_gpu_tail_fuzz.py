@@ -14,7 +14,7 @@ from tests._oracle import OracleContext
 SR = 48000
 
 
-def _session(ctx, seed, total_blocks):
+def _session(ctx, seed, total_blocks, ragged=False):
     rng = np.random.default_rng(seed)
     taps = int(rng.integers(17000, 46000))          # 3 .. 6 coarse partitions
     shared = PlayableAudioBuffer.FromChannelArrays([G.synth_ir(c, taps, seed0=seed) for c in range(2)], SR)
@@ -40,6 +40,8 @@ def _session(ctx, seed, total_blocks):
     log = []
     while pos < frames:
         n = int(min(frames - pos, rng.integers(1, 9) * 128 * int(rng.integers(1, 40))))
+        if ragged:   # pieces that end inside a block: the leftover frames come from the render cache (OfflineAudioContext.cs:55-75)
+            n = int(min(frames - pos, max(1, n + int(rng.integers(-127, 128)))))
         ctx.Render(out, n, pos)
         pos += n
         act = int(rng.integers(0, 8))
@@ -86,3 +88,18 @@ def test_tail_sessions_match_the_oracle(seed):
     assert err <= 1e-5 and err <= 2e-6 * sig, (seed, err, sig, log)
     if "ir" not in log and log.count("-") >= 3:   # (a member on another impulse response takes the tail away from the group)
         assert st["coarse_carried_outputs"] > 0, log
+
+
+@pytest.mark.parametrize("seed", [3, 7, 11, 19, 23, 31])
+def test_tail_sessions_with_pieces_that_end_inside_a_block(seed):
+    total_blocks = 500
+    o = OracleContext(SR)
+    ref, log = _session(o, seed, total_blocks, ragged=True)
+    o.Dispose()
+    h = OfflineAudioContext(SR)
+    h.SetOption("coarse_min_blocks", 1)
+    got, log2 = _session(h, seed, total_blocks, ragged=True)
+    h.Dispose()
+    assert log == log2
+    err, sig = G.rms(ref - got), G.rms(ref)
+    assert err <= 1e-5 and err <= 2e-6 * sig, (seed, err, sig, log)
