@@ -2357,10 +2357,23 @@ void Context::chunkPlanNodes(ChunkRun& r, int d) {
       if (ex.outViews[si].empty()) ex.outViews[si].resize(nodes.size());
       const int64_t f0 = sg.b0 * kBlock, nf = (sg.b1 - sg.b0) * kBlock, nb = sg.b1 - sg.b0;
       // nodes of this stage ordered by level
+      // (a stable counting sort: with tens of thousands of nodes a comparison sort that chases two node pointers per comparison
+      // was a quarter of the host time of a chunk)
       std::vector<const NodeSeg*> todo;
-      for (const NodeSeg& ns : sg.nodes)
-        if (nodes[ns.id]->depth == d) todo.push_back(&ns);
-      std::stable_sort(todo.begin(), todo.end(), [&](const NodeSeg* a, const NodeSeg* b2) { return nodes[a->id]->level < nodes[b2->id]->level; });
+      {
+        std::vector<std::pair<int, const NodeSeg*>> mine;
+        std::vector<int> count(maxLevel + 2, 0);
+        for (const NodeSeg& ns : sg.nodes) {
+          const NodeS& nd = *nodes[ns.id];
+          if (nd.depth != d) continue;
+          const int lv = std::min(std::max(nd.level, 0), maxLevel);
+          mine.push_back({lv, &ns});
+          count[lv + 1]++;
+        }
+        for (int lv = 0; lv <= maxLevel; lv++) count[lv + 1] += count[lv];
+        todo.resize(mine.size());
+        for (auto& m : mine) todo[count[m.first]++] = m.second;
+      }
       // biquad cascade fusion: A is absorbed by B when B's only input term is A, A's only consumer is B and both run
       // (non-silent) with the same channel count; chains are capped at kMaxBiquadSections
       // (dense tables indexed by node id, validated by a per-(stage, segment) stamp: no hashing on the per-node path)

@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Host-side sampling profile of the chunk engine on config 4 (4096 voices x 7 nodes): many short renders so that the control
+plane dominates.  LD_PRELOAD=tools/prof/libsigprof.so GA_SIGPROF_OUT=gpurun_out/prof.txt python tools/prof/host_profile_cfg4.py"""
+import ctypes, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from graphaudio_amd import OfflineAudioContext
+from tests import _graphs as G
+voices = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+pieces = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+frames = 128 * 64
+ctx = OfflineAudioContext(48000)
+ch = G.config4_eq(ctx, voices=voices, frames=frames * pieces)
+out = np.zeros((ch, frames), np.float32)
+ctx.Render(out, frames)
+t0 = time.time()
+for _ in range(pieces - 1):
+    ctx.Render(out, frames)
+print(f"{(time.time() - t0) / (pieces - 1) * 1e3:.2f} ms per render of {frames} frames, {voices} voices", flush=True)
+if os.environ.get("GA_SIGPROF_OUT"):
+    ctypes.CDLL(None).sigprof_dump()

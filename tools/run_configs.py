@@ -67,3 +67,7 @@ for rep in range(4):   # the first pieces carry one-time costs (formulation assi
 st = ctx.GetStats()
 print(json.dumps({k: st[k] for k in ("chunks", "segments", "kernel_launches", "device_ms_total", "mac_ms_total", "fft_ms_total", "other_ms_total", "device_bytes_in_use")}))
 print("rms", G.rms(out))
+
+if os.environ.get("GA_SIGPROF_OUT"):   # tools/prof/sigprof.c preloaded: write its samples before the process leaves through _exit
+    import ctypes
+    ctypes.CDLL(None).sigprof_dump()
