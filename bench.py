@@ -336,8 +336,11 @@ def main():
         per_launch_ms = d["ms_per_step"] / d["launches_per_step"]
         per_launch_bytes = d["necessary_gb_per_step"] * 1e9 / d["launches_per_step"]
         form = ("formulation D (DESIGN.md): overlap-save with coarse partitions of 8192 samples (8 per 65,536-tap IR instead of 512), "
-                "16,384-point real transforms in LDS, partition sum sliding over LDS-staged spectra with the destination sum fused in the "
-                "frequency domain" if "coarse_fwd" in stages else
+                "16,384-point real transforms in LDS per voice, the destination sum fused in the frequency domain"
+                + (" (voices that share the impulse response: their spectra are summed before the spectral multiply)" if not args.private_ir else
+                   " (a private impulse response per voice: every product evaluated)")
+                + ", output tails carried from step to step instead of re-transforming the input history" * (not args.no_tail)
+                if "coarse_fwd" in stages else
                 "formulation C: partition sum as an FFT convolution along the block axis" if not args.direct else
                 "formulation A: direct partition sum on the f32 matrix cores")
         dev_ms = (st1["device_ms_total"] - st0["device_ms_total"]) * per_step
