@@ -926,6 +926,10 @@ struct Exec {
       }
       float* out = forcedSlabs ? forcedSlabs[ch] : inMixed(nodeId, i + 64, ch);
       if (!out) continue;
+      if (l.size() == 1 && l[0] == out) {   // the only term was produced in place (Context::aliasBusToLeader)
+        views[ch] = out;
+        continue;
+      }
       MixJob mj;
       mj.out = out;
       mj.term0 = (int)terms.size();
@@ -2233,6 +2237,35 @@ void Context::chunkParamCurves(ChunkRun& r) {
 
 }
 
+// When everything the destination receives in this chunk is ONE fused group of formulation D convolvers (or a single one) with
+// the bus's channel count, the group's inverse transforms write the bus themselves: the leader's output slabs ARE the bus
+// rows (the caller's device rows or page-locked host rows when Context::render set busTarget), and the destination's mix -- a
+// copy of one term -- disappears (Exec::resolveInSeg skips a forced target that already holds its only term).
+void Context::aliasBusToLeader(ChunkRun& r) {
+  Exec& ex = *r.ex;
+  int leader = -1, nch = 0;
+  for (const Segment& sg : r.segs) {
+    if (sg.nodes.empty() || sg.nodes.back().id != 0 || sg.nodes.back().ins.empty()) return;   // (node 0 is the destination)
+    const InSeg& is = sg.nodes.back().ins[0];
+    for (const TermS& t : is.terms) {
+      const NodeS& nd = *nodes[t.node];
+      if (nd.type != GA_NODE_CONVOLVER || !nd.ir || nd.convPath != 4 || nd.dLeader < 0 || t.out != 0 || t.ch != is.bufCh) return;
+      if (leader < 0) {
+        leader = nd.dLeader;
+        nch = is.bufCh;
+      } else if (leader != nd.dLeader || nch != is.bufCh) {
+        return;
+      }
+    }
+  }
+  if (leader < 0 || nch < 1 || nch > (int)busSlabs.size()) return;
+  const NodeS& ld = *nodes[leader];
+  if (ld.outputs.empty() || ld.outputs[0].connectedInputs.size() != 1) return;
+  const InRef& to = ld.outputs[0].connectedInputs[0];
+  if (to.node != 0 || to.input != 0) return;
+  for (int ch = 0; ch < nch; ch++) ex.nodeSlab[((uint64_t)leader << 8) | (uint64_t)ch] = busTarget[ch] ? busTarget[ch] : busSlabs[ch];
+}
+
 // pass 5: convolver formulations of new nodes, fusion groups, scratch arenas (sized before any recorded launch captures them)
 void Context::chunkConvScratch(ChunkRun& r) {
   Context& c_ = *this; (void)c_;
@@ -2252,6 +2285,7 @@ void Context::chunkConvScratch(ChunkRun& r) {
   //      launch captures their address ----
   assignConvPaths(topo, n);
   planCoarseFusion(topo, segs);
+  aliasBusToLeader(r);
   bHistMax = 0;
   {
     size_t xMax = 0, yMax = 0;

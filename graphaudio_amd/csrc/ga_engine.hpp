@@ -490,6 +490,7 @@ struct Context {
   const float2* twiddles16pw();
   void ensureCoarseSpectra(IrSpectra& ir);
   void planCoarseFusion(const std::vector<int>& topo, const std::vector<Segment>& segs);
+  void aliasBusToLeader(ChunkRun& r);
   ConvRowRef addGroupRow(const std::shared_ptr<IrSpectra>& ir, int ch, int depth, int nodeId);
   void ensureGroupState(ConvGroup& g);
   const float2* twiddlesC(int N2);
