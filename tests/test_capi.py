@@ -50,3 +50,31 @@ def test_error_strings():
     api = _capi.product_api()
     assert api.strerror(0) == b"ok"
     assert b"range" in api.strerror(-2)
+
+
+def test_csharp_binding_covers_the_header():
+    """bindings/csharp/GraphAudioHip.cs: one P/Invoke stub per entry point of the header (what a GraphAudio maintainer binds)"""
+    cs = open(os.path.join(ROOT, "bindings", "csharp", "GraphAudioHip.cs")).read()
+    bound = set(re.findall(r'EntryPoint = "ga_(\w+)"', cs))
+    assert sorted(declared_symbols()) == sorted(bound)
+
+
+def test_ga_stats_layout_is_the_same_in_c_python_and_csharp(tmp_path):
+    """ga_get_stats writes the whole struct: the three declarations have to agree in size"""
+    import subprocess
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "graphaudio_hip.h"\nint main(void) { printf("%zu", sizeof(ga_stats)); return 0; }\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    c_size = int(subprocess.check_output([str(exe)]).decode())
+    assert C.sizeof(_capi.Stats) == c_size
+    cs = open(os.path.join(ROOT, "bindings", "csharp", "GraphAudioHip.cs")).read()
+    body = cs[cs.index("public unsafe struct Stats"):]
+    body = body[:body.index("}")]
+    size = 0
+    for decl in re.findall(r"public\s+(fixed\s+)?(long|double|int)\s+([^;]+);", body):
+        width = {"long": 8, "double": 8, "int": 4}[decl[1]]
+        for name in decl[2].split(","):
+            m = re.search(r"\[(\d+)\]", name)
+            size += width * (int(m.group(1)) if m else 1)
+    assert size == c_size
