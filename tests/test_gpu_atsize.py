@@ -75,6 +75,24 @@ def test_config3_all_1024_voices_short_form(formulation):
     assert err / sig < 2e-6
 
 
+def test_config3_all_1024_voices_second_call_from_the_carried_tails():
+    """the steady state of the benchmark's steps: the second render call of the 1024-voice graph starts from the output tails
+    the first one left, not from the voices' input histories"""
+    frames = 375 * 128
+    ref = _config3_reference(frames)
+    h = OfflineAudioContext(SR)
+    G.config3_convolver(h, voices=1024, taps=65536, frames=frames)
+    got = np.zeros((2, frames), np.float32)
+    h.Render(got, 256 * 128, 0)
+    h.Render(got, frames - 256 * 128, 256 * 128)
+    st = h.GetStats()
+    h.Dispose()
+    assert st["coarse_carried_outputs"] == 2
+    err, sig = report("config 3, 1024 voices, 256 + 119 blocks (second call from the carried tails)", ref, got)
+    assert err <= TOL_RMS, err
+    assert err / sig < 2e-6
+
+
 def test_config3_256_voices_with_private_impulse_responses_in_two_calls():
     """the general multiply-accumulate kernel at scale (8 jobs of 32 terms, every term its own 65,536-tap stereo IR), rendered in
     two calls so that the second one starts from the input histories (private impulse responses carry no output tails)"""
