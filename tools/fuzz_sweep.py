@@ -1,34 +1,23 @@
-import sys, numpy as np
+#!/usr/bin/env python3
+"""One-off wider sweeps of the GPU fuzzers (not part of the test suite): tools/fuzz_sweep.py FIRST LAST [coarse values]"""
+import sys, time
 sys.path.insert(0, ".")
-from graphaudio_amd import NotSupportedException, OfflineAudioContext
-from tests import _graphs as G
-from tests._fuzz import build_random_graph
-from tests._oracle import OracleContext
-bad = []; skipped = 0; errs = 0; worst = 0.0
-for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 440):
-    frames = 128 * 36
-    o = OracleContext(48000); ch = build_random_graph(o, seed, frames)
-    ref = np.zeros((ch, frames), np.float32)
-    try:
-        o.Render(ref, frames)
-    except Exception as e:
-        errs += 1
-        h = OfflineAudioContext(48000); build_random_graph(h, seed, frames)
-        try:
-            h.Render(np.zeros((ch, frames), np.float32), frames); bad.append((seed, "no error on device", type(e).__name__))
-        except Exception as e2:
-            if type(e2) is not type(e): bad.append((seed, "different error", type(e).__name__, type(e2).__name__))
-        continue
-    h = OfflineAudioContext(48000); h.SetOption("max_chunk_blocks", 11); build_random_graph(h, seed, frames)
-    got = np.zeros_like(ref); pos = 0; rng = np.random.default_rng(1000 + seed)
-    try:
-        while pos < frames:
-            n = int(min(frames - pos, rng.integers(1, 128 * 9))); h.Render(got, n, pos); pos += n
-    except NotSupportedException:
-        skipped += 1; continue
-    except Exception as e:
-        bad.append((seed, "device exception", repr(e))); continue
-    err = G.rms(ref - got); scale = max(G.rms(ref), 1e-3); worst = max(worst, err / scale)
-    # either bound: large-amplitude transients of automated biquads differ by the device sinf/cosf vs glibc ulps
-    if not (err <= 1e-5 or err <= 5e-5 * scale): bad.append((seed, err, scale))
-print("bad", bad); print("skipped", skipped, "oracle-error cases", errs, "worst rel", worst)
+import pytest
+from tests.test_gpu_fuzz import test_random_graph_matches_oracle, test_random_edit_session_matches_oracle
+first, last = int(sys.argv[1]), int(sys.argv[2])
+coarse_values = [int(x) for x in sys.argv[3:]] or [1]
+bad = []
+t0 = time.time()
+for seed in range(first, last):
+    for coarse in coarse_values:
+        for fn in (test_random_graph_matches_oracle, test_random_edit_session_matches_oracle):
+            try:
+                fn(seed, coarse)
+            except pytest.skip.Exception:
+                pass
+            except Exception as e:   # noqa: BLE001
+                bad.append((fn.__name__, seed, coarse, repr(e)[:200]))
+                print("FAIL", bad[-1], flush=True)
+    if seed % 50 == 0:
+        print(f"seed {seed}  {time.time() - t0:.0f} s  failures {len(bad)}", flush=True)
+print("done", last - first, "seeds,", len(bad), "failures", bad[:5])
