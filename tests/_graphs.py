@@ -101,6 +101,21 @@ def config4_eq(ctx, voices=4096, frames=48000, sr=48000, src_sr=44100):
     return 2
 
 
+def config5_ambisonic(ctx, sources=64, taps=32768, frames=48000, ir_channels=16, v0=0, sr=48000):
+    """sources -> per-source ConvolverNode with its own 16-channel impulse response -> 16-channel destination
+    (BASELINE.json configs[4]; one GPU's shard is 64 of the 512 sources, `v0` = first source of the shard)."""
+    ctx.Destination.SetChannelCount(ir_channels)
+    for v in range(v0, v0 + sources):
+        s = AudioBufferSourceNode(ctx)
+        s.Buffer = PlayableAudioBuffer.FromMonoArray(voice(v, frames + 256), sr)
+        cv = ConvolverNode(ctx)
+        cv.Buffer = PlayableAudioBuffer.FromChannelArrays(
+            [synth_ir(c, taps, seed0=7 + 100 * v) for c in range(ir_channels)], sr)
+        s.Connect(cv).Connect(ctx.Destination)
+        s.Start()
+    return ir_channels
+
+
 def kit_scene(ctx, voices=64, frames=48000, sr=48000, taps=32768):
     """the graph shapes GraphAudio.Kit builds around the hot path.
     Voices (Sound: source -> StereoPanner, GraphAudio.Kit Sound's panner) -> two child buses (AudioBus = one GainNode,

@@ -114,17 +114,7 @@ def test_config3_256_voices_with_private_impulse_responses_in_two_calls():
     assert err / sig < 2e-6
 
 
-def _config5(ctx, sources, taps, frames, ir_channels=16):
-    ctx.Destination.SetChannelCount(ir_channels)
-    for v in range(sources):
-        s = AudioBufferSourceNode(ctx)
-        s.Buffer = PlayableAudioBuffer.FromMonoArray(G.voice(v, frames + 256), SR)
-        cv = ConvolverNode(ctx)
-        cv.Buffer = PlayableAudioBuffer.FromChannelArrays(
-            [G.synth_ir(c, taps, seed0=7 + 100 * v) for c in range(ir_channels)], SR)
-        s.Connect(cv).Connect(ctx.Destination)
-        s.Start()
-    return ir_channels
+_config5 = G.config5_ambisonic
 
 
 @pytest.mark.parametrize("coarse", [1, 0])
