@@ -9,25 +9,35 @@ the same render (DSP state persists), voices loop over a 10 s buffer so inputs s
 
 Multi-GPU (--gpus N): one rank per GPU.  Launched by `torch.distributed.run --nproc-per-node N` the ranks come from the
 environment; launched plainly with --gpus N > 1 this script starts the N rank processes itself (before anything touches a
-GPU) and relays rank 0's line.  The voices are sharded V/N per rank (strong scaling: the job is the same 1024-voice mix);
-every rank calls ga_render_reduce: render its share, ONE RCCL sum of the destination bus per step inside the product
-library (include/graphaudio_hip.h "sharded render"), the result lands in rank 0's page-locked host buffer.  The process
-group (gloo) only carries the communicator id, the barrier and the max-over-ranks time.
+GPU), watches all of them and relays rank 0's line.  `--scaling strong` (default): the 1024 voices are sharded V/N per rank;
+`--scaling weak`: every rank renders `--voices` voices of its own (the job grows with N).  Every rank calls ga_render_reduce:
+render its share, ONE RCCL sum of the destination bus per step inside the product library (include/graphaudio_hip.h "sharded
+render"), the result lands in rank 0's page-locked host buffer.  The process group (gloo) only carries the communicator id,
+the barrier, the max-over-ranks time and the float64 check's input sum.
 
 One JSON line on stdout (rank 0).  Besides the contract keys:
-  roofline       -- the dominant kernel of the EXECUTED formulation (default: formulation D, coarse partitions; its forward
-                    transform coarse_fwd_kernel).  `achieved` = the HBM bytes the launch HAS to move in that formulation
-                    (inputs read once + outputs written once, computed by the planner, ga_stats.stage_bytes) / its average
-                    launch duration measured live with HIP events on the context's stream; `peak` = 8 TB/s; `traffic` = null
-                    here (the PMC measurement of the same command, with the guide's gfx950 FETCH_SIZE correction, is in
-                    profiles/: it needs its own rocprofv3 passes).
-  stages         -- the same three numbers for every stage of the step, and `whole_step` for their sum.
+  roofline       -- the dominant kernel of the EXECUTED formulation; its name is what the library reports it ran
+                    (ga_stats.stage_kernel).  `achieved` = the HBM bytes the launch HAS to move in that formulation (inputs read
+                    once + outputs written once, computed by the planner, ga_stats.stage_bytes) / its average launch duration
+                    measured live with HIP events on the context's stream; `peak` = 8 TB/s; `flops_frac` = the planner's count
+                    of the floating-point operations the launch executes / that time / 157.3 TFLOP/s; `traffic` = null here (the
+                    PMC measurement of the same command, with the guide's gfx950 FETCH_SIZE correction, is in profiles/: it needs
+                    its own rocprofv3 passes).
+  stages         -- the same numbers for every stage of the step, and `whole_step` for their sum.
+  variants       -- the SAME measurement on the graphs / formulations the headline's algebra does not apply to, each with its own
+                    dominant kernel and both roofline fractions (a4, the per-voice spectral multiply-accumulate, is measured here):
+                      per_voice_spectra : headline graph, every voice transformed, spectra summed (option coarse_premix = 0)
+                      private_ir        : every voice its own 65,536-tap stereo impulse response (general multiply-accumulate)
+                      config5_1gpu      : BASELINE.json configs[4] whole on one GPU: 512 sources x 16-channel 32,768-tap private IRs
+  parity         -- (a) timed_step_rms_vs_f64: the output of the LAST TIMED STEP against float64 mathematics -- the voices loop over
+                    exactly one step, so the steady-state bus is the circular convolution of sum_v x_v with the scaled impulse
+                    response (one numpy rfft of a step's length); (b) the GPU path against the CPU oracle on the 1 s short form
+                    of the same 1024-voice graph.
   streaming_formulation -- SURVEY.md 8(d)'s per-block STREAMING bytes of the reference's algorithm (1.086 GB/block here) over the
                     step time: how much of the reference's traffic the formulation removes (not a roofline fraction).
   cpu_baseline   -- the CPU oracle (C++ restatement of the reference's single-threaded render; .NET cannot run here) timed on
                     this host: 1 thread on the full 1024-voice graph (the reference renders on one thread), and all cores
                     with the voices partitioned across processes.
-  parity         -- RMS error of this GPU path against the oracle on the 1 s short form of the SAME 1024-voice graph.
 """
 import argparse
 import json
@@ -44,34 +54,74 @@ sys.path.insert(0, ROOT)
 SR = 48000
 PEAK_F32_TFLOPS = 157.3        # MI355X_MICROARCH.md: peak FP32 (vector = matrix)
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak (spec); ~6.3 TB/s is what a streaming copy reaches
-STAGES = ("other", "mix", "rfft_fwd", "mac", "rfft_inv", "coarse_fwd", "coarse_mac", "coarse_inv", "coarse_hist", "coarse_section")
-STAGE_KERNELS = {
-    "mix": "mix_kernel (AudioNodeInput.MixBuffer)",
-    "rfft_fwd": "hist_copy_b_kernel + rfft_fwd_b_kernel (256-point forward transforms)",
-    "mac": "tconv16_kernel (partition sum as an FFT convolution along the block axis) / spectral_mac_* (matrix cores)",
-    "rfft_inv": "irfft_ola_b_kernel (256-point inverse transforms + overlap-add)",
-    "coarse_fwd": "coarse_fwd_kernel (16,384-point real transforms of the input windows: two 4096-point complex radix-16 "
-                  "transforms per window in LDS + combine pass)",
-    "coarse_mac": "coarse_mac_kernel (sliding partition sum over LDS-staged spectra, accumulators of 32 voices in registers)",
-    "coarse_inv": "coarse_inv_kernel (frequency-domain mix + inverse transforms)",
-    "coarse_hist": "coarse_hist_kernel (input history of the next chunk)",
+STAGES = ("other", "mix", "rfft_fwd", "mac", "rfft_inv", "coarse_fwd", "coarse_mac", "coarse_inv", "coarse_hist", "coarse_section",
+          "coarse_premix")
+STAGE_NOTES = {   # what the stage computes (the kernel NAME comes from the library: ga_stats.stage_kernel)
+    "mix": "AudioNodeInput.MixBuffer sums",
+    "rfft_fwd": "256-point forward transforms (formulations A/B/C)",
+    "mac": "partition sum of formulations A/B/C",
+    "rfft_inv": "256-point inverse transforms + overlap-add",
+    "coarse_premix": "time-domain sum of the voices that share one impulse response (+ their input histories of the next chunk)",
+    "coarse_fwd": "16,384-point real transforms of the input windows (two 4096-point complex radix-16 transforms in LDS + combine pass)",
+    "coarse_mac": "partition sum over coarse partitions + the consumer's sum in the frequency domain",
+    "coarse_inv": "frequency-domain mix + inverse transforms (+ the bus written to the caller's page-locked rows)",
+    "coarse_hist": "input history of the next chunk",
 }
 
 
-def build_graph(ctx, voices, v0, taps, loop_frames, G, loop=True, private_ir=False):
+_voices = {}
+
+
+def voice(G, v, n):
+    """the synthetic voice v (tests/_graphs.py::voice), generated once per process: the main graph and the variants play the same voices"""
+    key = (v, n)
+    if key not in _voices:
+        _voices[key] = G.voice(v, n)
+    return _voices[key]
+
+
+def shared_ir(G, taps):
+    return [G.synth_ir(c, taps) for c in range(2)]
+
+
+def private_ir(G, taps, v):
+    return [np.roll(G.synth_ir(c, taps), 37 * v) for c in range(2)]
+
+
+def build_graph(ctx, voices, v0, taps, loop_frames, G, loop=True, private=False, xsum=None):
+    """voices [v0, v0 + voices) of the headline graph; `xsum` (float64, loop_frames) accumulates the voices' samples"""
     from graphaudio_amd import AudioBufferSourceNode, ConvolverNode, PlayableAudioBuffer
-    irbuf = PlayableAudioBuffer.FromChannelArrays([G.synth_ir(c, taps) for c in range(2)], SR)
+    irbuf = PlayableAudioBuffer.FromChannelArrays(shared_ir(G, taps), SR)
     ctx.Destination.SetChannelCount(2)
     for v in range(v0, v0 + voices):
         s = AudioBufferSourceNode(ctx)
-        s.Buffer = PlayableAudioBuffer.FromMonoArray(G.voice(v, loop_frames), SR)
+        x = voice(G, v, loop_frames) if loop else G.voice(v, loop_frames)
+        if xsum is not None:
+            xsum += x
+        s.Buffer = PlayableAudioBuffer.FromMonoArray(x, SR)
         s.Loop = loop
         cv = ConvolverNode(ctx)
-        if private_ir:   # --private-ir: every voice its own impulse response (the general multiply-accumulate path; not the headline)
-            irbuf = PlayableAudioBuffer.FromChannelArrays([np.roll(G.synth_ir(c, taps), 37 * v) for c in range(2)], SR)
+        if private:   # every voice its own impulse response (the general multiply-accumulate path; not the headline)
+            irbuf = PlayableAudioBuffer.FromChannelArrays(private_ir(G, taps, v), SR)
         cv.Buffer = irbuf
         s.Connect(cv).Connect(ctx.Destination)
         s.Start()
+    return 2
+
+
+def build_config5(ctx, sources, v0, taps, loop_frames, G, channels=16):
+    """BASELINE.json configs[4]: sources -> ConvolverNode with its own 16-channel impulse response -> 16-channel destination"""
+    from graphaudio_amd import AudioBufferSourceNode, ConvolverNode, PlayableAudioBuffer
+    ctx.Destination.SetChannelCount(channels)
+    for v in range(v0, v0 + sources):
+        s = AudioBufferSourceNode(ctx)
+        s.Buffer = PlayableAudioBuffer.FromMonoArray(voice(G, v, loop_frames), SR)
+        s.Loop = True
+        cv = ConvolverNode(ctx)
+        cv.Buffer = PlayableAudioBuffer.FromChannelArrays([G.synth_ir(c, taps, seed0=7 + 100 * v) for c in range(channels)], SR)
+        s.Connect(cv).Connect(ctx.Destination)
+        s.Start()
+    return channels
 
 
 def _cpu_name():
@@ -169,8 +219,13 @@ def cpu_baseline_and_parity(voices, taps, G, args, all_cores):
 
 
 def spawn_ranks(n):
-    """`python bench.py --gpus N` without a launcher: start the N rank processes (this process never touches a GPU)."""
+    """`python bench.py --gpus N` without a launcher: start the N rank processes (this process never touches a GPU), watch ALL of
+    them, and take the others down when one fails -- a rank that dies early would otherwise leave its peers waiting in the
+    rendezvous or in the collective for ever."""
     import socket
+    if any(k in os.environ for k in ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "HSA_TOOLS_LIB")):
+        sys.exit("bench.py: refusing to start rank processes under a profiler preload (the preloaded library has initialised the GPU in "
+                 "this process; profile one rank: --gpus 1)")
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -181,12 +236,177 @@ def spawn_ranks(n):
                    GA_BENCH_CHILD="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out = procs[0].communicate()[0].decode()
+    import threading
+    out = []
+    reader = threading.Thread(target=lambda: out.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
     rc = 0
-    for p in procs:
-        rc = rc or p.wait()
-    sys.stdout.write(out)
+    live = set(range(n))
+    while live and rc == 0:
+        time.sleep(0.2)
+        for r in list(live):
+            code = procs[r].poll()
+            if code is not None:
+                live.discard(r)
+                if code != 0:
+                    rc = code
+                    sys.stderr.write(f"bench.py: rank {r} exited with code {code}; stopping the other ranks\n")
+    if rc != 0:
+        for r in live:
+            procs[r].terminate()
+        deadline = time.time() + 10
+        for r in live:
+            try:
+                procs[r].wait(max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+    reader.join(5)
+    sys.stdout.write(b"".join(out).decode())
     sys.exit(rc)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+def stage_table(st0, st1, steps):
+    """per-stage numbers of the timed region.  Times come from the chunks that recorded events (every --profile-every-th), scaled
+    to a step; launches, bytes and flops count every chunk."""
+    nprof = max(st1["profiled_chunks"] - st0["profiled_chunks"], 1)
+    per_step = (st1["chunks"] - st0["chunks"]) / steps / nprof
+    stages = {}
+    tot_ms = tot_b = 0.0
+    for i, name in enumerate(STAGES):
+        ms = (st1["stage_ms"][i] - st0["stage_ms"][i]) * per_step
+        nl = (st1["stage_launches"][i] - st0["stage_launches"][i]) / steps
+        by = (st1["stage_bytes"][i] - st0["stage_bytes"][i]) / steps
+        fl = (st1["stage_flops"][i] - st0["stage_flops"][i]) / steps
+        if nl <= 0:
+            continue
+        gbs = by / (ms * 1e-3) / 1e9 if ms > 0 and by > 0 else None
+        tfs = fl / (ms * 1e-3) / 1e12 if ms > 0 and fl > 0 else None
+        stages[name] = {"ms_per_step": ms, "launches_per_step": nl, "necessary_gb_per_step": by / 1e9 if by > 0 else None,
+                        "gb_per_s": gbs, "frac_of_hbm_peak": gbs / PEAK_HBM_GBS if gbs else None,
+                        "gflop_per_step": fl / 1e9 if fl > 0 else None, "tflop_per_s": tfs,
+                        "frac_of_f32_peak": tfs / PEAK_F32_TFLOPS if tfs else None,
+                        "kernel": st1["stage_kernel"][i] or name, "computes": STAGE_NOTES.get(name, name)}
+        if by > 0 and name != "coarse_section":
+            tot_ms += ms
+            tot_b += by
+    whole = {"necessary_gb": tot_b / 1e9, "kernel_ms": tot_ms, "gb_per_s": tot_b / (tot_ms * 1e-3) / 1e9 if tot_ms else None,
+             "frac_of_hbm_peak": tot_b / (tot_ms * 1e-3) / 1e9 / PEAK_HBM_GBS if tot_ms else None}
+    return stages, whole, nprof, per_step
+
+
+def roofline_of(stages):
+    cands = [n for n in stages if stages[n]["necessary_gb_per_step"] and n != "coarse_section"]
+    if not cands:
+        return None
+    dom = max(cands, key=lambda n: stages[n]["ms_per_step"])
+    d = stages[dom]
+    per_launch_ms = d["ms_per_step"] / d["launches_per_step"]
+    per_launch_bytes = d["necessary_gb_per_step"] * 1e9 / d["launches_per_step"]
+    ach = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": None,
+            "kernel": d["kernel"], "computes": d["computes"], "stage": dom, "avg_launch_ms": per_launch_ms,
+            "launches_per_step": d["launches_per_step"], "necessary_bytes_per_launch": per_launch_bytes,
+            "flops_per_launch": (d["gflop_per_step"] or 0.0) * 1e9 / d["launches_per_step"],
+            "tflop_per_s": d["tflop_per_s"], "flops_frac": d["frac_of_f32_peak"], "f32_peak_tflops": PEAK_F32_TFLOPS,
+            "bytes_definition": "HBM bytes the launch has to move in the executed formulation: inputs read once + outputs "
+                                "written once (planner, ga_stats.stage_bytes); HIP-event time on the context's stream",
+            "traffic_note": "PMC traffic of this command (FETCH_SIZE x2 on gfx950, WRITE_SIZE): profiles/"}
+
+
+def timed_steps(ctx, step, sync, steps, warmup):
+    for _ in range(warmup):
+        step()
+    sync()
+    st0 = ctx.GetStats()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    t_enq = time.perf_counter() - t0   # host time to issue all steps (== dt when every step blocks)
+    sync()
+    dt = time.perf_counter() - t0
+    return dt, t_enq, st0, ctx.GetStats()
+
+
+def circular_truth(xsum, irs):
+    """steady-state bus of looping voices: circular convolution (period = the loop) of the summed input with the scaled taps"""
+    from tests import _f64model as M
+    return np.stack([M.circular_conv(xsum, M.scaled_ir64(h)) for h in irs])
+
+
+def _truth_worker(job):
+    """float64 truth of a variant whose voices have impulse responses of their own, for voices [v0, v1): the spectrum of
+    sum_v circ(x_v, h_{v,c}) (period = one step), accumulated in the frequency domain.  Runs in worker processes before the parent
+    touches the GPU."""
+    kind, v0, v1, frames, taps = job
+    from tests import _f64model as M
+    from tests import _graphs as G
+    channels = 16 if kind == "config5_1gpu" else 2
+    acc = np.zeros((channels, frames // 2 + 1), np.complex128)
+    h = np.zeros(frames, np.float64)
+    for v in range(v0, v1):
+        X = np.fft.rfft(G.voice(v, frames).astype(np.float64))
+        irs = private_ir(G, taps, v) if kind == "private_ir" else [G.synth_ir(c, taps, seed0=7 + 100 * v) for c in range(channels)]
+        for c in range(channels):
+            hc = M.scaled_ir64(irs[c])
+            h[:len(hc)] = hc
+            acc[c] += X * np.fft.rfft(h)
+    return acc
+
+
+def precompute_truths(args, frames, voices_total):
+    """the variants' float64 truths (circular convolutions, see circular_truth), on all cores, before the GPU is initialised"""
+    import multiprocessing as mp
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(avail, 16))
+    cases = {"private_ir": (min(voices_total, 1024), args.taps), "config5_1gpu": (512, 32768)}
+    jobs = []
+    for kind, (nv, taps) in cases.items():
+        per = max(1, (nv + 4 * cores - 1) // (4 * cores))
+        jobs += [(kind, a, min(nv, a + per), frames, taps) for a in range(0, nv, per)]
+    with mp.get_context("spawn").Pool(cores) as pool:
+        parts = pool.map(_truth_worker, jobs, chunksize=1)
+    out = {}
+    for kind in cases:
+        acc = sum(p for j, p in zip(jobs, parts) if j[0] == kind)
+        out[kind] = np.fft.irfft(acc, n=frames, axis=1)
+    return out
+
+
+def run_variant(name, torch, G, frames, steps, warmup, build, channels, options, describe, truth=None):
+    """one more measurement on a context of its own: same step loop, same stage table, its own dominant kernel"""
+    from graphaudio_amd import OfflineAudioContext
+    from tests import _f64model as M
+    t_build = time.perf_counter()
+    ctx = OfflineAudioContext(SR)
+    ctx.SetOption("profile", 1)
+    ctx.SetOption("profile_every", 1)
+    ctx.SetOption("max_chunk_blocks", 4096)
+    ctx.SetOption("async", 1)
+    for k, v in options.items():
+        ctx.SetOption(k, v)
+    build(ctx)
+    host = torch.zeros((channels, frames), dtype=torch.float32).pin_memory()
+    out = host.numpy()
+    t_build = time.perf_counter() - t_build
+
+    def sync():
+        ctx.Synchronize()
+        torch.cuda.synchronize()
+    dt, t_enq, st0, st1 = timed_steps(ctx, lambda: ctx.Render(out, frames), sync, steps, warmup)
+    stages, whole, _, per_step = stage_table(st0, st1, steps)
+    rec = {"description": describe, "ms_per_step": dt / steps * 1e3, "frames_per_s": frames * steps / dt, "steps": steps, "warmup": warmup,
+           "frames_per_step": frames, "host_issue_ms_per_step": t_enq / steps * 1e3,
+           "device_ms_per_step": (st1["device_ms_total"] - st0["device_ms_total"]) * per_step,
+           "roofline": roofline_of(stages), "stages": stages, "whole_step": whole, "setup_s": t_build}
+    if truth is not None:
+        ref = truth()
+        err, sig = M.rms(out - ref), M.rms(ref)
+        rec["timed_step_rms_vs_f64"] = {"rms_abs": err, "rms_relative_to_bus": err / sig, "bus_rms": sig, "tolerance_rms_abs": 1e-5}
+    ctx.Dispose()
+    del host
+    return rec
 
 
 def main():
@@ -197,11 +417,17 @@ def main():
     ap.add_argument("--seconds", type=float, default=10.0, help="audio seconds rendered per step")
     ap.add_argument("--voices", type=int, default=1024)
     ap.add_argument("--taps", type=int, default=65536)
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="strong: --voices in total, sharded over the ranks; weak: --voices per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the per-voice / private-IR / config 5 variants of the default run")
+    ap.add_argument("--no-check", action="store_true", help="skip the float64 check of the last timed step")
+    ap.add_argument("--variant-steps", type=int, default=6)
     ap.add_argument("--baseline-blocks", type=int, default=375)
     ap.add_argument("--baseline-cores", type=int, default=0)
     ap.add_argument("--direct", action="store_true", help="direct (matrix-core) partition sum, formulation A")
     ap.add_argument("--no-coarse", action="store_true", help="formulation C (block-axis FFT) instead of D (coarse partitions)")
+    ap.add_argument("--no-premix", action="store_true", help="formulation D without the time-domain pre-mix: every voice is transformed, the spectra are summed")
     ap.add_argument("--overlap", action="store_true", help="formulation D: forward and multiply-accumulate stages concurrently on two streams (measured slower)")
     ap.add_argument("--profile-every", type=int, default=4, help="record the per-stage HIP events on every k-th chunk of the timed region")
     ap.add_argument("--no-profile", action="store_true", help="no per-stage HIP events (measurement of their cost; the roofline object is then empty)")
@@ -222,25 +448,34 @@ def main():
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
 
+    frames = int(round(args.seconds * SR)) // 128 * 128
     all_cores = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         all_cores = cpu_all_cores(args.voices, args.taps, args)   # before anything initialises the GPU in this process
+    with_variants = (rank == 0 and world == 1 and not args.no_variants
+                     and not (args.private_ir or args.no_premix or args.no_coarse or args.direct or args.no_profile))
+    truths = precompute_truths(args, frames, args.voices) if with_variants and not args.no_check else None
 
     import torch   # (first: its bundled HIP runtime has to be the one in the process, tests/conftest.py)
     dist = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
-        dist.init_process_group("gloo", rank=rank, world_size=world)   # control plane only; the bus sum is RCCL inside the library
+        # control plane only; the bus sum is RCCL inside the library.  A finite timeout: a peer that died must not hang this rank.
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
 
     from graphaudio_amd import OfflineAudioContext
     from graphaudio_amd.distributed import init_sharded, shard_range
     from tests import _graphs as G
 
-    frames = int(round(args.seconds * SR)) // 128 * 128
-    voices_total = args.voices
-    v0, v1 = shard_range(voices_total, world, rank)
+    if args.scaling == "weak":
+        voices_total = args.voices * world
+        v0, v1 = rank * args.voices, (rank + 1) * args.voices
+    else:
+        voices_total = args.voices
+        v0, v1 = shard_range(voices_total, world, rank)
     use_reduce = world > 1 or args.force_dist
 
     ctx = OfflineAudioContext(SR, device=local_rank)
@@ -252,6 +487,8 @@ def main():
         ctx.SetOption("time_fft", 0)
     if args.no_coarse:
         ctx.SetOption("coarse", 0)
+    if args.no_premix:
+        ctx.SetOption("coarse_premix", 0)
     if args.overlap:
         ctx.SetOption("coarse_overlap", 1)
     if args.no_carry:
@@ -262,7 +499,9 @@ def main():
         ctx.SetOption("host_direct", 0)
     if args.copy_stream:
         ctx.SetOption("host_copy_stream", 1)
-    build_graph(ctx, v1 - v0, v0, args.taps, frames, G, private_ir=args.private_ir)
+    check = not args.no_check and not args.no_profile
+    xsum = np.zeros(frames, np.float64) if check and not args.private_ir else None
+    build_graph(ctx, v1 - v0, v0, args.taps, frames, G, private=args.private_ir, xsum=xsum)
     if use_reduce:
         init_sharded(ctx, rank, world)
 
@@ -289,56 +528,33 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    st0 = ctx.GetStats()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    t_enq = time.perf_counter() - t0   # host time to issue all steps (== dt when every step blocks)
-    sync()
-    dt = time.perf_counter() - t0
-    st1 = ctx.GetStats()
+    dt, t_enq, st0, st1 = timed_steps(ctx, step, sync, args.steps, args.warmup)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        if xsum is not None:   # the float64 check needs the sum over ALL ranks' voices
+            xs = torch.from_numpy(xsum)
+            dist.reduce(xs, dst=0, op=dist.ReduceOp.SUM)
 
     if rank == 0:
+        from tests import _f64model as M
         value = frames * args.steps / dt
         blocks = frames // 128
-        stages = {}
-        tot_ms = tot_b = 0.0
-        # stage times come from the chunks that recorded events (every --profile-every-th), scaled to a step
-        nprof = max(st1["profiled_chunks"] - st0["profiled_chunks"], 1)
-        per_step = (st1["chunks"] - st0["chunks"]) / args.steps / nprof
-        for i, name in enumerate(STAGES):
-            ms = (st1["stage_ms"][i] - st0["stage_ms"][i]) * per_step
-            nl = (st1["stage_launches"][i] - st0["stage_launches"][i]) / args.steps
-            by = (st1["stage_bytes"][i] - st0["stage_bytes"][i]) / args.steps
-            if nl <= 0:
-                continue
-            gbs = by / (ms * 1e-3) / 1e9 if ms > 0 and by > 0 else None
-            stages[name] = {"ms_per_step": ms, "launches_per_step": nl, "necessary_gb_per_step": by / 1e9 if by > 0 else None,
-                            "gb_per_s": gbs, "frac_of_hbm_peak": gbs / PEAK_HBM_GBS if gbs else None,
-                            "kernel": STAGE_KERNELS.get(name, name)}
-            if by > 0:
-                tot_ms += ms
-                tot_b += by
+        stages, whole, nprof, per_step = stage_table(st0, st1, args.steps)
         if args.no_profile or not stages:   # --no-profile (measurement of the events' cost): nothing to price
             print(json.dumps({"ms_per_step": dt / args.steps * 1e3, "value": value, "host_issue_ms_per_step": t_enq / args.steps * 1e3,
                               "device_ms_per_step": 0.0, "stages": {}}))
             return
-        dom = max((n for n in stages if stages[n]["necessary_gb_per_step"]), key=lambda n: stages[n]["ms_per_step"])
-        d = stages[dom]
-        per_launch_ms = d["ms_per_step"] / d["launches_per_step"]
-        per_launch_bytes = d["necessary_gb_per_step"] * 1e9 / d["launches_per_step"]
+        premixed = "coarse_premix" in stages
         form = ("formulation D (DESIGN.md): overlap-save with coarse partitions of 8192 samples (8 per 65,536-tap IR instead of 512), "
-                "16,384-point real transforms in LDS per voice, the destination sum fused in the frequency domain"
-                + (" (voices that share the impulse response: their spectra are summed before the spectral multiply)" if not args.private_ir else
-                   " (a private impulse response per voice: every product evaluated)")
+                "16,384-point real transforms in LDS"
+                + (", the voices that share the impulse response summed in the TIME domain in front of ONE set of transforms "
+                   "(sum_v (x_v * h) = (sum_v x_v) * h; planner decision, option coarse_premix; the per-voice route is variants.per_voice_spectra)"
+                   if premixed else
+                   " per voice, the destination sum fused in the frequency domain"
+                   + (" (voices that share the impulse response: their spectra are summed before the spectral multiply)" if not args.private_ir else
+                      " (a private impulse response per voice: every product evaluated)"))
                 + ", output tails carried from step to step instead of re-transforming the input history" * (not args.no_tail)
                 if "coarse_fwd" in stages else
                 "formulation C: partition sum as an FFT convolution along the block axis" if not args.direct else
@@ -348,44 +564,77 @@ def main():
         rec = {
             "metric": "rendered frames/sec @48kHz, 1024-voice convolver graph",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{voices_total} voices -> PartitionedConvolver, {args.taps}-tap stereo IR {'of its own per voice' if args.private_ir else 'shared by all voices'} "
                                    f"(P={(args.taps + 127) // 128}), 128-sample blocks, 48 kHz, {blocks} blocks per step",
-                       "voices": voices_total, "taps": args.taps, "frames_per_step": frames,
+                       "voices": voices_total, "voices_per_gpu": v1 - v0, "taps": args.taps, "frames_per_step": frames,
                        "parallelism": f"voice-shard x{world}, one RCCL reduce of the bus per step (ga_render_reduce)" if world > 1 else "single GPU",
                        "steps_pipelined": pipelined, "formulation": form},
             "realtime_factor": value / SR,
             "host_issue_ms_per_step": t_enq / args.steps * 1e3,
             "device_ms_per_step": dev_ms,
             "profiled_chunks": nprof,
-            "roofline": {"bound": "hbm", "achieved": per_launch_bytes / (per_launch_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": per_launch_bytes / (per_launch_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
-                         "kernel": d["kernel"], "stage": dom, "avg_launch_ms": per_launch_ms, "launches_per_step": d["launches_per_step"],
-                         "necessary_bytes_per_launch": per_launch_bytes,
-                         "bytes_definition": "HBM bytes the launch has to move in the executed formulation: inputs read once + outputs "
-                                             "written once (planner, ga_stats.stage_bytes); HIP-event time on the context's stream",
-                         "traffic_note": "PMC traffic of this command (FETCH_SIZE x2 on gfx950, WRITE_SIZE): profiles/"},
+            "roofline": roofline_of(stages),
             "stages": stages,
-            "whole_step": {"necessary_gb": tot_b / 1e9, "kernel_ms": tot_ms, "gb_per_s": tot_b / (tot_ms * 1e-3) / 1e9 if tot_ms else None,
-                           "frac_of_hbm_peak": tot_b / (tot_ms * 1e-3) / 1e9 / PEAK_HBM_GBS if tot_ms else None},
+            "whole_step": whole,
             "streaming_formulation": {"bytes_per_step": stream_bytes, "tb_per_s_if_streamed": stream_bytes / (dt / args.steps) / 1e12,
                                       "note": "SURVEY.md 8(d) per-block streaming bytes of the reference's algorithm over the step time: "
                                               "the factor of traffic the executed formulation removes, not a roofline fraction"},
             "device_bytes_in_use": st1["device_bytes_in_use"],
         }
+        parity = {}
+        if check and args.warmup + args.steps >= 2 and frames >= args.taps:
+            # the output of the LAST TIMED STEP, as it sits in the caller's page-locked rows, against float64 mathematics
+            if args.private_ir:
+                truth = np.fft.irfft(sum(_truth_worker(("private_ir", a, min(voices_total, a + 64), frames, args.taps))
+                                         for a in range(0, voices_total, 64)), n=frames, axis=1)
+            else:
+                truth = circular_truth(xsum, shared_ir(G, args.taps))
+            err, sig = M.rms(host_out - truth), M.rms(truth)
+            parity["timed_step_rms_vs_f64"] = {
+                "rms_abs": err, "rms_relative_to_bus": err / sig, "bus_rms": sig, "tolerance_rms_abs": 1e-5,
+                "what": f"the {frames}-frame output of the last timed step (all {voices_total} voices, all ranks) vs the circular convolution of "
+                        "the summed looping voices with the scaled impulse response in float64 (tests/_f64model.py)"}
+            rec["timed_step_rms_vs_f64"] = err
         if not args.no_cpu_baseline and world == 1:
-            rec["cpu_baseline"], rec["parity"] = cpu_baseline_and_parity(voices_total, args.taps, G, args, all_cores)
-            rec["parity_rms"] = rec["parity"]["rms_abs"]
+            rec["cpu_baseline"], vs_oracle = cpu_baseline_and_parity(voices_total, args.taps, G, args, all_cores)
+            parity.update(vs_oracle)
+            rec["parity_rms"] = vs_oracle["rms_abs"]
             rec["speedup_vs_cpu_1thread"] = value / rec["cpu_baseline"]["value"]
             rec["speedup_vs_cpu_all_cores"] = value / rec["cpu_baseline"]["all_cores"]["value"]
         else:
             rec["cpu_baseline"] = None
-        print(json.dumps(rec))
-        sys.stdout.flush()
+        rec["parity"] = parity or None
     if use_reduce:
         ctx.CommDestroy()
     ctx.Dispose()
+    del host_pin
+    if rank == 0:
+        if with_variants:
+            # the graphs / formulations the headline's algebra does not apply to, measured the same way
+            vs, vw = args.variant_steps, 2
+            variants = {}
+            variants["per_voice_spectra"] = run_variant(
+                "per_voice_spectra", torch, G, frames, vs, vw, lambda c: build_graph(c, voices_total, 0, args.taps, frames, G), 2,
+                {"coarse_premix": 0},
+                "the headline graph with option coarse_premix = 0: every voice's input transformed, the spectra of the voices summed "
+                "before ONE spectral multiply (round 2's default path)",
+                truth=(lambda: circular_truth(xsum, shared_ir(G, args.taps))) if xsum is not None else None)
+            pv = min(voices_total, 1024)
+            variants["private_ir"] = run_variant(
+                "private_ir", torch, G, frames, vs, vw, lambda c: build_graph(c, pv, 0, args.taps, frames, G, private=True), 2, {},
+                f"{pv} voices, each through its OWN {args.taps}-tap stereo impulse response: every voice's spectral multiply-accumulate is "
+                "evaluated (SURVEY.md 8(d) 'unique-IR-per-voice variant'; row a4)",
+                truth=(lambda: truths["private_ir"]) if truths else None)
+            variants["config5_1gpu"] = run_variant(
+                "config5_1gpu", torch, G, frames, vs, vw, lambda c: build_config5(c, 512, 0, 32768, frames, G), 16, {},
+                "BASELINE.json configs[4] whole on ONE GPU: 512 sources x 16-channel 32,768-tap private impulse responses -> 16-channel bus "
+                "(its 8-GPU form shards 64 sources per GPU)",
+                truth=(lambda: truths["config5_1gpu"]) if truths else None)
+            rec["variants"] = variants
+        print(json.dumps(rec))
+        sys.stdout.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -36,6 +36,9 @@ internal static unsafe partial class GraphAudioHip
         public fixed double stage_bytes[16];
         public long profiled_chunks;
         public long coarse_carried_outputs;
+        public fixed double stage_flops[16];
+        public fixed byte stage_kernel[1024];    // [16][64] zero-terminated names
+        public long coarse_premixed_signals;
     }
 
     [LibraryImport(Lib, EntryPoint = "ga_strerror")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]

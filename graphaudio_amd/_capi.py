@@ -80,6 +80,9 @@ class Stats(C.Structure):
         ("stage_bytes", C.c_double * 16),
         ("profiled_chunks", C.c_int64),
         ("coarse_carried_outputs", C.c_int64),
+        ("stage_flops", C.c_double * 16),
+        ("stage_kernel", (C.c_char * 64) * 16),
+        ("coarse_premixed_signals", C.c_int64),
     ]
     STAGES = ("other", "mix", "rfft_fwd", "mac", "rfft_inv", "coarse_fwd", "coarse_mac", "coarse_inv", "coarse_hist", "coarse_section")
 
@@ -87,7 +90,10 @@ class Stats(C.Structure):
         d = {}
         for name, _ in self._fields_:
             v = getattr(self, name)
-            d[name] = list(v) if hasattr(v, "__len__") else v
+            if name == "stage_kernel":
+                d[name] = [bytes(row.value).decode("ascii", "replace") for row in v]
+            else:
+                d[name] = list(v) if hasattr(v, "__len__") else v
         return d
 
 

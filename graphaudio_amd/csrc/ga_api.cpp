@@ -107,7 +107,7 @@ int64_t Context::chunkLimit(int64_t) {
         budget += (double)(planes[0].bytes + planes[1].bytes + planes[2].bytes + planes[3].bytes);
         budget += (double)(planesB[0].bytes + planesB[1].bytes + planesB[2].bytes + planesB[3].bytes + planesBalt[0].bytes + planesBalt[1].bytes);
         budget += (double)slabAll.size() * (double)slabFrames * 4.0;
-        budget += (double)(coarseX.bytes + coarseY.bytes);
+        budget += (double)(coarseX.bytes + coarseY.bytes + coarseM.bytes);
         int64_t byMem = (int64_t)(budget / std::max(perBlock, 1.0));
         limit = std::max<int64_t>(1, std::min<int64_t>(limit, byMem));
       }
@@ -343,6 +343,7 @@ int ga_set_option(ga_context* ctx, const char* key, double value) {
     else if (k == "coarse_overlap") c.coarseOverlap = value != 0;
     else if (k == "coarse_carry") c.coarseCarry = value != 0;
     else if (k == "coarse_tail") c.coarseTail = value != 0;
+    else if (k == "coarse_premix") c.coarsePremix = value != 0;
     else if (k == "host_direct") c.hostDirect = value != 0;
     else if (k == "host_copy_stream") c.hostCopyStream = value != 0;
     else if (k == "coarse_min_blocks") c.coarseMinBlocks = std::max<int64_t>(1, (int64_t)value);

@@ -27,6 +27,7 @@ struct Plan {
     std::function<void(uint8_t*)> fn;
     int kind;
     double bytes;   // HBM bytes the launch has to move (inputs once + outputs once); 0 = not accounted
+    double flops;   // floating-point operations it executes; 0 = not accounted
   };
   std::vector<L> launches;
   size_t put(const void* p, size_t bytes) {
@@ -39,7 +40,9 @@ struct Plan {
   size_t putv(const std::vector<T>& v) {
     return put(v.data(), v.size() * sizeof(T));
   }
-  void add(int kind, std::function<void(uint8_t*)> fn, double bytes = 0.0) { launches.push_back(L{std::move(fn), kind, bytes}); }
+  void add(int kind, std::function<void(uint8_t*)> fn, double bytes = 0.0, double flops = 0.0) {
+    launches.push_back(L{std::move(fn), kind, bytes, flops});
+  }
 };
 
 // ======================================================================================================
@@ -1447,7 +1450,20 @@ struct CoarseStage {
     int maxP = 0, nIn = 0, nOut = 0;
     const void* ir0 = nullptr;
     bool oneIr = true, tail = false, carried = false, fresh = true, noHist = false;
+    // time-domain pre-mix (option "coarse_premix"): every member convolves with the same spectra and has the same channel
+    // layout, so the group's inputs are added up in front of ONE set of transforms
+    bool uniform = true, premix = false;
+    int members = 0, nxr = 0, bInCh0 = 0, bSlots0 = 0;
+    bool ts0 = false;
+    int64_t hl0 = 0;
+    std::vector<PremixTerm> inTerms[32], histTerms[32];   // per input channel of the group
   };
+  std::map<int, std::vector<const float*>> chInOf;   // node -> chunk-long views of its input channels
+  std::vector<PremixJob> pmJobs;
+  std::vector<PremixTerm> pmTerms;
+  size_t pmUsed = 0;       // bytes of the pre-mix arena handed out
+  int64_t pmMaxN = 0;
+  double pmBytes = 0;
   std::vector<CoarseXRow> xrows;
   std::vector<CoarseHistJob> hjobs;
   std::vector<Piece> pieces;
@@ -1465,7 +1481,8 @@ struct CoarseStage {
   std::vector<CoarseJob> jobs[6][8];
   int maxT[6] = {0, 0, 0, 0, 0, 0}, maxP[6] = {0, 0, 0, 0, 0, 0};
   int pbOf[6] = {4, 4, 4, 4, 4, 4};   // largest of 4, 2, 1 dividing every job's partition count (the sweep's register block)
-  double macBytes[6][8] = {};
+  double macBytes[6][8] = {}, macFlops[6][8] = {};
+  double pmFlops = 0, invFlops = 0;
   std::map<std::pair<int, int>, std::vector<int>> outRows;   // (leader, channel) -> Y rows to sum
   int yNext = 0;
   std::vector<CoarseOut> outs;
@@ -1475,12 +1492,45 @@ struct CoarseStage {
 
   CoarseStage(Context& c_, Exec& ex_, const std::vector<int>& d, int64_t n_)
       : c(c_), ex(ex_), dNodes(d), n(n_), frames(n_ * kBlock), nT((int)((n_ * kBlock + kCoarseBlock - 1) / kCoarseBlock)), tails(c_.coarseTail) {}
-  void classifyGroups();   // which groups carry a tail, which can use the one the previous chunk left
-  void buildRows();        // signals to transform, history hand-over, pieces (signal x columns)
+  void resolveInputs();    // chunk-long input views of every node (materialised where the segments disagree)
+  void classifyGroups();   // which groups are pre-mixed, carry a tail, can use the one the previous chunk left
+  void buildRows();        // signals to transform (pre-mixed groups: one per channel), history hand-over, pieces (signal x columns)
+  void addPieces(NodeS& nd, int leader, int nxr, const int* xFrame, const int* xIndex);
   void buildJobs();        // multiply-accumulate jobs and their terms
   void buildOutputs();     // inverse-transform outputs, tail buffers
   void enqueue();          // tables into the plan, launches
 };
+
+void CoarseStage::resolveInputs() {
+  for (int id : dNodes) {
+    NodeS& nd = *c.nodes[id];
+    const int64_t hl = nd.dHistLen;
+    auto& ci = ex.convIn[id];
+    std::vector<const float*>& chIn = chInOf[id];
+    chIn.assign(nd.bInCh, nullptr);
+    auto viewOf = [&](size_t si, int ch) { return (ci[si].empty() || ch >= (int)ci[si].size()) ? (const float*)nullptr : ci[si][ch]; };
+    for (int ch = 0; ch < nd.bInCh; ch++) {
+      // a channel that shows the same view as an earlier one in every segment IS that channel (a mono signal copied to all
+      // channels of an explicit input, AudioNodeInput.cs:201-213): one chunk-long view -- one materialised copy -- serves both
+      int same = -1;
+      for (int e = 0; e < ch && same < 0; e++) {
+        bool eq = true;
+        for (size_t si = 0; si < ex.segs.size() && eq; si++) eq = viewOf(si, e) == viewOf(si, ch);
+        if (eq) same = e;
+      }
+      chIn[ch] = same >= 0 ? chIn[same] : convChunkInput(c, ex, ci, ch);
+    }
+    bool allSame = true;
+    for (int ch = 1; ch < nd.bInCh; ch++) allSame = allSame && (chIn[ch] == chIn[0]);
+    if (nd.bShared && !allSame) {   // the channels start to differ: every channel inherits the (so far common) history
+      if (!nd.dHistZero)
+        for (int ch = 1; ch < nd.bInCh; ch++)
+          GA_HIP(hipMemcpyAsync(nd.dHist[nd.dHistCur] + (size_t)ch * hl, nd.dHist[nd.dHistCur], (size_t)hl * sizeof(float),
+                                hipMemcpyDeviceToDevice, c.stream));
+      nd.bShared = false;
+    }
+  }
+}
 
 void CoarseStage::classifyGroups() {
   // ---- carried tails (option "coarse_tail"): every output of the stage keeps, from chunk to chunk, what the input so far adds to
@@ -1503,13 +1553,26 @@ void CoarseStage::classifyGroups() {
       if (!g.ir0) g.ir0 = nd.ir.get();
       g.oneIr = g.oneIr && g.ir0 == nd.ir.get();
       g.nOut = std::max(g.nOut, nd.isTrueStereo ? 2 : nd.bSlots);
+      const int nxr = nd.bShared ? 1 : nd.bInCh;
+      if (g.members++ == 0) {
+        g.nxr = nxr;
+        g.bInCh0 = nd.bInCh;
+        g.bSlots0 = nd.bSlots;
+        g.ts0 = nd.isTrueStereo;
+        g.hl0 = nd.dHistLen;
+      } else {
+        g.uniform = g.uniform && g.nxr == nxr && g.bInCh0 == nd.bInCh && g.bSlots0 == nd.bSlots && g.ts0 == nd.isTrueStereo && g.hl0 == nd.dHistLen;
+      }
     }
     for (auto& kv : groups) {
       NodeS& ld = *c.nodes[kv.first];
       // a tail costs P' more inverse transforms per output channel and chunk and saves P' - 2 forward transforms per input row:
       // worth it for sums of many signals, not for a convolver on its own; and the P' more output blocks are nearly free only
       // in the reduction kernel (one impulse response for the whole group) -- the general kernel would multiply through them
-      kv.second.tail = tails && kv.second.oneIr && (int64_t)kv.second.nIn * (kv.second.maxP - 2) >= (int64_t)kv.second.nOut * kv.second.maxP;
+      kv.second.premix = c.coarsePremix && kv.second.members >= 2 && kv.second.oneIr && kv.second.uniform && kv.second.nxr <= 32;
+      // (a pre-mixed group always keeps its tail: reading every member's history again would cost members x (P' - 1) blocks)
+      kv.second.tail = tails && kv.second.oneIr &&
+                       (kv.second.premix || (int64_t)kv.second.nIn * (kv.second.maxP - 2) >= (int64_t)kv.second.nOut * kv.second.maxP);
       kv.second.carried = kv.second.tail && ld.dTail[0] && ld.dTailSeq + 1 == c.chunkSeq && ld.dTailSig == kv.second.sig &&
                           ld.dTailLen == (int64_t)(kv.second.maxP + 1) * kCoarseBlock;
       kv.second.noHist = kv.second.carried || (kv.second.tail && kv.second.fresh);
@@ -1517,29 +1580,75 @@ void CoarseStage::classifyGroups() {
   }
 }
 
+// columns of a node's input rows: discrete -> slot c reads input c, IR channel c, output c ; true stereo -> (L,h0,outL) (L,h1,outR)
+// (R,h2,outL) (R,h3,outR)  (ConvolverNode.cs:127-151).  Pieces of 4, 2, 1 columns per row.
+void CoarseStage::addPieces(NodeS& nd, int leader, int nxr, const int* xFrame, const int* xIndex) {
+  IrSpectra& ir = *nd.ir;
+  for (int xc = 0; xc < nxr; xc++) {
+    int cols[32][2], ncols = 0;
+    for (int slot = 0; slot < nd.bSlots; slot++) {
+      const int inc = nd.isTrueStereo ? (slot >> 1) : slot;
+      if (!(nd.bShared || inc == xc)) continue;
+      cols[ncols][0] = slot;                               // slot index == IR channel index in both modes
+      cols[ncols][1] = nd.isTrueStereo ? (slot & 1) : slot;
+      ncols++;
+    }
+    for (int c0 = 0; c0 < ncols;) {
+      const int left = ncols - c0;
+      const int w = left >= 4 ? 4 : (left >= 2 ? 2 : 1);
+      Piece pc{};
+      pc.frame0 = xFrame[xc];
+      pc.xrow = xIndex[xc];
+      pc.u0 = xrows[xIndex[xc]].u0;
+      pc.P = ir.coarseP;
+      pc.ir = &ir;
+      pc.leader = leader;
+      pc.ncol = w;
+      for (int j = 0; j < w; j++) {
+        pc.irCh[j] = cols[c0 + j][0];
+        pc.outCh[j] = cols[c0 + j][1];
+      }
+      pieces.push_back(pc);
+      c0 += w;
+    }
+  }
+}
+
 void CoarseStage::buildRows() {
-  std::vector<const float*> chIn;
   for (int id : dNodes) {
     NodeS& nd = *c.nodes[id];
     IrSpectra& ir = *nd.ir;
     const int P = ir.coarseP;
     if (P < 1 || P > kCoarseMaxP) fail(GA_ERR_INVALID_OPERATION, "internal: coarse partition count out of range");
     const int64_t hl = nd.dHistLen;
-    const GroupInfo& gi0 = groups[nd.dLeader >= 0 ? nd.dLeader : id];
+    GroupInfo& gi0 = groups[nd.dLeader >= 0 ? nd.dLeader : id];
     const bool carried = gi0.noHist;   // no windows in front of the chunk
-    auto& ci = ex.convIn[id];
-    chIn.assign(nd.bInCh, nullptr);
-    for (int ch = 0; ch < nd.bInCh; ch++) chIn[ch] = convChunkInput(c, ex, ci, ch);
-    bool allSame = true;
-    for (int ch = 1; ch < nd.bInCh; ch++) allSame = allSame && (chIn[ch] == chIn[0]);
-    if (nd.bShared && !allSame) {   // the channels start to differ: every channel inherits the (so far common) history
-      if (!nd.dHistZero)
-        for (int ch = 1; ch < nd.bInCh; ch++)
-          GA_HIP(hipMemcpyAsync(nd.dHist[nd.dHistCur] + (size_t)ch * hl, nd.dHist[nd.dHistCur], (size_t)hl * sizeof(float),
-                                hipMemcpyDeviceToDevice, c.stream));
-      nd.bShared = false;
-    }
+    const std::vector<const float*>& chIn = chInOf[id];
     const int nxr = nd.bShared ? 1 : nd.bInCh;
+    c.stats.mac_flops_total += 8.0 * ir.P * kBins * (double)nd.bSlots * (double)n;
+    c.stats.mac_bytes_total += ((double)ir.P * kBins * 8.0 + kBins * 8.0 + 512.0) * nd.bSlots * (double)n;
+    if (gi0.premix) {
+      // a member of a pre-mixed group: nothing to transform for it; its samples join the group's sum and its own history of the
+      // next chunk is written on the way (or by a copy job where that is not possible)
+      for (int ch = 0; ch < nxr; ch++) {
+        const float* oldHist = nd.dHistZero ? nullptr : nd.dHist[nd.dHistCur] + (size_t)ch * hl;
+        float* nextHist = nd.dHist[nd.dHistCur ^ 1] + (size_t)ch * hl;
+        PremixTerm t{chIn[ch], nullptr};
+        if (c.coarseCarry && chIn[ch] && frames >= hl && ((uintptr_t)nextHist & 15) == 0) {
+          t.carry = nextHist;
+          pmBytes += (double)hl * 4.0;
+        } else {
+          hjobs.push_back(CoarseHistJob{oldHist, chIn[ch], nextHist, hl, frames});
+          maxHist = std::max(maxHist, hl);
+          histBytes += 2.0 * (double)hl * 4.0;
+        }
+        gi0.inTerms[ch].push_back(t);
+        if (!carried) gi0.histTerms[ch].push_back(PremixTerm{oldHist, nullptr});
+      }
+      nd.dHistCur ^= 1;
+      nd.dHistZero = false;
+      continue;
+    }
     int xFrame[32], xIndex[32];
     for (int ch = 0; ch < nxr; ch++) {
       CoarseXRow r;
@@ -1576,42 +1685,58 @@ void CoarseStage::buildRows() {
     }
     nd.dHistCur ^= 1;
     nd.dHistZero = false;
-    // columns: discrete -> slot c reads input c, IR channel c, output c ; true stereo -> (L,h0,outL) (L,h1,outR) (R,h2,outL)
-    // (R,h3,outR)  (ConvolverNode.cs:127-151)
-    const int leader = nd.dLeader >= 0 ? nd.dLeader : id;
-    for (int xc = 0; xc < nxr; xc++) {
-      int cols[32][2], ncols = 0;
-      for (int slot = 0; slot < nd.bSlots; slot++) {
-        const int inc = nd.isTrueStereo ? (slot >> 1) : slot;
-        if (!(nd.bShared || inc == xc)) continue;
-        cols[ncols][0] = slot;                               // slot index == IR channel index in both modes
-        cols[ncols][1] = nd.isTrueStereo ? (slot & 1) : slot;
-        ncols++;
-      }
-      for (int c0 = 0; c0 < ncols;) {   // pieces of 4, 2, 1 columns
-        const int left = ncols - c0;
-        const int w = left >= 4 ? 4 : (left >= 2 ? 2 : 1);
-        Piece pc{};
-        pc.frame0 = xFrame[xc];
-        pc.xrow = xIndex[xc];
-        pc.u0 = xrows[xIndex[xc]].u0;
-        pc.P = P;
-        pc.ir = &ir;
-        pc.leader = leader;
-        pc.ncol = w;
-        for (int j = 0; j < w; j++) {
-          pc.irCh[j] = cols[c0 + j][0];
-          pc.outCh[j] = cols[c0 + j][1];
+    addPieces(nd, nd.dLeader >= 0 ? nd.dLeader : id, nxr, xFrame, xIndex);
+  }
+  // ---- pre-mixed groups: one mixed signal [history | chunk] per input channel, transformed like a single convolver's input ----
+  for (auto& kv : groups) {
+    GroupInfo& g = kv.second;
+    if (!g.premix) continue;
+    NodeS& ld = *c.nodes[kv.first];
+    const int64_t hl = g.hl0;
+    int xFrame[32], xIndex[32];
+    for (int ch = 0; ch < g.nxr; ch++) {
+      const size_t bytes = (size_t)(hl + frames) * sizeof(float);
+      if (pmUsed + bytes > c.coarseM.bytes) fail(GA_ERR_INVALID_OPERATION, "internal: the pre-mix arena is too small for the plan");
+      float* mixed = (float*)((char*)c.coarseM.p + pmUsed);
+      pmUsed += (bytes + 255) & ~(size_t)255;
+      auto job = [&](float* out, const std::vector<PremixTerm>& tv, int64_t len, int64_t carryFrom) {
+        PremixJob j{out, (int)pmTerms.size(), 0, len, carryFrom, 1, 0};
+        for (const PremixTerm& t : tv) {
+          if (!t.in) continue;   // (silent: adds nothing, and has no carry)
+          pmTerms.push_back(t);
+          j.nterms++;
+          if ((uintptr_t)t.in & 15) j.flags &= ~1;
+          if (t.carry) j.flags |= 2;
+          pmBytes += (double)len * 4.0;
+          pmFlops += (double)len * 4.0;   // (compensated summation: four operations per sample)
         }
-        pieces.push_back(pc);
-        c0 += w;
-      }
+        pmJobs.push_back(j);
+        pmMaxN = std::max(pmMaxN, len);
+        pmBytes += (double)len * 4.0;
+      };
+      if (!g.noHist) job(mixed, g.histTerms[ch], hl, hl);
+      job(mixed + hl, g.inTerms[ch], frames, std::max<int64_t>(0, frames - hl));
+      CoarseXRow r{};
+      r.hist = g.noHist ? nullptr : mixed;
+      r.in = mixed + hl;
+      r.nvalid = frames;
+      r.frame0 = frameNext;
+      r.u0 = g.noHist ? 0 : -(g.maxP - 1);
+      r.n_frames = (g.tail ? nT + 1 : nT) - r.u0;
+      r.hist_len = (int)hl;
+      r.flags = 0;
+      r.scale = 1.0f;
+      r.carry = nullptr;
+      r.carry_from = 0;
+      xFrame[ch] = frameNext;
+      xIndex[ch] = (int)xrows.size();
+      frameNext += r.n_frames;
+      xrows.push_back(r);
     }
-    c.stats.mac_flops_total += 8.0 * ir.P * kBins * (double)nd.bSlots * (double)n;
-    c.stats.mac_bytes_total += ((double)ir.P * kBins * 8.0 + kBins * 8.0 + 512.0) * nd.bSlots * (double)n;
+    addPieces(ld, kv.first, g.nxr, xFrame, xIndex);
+    c.stats.coarse_premixed_signals += (int64_t)g.members * g.nxr;
   }
   ex.flushLevel();   // (materialised inputs)
-
 }
 
 void CoarseStage::buildJobs() {
@@ -1681,6 +1806,10 @@ void CoarseStage::buildJobs() {
         const int fread = std::max(0, std::min(jb_.u_hi, t0 + jb_.n_t - 1) - std::max(jb_.u_lo, t0 - (k.P - 1)) + 1);   // frames that exist
         macBytes[cj][grp] += (double)jb_.n_terms * fread * kCoarseBins * 8.0 +
                              (double)(shared ? 1 : jb_.n_terms) * k.P * cw * kCoarseBins * 8.0 + (double)cw * jb_.n_t * kCoarseBins * 8.0;
+        // complex multiply-adds (8 flops): every term's products in the general kernel; in the reduction the terms' frames are
+        // added up first (2 flops per complex value) and the sum is multiplied once
+        macFlops[cj][grp] += shared ? ((double)jb_.n_terms * fread * 2.0 + (double)k.P * jb_.n_t * cw * 8.0) * kCoarseBins
+                                    : (double)jb_.n_terms * k.P * jb_.n_t * cw * 8.0 * kCoarseBins;
       }
     }
   }
@@ -1735,6 +1864,7 @@ void CoarseStage::buildOutputs() {
     ylist.insert(ylist.end(), kv.second.begin(), kv.second.end());
     outs.push_back(o);
     invBytes += (double)o.ny * o.n_y * kCoarseBins * 8.0 + (double)frames * 4.0;
+    invFlops += (double)o.n_y * (kCoarseTransformFlops + (double)o.ny * 2.0 * kCoarseBins);
   }
   if (tails)
     for (auto& kv : groups) {   // this chunk's tails are the next chunk's, if the group is still the same then
@@ -1754,13 +1884,17 @@ void CoarseStage::enqueue() {
   const int G = this->G, yFrames = this->yFrames, invBlocks = this->invBlocks, nxAll = this->nxAll;
   const double invBytes = this->invBytes, histBytes = this->histBytes;
   const size_t xo = ex.plan.putv(xrows), ho = ex.plan.putv(hjobs), to = ex.plan.putv(terms), oo = ex.plan.putv(outs), yo = ex.plan.putv(ylist);
-  struct MacLaunch { size_t off; int nj, cw, mt, mp, pb, grp; bool ap; double bytes; };
+  const size_t pjo = ex.plan.putv(pmJobs), pto = ex.plan.putv(pmTerms);
+  const int npm = (int)pmJobs.size();
+  const int64_t pmMaxN = this->pmMaxN;
+  const double pmBytes = this->pmBytes, pmFlops = this->pmFlops, invFlops = this->invFlops;
+  struct MacLaunch { size_t off; int nj, cw, mt, mp, pb, grp; bool ap; double bytes, flops; };
   std::vector<MacLaunch> macs;
   for (int g = 0; g < G; g++)
     for (int i = 0; i < 6; i++) {
       if (jobs[i][g].empty()) continue;
       macs.push_back(MacLaunch{ex.plan.putv(jobs[i][g]), (int)jobs[i][g].size(), 1 << (i >> 1), maxT[i], maxP[i], pbOf[i], g, (i & 1) == 0,
-                               macBytes[i][g]});
+                               macBytes[i][g], macFlops[i][g]});
       c.stats.mac_launches += 1;
     }
   hipStream_t st = c.stream;
@@ -1772,13 +1906,14 @@ void CoarseStage::enqueue() {
   const int nh = (int)hjobs.size(), no = (int)outs.size();
   // per group: rows, longest row, bytes, windows per workgroup (long runs fetch every input sample once; keep >= ~4
   // workgroups per CU's worth of parallelism)
-  struct FwdLaunch { int x0, nx, maxFrames, run; double bytes; };
+  struct FwdLaunch { int x0, nx, maxFrames, run; double bytes, flops; };
   std::vector<FwdLaunch> fwds;
   for (int g = 0; g < G; g++) {
-    FwdLaunch f{this->gBegin[g], this->gBegin[g + 1] - this->gBegin[g], 0, 1, 0.0};
+    FwdLaunch f{this->gBegin[g], this->gBegin[g + 1] - this->gBegin[g], 0, 1, 0.0, 0.0};
     for (int x = f.x0; x < f.x0 + f.nx; x++) {
       f.maxFrames = std::max(f.maxFrames, xrows[x].n_frames);
       f.bytes += (double)(xrows[x].n_frames + 1) * kCoarseBlock * 4.0 + (double)xrows[x].n_frames * kCoarseBins * 8.0;
+      f.flops += (double)xrows[x].n_frames * kCoarseTransformFlops;
       if (auto it = carryBytes.find(x); it != carryBytes.end()) f.bytes += it->second;
     }
     while (f.run < 16 && (int64_t)nxAll * ((f.maxFrames + 2 * f.run - 1) / (2 * f.run)) >= 1024) f.run *= 2;
@@ -1793,14 +1928,14 @@ void CoarseStage::enqueue() {
   Context* cp = &c;
   ex.plan.add(GA_STAGE_COARSE_SECTION, [=](uint8_t* base) {
     // one piece of the section: a launch with its own profile events (the two stages overlap on two streams)
-    auto timed = [&](hipStream_t sx, int kind, double bytes, const std::function<void()>& launch) {
+    auto timed = [&](hipStream_t sx, int kind, double bytes, double flops, const std::function<const char*()>& launch) {
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (cp->profileNow) {
         GA_HIP(hipEventCreate(&e0));
         GA_HIP(hipEventCreate(&e1));
         GA_HIP(hipEventRecord(e0, sx));
       }
-      launch();
+      cp->noteKernel(kind, launch());
       if (cp->profileNow) {
         GA_HIP(hipEventRecord(e1, sx));
         cp->extraProf.push_back(Context::ExtraProf{e0, e1, kind, bytes});
@@ -1808,20 +1943,23 @@ void CoarseStage::enqueue() {
       cp->stats.kernel_launches++;
       cp->stats.stage_launches[kind]++;
       cp->stats.stage_bytes[kind] += bytes;
+      cp->stats.stage_flops[kind] += flops;
     };
     hipStream_t s2 = G > 1 ? cp->stream2 : st;
+    if (npm > 0)
+      timed(st, LK_CPREMIX, pmBytes, pmFlops, [&] { return launch_coarse_premix(st, (const PremixJob*)(base + pjo), npm, (const PremixTerm*)(base + pto), pmMaxN); });
     for (int g = 0; g < G; g++) {
       const FwdLaunch& f = fwds[g];
       if (f.nx > 0)
-        timed(st, LK_CFWD, f.bytes, [&] { launch_coarse_fwd(st, (const CoarseXRow*)(base + xo) + f.x0, f.nx, f.maxFrames, f.run, X, twFwd, twab); });
+        timed(st, LK_CFWD, f.bytes, f.flops, [&] { return launch_coarse_fwd(st, (const CoarseXRow*)(base + xo) + f.x0, f.nx, f.maxFrames, f.run, X, twFwd, twab); });
       if (G > 1) {
         GA_HIP(hipEventRecord(cp->dGroupEv[g], st));
         GA_HIP(hipStreamWaitEvent(s2, cp->dGroupEv[g], 0));
       }
       for (const MacLaunch& m : macs)
         if (m.grp == g)
-          timed(s2, LK_CMAC, m.bytes, [&] {
-            launch_coarse_mac(s2, (const CoarseJob*)(base + m.off), m.nj, (const CoarseTerm*)(base + to), X, Y, yFrames, m.cw, m.mt, m.mp, m.ap, m.pb);
+          timed(s2, LK_CMAC, m.bytes, m.flops, [&] {
+            return launch_coarse_mac(s2, (const CoarseJob*)(base + m.off), m.nj, (const CoarseTerm*)(base + to), X, Y, yFrames, m.cw, m.mt, m.mp, m.ap, m.pb);
           });
     }
     if (G > 1) {   // join: the inverse transforms (and the next chunk's forward transforms, which reuse X) wait for every job
@@ -1830,8 +1968,8 @@ void CoarseStage::enqueue() {
     }
   });
   ex.plan.add(LK_CINV, [=](uint8_t* base) {
-    launch_coarse_inv(st, (const CoarseOut*)(base + oo), no, invBlocks, (const int*)(base + yo), Y, yFrames, tw16, twab);
-  }, invBytes);
+    cp->noteKernel(LK_CINV, launch_coarse_inv(st, (const CoarseOut*)(base + oo), no, invBlocks, (const int*)(base + yo), Y, yFrames, tw16, twab));
+  }, invBytes, invFlops);
   const int64_t mh = maxHist;
   if (nh > 0) ex.plan.add(LK_CHIST, [=](uint8_t* base) { launch_coarse_hist(st, (const CoarseHistJob*)(base + ho), nh, mh); }, histBytes);
 }
@@ -1839,6 +1977,7 @@ void CoarseStage::enqueue() {
 
 static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes, int64_t n) {
   CoarseStage s(c, ex, dNodes, n);
+  s.resolveInputs();
   s.classifyGroups();
   s.buildRows();
   s.buildJobs();
@@ -2331,6 +2470,22 @@ void Context::chunkConvScratch(ChunkRun& r) {
       if (xf) {
         ensure(coarseX, xf * kCoarseBins * sizeof(float2));
         ensure(coarseY, yf * kCoarseBins * sizeof(float2));
+      }
+      if (coarsePremix) {   // pre-mixed groups: [history | chunk] of the mixed signal per input channel of the group
+        std::map<int, int> members;
+        for (int id : topo) {
+          NodeS& nd = *nodes[id];
+          if (nd.type == GA_NODE_CONVOLVER && nd.ir && nd.convPath == 4) members[nd.dLeader >= 0 ? nd.dLeader : id]++;
+        }
+        std::map<int, size_t> pmDepth;
+        for (auto& kv : members) {
+          if (kv.second < 2) continue;
+          const NodeS& ld = *nodes[kv.first];
+          pmDepth[ld.depth] += (size_t)ld.bInCh * ((((size_t)(ld.dHistLen + n * kBlock) * sizeof(float)) + 255) & ~(size_t)255);
+        }
+        size_t pm = 0;
+        for (auto& kv : pmDepth) pm = std::max(pm, kv.second);
+        if (pm) ensure(coarseM, pm);
       }
     }
     bRowX = bRowY = 0;
@@ -3317,6 +3472,7 @@ void Context::chunkExecute(ChunkRun& r) {
     if (l.kind >= 0 && l.kind < 16) {
       stats.stage_launches[l.kind]++;
       stats.stage_bytes[l.kind] += l.bytes;
+      stats.stage_flops[l.kind] += l.flops;
     }
   }
   for (auto& x : extraProf) {   // pieces timed inside a launch (formulation D's overlapped section)

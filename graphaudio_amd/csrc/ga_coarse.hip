@@ -31,6 +31,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <string>
 #include <type_traits>
 #include <cstdio>
 #include <cstdlib>
@@ -255,9 +256,9 @@ __global__ __launch_bounds__(256, 3) void coarse_fwd_kernel(const CoarseXRow* __
   }
 }
 
-void launch_coarse_fwd(hipStream_t s, const CoarseXRow* rows_dev, int nrows, int max_frames, int run, float2* X, const float2* tw16,
-                       const float2* twab) {
-  if (nrows <= 0 || max_frames <= 0) return;
+const char* launch_coarse_fwd(hipStream_t s, const CoarseXRow* rows_dev, int nrows, int max_frames, int run, float2* X, const float2* tw16,
+                              const float2* twab) {
+  if (nrows <= 0 || max_frames <= 0) return "";
   using PL = R16Plan<CM>;
   const size_t lds = (size_t)(PL::T2 + kFwdTw3 + CPAD + kFwdPark * 256) * sizeof(float2);
   static const int exp = (getenv("GA_COARSE_EXP") ? atoi(getenv("GA_COARSE_EXP")) : 0) & 15;   // timing experiments only
@@ -269,6 +270,7 @@ void launch_coarse_fwd(hipStream_t s, const CoarseXRow* rows_dev, int nrows, int
     dim3 grid((max_frames + run - 1) / run, std::min(32768, nrows - r0));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, rows_dev + r0, run, X, tw16, twab, exp);
   }
+  return "coarse_fwd_kernel";
 }
 
 // =====================================================================================================================
@@ -565,7 +567,7 @@ __global__ __launch_bounds__(kSumThreads, 4) void coarse_sum_kernel(const Coarse
 }
 
 template <int CW>
-static void launch_coarse_sum(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
+static const char* launch_coarse_sum(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
                               int y_frames, int max_t, int maxP) {
   static const int exp = getenv("GA_COARSE_EXP") ? atoi(getenv("GA_COARSE_EXP")) : 0;   // timing experiments only
   constexpr int TW = kCoarseSumJobBlocks(CW) / kSumWaves;
@@ -586,10 +588,11 @@ static void launch_coarse_sum(hipStream_t s, const CoarseJob* jobs_dev, int njob
   for (int j0 = 0; j0 < njobs; j0 += 32768)
     hipLaunchKernelGGL((coarse_sum_kernel<CW>), dim3(kCoarseBins / 64, std::min(32768, njobs - j0)), dim3(kSumThreads), lds, s, jobs_dev + j0, terms_dev, X,
                        Y, y_frames, NFA, exp >> 4);
+  return CW == 1 ? "coarse_sum_kernel<1>" : (CW == 2 ? "coarse_sum_kernel<2>" : "coarse_sum_kernel<4>");
 }
 
 template <int CW, int TW, int PB>
-static void launch_coarse_mac_t(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
+static const char* launch_coarse_mac_t(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
                                 int y_frames, int max_t, int maxP, bool any_private) {
   static const int exp = getenv("GA_COARSE_EXP") ? atoi(getenv("GA_COARSE_EXP")) : 0;   // timing experiments only
   // frames the sweep of the last active wave touches: t0w + TW + P - 1 with t0w = (active waves - 1) * ceil(n_t / waves)
@@ -611,29 +614,31 @@ static void launch_coarse_mac_t(hipStream_t s, const CoarseJob* jobs_dev, int nj
   for (int j0 = 0; j0 < njobs; j0 += 32768)
     hipLaunchKernelGGL((coarse_mac_kernel<CW, TW, PB>), dim3(kCoarseBins / 64, std::min(32768, njobs - j0)), dim3(kMacThreads), lds, s,
                        jobs_dev + j0, terms_dev, X, Y, y_frames, NFA, exp >> 4);
+  static const std::string name = "coarse_mac_kernel<" + std::to_string(CW) + "," + std::to_string(TW) + "," + std::to_string(PB) + ">";
+  return name.c_str();
 }
 // all jobs of one launch have the same column count `cw` (1, 2 or 4), at most `max_t` coarse blocks (<= kCoarseJobBlocks(cw))
 // and partition counts that are multiples of `pb` (1, 2 or 4: the register block of the sweep)
 template <int CW>
-static void launch_coarse_mac_cw(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
+static const char* launch_coarse_mac_cw(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
                                  int y_frames, int max_t, int maxP, bool any_private, int pb) {
   constexpr int TWL = CW <= 2 ? GA_MAC_TW : GA_MAC_TW / 2;   // accumulators: TW x CW complex values per lane
   if (!any_private) return launch_coarse_sum<CW>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP);   // (the planner cut these jobs for it)
-  if (max_t <= 2 * kMacWaves) launch_coarse_mac_t<CW, 2, 1>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
-  else if (pb >= 4 && (CW == 1 || (CW == 2 && GA_MAC_PB2 == 4))) launch_coarse_mac_t<CW, TWL, 4>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
-  else if (pb >= 2) launch_coarse_mac_t<CW, TWL, 2>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
-  else launch_coarse_mac_t<CW, TWL, 1>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
+  if (max_t <= 2 * kMacWaves) return launch_coarse_mac_t<CW, 2, 1>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
+  if (pb >= 4 && (CW == 1 || (CW == 2 && GA_MAC_PB2 == 4))) return launch_coarse_mac_t<CW, TWL, 4>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
+  if (pb >= 2) return launch_coarse_mac_t<CW, TWL, 2>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
+  return launch_coarse_mac_t<CW, TWL, 1>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
 }
-void launch_coarse_mac(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
+const char* launch_coarse_mac(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
                        int y_frames, int cw, int max_t, int maxP, bool any_private, int pb) {
-  if (njobs <= 0) return;
+  if (njobs <= 0) return "";
   if (max_t > (any_private ? kCoarseJobBlocks(cw) : kCoarseSumJobBlocks(cw))) launch_fail("coarse multiply-accumulate: too many coarse blocks in a job");
   if (const char* e = getenv("GA_COARSE_PB")) pb = std::min(pb, std::max(1, atoi(e)));   // measurements only
   if (pb != 1 && pb != 2 && pb != 4 && pb != 8 && pb != 16) launch_fail("coarse multiply-accumulate: unsupported partition block");
-  if (cw == 1) launch_coarse_mac_cw<1>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private, pb);
-  else if (cw == 2) launch_coarse_mac_cw<2>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private, pb);
-  else if (cw == 4) launch_coarse_mac_cw<4>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private, pb);
-  else launch_fail("coarse multiply-accumulate: unsupported column count");
+  if (cw == 1) return launch_coarse_mac_cw<1>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private, pb);
+  if (cw == 2) return launch_coarse_mac_cw<2>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private, pb);
+  if (cw == 4) return launch_coarse_mac_cw<4>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private, pb);
+  launch_fail("coarse multiply-accumulate: unsupported column count");
 }
 
 // =====================================================================================================================
@@ -756,10 +761,10 @@ __global__ __launch_bounds__(512) void coarse_inv_kernel(const CoarseOut* __rest
 }
 
 // n_blocks: coarse blocks of the longest output, carried tail included (outputs return early behind their own end)
-void launch_coarse_inv(hipStream_t s, const CoarseOut* outs_dev, int nouts, int n_blocks, const int* ylist_dev, const float2* Y, int y_frames,
-                       const float2* tw16, const float2* twab) {
+const char* launch_coarse_inv(hipStream_t s, const CoarseOut* outs_dev, int nouts, int n_blocks, const int* ylist_dev, const float2* Y, int y_frames,
+                              const float2* tw16, const float2* twab) {
   const int n_t = n_blocks;
-  if (nouts <= 0 || n_t <= 0) return;
+  if (nouts <= 0 || n_t <= 0) return "";
   using PL = R16Plan<CM>;
   const size_t lds = (size_t)(PL::T2 + PL::T3 + 2 * CPAD) * sizeof(float2);
   if (hipFuncSetAttribute((const void*)coarse_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -767,6 +772,7 @@ void launch_coarse_inv(hipStream_t s, const CoarseOut* outs_dev, int nouts, int 
   for (int r0 = 0; r0 < nouts; r0 += 32768)
     hipLaunchKernelGGL(coarse_inv_kernel, dim3(n_t, std::min(32768, nouts - r0)), dim3(512), lds, s, outs_dev + r0, ylist_dev, Y, y_frames,
                        tw16, twab);
+  return "coarse_inv_kernel";
 }
 
 // =====================================================================================================================
@@ -797,6 +803,118 @@ __global__ __launch_bounds__(256) void coarse_hist_kernel(const CoarseHistJob* _
     stg1(J.new_hist + i, v);
   }
 }
+// =====================================================================================================================
+//  pre-mix: out[f] = sum over the terms of in_t[f].  Workgroup = 256 consecutive frames (one 16-byte word = 4 frames per lane) x
+//  all terms of the job; its four waves take a quarter of the terms each (four times the waves to keep words in flight, also
+//  for short chunks), stream them from global memory kPremixAhead words at a time per lane, and wave 0 adds the four partial
+//  sums.  Term descriptors come 64 at a time, one per lane, and are handed out with v_readlane: the addresses are scalar base +
+//  32-bit lane offset.  All sums are Kahan-compensated -- four VALU operations per word in a kernel that waits for HBM -- so
+//  the result is the correctly rounded sum to within an ulp whatever the number of terms.  While a wave holds a member's
+//  samples it writes the member's input history of the next chunk (`carry`).
+//  Job flags (planner): bit 0 = every `in` is 16-byte aligned, bit 1 = some term has a carry.
+// =====================================================================================================================
+constexpr int kPremixAhead = 8, kPremixWaves = 4;
+struct Kahan4 {
+  v4f s, c;
+  __device__ __forceinline__ void add(v4f x) {
+    const v4f y = x - c, t = s + y;
+    c = (t - s) - y;
+    s = t;
+  }
+};
+template <bool ALIGNED, bool CARRY>
+__device__ __forceinline__ void premix_stream(const PremixJob& J, const PremixTerm* __restrict terms, int t0, int t1, int lane, uint32_t off,
+                                              bool live, bool keep, uint32_t coff, Kahan4& acc) {
+  typedef const GA_GLOBAL char* gcp;
+  typedef GA_GLOBAL char* gp;
+  auto fetch = [&](gcp in) -> v4f {       // `in` is wave-uniform; lanes behind the end re-read word 0 and drop the result
+    if (ALIGNED) return *(const GA_GLOBAL v4f*)(in + off);
+    const GA_GLOBAL float* p = (const GA_GLOBAL float*)(in + off);
+    return v4f{p[0], p[1], p[2], p[3]};
+  };
+  for (int base = t0; base < t1; base += 64) {
+    const int nb = min(64, t1 - base);
+    uint64_t pin = 0, pcar = 0;
+    if (lane < nb) {
+      const GA_GLOBAL PremixTerm* T = (const GA_GLOBAL PremixTerm*)terms + (J.term0 + base + lane);
+      pin = (uint64_t)(uintptr_t)T->in;
+      if (CARRY) pcar = (uint64_t)(uintptr_t)T->carry;
+    }
+    const int pin_lo = (int)(uint32_t)pin, pin_hi = (int)(uint32_t)(pin >> 32), pc_lo = (int)(uint32_t)pcar, pc_hi = (int)(uint32_t)(pcar >> 32);
+    auto in_of = [&](int j) {
+      return (gcp)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(pin_hi, j) << 32) | (uint32_t)__builtin_amdgcn_readlane(pin_lo, j));
+    };
+    auto carry_of = [&](int j) {
+      return (gp)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(pc_hi, j) << 32) | (uint32_t)__builtin_amdgcn_readlane(pc_lo, j));
+    };
+    int j = 0;
+    for (; j + kPremixAhead <= nb; j += kPremixAhead) {
+      v4f x[kPremixAhead];
+#pragma unroll
+      for (int u = 0; u < kPremixAhead; u++) x[u] = fetch(in_of(j + u));
+#pragma unroll
+      for (int u = 0; u < kPremixAhead; u++) {
+        if (CARRY) {
+          gp car = carry_of(j + u);
+          if (car && keep) *(GA_GLOBAL v4f*)(car + coff) = x[u];
+        }
+        acc.add(x[u]);
+      }
+    }
+    for (; j < nb; j++) {
+      const v4f x = fetch(in_of(j));
+      if (CARRY) {
+        gp car = carry_of(j);
+        if (car && keep) *(GA_GLOBAL v4f*)(car + coff) = x;
+      }
+      acc.add(x);
+    }
+  }
+}
+__global__ __launch_bounds__(64 * kPremixWaves) void coarse_premix_kernel(const PremixJob* __restrict jobs, const PremixTerm* __restrict terms) {
+  __shared__ v4f part[kPremixWaves - 1][2][64];
+  const PremixJob J = jobs[blockIdx.y];
+  if ((int64_t)blockIdx.x * 256 >= J.n) return;   // (uniform)
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t f = ((int64_t)blockIdx.x * 64 + lane) * 4;
+  const bool live = f < J.n;
+  const bool keep = live && f >= J.carry_from;
+  const uint32_t off = live ? (uint32_t)(f * 4) : 0u, coff = (uint32_t)((f - J.carry_from) * 4);   // (chunks and histories are far below 4 GB)
+  // this wave's share of the terms: a multiple of kPremixAhead each
+  const int per = ((J.nterms + kPremixWaves - 1) / kPremixWaves + kPremixAhead - 1) / kPremixAhead * kPremixAhead;
+  const int t0 = min(J.nterms, wv * per), t1 = min(J.nterms, t0 + per);
+  Kahan4 acc{v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};
+  const bool carry_here = (J.flags & 2) && (int64_t)blockIdx.x * 256 + 256 > J.carry_from;   // (uniform)
+  if (J.flags & 1) {
+    if (carry_here) premix_stream<true, true>(J, terms, t0, t1, lane, off, live, keep, coff, acc);
+    else premix_stream<true, false>(J, terms, t0, t1, lane, off, live, keep, coff, acc);
+  } else {
+    if (carry_here) premix_stream<false, true>(J, terms, t0, t1, lane, off, live, keep, coff, acc);
+    else premix_stream<false, false>(J, terms, t0, t1, lane, off, live, keep, coff, acc);
+  }
+  if (wv > 0) {
+    part[wv - 1][0][lane] = acc.s;
+    part[wv - 1][1][lane] = acc.c;
+  }
+  __syncthreads();
+  if (wv == 0) {
+#pragma unroll
+    for (int w = 0; w < kPremixWaves - 1; w++) {   // (a partial sum is s - c: add both parts)
+      acc.add(part[w][0][lane]);
+      acc.add(-part[w][1][lane]);
+    }
+    if (live) stg4(J.out + f, acc.s);
+  }
+}
+const char* launch_coarse_premix(hipStream_t s, const PremixJob* jobs_dev, int njobs, const PremixTerm* terms_dev, int64_t max_n) {
+  if (njobs <= 0 || max_n <= 0) return "";
+  const int64_t gx = (max_n + 255) / 256;
+  if (gx > 0x7fffffff || max_n >= ((int64_t)1 << 29)) launch_fail("coarse pre-mix: chunk too long");
+  for (int j0 = 0; j0 < njobs; j0 += 32768)
+    hipLaunchKernelGGL(coarse_premix_kernel, dim3((unsigned)gx, std::min(32768, njobs - j0)), dim3(64 * kPremixWaves), 0, s, jobs_dev + j0, terms_dev);
+  return "coarse_premix_kernel";
+}
+
 void launch_coarse_hist(hipStream_t s, const CoarseHistJob* jobs_dev, int njobs, int64_t max_len) {
   if (njobs <= 0 || max_len <= 0) return;
   const int gx = (int)std::min<int64_t>((max_len / 4 + 255) / 256, 64);

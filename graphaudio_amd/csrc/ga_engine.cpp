@@ -117,6 +117,7 @@ Context::~Context() {
   for (auto& x : extraProf) { (void)hipEventDestroy(x.e0); (void)hipEventDestroy(x.e1); }
   if (coarseX.p) (void)hipFree(coarseX.p);
   if (coarseY.p) (void)hipFree(coarseY.p);
+  if (coarseM.p) (void)hipFree(coarseM.p);
   if (ilvDev) (void)hipFree(ilvDev);
   if (tables.p) (void)hipFree(tables.p);
   if (tablesHost) (void)hipHostFree(tablesHost);

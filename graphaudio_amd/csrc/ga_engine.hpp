@@ -10,6 +10,7 @@
 //   2. DATA PLANE (device).  For every segment the nodes are executed level by level as batched kernels over all
 //      blocks of the segment at once; convolvers run once per chunk over all blocks (time-batched spectral MAC).
 #pragma once
+#include <cstring>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -329,7 +330,7 @@ inline int tapFftSize(int P) {
 // which statistics bucket a recorded launch belongs to: the GA_STAGE_* indices of ga_stats
 enum LaunchKind { LK_OTHER = GA_STAGE_OTHER, LK_MIX = GA_STAGE_MIX, LK_FFT = GA_STAGE_RFFT_FWD, LK_MAC = GA_STAGE_MAC,
                   LK_IFFT = GA_STAGE_RFFT_INV, LK_CFWD = GA_STAGE_COARSE_FWD, LK_CMAC = GA_STAGE_COARSE_MAC,
-                  LK_CINV = GA_STAGE_COARSE_INV, LK_CHIST = GA_STAGE_COARSE_HIST };
+                  LK_CINV = GA_STAGE_COARSE_INV, LK_CHIST = GA_STAGE_COARSE_HIST, LK_CPREMIX = GA_STAGE_COARSE_PREMIX };
 
 struct DevArena {  // grow-only device scratch
   void* p = nullptr;
@@ -479,10 +480,17 @@ struct Context {
   bool coarseOverlap = false;
   bool coarseTail = true;    // option "coarse_tail": outputs carry their tails from chunk to chunk (0: input histories only)
   bool coarseCarry = true;   // option "coarse_carry": the forward kernel writes the next chunk's history (0: always the copy kernel)
+  bool coarsePremix = true;  // option "coarse_premix": fused groups on ONE impulse response are summed in the time domain, in front of
+                             // one set of transforms (0: every member is transformed, the spectra are summed -- coarse_sum_kernel)
   void ensureOverlapStream();
   // event pairs recorded by launches that time their own pieces (several kernels, two streams); folded into the chunk's profile batch
+  void noteKernel(int kind, const char* name) {   // ga_stats.stage_kernel: the kernel instance a stage's latest launch ran
+    if (kind < 0 || kind >= 16 || !name || !*name) return;
+    std::strncpy(stats.stage_kernel[kind], name, sizeof(stats.stage_kernel[kind]) - 1);
+  }
   struct ExtraProf { hipEvent_t e0, e1; int kind; double bytes; };
   std::vector<ExtraProf> extraProf;
+  DevArena coarseM;                 // mixed input signals of pre-mixed groups
   DevArena coarseX, coarseY;        // spectra frames of a convolver stage (shared by the stages of a chunk, which run in order)
   float2* coarseTw = nullptr;       // combine-pass twiddles [2][2049]: W_8192^k, W_16384^k
   const float2* coarseTwab();

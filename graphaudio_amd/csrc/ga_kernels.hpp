@@ -117,6 +117,9 @@ constexpr int kCoarseJobTerms = 32;   // terms (signals) whose products one mult
 // carried tail is 59 + 8 output blocks
 constexpr int kCoarseSumJobBlocks(int columns) { return columns <= 2 ? 72 : 40; }
 constexpr int kCoarseJobBlocks(int columns) { return columns <= 2 ? 64 : 32; }   // coarse blocks one multiply-accumulate job covers: 8 waves x 8 (x 4)
+// floating-point operations of one 16,384-point real transform as the kernels evaluate it: two complex radix-16 transforms of 4096
+// points (3 passes x 256 radix-16 butterflies of ~ 200 flops incl. twiddles, each) + the combine pass (~ 30 flops per bin quad pair)
+constexpr double kCoarseTransformFlops = 2.0 * 3.0 * 256.0 * 200.0 + 2048.0 * 60.0;
 constexpr int kCoarseBins = 8192;    // packed complex bins of one 16,384-point real spectrum (bin 0 = (X[0], X[8192]))
 struct CoarseXRow {        // one transformed signal: a convolver input channel, or an impulse-response channel
   const float* hist;       // the hist_len samples in front of the chunk (nullptr = zeros)
@@ -168,12 +171,32 @@ struct CoarseHistJob {
   float* new_hist;
   int64_t hist_len, n;
 };
+// Time-domain pre-mix of a fused group whose members all convolve with ONE impulse response (option "coarse_premix"):
+//   sum_v (x_v * h) = (sum_v x_v) * h     -- the distributive law once more, in front of the transforms --
+// so the group is ONE signal to transform: out[f] = sum over the job's terms of in_t[f] (compensated float32 summation: the
+// result is the correctly rounded sum to within an ulp, whatever the number of terms).  While a thread holds a member's
+// samples it also writes the member's own input history of the next chunk (carry), exactly as the forward kernel does for
+// rows it transforms itself: members keep their private state, so a group can re-form or dissolve between chunks.
+struct PremixTerm {
+  const float* in;         // chunk-frame indexed (or a history row); never nullptr (silent members are left out of the list)
+  float* carry;            // carry[f - carry_from] = in[f] for carry_from <= f < n (16-byte aligned); nullptr = none
+};
+struct PremixJob {
+  float* out;              // n floats, 16-byte aligned
+  int term0, nterms;       // (no terms: zeros)
+  int64_t n;               // multiple of 4
+  int64_t carry_from;      // multiple of 4
+  int flags;               // bit 0: every `in` is 16-byte aligned ; bit 1: some term has a carry
+  int pad_;
+};
+const char* launch_coarse_premix(hipStream_t s, const PremixJob* jobs_dev, int njobs, const PremixTerm* terms_dev, int64_t max_n);
+// (the coarse launchers return the name of the kernel instance they ran: ga_stats.stage_kernel)
 // forward: tw16 = Context::twiddles16pw() ; inverse: tw16 = Context::twiddles16(4096) ; twab = [2][2049]: W_8192^k, W_16384^k
-void launch_coarse_fwd(hipStream_t s, const CoarseXRow* rows_dev, int nrows, int max_frames, int run, float2* X, const float2* tw16,
+const char* launch_coarse_fwd(hipStream_t s, const CoarseXRow* rows_dev, int nrows, int max_frames, int run, float2* X, const float2* tw16,
                        const float2* twab);
-void launch_coarse_mac(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
+const char* launch_coarse_mac(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
                        int y_frames, int cw, int max_t, int maxP, bool any_private, int pb);
-void launch_coarse_inv(hipStream_t s, const CoarseOut* outs_dev, int nouts, int n_t, const int* ylist_dev, const float2* Y, int y_frames,
+const char* launch_coarse_inv(hipStream_t s, const CoarseOut* outs_dev, int nouts, int n_t, const int* ylist_dev, const float2* Y, int y_frames,
                        const float2* tw16, const float2* twab);
 void launch_coarse_hist(hipStream_t s, const CoarseHistJob* jobs_dev, int njobs, int64_t max_len);
 

@@ -108,6 +108,12 @@ typedef struct ga_stats {
                                    "profile_every"); stage_launches[] and stage_bytes[] count every chunk */
   int64_t coarse_carried_outputs; /* formulation D: (output channel, chunk) pairs rendered from a carried tail instead of the
                                      members' input histories */
+  double  stage_flops[16];      /* floating-point operations the stage's launches execute in the formulation that ran (counted by the
+                                   planner from the job tables: complex multiply-adds of the partition sums, butterflies of the
+                                   transforms); 0 where not accounted */
+  char    stage_kernel[16][64]; /* name of the kernel (template instance) the stage's most recent launch ran, "" if none */
+  int64_t coarse_premixed_signals; /* formulation D: (member input channel, chunk) pairs that were summed in the time domain in
+                                      front of their group's transforms instead of being transformed one by one */
 } ga_stats;
 enum {
   GA_STAGE_OTHER = 0,        /* sources, biquads, gains, parameter curves, ... */
@@ -121,7 +127,9 @@ enum {
   GA_STAGE_COARSE_HIST = 8,  /* formulation D: input history of the next chunk */
   GA_STAGE_COARSE_SECTION = 9, /* formulation D: wall time of the forward || multiply-accumulate section (the two stages overlap
                                   on two streams, so their own times add up to more than this) */
-  GA_STAGE_COUNT = 10
+  GA_STAGE_COARSE_PREMIX = 10, /* formulation D: time-domain sum of a fused group that shares one impulse response (+ the members'
+                                  input histories of the next chunk) */
+  GA_STAGE_COUNT = 11
 };
 
 /* ---- library ---- */

@@ -72,8 +72,8 @@ def test_ga_stats_layout_is_the_same_in_c_python_and_csharp(tmp_path):
     body = cs[cs.index("public unsafe struct Stats"):]
     body = body[:body.index("}")]
     size = 0
-    for decl in re.findall(r"public\s+(fixed\s+)?(long|double|int)\s+([^;]+);", body):
-        width = {"long": 8, "double": 8, "int": 4}[decl[1]]
+    for decl in re.findall(r"public\s+(fixed\s+)?(long|double|int|byte)\s+([^;]+);", body):
+        width = {"long": 8, "double": 8, "int": 4, "byte": 1}[decl[1]]
         for name in decl[2].split(","):
             m = re.search(r"\[(\d+)\]", name)
             size += width * (int(m.group(1)) if m else 1)

@@ -71,14 +71,16 @@ def _session(ctx, seed, total_blocks, ragged=False):
     return out, log
 
 
+@pytest.mark.parametrize("premix", [1, 0])
 @pytest.mark.parametrize("seed", list(range(24)))
-def test_tail_sessions_match_the_oracle(seed):
+def test_tail_sessions_match_the_oracle(seed, premix):
     total_blocks = 700
     o = OracleContext(SR)
     ref, log = _session(o, seed, total_blocks)
     o.Dispose()
     h = OfflineAudioContext(SR)
     h.SetOption("coarse_min_blocks", 1)
+    h.SetOption("coarse_premix", premix)
     got, log2 = _session(h, seed, total_blocks)
     st = h.GetStats()
     h.Dispose()
@@ -88,6 +90,7 @@ def test_tail_sessions_match_the_oracle(seed):
     assert err <= 1e-5 and err <= 2e-6 * sig, (seed, err, sig, log)
     if "ir" not in log and log.count("-") >= 3:   # (a member on another impulse response takes the tail away from the group)
         assert st["coarse_carried_outputs"] > 0, log
+    assert (st["coarse_premixed_signals"] > 0) == bool(premix)
 
 
 @pytest.mark.parametrize("seed", [3, 7, 11, 19, 23, 31])
