@@ -573,6 +573,7 @@ struct Sim {
     bool mixed = false;
     for (size_t k = 0; k < in.connected.size(); k++) {
       Conn cn = in.connected[k];
+      if (k + 2 < in.connected.size()) __builtin_prefetch(c.nodes[in.connected[k + 2].node].get());   // (tens of thousands of nodes: the walk is bound by cache misses)
       evalNode(cn.node);
       OutputS& o = c.nodes[cn.node]->outputs[cn.out];
       if (o.bufCh != 0 && !o.silent) {
@@ -595,8 +596,10 @@ struct Sim {
     ns.id = id;
     ns.ins.resize(n_.inputs.size());
     // params first: ComputeValues pulls the modulation input (1 channel, explicit) before the node's inputs (:167-175)
-    ns.pins.resize(n_.params.size());
-    for (int p = 0; p < (int)n_.params.size(); p++) {
+    bool anyMod = false;
+    for (auto& ps : n_.params) anyMod = anyMod || !ps.modulation.empty();
+    if (anyMod) ns.pins.resize(n_.params.size());
+    for (int p = 0; anyMod && p < (int)n_.params.size(); p++) {
       auto& mod = n_.params[p].modulation;
       InSeg& is = ns.pins[p];
       is.bufCh = 1;
@@ -631,7 +634,7 @@ struct Sim {
         n_.outputs[0].bufCh = ns.ins[0].bufCh;
         n_.outputs[0].silent = ns.ins[0].silent;
         ns.bqDynamic = !n_.params[0].events.empty() || !n_.params[1].events.empty() || !n_.params[2].events.empty() ||
-                       !ns.pins[0].silent || !ns.pins[1].silent || !ns.pins[2].silent;   // a modulated parameter moves per sample
+                       !ns.pinSilent(0) || !ns.pinSilent(1) || !ns.pinSilent(2);   // a modulated parameter moves per sample
         if (!ns.ins[0].silent && ns.bqDynamic) {
           ns.bqActive = true;   // coefficients are refreshed per sample on the device
         } else if (!ns.ins[0].silent) {
@@ -717,7 +720,7 @@ struct Sim {
         n_.outputs[0].bufCh = 2;
         n_.outputs[0].silent = ns.ins[0].silent;
         ns.panMode = ns.ins[0].bufCh == 1 ? 1 : 2;
-        if (!ns.ins[0].silent && (!n_.params[0].events.empty() || !ns.pins[0].silent)) {
+        if (!ns.ins[0].silent && (!n_.params[0].events.empty() || !ns.pinSilent(0))) {
           ns.panDyn = true;   // gains follow the a-rate curve on the device (stereo_panner_dynamic_kernel)
         } else if (!ns.ins[0].silent) {
           float pan = std::min(std::max(n_.params[0].value, -1.0f), 1.0f);
@@ -766,7 +769,7 @@ struct Sim {
         // The output buffer's non-silent flag is set by the first non-zero output SAMPLE and never cleared (:72,:92,:96-97).
         // Data is not visible to the control plane: samples that came from a non-silent input block are taken to be non-zero.
         int dmin = 1, dmax = maxD;
-        if (n_.params[0].events.empty() && ns.pins[0].silent) {
+        if (n_.params[0].events.empty() && ns.pinSilent(0)) {
           int d = (int)(n_.params[0].value * (float)c.sampleRate);
           d = std::min(std::max(d, 0), maxD);
           dmin = dmax = d;
@@ -829,8 +832,9 @@ struct Exec {
   int64_t n, frames;
   Plan plan;
   std::vector<Segment>& segs;
-  std::unordered_map<uint64_t, float*> nodeSlab, inSlab;
-  std::vector<std::vector<std::vector<const float*>>> outViews;  // [segment][node][channel]
+  std::unordered_map<uint64_t, float*> nodeSlab, inSlab;   // (node outputs: channels >= 2 only, see nodeOut)
+  std::vector<float*> nodeSlab01;   // [node][channel 0, 1]: a dense table for the slabs nearly every node asks for
+  std::vector<std::vector<Views>> outViews;  // [segment][node][channel]
   // per (level) batch tables
   std::vector<const float*> terms;
   std::vector<MixJob> mixJobs;
@@ -852,11 +856,10 @@ struct Exec {
   std::vector<ResampleBlock> traj;  // per-chunk trajectory table (all rates + custom tail blocks)
   bool mixAligned = true;
   // conv inputs: node -> slot -> per segment view
-  std::unordered_map<int, std::vector<std::vector<const float*>>> convIn;
+  std::unordered_map<int, std::vector<Views>> convIn;
 
   Exec(Context& c_, int64_t n_, std::vector<Segment>& s) : c(c_), n(n_), frames(n_ * kBlock), segs(s) {
-    nodeSlab.reserve(c.nodes.size() * 2 + 64);
-    inSlab.reserve(c.nodes.size() + 64);
+    nodeSlab01.assign(c.nodes.size() * 2, nullptr);
   }
 
   float* slabFor(std::unordered_map<uint64_t, float*>& m, uint64_t key) {
@@ -866,7 +869,18 @@ struct Exec {
     m[key] = p;
     return p;
   }
-  float* nodeOut(int node, int ch) { return slabFor(nodeSlab, ((uint64_t)node << 8) | (uint64_t)ch); }
+  float* nodeOut(int node, int ch) {
+    if (ch < 2 && (size_t)node * 2 + 1 < nodeSlab01.size()) {
+      float*& p = nodeSlab01[(size_t)node * 2 + ch];
+      if (!p) p = getSlab(c);
+      return p;
+    }
+    return slabFor(nodeSlab, ((uint64_t)node << 8) | (uint64_t)ch);
+  }
+  void setNodeOut(int node, int ch, float* p) {   // a node output that is produced in place somewhere else (Context::aliasBusToLeader)
+    if (ch < 2 && (size_t)node * 2 + 1 < nodeSlab01.size()) nodeSlab01[(size_t)node * 2 + ch] = p;
+    else nodeSlab[((uint64_t)node << 8) | (uint64_t)ch] = p;
+  }
   float* inMixed(int node, int input, int ch) { return slabFor(inSlab, ((uint64_t)node << 16) | ((uint64_t)input << 8) | (uint64_t)ch); }
 
   void noteAlign(const float* p, int64_t f0) {
@@ -874,19 +888,19 @@ struct Exec {
   }
 
   // AudioNodeInput.Pull + MixBuffer (AudioNodeInput.cs:100-138,182-244) for one input over one segment
-  std::vector<const float*> resolveInput(int si, const NodeSeg& ns, int i, bool force, float* const* forcedSlabs) {
+  Views resolveInput(int si, const NodeSeg& ns, int i, bool force, float* const* forcedSlabs) {
     return resolveInSeg(si, ns.id, i, ns.ins[i], force, forcedSlabs);
   }
   // i >= 0: node input i ; i < 0: modulation input of param (-1 - i)
-  std::vector<const float*> resolveInSeg(int si, int nodeId, int i, const InSeg& is, bool force, float* const* forcedSlabs) {
+  Views resolveInSeg(int si, int nodeId, int i, const InSeg& is, bool force, float* const* forcedSlabs) {
     const Segment& sg = segs[si];
     const int dstCh = is.bufCh;
     const int64_t f0 = sg.b0 * kBlock, nf = (sg.b1 - sg.b0) * kBlock;
-    std::vector<std::vector<const float*>> lists(dstCh);
+    SmallVec<SmallVec<const float*, 2>, 4> lists((size_t)dstCh);
     for (const TermS& t : is.terms) {
       const auto& uvAll = outViews[si][t.node];
       // a ChannelSplitterNode keeps one mono view per OUTPUT; every other node has one output with t.ch channels
-      std::vector<const float*> uvOne;
+      Views uvOne;
       if (c.nodes[t.node]->type == GA_NODE_CHANNEL_SPLITTER) uvOne.assign(1, t.out < (int)uvAll.size() ? uvAll[t.out] : nullptr);
       const auto& uv = c.nodes[t.node]->type == GA_NODE_CHANNEL_SPLITTER ? uvOne : uvAll;
       const int srcCh = t.ch;
@@ -917,7 +931,7 @@ struct Exec {
           if (uv[ch]) lists[ch].push_back(uv[ch]);
       }
     }
-    std::vector<const float*> views(dstCh, nullptr);
+    Views views((size_t)dstCh, nullptr);
     for (int ch = 0; ch < dstCh; ch++) {
       auto& l = lists[ch];
       if (!force) {
@@ -1402,7 +1416,7 @@ void Context::planCoarseFusion(const std::vector<int>& topo, const std::vector<S
 }
 
 // chunk-long view of input channel `c` of a convolver: the segment views when they agree, else a materialised copy
-static const float* convChunkInput(Context& c, Exec& ex, const std::vector<std::vector<const float*>>& ci, int ch) {
+static const float* convChunkInput(Context& c, Exec& ex, const std::vector<Views>& ci, int ch) {
   const auto& segs = ex.segs;
   const float* stable = nullptr;
   bool same = true, first = true;
@@ -1988,6 +2002,7 @@ static void planCoarseStage(Context& c, Exec& ex, const std::vector<int>& dNodes
 // ======================================================================================================
 // runChunk
 // ======================================================================================================
+static const bool timing = getenv("GA_TIMING") != nullptr;   // measurements only: host phase times per chunk on stderr
 static double nowMs() {
   timespec ts;
   clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -2002,7 +2017,9 @@ void Context::runChunk(int64_t n, float* const* bus) {
   if (faulted) fail(GA_ERR_INVALID_OPERATION, "context is faulted by an earlier render error (" + faultMsg + "); create a new context");
   chunkPhase = 0;
   try {
+    const double t0 = timing ? nowMs() : 0.0;
     runChunkImpl(n, bus);
+    if (timing) fprintf(stderr, "[ga]   chunk total on the host (incl. destructors): %.3f ms\n", nowMs() - t0);
   } catch (const Err& e) {
     if (chunkPhase > 0) {
       faulted = true;
@@ -2196,6 +2213,11 @@ void Context::chunkSimulate(ChunkRun& r) {
         for (int id : g->second) doDispose(id);  // queued Dispose() runs in the next block's DrainCommands
       Segment sg;
       sg.b0 = b;
+      if (!segNodePool.empty()) {   // (storage of an earlier chunk's segment: warm, and no page faults of a fresh allocation)
+        sg.nodes = std::move(segNodePool.back());
+        segNodePool.pop_back();
+      }
+      sg.nodes.reserve(topo.size());
       sim.cur = &sg;
       sim.brel = b;
       sim.blockNumber = currentBlock + b + 1;
@@ -2402,7 +2424,7 @@ void Context::aliasBusToLeader(ChunkRun& r) {
   if (ld.outputs.empty() || ld.outputs[0].connectedInputs.size() != 1) return;
   const InRef& to = ld.outputs[0].connectedInputs[0];
   if (to.node != 0 || to.input != 0) return;
-  for (int ch = 0; ch < nch; ch++) ex.nodeSlab[((uint64_t)leader << 8) | (uint64_t)ch] = busTarget[ch] ? busTarget[ch] : busSlabs[ch];
+  for (int ch = 0; ch < nch; ch++) ex.setNodeOut(leader, ch, busTarget[ch] ? busTarget[ch] : busSlabs[ch]);
 }
 
 // pass 5: convolver formulations of new nodes, fusion groups, scratch arenas (sized before any recorded launch captures them)
@@ -2543,7 +2565,14 @@ void Context::chunkPlanNodes(ChunkRun& r, int d) {
   Exec& ex = *r.ex;
     for (size_t si = 0; si < segs.size(); si++) {
       Segment& sg = segs[si];
-      if (ex.outViews[si].empty()) ex.outViews[si].resize(nodes.size());
+      if (ex.outViews[si].empty()) {
+        if (!viewsPool.empty()) {
+          ex.outViews[si] = std::move(viewsPool.back());
+          viewsPool.pop_back();
+          for (Views& v : ex.outViews[si]) v.clear();
+        }
+        ex.outViews[si].resize(nodes.size());
+      }
       const int64_t f0 = sg.b0 * kBlock, nf = (sg.b1 - sg.b0) * kBlock, nb = sg.b1 - sg.b0;
       // nodes of this stage ordered by level
       // (a stable counting sort: with tens of thousands of nodes a comparison sort that chases two node pointers per comparison
@@ -2606,7 +2635,14 @@ void Context::chunkPlanNodes(ChunkRun& r, int d) {
         fuseLen[b_.id] = la_ + 1;
       }
       int curLevel = -1;
-      for (const NodeSeg* nsp : todo) {
+      for (size_t ti = 0; ti < todo.size(); ti++) {
+        const NodeSeg* nsp = todo[ti];
+        if (ti + 4 < todo.size()) {   // (the sweep is bound by cache misses on the node records)
+          const char* nx = (const char*)nodes[todo[ti + 4]->id].get();
+          __builtin_prefetch(nx);
+          __builtin_prefetch(nx + 64);
+          __builtin_prefetch(nx + 128);
+        }
         const NodeSeg& ns = *nsp;
         NodeS& nd = *nodes[ns.id];
         if (nd.level != curLevel) {
@@ -2681,7 +2717,7 @@ void Context::chunkPlanNodes(ChunkRun& r, int d) {
             }
             // append this segment's input to the rings that are processed (a ring beyond the input's channel count does not
             // move, DelayNode.cs:62-94), then gather
-            std::vector<const float*> iv;
+            Views iv;
             if (!ns.ins[0].silent) iv = ex.resolveInput((int)si, ns, 0, false, nullptr);
             const float* delayCurve = ex.paramView((int)si, ns, 0);
             for (int cch = 0; cch < ch; cch++) {
@@ -2932,13 +2968,13 @@ void Context::chunkPlanNodes(ChunkRun& r, int d) {
             }
             if (absorbedBy.get(ns.id) >= 0) break;  // evaluated inside the cascade job of a downstream biquad
             // chain head ... this node: biquads connected output -> single input with equal channel counts
-            std::vector<const NodeSeg*> chain{&ns};
+            SmallVec<const NodeSeg*, kMaxBiquadSections> chain{&ns};
             while (true) {
               const NodeSeg* h = chain.front();
               if (h->ins[0].terms.size() != 1) break;
               int up = h->ins[0].terms[0].node;
               if (absorbedBy.get(up) != h->id) break;
-              chain.insert(chain.begin(), segNode.find(up));
+              chain.insert_front(segNode.find(up));
             }
             auto iv = ex.resolveInput((int)si, *chain.front(), 0, false, nullptr);
             for (const NodeSeg* cn : chain) {
@@ -2969,7 +3005,7 @@ void Context::chunkPlanNodes(ChunkRun& r, int d) {
             auto iv = ex.resolveInput((int)si, ns, 0, false, nullptr);
             if (!nd.ir) break;  // no IR: cleared output (ConvolverNode.cs:107-119)
             auto& ci = ex.convIn[ns.id];
-            if (ci.empty()) ci.assign(segs.size(), std::vector<const float*>());
+            if (ci.empty()) ci.assign(segs.size(), Views());
             ci[si] = iv;
             // formulation D: the outputs of a fused group are summed as spectra; the sum is the LEADER's output, the other
             // members hand their consumer a null (= contributes nothing) view (Context::planCoarseFusion)
@@ -2979,7 +3015,7 @@ void Context::chunkPlanNodes(ChunkRun& r, int d) {
           }
           case GA_NODE_DESTINATION: {
             // the destination aliases its input buffer (AudioDestinationNode.cs:44-50): mix straight into the bus
-            std::vector<float*> forced(std::max(ns.ins[0].bufCh, 1), nullptr);
+            SmallVec<float*, 4> forced((size_t)std::max(ns.ins[0].bufCh, 1), nullptr);
             for (int ch = 0; ch < ns.ins[0].bufCh && ch < (int)busSlabs.size(); ch++) forced[ch] = busTarget[ch] ? busTarget[ch] : busSlabs[ch];
             ex.resolveInput((int)si, ns, 0, true, forced.data());
             break;
@@ -3411,7 +3447,6 @@ void Context::chunkDelayCommit(ChunkRun& r) {
 
 // pass 9: upload the job tables, enqueue every recorded launch in order, profile events
 void Context::chunkExecute(ChunkRun& r) {
-  static const bool timing = getenv("GA_TIMING") != nullptr;
   Context& c_ = *this; (void)c_;
   int& maxDepth = r.maxDepth; int& maxLevel = r.maxLevel; (void)maxDepth; (void)maxLevel;
   int64_t& n = r.n; (void)n;
@@ -3596,15 +3631,35 @@ void Context::runChunkImpl(int64_t nblocks, float* const* /*unused*/) {
   r.ex->outViews.resize(r.segs.size());
   r.ex->plan.host.resize(16);  // reserved header
   chunkParamCurves(r);
+  const double tmPar = nowMs();
   chunkConvScratch(r);
   r.tmPre = nowMs();
+  double tmNodes = 0, tmConv = 0;
   for (int d = 0; d <= r.maxDepth; d++) {   // stages: convolver depth d
+    const double a = nowMs();
     chunkPlanNodes(r, d);
+    const double b = nowMs();
     chunkPlanConvolvers(r, d);
+    tmNodes += b - a;
+    tmConv += nowMs() - b;
   }
   chunkDelayCommit(r);
   chunkExecute(r);
+  const double tmEx = nowMs();
   chunkCommit(r);
+  // the big per-node tables go back to the pools
+  for (auto& ov : r.ex->outViews)
+    if (!ov.empty() && viewsPool.size() < 8) viewsPool.push_back(std::move(ov));
+  for (Segment& sg : r.segs) {
+    sg.nodes.clear();
+    if (segNodePool.size() < 8) segNodePool.push_back(std::move(sg.nodes));
+  }
+  if (timing) {
+    const double tmCm = nowMs();
+    r.ex.reset();
+    fprintf(stderr, "[ga]   host detail: param curves %.3f, conv scratch %.3f, plan nodes %.3f, plan convolvers %.3f, commit %.3f, ~Exec %.3f ms\n",
+            tmPar - r.tmRes, r.tmPre - tmPar, tmNodes, tmConv, tmCm - tmEx, nowMs() - tmCm);
+  }
 }
 
 }  // namespace ga

@@ -597,6 +597,12 @@ void Context::assignConvPaths(const std::vector<int>& topo, int64_t chunkBlocks)
 // BiQuadFilterNode.UpdateCoefficients (BiQuadFilterNode.cs:149-258), float32, host libm
 // ------------------------------------------------------------------------------------------------------
 void Context::updateBiquadCoefficients(NodeS& n, float frequency, float q, float gain) {
+  // The reference recomputes the coefficients at sample 0 of every block (BiQuadFilterNode.cs:111-126: its "last" values are
+  // never updated) -- with unchanged parameters that is the same arithmetic on the same inputs: remember the result.
+  if (n.coefMemoValid && n.coefMemoType == n.filterType && n.coefMemoIn[0] == frequency && n.coefMemoIn[1] == q && n.coefMemoIn[2] == gain) {
+    n.b0 = n.coefMemoOut[0]; n.b1 = n.coefMemoOut[1]; n.b2 = n.coefMemoOut[2]; n.a1 = n.coefMemoOut[3]; n.a2 = n.coefMemoOut[4];
+    return;
+  }
   const float PI = 3.14159274f;
   float w0 = 2.f * PI * frequency / sampleRate;
   float cosW0 = std::cos(w0);
@@ -663,6 +669,10 @@ void Context::updateBiquadCoefficients(NodeS& n, float frequency, float q, float
   n.b2 = B2 / a0;
   n.a1 = A1 / a0;
   n.a2 = A2 / a0;
+  n.coefMemoValid = true;
+  n.coefMemoType = n.filterType;
+  n.coefMemoIn[0] = frequency; n.coefMemoIn[1] = q; n.coefMemoIn[2] = gain;
+  n.coefMemoOut[0] = n.b0; n.coefMemoOut[1] = n.b1; n.coefMemoOut[2] = n.b2; n.coefMemoOut[3] = n.a1; n.coefMemoOut[4] = n.a2;
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -11,6 +11,8 @@
 //      blocks of the segment at once; convolvers run once per chunk over all blocks (time-batched spectral MAC).
 #pragma once
 #include <cstring>
+#include <initializer_list>
+#include <new>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -208,6 +210,9 @@ struct NodeS {
   int filterType = GA_FILTER_LOWPASS;
   float b0 = 0, b1 = 0, b2 = 0, a1 = 0, a2 = 0;
   bool coefDirty = true;
+  bool coefMemoValid = false;      // Context::updateBiquadCoefficients: its last arguments and result
+  int coefMemoType = -1;
+  float coefMemoIn[3] = {0, 0, 0}, coefMemoOut[5] = {0, 0, 0, 0, 0};
   BiquadDynState* bqDyn = nullptr;  // device: coefficients + dirty flag + {W1, W2} per channel
   float* bqState = nullptr;         // = bqDyn->w
   bool coefOnDevice = false;        // the device copy of the coefficients is newer than b0..a2 above (automated run)
@@ -271,6 +276,115 @@ struct NodeS {
   int dLeader = -1;
 };
 
+// A vector with inline room for N elements (heap only beyond): the per-node, per-segment records of the control-plane
+// simulation and of the planner are almost always one input with one term and a channel or two, and with tens of thousands of
+// nodes their heap traffic (five to ten allocations per node and segment) was most of the host time of a chunk.
+// The subset of std::vector's interface the engine uses; elements may be non-trivial (InSeg holds a SmallVec itself).
+template <class T, int N>
+class SmallVec {
+ public:
+  SmallVec() {}
+  explicit SmallVec(size_t n) { resize(n); }
+  SmallVec(size_t n, const T& v) { assign(n, v); }
+  SmallVec(std::initializer_list<T> il) { for (const T& v : il) push_back(v); }
+  SmallVec(const SmallVec& o) { for (const T& v : o) push_back(v); }
+  SmallVec(SmallVec&& o) noexcept { take(std::move(o)); }
+  ~SmallVec() { clear(); release(); }
+  SmallVec& operator=(const SmallVec& o) {
+    if (this != &o) { clear(); reserve(o.n_); for (const T& v : o) push_back(v); }
+    return *this;
+  }
+  SmallVec& operator=(SmallVec&& o) noexcept {
+    if (this != &o) { clear(); release(); take(std::move(o)); }
+    return *this;
+  }
+  size_t size() const { return n_; }
+  bool empty() const { return n_ == 0; }
+  T* data() { return p_; }
+  const T* data() const { return p_; }
+  T& operator[](size_t i) { return p_[i]; }
+  const T& operator[](size_t i) const { return p_[i]; }
+  T* begin() { return p_; }
+  T* end() { return p_ + n_; }
+  const T* begin() const { return p_; }
+  const T* end() const { return p_ + n_; }
+  T& front() { return p_[0]; }
+  const T& front() const { return p_[0]; }
+  T& back() { return p_[n_ - 1]; }
+  const T& back() const { return p_[n_ - 1]; }
+  void clear() {
+    for (size_t i = 0; i < n_; i++) p_[i].~T();
+    n_ = 0;
+  }
+  void reserve(size_t c) {
+    if (c <= cap_) return;
+    size_t nc = std::max<size_t>(c, 2 * cap_);
+    T* np = static_cast<T*>(::operator new(nc * sizeof(T)));
+    for (size_t i = 0; i < n_; i++) {
+      new (np + i) T(std::move(p_[i]));
+      p_[i].~T();
+    }
+    release();
+    p_ = np;
+    cap_ = nc;
+  }
+  void push_back(const T& v) {
+    if (n_ == cap_) { T tmp(v); reserve(n_ + 1); new (p_ + n_) T(std::move(tmp)); }
+    else new (p_ + n_) T(v);
+    n_++;
+  }
+  void push_back(T&& v) {
+    if (n_ == cap_) { T tmp(std::move(v)); reserve(n_ + 1); new (p_ + n_) T(std::move(tmp)); }
+    else new (p_ + n_) T(std::move(v));
+    n_++;
+  }
+  void resize(size_t n) {
+    while (n_ > n) p_[--n_].~T();
+    reserve(n);
+    while (n_ < n) new (p_ + n_++) T();
+  }
+  void assign(size_t n, const T& v) {
+    clear();
+    reserve(n);
+    while (n_ < n) new (p_ + n_++) T(v);
+  }
+  void insert_front(const T& v) {   // (the biquad cascade walks upstream: at most kMaxBiquadSections elements)
+    T tmp(v);
+    push_back(tmp);
+    for (size_t i = n_ - 1; i > 0; i--) p_[i] = std::move(p_[i - 1]);
+    p_[0] = std::move(tmp);
+  }
+
+ private:
+  T* inl() { return reinterpret_cast<T*>(buf_); }
+  void release() {
+    if (p_ != inl()) ::operator delete(p_);
+    p_ = inl();
+    cap_ = N;
+  }
+  void take(SmallVec&& o) {   // *this is empty and inline
+    if (o.p_ != o.inl()) {
+      p_ = o.p_;
+      cap_ = o.cap_;
+      n_ = o.n_;
+      o.p_ = o.inl();
+      o.cap_ = N;
+      o.n_ = 0;
+    } else {
+      for (size_t i = 0; i < o.n_; i++) {
+        new (p_ + i) T(std::move(o.p_[i]));
+        o.p_[i].~T();
+      }
+      n_ = o.n_;
+      o.n_ = 0;
+    }
+  }
+  alignas(T) unsigned char buf_[sizeof(T) * N];
+  T* p_ = inl();
+  uint32_t n_ = 0, cap_ = N;
+};
+using Views = SmallVec<const float*, 4>;   // per-channel views (device pointers; nullptr = silent) of a node output / a mixed input
+
 // one evaluated control state of a node within a segment
 struct TermS {
   int node, out, ch;
@@ -278,12 +392,15 @@ struct TermS {
 struct InSeg {
   int bufCh = 0;
   bool silent = true;
-  std::vector<TermS> terms;  // non-silent contributors in connection order
+  SmallVec<TermS, 2> terms;  // non-silent contributors in connection order
 };
 struct NodeSeg {
   int id = 0;
-  std::vector<InSeg> ins;
-  std::vector<InSeg> pins;  // AudioParam modulation inputs (AudioParam.cs:97-101), one per param
+  SmallVec<InSeg, 1> ins;
+  // AudioParam modulation inputs (AudioParam.cs:97-101), one per param -- sized only when some parameter of the node HAS a
+  // modulation input (rare); otherwise empty, which reads as "every pin silent" (pinSilent)
+  SmallVec<InSeg, 1> pins;
+  bool pinSilent(int p) const { return p >= (int)pins.size() || pins[p].silent; }
   bool bqDynamic = false;   // biquad with automated parameters
   int outCh = 0;
   bool outSilent = true;
@@ -490,6 +607,10 @@ struct Context {
   }
   struct ExtraProf { hipEvent_t e0, e1; int kind; double bytes; };
   std::vector<ExtraProf> extraProf;
+  // host-side storage of a chunk's per-node records, handed from chunk to chunk (a fresh allocation of megabytes per chunk costs
+  // its page faults again every time)
+  std::vector<std::vector<NodeSeg>> segNodePool;
+  std::vector<std::vector<Views>> viewsPool;
   DevArena coarseM;                 // mixed input signals of pre-mixed groups
   DevArena coarseX, coarseY;        // spectra frames of a convolver stage (shared by the stages of a chunk, which run in order)
   float2* coarseTw = nullptr;       // combine-pass twiddles [2][2049]: W_8192^k, W_16384^k
