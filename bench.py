@@ -437,6 +437,7 @@ def main():
     ap.add_argument("--no-carry", action="store_true", help="formulation D: copy the input history with its own kernel instead of from the forward transforms (measurement)")
     ap.add_argument("--copy-stream", action="store_true", help="hand the bus to the host on a copy stream of its own (measurement)")
     ap.add_argument("--sync-steps", action="store_true", help="one blocking render per step (no host/device pipelining)")
+    ap.add_argument("--library", default="", help="load this build of the library instead of the product (tools/build_variant.sh; measurements)")
     ap.add_argument("--force-dist", action="store_true", help="exercise the sharded-render path (ga_render_reduce) even with one rank")
     args = ap.parse_args()
 
@@ -466,6 +467,9 @@ def main():
         # control plane only; the bus sum is RCCL inside the library.  A finite timeout: a peer that died must not hang this rank.
         dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
 
+    if args.library:
+        from graphaudio_amd import _capi
+        _capi.use_library(os.path.abspath(args.library))
     from graphaudio_amd import OfflineAudioContext
     from graphaudio_amd.distributed import init_sharded, shard_range
     from tests import _graphs as G

@@ -39,6 +39,7 @@ internal static unsafe partial class GraphAudioHip
         public fixed double stage_flops[16];
         public fixed byte stage_kernel[1024];    // [16][64] zero-terminated names
         public long coarse_premixed_signals;
+        public long deferred_handovers;
     }
 
     [LibraryImport(Lib, EntryPoint = "ga_strerror")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]

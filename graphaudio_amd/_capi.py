@@ -83,6 +83,7 @@ class Stats(C.Structure):
         ("stage_flops", C.c_double * 16),
         ("stage_kernel", (C.c_char * 64) * 16),
         ("coarse_premixed_signals", C.c_int64),
+        ("deferred_handovers", C.c_int64),
     ]
     STAGES = ("other", "mix", "rfft_fwd", "mac", "rfft_inv", "coarse_fwd", "coarse_mac", "coarse_inv", "coarse_hist", "coarse_section")
 
@@ -191,9 +192,20 @@ class CApi:
 _product_api = None
 
 
+_library_override = None
+
+
+def use_library(path: str) -> None:
+    """Load a differently built library (kernel-variant measurements: tools/build_variant.sh, bench.py --library).  An explicit
+    call before the first context -- no environment variable swaps the product library."""
+    global _library_override, _product_api
+    if _product_api is not None:
+        raise RuntimeError("use_library() has to be called before the library is first used")
+    _library_override = path
+
+
 def library_path() -> str:
-    # GA_LIBRARY: a differently built library for kernel-variant measurements (tools/); never set in tests or bench runs
-    return os.environ.get("GA_LIBRARY") or os.path.join(_HERE, LIB_NAME)
+    return _library_override or os.path.join(_HERE, LIB_NAME)
 
 
 def product_api() -> CApi:

@@ -649,7 +649,7 @@ class OfflineAudioContext(AudioContextBase):
         if getattr(self, "_async", False):
             # the device writes these rows after the call has returned: the context holds a reference until the next
             # Synchronize() / GetStats() so that a caller dropping its array cannot free memory a copy is still aimed at
-            self._pending_outputs = getattr(self, "_pending_outputs", [])[-3:] + [rows]
+            self._hold_output(rows)
         self._call("render", ptrs, len(rows), int(frameCount), int(startIndex))
         self._raise_ended()
         return output
@@ -688,9 +688,23 @@ class OfflineAudioContext(AudioContextBase):
             if row.shape[0] < startIndex + frameCount:
                 raise ArgumentException(f"Channel {ch} buffer is too small.")
             ptrs[ch] = row.ctypes.data
-        self._pending_outputs = getattr(self, "_pending_outputs", [])[-3:] + [output]   # alive until Synchronize() (async contexts)
+        if getattr(self, "_async", False):
+            self._hold_output(output)   # alive until Synchronize()
         self._call("render_reduce", ptrs, n, int(frameCount), int(startIndex), int(root))
         self._raise_ended()
+
+    def _hold_output(self, rows):
+        """Asynchronous renders: EVERY output still in flight stays referenced until Synchronize() -- the device (a kernel that
+        writes page-locked rows, or a copy) is aimed at that memory.  The same arrays rendered into again are held once; a
+        caller that never synchronises is synchronised here every 64 distinct outputs instead of losing references."""
+        pend = self.__dict__.setdefault("_pending_outputs", [])
+        key = tuple(id(r) for r in rows)
+        if any(k == key for k, _ in pend):
+            return
+        if len(pend) >= 64:
+            self.Synchronize()
+            pend = self._pending_outputs
+        pend.append((key, rows))
 
     def SetStream(self, hip_stream: int):
         self._call("context_set_stream", C.c_void_p(int(hip_stream)))

@@ -119,6 +119,7 @@ int64_t Context::chunkLimit(int64_t) {
 void Context::processBlocks(float* const* outPlanar, float* outInterleaved, int channels, int64_t blockCount, bool deviceOut) {
   if (blockCount < 0) fail(GA_ERR_OUT_OF_RANGE, "blockCount");
   if (disposed) fail(GA_ERR_DISPOSED, "context disposed");
+  flushHandOver();
   if (outInterleaved || outPlanar == nullptr) {
     if (channels < 1 || channels > 32) fail(GA_ERR_OUT_OF_RANGE, "channels");
     if (!outInterleaved) fail(GA_ERR_INVALID_ARGUMENT, "Buffer too small for interleaved output.");
@@ -236,9 +237,29 @@ void Context::render(float* const* out, int channels, int64_t frameCount, int64_
       Context& c;
       ~Target() { std::memset(c.busTarget, 0, sizeof(c.busTarget)); }
     } target{*this};
-    if (direct)
-      for (int ch = 0; ch < channels; ch++) busTarget[ch] = tgt[ch];
-    runChunk(nblk, nullptr);
+    // an asynchronous render into page-locked rows: the bus stays on the device and crosses PCIe under the next chunk's kernels
+    const bool defer = direct && !deviceOut && pipelined.callerAsync && hostDefer;
+    if (defer) {
+      const size_t rowBytes = ((size_t)nblk * kBlock * sizeof(float) + 255) & ~(size_t)255;
+      if (deferStageBytes < rowBytes * 32) {
+        flushHandOver();
+        if (deferStage) {
+          GA_HIP(hipStreamSynchronize(stream));
+          dfree(deferStage, deferStageBytes);
+        }
+        deferStageBytes = rowBytes * 32;
+        deferStage = (float*)dalloc(deferStageBytes);
+      }
+      for (int ch = 0; ch < channels; ch++) busTarget[ch] = (float*)((char*)deferStage + (size_t)ch * (deferStageBytes / 32));
+    } else {
+      flushHandOver();
+      if (direct)
+        for (int ch = 0; ch < channels; ch++) busTarget[ch] = tgt[ch];
+    }
+    runChunk(nblk, nullptr);   // (takes the previous chunk's pending hand-over with it)
+    if (defer)
+      for (int ch = 0; ch < channels; ch++)
+        pendingHandOver.push_back(HandOver{busTarget[ch], tgt[ch], out[ch] + startIndex + written, chunkBlocksDone * kBlock});
     std::memset(busTarget, 0, sizeof(busTarget));
     const int64_t done = chunkBlocksDone;
     if (done <= 0) fail(GA_ERR_INVALID_OPERATION, "render made no progress");
@@ -345,6 +366,7 @@ int ga_set_option(ga_context* ctx, const char* key, double value) {
     else if (k == "coarse_tail") c.coarseTail = value != 0;
     else if (k == "coarse_premix") c.coarsePremix = value != 0;
     else if (k == "host_direct") c.hostDirect = value != 0;
+    else if (k == "host_defer") c.hostDefer = value != 0;
     else if (k == "host_copy_stream") c.hostCopyStream = value != 0;
     else if (k == "coarse_min_blocks") c.coarseMinBlocks = std::max<int64_t>(1, (int64_t)value);
     else if (k == "debug_tconv_n2") c.debugTconvN2 = (int)value;   // tests only: plan the block-axis FFT with this (possibly unsupported) length
@@ -369,6 +391,7 @@ int ga_synchronize(ga_context* ctx) {
 }
 int ga_context_set_stream(ga_context* ctx, void* hip_stream) {
   return guard(ctx, [&](Context& c) {
+    c.flushHandOver();
     GA_HIP(hipStreamSynchronize(c.stream));
     c.waitHostCopies();
     if (c.ownStream && c.stream) (void)hipStreamDestroy(c.stream);
@@ -391,7 +414,7 @@ int ga_buffer_create(ga_context* ctx, const float* const* planar, int channels, 
     b->host.resize(channels);
     GA_HIP(hipSetDevice(c.device));
     size_t bytes = (size_t)b->stride * channels * sizeof(float);
-    b->dev = (float*)c.dalloc(bytes);
+    b->dev = c.dallocSkewed(bytes, &b->devBase, &b->devBytes);
     GA_HIP(hipMemsetAsync(b->dev, 0, bytes, c.stream));
     for (int i = 0; i < channels; i++) {
       if (!planar[i]) fail(GA_ERR_INVALID_ARGUMENT, "null channel pointer");

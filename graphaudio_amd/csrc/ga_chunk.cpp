@@ -1750,6 +1750,20 @@ void CoarseStage::buildRows() {
     addPieces(ld, kv.first, g.nxr, xFrame, xIndex);
     c.stats.coarse_premixed_signals += (int64_t)g.members * g.nxr;
   }
+  // the previous chunk's bus on its way to the caller's page-locked rows (Context::pendingHandOver): one-term jobs at the head of
+  // this launch -- their workgroups write over PCIe while the others stream the members' samples from HBM
+  if (!pmJobs.empty() && !c.pendingHandOver.empty()) {
+    std::vector<PremixJob> head;
+    for (const Context::HandOver& h : c.pendingHandOver) {
+      head.push_back(PremixJob{h.dst_dev, (int)pmTerms.size(), 1, h.n, h.n, 1 | 4, 0});
+      pmTerms.push_back(PremixTerm{h.src, nullptr});
+      pmMaxN = std::max(pmMaxN, h.n);
+      pmBytes += 2.0 * (double)h.n * 4.0;
+    }
+    pmJobs.insert(pmJobs.begin(), head.begin(), head.end());
+    c.pendingHandOver.clear();
+    c.stats.deferred_handovers++;
+  }
   ex.flushLevel();   // (materialised inputs)
 }
 
@@ -1935,7 +1949,7 @@ void CoarseStage::enqueue() {
       const int k = (f.maxFrames + 11) / 12;
       f.run = (f.maxFrames + k - 1) / k;
     }
-    if (const char* e = getenv("GA_COARSE_RUN")) f.run = std::max(1, atoi(e));   // measurements only
+    if (const char* e = expenv("GA_COARSE_RUN")) f.run = std::max(1, atoi(e));   // measurements only
     fwds.push_back(f);
   }
   if (G > 1) c.ensureOverlapStream();
@@ -3354,8 +3368,8 @@ void Context::chunkPlanConvolvers(ChunkRun& r, int d) {
       if (ns_ > 0) ex.plan.add(LK_MAC, [=](uint8_t* base) { launch_spectral_mac_b(st, (const ConvSetB*)(base + so), ns_, nn, hist, plb); });
       for (auto& kv : setsC) {
         const int Pc = kv.first;
-        static const char* r16env = getenv("GA_TCONV_RADIX16");   // A/B switches for measurements
-        static const char* planenv = getenv("GA_TCONV_MIXED");
+        static const char* r16env = expenv("GA_TCONV_RADIX16");   // A/B switches for measurements
+        static const char* planenv = expenv("GA_TCONV_MIXED");
         const bool r16 = r16env ? atoi(r16env) != 0 : useRadix16;
         std::vector<TconvLaunch> tplan;
         if (debugTconvN2 > 0) {   // tests: a length no kernel exists for must come back as an error code, not abort the host
@@ -3458,6 +3472,14 @@ void Context::chunkExecute(ChunkRun& r) {
   int& bHistMax = r.bHistMax; (void)bHistMax;
   Exec& ex = *r.ex;
   r.tmPlan = nowMs();
+  if (!pendingHandOver.empty()) {   // no pre-mix launch in this chunk took the previous chunk's hand-over along: copies in front
+    std::vector<HandOver> hv;
+    hv.swap(pendingHandOver);
+    hipStream_t st = stream;
+    ex.plan.launches.insert(ex.plan.launches.begin(), Plan::L{[hv, st](uint8_t*) {
+      for (const HandOver& h : hv) GA_HIP(hipMemcpyAsync(h.dst_host, h.src, sizeof(float) * (size_t)h.n, hipMemcpyDeviceToHost, st));
+    }, LK_OTHER, 0.0, 0.0});
+  }
   // ---- upload tables, run ----
   ex.trajOffFinal = ex.plan.putv(ex.traj);
   size_t tbytes = ex.plan.host.size();

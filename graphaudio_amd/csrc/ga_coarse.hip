@@ -12,9 +12,11 @@
 // "Terms" is where the destination mix goes (AudioNodeInput.cs:118-132,195-198): convolver outputs that are only consumed by
 // one summing input are accumulated as spectra, so a 1024-voice bus costs one inverse transform per output channel and
 // coarse block instead of one per voice -- the per-voice spectra Y and the per-voice output slabs never exist in HBM.
-// Every voice's forward transform and its product with its OWN impulse-response spectra are evaluated per voice; nothing is
-// pre-summed across voices in front of the convolution.  State between chunks is the last P' x CB INPUT samples per row
-// (time domain): overlap-save has no output-side state, so nodes keep nothing that depends on who consumes them.
+// Where the algebra allows it the sum moves further forward: terms that share one impulse response are summed as spectra before ONE
+// multiply (coarse_sum_kernel), and a whole fused group on one impulse response is summed in the TIME domain in front of one set
+// of transforms (coarse_premix_kernel, option coarse_premix).  Terms with impulse responses of their own are transformed and
+// multiplied one by one (coarse_mac_kernel).  State between chunks is the last P' x CB INPUT samples per row (time domain):
+// overlap-save has no output-side state, so nodes keep nothing that depends on who consumes them.
 //
 // HBM traffic per 10 s step of config 3 (1024 voices): input 2.0 GB (+0.3 history) in, X 4.4 GB out, 4.4 GB in, Y 0.25 GB
 // out + in, bus out -- ~11 GB against ~35 GB for formulation C.
@@ -31,12 +33,31 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <string>
 #include <type_traits>
 #include <cstdio>
 #include <cstdlib>
 
 namespace ga {
+
+// The dynamic-LDS limit of a kernel is raised once per (kernel, device), not on every launch: to the CU's 160 KB where the
+// runtime takes that, else to what the launch at hand needs (then again per launch).
+struct LdsLimit {
+  std::atomic<uint64_t> done{0};
+  void raise(const void* kern, size_t need, const char* what) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_relaxed) & bit) return;
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess) {
+      done.fetch_or(bit);
+      return;
+    }
+    (void)hipGetLastError();
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(need, 65536)) != hipSuccess) launch_fail(what);
+  }
+};
 
 constexpr int CM = 4096;                       // complex transform length
 constexpr int CPAD = TC16_PADDED(CM);          // LDS slots of one transform buffer (one pad slot per 32)
@@ -261,10 +282,10 @@ const char* launch_coarse_fwd(hipStream_t s, const CoarseXRow* rows_dev, int nro
   if (nrows <= 0 || max_frames <= 0) return "";
   using PL = R16Plan<CM>;
   const size_t lds = (size_t)(PL::T2 + kFwdTw3 + CPAD + kFwdPark * 256) * sizeof(float2);
-  static const int exp = (getenv("GA_COARSE_EXP") ? atoi(getenv("GA_COARSE_EXP")) : 0) & 15;   // timing experiments only
+  static const int exp = (expenv("GA_COARSE_EXP") ? atoi(expenv("GA_COARSE_EXP")) : 0) & 15;   // timing experiments only
   auto kern = exp ? coarse_fwd_kernel<true> : coarse_fwd_kernel<false>;
-  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    launch_fail("cannot raise the dynamic LDS limit of the coarse forward transform");
+  static LdsLimit lim[2];
+  lim[exp ? 1 : 0].raise((const void*)kern, lds, "cannot raise the dynamic LDS limit of the coarse forward transform");
   run = std::max(run, 1);
   for (int r0 = 0; r0 < nrows; r0 += 32768) {
     dim3 grid((max_frames + run - 1) / run, std::min(32768, nrows - r0));
@@ -569,7 +590,7 @@ __global__ __launch_bounds__(kSumThreads, 4) void coarse_sum_kernel(const Coarse
 template <int CW>
 static const char* launch_coarse_sum(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
                               int y_frames, int max_t, int maxP) {
-  static const int exp = getenv("GA_COARSE_EXP") ? atoi(getenv("GA_COARSE_EXP")) : 0;   // timing experiments only
+  static const int exp = expenv("GA_COARSE_EXP") ? atoi(expenv("GA_COARSE_EXP")) : 0;   // timing experiments only
   constexpr int TW = kCoarseSumJobBlocks(CW) / kSumWaves;
   int NFA = 0;   // frames the sweep of the last active wave touches
   for (int nt = 1; nt <= max_t; nt++) {
@@ -578,9 +599,9 @@ static const char* launch_coarse_sum(hipStream_t s, const CoarseJob* jobs_dev, i
   }
   const size_t lds = ((size_t)NFA * 64 + (size_t)maxP * CW * 64) * sizeof(float2);
   if (lds > 160 * 1024) launch_fail("coarse multiply-accumulate: staging does not fit the LDS");
-  if (hipFuncSetAttribute((const void*)coarse_sum_kernel<CW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(lds, 65536)) != hipSuccess)
-    launch_fail("cannot raise the dynamic LDS limit of the coarse multiply-accumulate");
-  if (getenv("GA_COARSE_EXP")) {
+  static LdsLimit lim;
+  lim.raise((const void*)coarse_sum_kernel<CW>, lds, "cannot raise the dynamic LDS limit of the coarse multiply-accumulate");
+  if (expenv("GA_COARSE_EXP")) {
     int occ = -1;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, coarse_sum_kernel<CW>, kSumThreads, lds);
     fprintf(stderr, "[coarse_sum<%d>] lds %zu B, NFA %d, occupancy %d workgroups/CU, %d jobs\n", CW, lds, NFA, occ, njobs);
@@ -594,7 +615,7 @@ static const char* launch_coarse_sum(hipStream_t s, const CoarseJob* jobs_dev, i
 template <int CW, int TW, int PB>
 static const char* launch_coarse_mac_t(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
                                 int y_frames, int max_t, int maxP, bool any_private) {
-  static const int exp = getenv("GA_COARSE_EXP") ? atoi(getenv("GA_COARSE_EXP")) : 0;   // timing experiments only
+  static const int exp = expenv("GA_COARSE_EXP") ? atoi(expenv("GA_COARSE_EXP")) : 0;   // timing experiments only
   // frames the sweep of the last active wave touches: t0w + TW + P - 1 with t0w = (active waves - 1) * ceil(n_t / waves)
   int NFA = 0;
   for (int nt = 1; nt <= max_t; nt++) {
@@ -603,10 +624,9 @@ static const char* launch_coarse_mac_t(hipStream_t s, const CoarseJob* jobs_dev,
   }
   const size_t lds = ((size_t)2 * NFA * 64 + (size_t)(any_private ? 2 : 1) * maxP * CW * 64) * sizeof(float2);
   if (lds > 160 * 1024) launch_fail("coarse multiply-accumulate: staging does not fit the LDS");
-  if (hipFuncSetAttribute((const void*)coarse_mac_kernel<CW, TW, PB>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)std::max<size_t>(lds, 65536)) != hipSuccess)
-    launch_fail("cannot raise the dynamic LDS limit of the coarse multiply-accumulate");
-  if (getenv("GA_COARSE_EXP")) {
+  static LdsLimit lim;
+  lim.raise((const void*)coarse_mac_kernel<CW, TW, PB>, lds, "cannot raise the dynamic LDS limit of the coarse multiply-accumulate");
+  if (expenv("GA_COARSE_EXP")) {
     int occ = -1;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, coarse_mac_kernel<CW, TW, PB>, kMacThreads, lds);
     fprintf(stderr, "[coarse_mac<%d,%d,%d>] lds %zu B, NFA %d, occupancy %d workgroups/CU, %d jobs\n", CW, TW, PB, lds, NFA, occ, njobs);
@@ -633,7 +653,7 @@ const char* launch_coarse_mac(hipStream_t s, const CoarseJob* jobs_dev, int njob
                        int y_frames, int cw, int max_t, int maxP, bool any_private, int pb) {
   if (njobs <= 0) return "";
   if (max_t > (any_private ? kCoarseJobBlocks(cw) : kCoarseSumJobBlocks(cw))) launch_fail("coarse multiply-accumulate: too many coarse blocks in a job");
-  if (const char* e = getenv("GA_COARSE_PB")) pb = std::min(pb, std::max(1, atoi(e)));   // measurements only
+  if (const char* e = expenv("GA_COARSE_PB")) pb = std::min(pb, std::max(1, atoi(e)));   // measurements only
   if (pb != 1 && pb != 2 && pb != 4 && pb != 8 && pb != 16) launch_fail("coarse multiply-accumulate: unsupported partition block");
   if (cw == 1) return launch_coarse_mac_cw<1>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private, pb);
   if (cw == 2) return launch_coarse_mac_cw<2>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private, pb);
@@ -767,8 +787,8 @@ const char* launch_coarse_inv(hipStream_t s, const CoarseOut* outs_dev, int nout
   if (nouts <= 0 || n_t <= 0) return "";
   using PL = R16Plan<CM>;
   const size_t lds = (size_t)(PL::T2 + PL::T3 + 2 * CPAD) * sizeof(float2);
-  if (hipFuncSetAttribute((const void*)coarse_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    launch_fail("cannot raise the dynamic LDS limit of the coarse inverse transform");
+  static LdsLimit lim;
+  lim.raise((const void*)coarse_inv_kernel, lds, "cannot raise the dynamic LDS limit of the coarse inverse transform");
   for (int r0 = 0; r0 < nouts; r0 += 32768)
     hipLaunchKernelGGL(coarse_inv_kernel, dim3(n_t, std::min(32768, nouts - r0)), dim3(512), lds, s, outs_dev + r0, ylist_dev, Y, y_frames,
                        tw16, twab);
@@ -811,26 +831,50 @@ __global__ __launch_bounds__(256) void coarse_hist_kernel(const CoarseHistJob* _
 //  32-bit lane offset.  All sums are Kahan-compensated -- four VALU operations per word in a kernel that waits for HBM -- so
 //  the result is the correctly rounded sum to within an ulp whatever the number of terms.  While a wave holds a member's
 //  samples it writes the member's input history of the next chunk (`carry`).
-//  Job flags (planner): bit 0 = every `in` is 16-byte aligned, bit 1 = some term has a carry.
+//  Job flags (planner): bit 0 = every `in` is 16-byte aligned, bit 1 = some term has a carry, bit 2 = hand-over of a finished bus
+//  to page-locked host rows (one term, plain copy; Context::pendingHandOver).
 // =====================================================================================================================
-constexpr int kPremixAhead = 8, kPremixWaves = 4;
+#ifndef GA_PREMIX_AHEAD
+#define GA_PREMIX_AHEAD 8
+#endif
+#ifndef GA_PREMIX_WAVES
+#define GA_PREMIX_WAVES 4
+#endif
+#ifndef GA_PREMIX_NT
+#define GA_PREMIX_NT 0      // 1: non-temporal loads of the members' samples ; 2: and non-temporal stores of their histories
+#endif
+constexpr int kPremixAhead = GA_PREMIX_AHEAD, kPremixWaves = GA_PREMIX_WAVES;
+#ifndef GA_PREMIX_WORDS
+#define GA_PREMIX_WORDS 1   // 16-byte words per lane and term: a wave reads GA_PREMIX_WORDS KB in a row from a member before it moves on
+#endif
+constexpr int kPremixCopyWgs = 32;   // workgroups that carry one row of a hand-over across PCIe
+constexpr int kPremixWords = GA_PREMIX_WORDS, kPremixTile = 256 * kPremixWords;   // frames per workgroup
 struct Kahan4 {
   v4f s, c;
   __device__ __forceinline__ void add(v4f x) {
+#ifdef GA_PREMIX_PLAIN   // (measurement: plain float sum)
+    s += x;
+    return;
+#endif
     const v4f y = x - c, t = s + y;
     c = (t - s) - y;
     s = t;
   }
 };
 template <bool ALIGNED, bool CARRY>
-__device__ __forceinline__ void premix_stream(const PremixJob& J, const PremixTerm* __restrict terms, int t0, int t1, int lane, uint32_t off,
-                                              bool live, bool keep, uint32_t coff, Kahan4& acc) {
+__device__ __forceinline__ void premix_stream(const PremixJob& J, const PremixTerm* __restrict terms, int t0, int t1, int lane,
+                                              const uint32_t (&off)[kPremixWords], const bool (&keep)[kPremixWords],
+                                              const uint32_t (&coff)[kPremixWords], Kahan4 (&acc)[kPremixWords]) {
   typedef const GA_GLOBAL char* gcp;
   typedef GA_GLOBAL char* gp;
-  auto fetch = [&](gcp in) -> v4f {       // `in` is wave-uniform; lanes behind the end re-read word 0 and drop the result
-    if (ALIGNED) return *(const GA_GLOBAL v4f*)(in + off);
-    const GA_GLOBAL float* p = (const GA_GLOBAL float*)(in + off);
+  auto fetch = [&](gcp in, uint32_t o) -> v4f {       // `in` is wave-uniform; words behind the end re-read word 0 and are dropped
+    if (ALIGNED) return GA_PREMIX_NT ? __builtin_nontemporal_load((const GA_GLOBAL v4f*)(in + o)) : *(const GA_GLOBAL v4f*)(in + o);
+    const GA_GLOBAL float* p = (const GA_GLOBAL float*)(in + o);
     return v4f{p[0], p[1], p[2], p[3]};
+  };
+  auto put = [&](gp car, uint32_t o, v4f x) {
+    if (GA_PREMIX_NT >= 2) __builtin_nontemporal_store(x, (GA_GLOBAL v4f*)(car + o));
+    else *(GA_GLOBAL v4f*)(car + o) = x;
   };
   for (int base = t0; base < t1; base += 64) {
     const int nb = min(64, t1 - base);
@@ -849,66 +893,106 @@ __device__ __forceinline__ void premix_stream(const PremixJob& J, const PremixTe
     };
     int j = 0;
     for (; j + kPremixAhead <= nb; j += kPremixAhead) {
-      v4f x[kPremixAhead];
+      v4f x[kPremixAhead][kPremixWords];
 #pragma unroll
-      for (int u = 0; u < kPremixAhead; u++) x[u] = fetch(in_of(j + u));
+      for (int u = 0; u < kPremixAhead; u++) {
+        gcp in = in_of(j + u);
+#pragma unroll
+        for (int w = 0; w < kPremixWords; w++) x[u][w] = fetch(in, off[w]);
+      }
 #pragma unroll
       for (int u = 0; u < kPremixAhead; u++) {
         if (CARRY) {
           gp car = carry_of(j + u);
-          if (car && keep) *(GA_GLOBAL v4f*)(car + coff) = x[u];
+#pragma unroll
+          for (int w = 0; w < kPremixWords; w++)
+            if (car && keep[w]) put(car, coff[w], x[u][w]);
         }
-        acc.add(x[u]);
+#pragma unroll
+        for (int w = 0; w < kPremixWords; w++) acc[w].add(x[u][w]);
       }
     }
     for (; j < nb; j++) {
-      const v4f x = fetch(in_of(j));
-      if (CARRY) {
-        gp car = carry_of(j);
-        if (car && keep) *(GA_GLOBAL v4f*)(car + coff) = x;
+      gcp in = in_of(j);
+      gp car = CARRY ? carry_of(j) : nullptr;
+#pragma unroll
+      for (int w = 0; w < kPremixWords; w++) {
+        const v4f x = fetch(in, off[w]);
+        if (CARRY && car && keep[w]) put(car, coff[w], x);
+        acc[w].add(x);
       }
-      acc.add(x);
     }
   }
 }
 __global__ __launch_bounds__(64 * kPremixWaves) void coarse_premix_kernel(const PremixJob* __restrict jobs, const PremixTerm* __restrict terms) {
-  __shared__ v4f part[kPremixWaves - 1][2][64];
+  __shared__ v4f part[kPremixWaves - 1][2][kPremixWords][64];
   const PremixJob J = jobs[blockIdx.y];
-  if ((int64_t)blockIdx.x * 256 >= J.n) return;   // (uniform)
+  if (J.flags & 4) {
+    // hand-over job: out is page-locked HOST memory.  A few workgroups walk the whole row -- they sit on a handful of wave slots
+    // for as long as PCIe needs (~ 70 us for a 10 s stereo bus) while every other workgroup of the launch streams HBM.  (As
+    // ordinary jobs -- one short-lived workgroup per 256 frames -- the copies filled the whole chip until PCIe had drained them.)
+    if (blockIdx.x >= (unsigned)kPremixCopyWgs) return;
+    const GA_GLOBAL v4f* src = (const GA_GLOBAL v4f*)terms[J.term0].in;
+    GA_GLOBAL v4f* dst = (GA_GLOBAL v4f*)J.out;
+    const int64_t nw = J.n / 4, step = (int64_t)kPremixCopyWgs * blockDim.x * 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x * 2 + threadIdx.x; i < nw; i += step) {
+      const int64_t i2 = i + blockDim.x;
+      const v4f a = src[i], b = i2 < nw ? src[i2] : a;
+      dst[i] = a;
+      if (i2 < nw) dst[i2] = b;
+    }
+    return;
+  }
+  const int64_t tile0 = (int64_t)blockIdx.x * kPremixTile;
+  if (tile0 >= J.n) return;   // (uniform)
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t f = ((int64_t)blockIdx.x * 64 + lane) * 4;
-  const bool live = f < J.n;
-  const bool keep = live && f >= J.carry_from;
-  const uint32_t off = live ? (uint32_t)(f * 4) : 0u, coff = (uint32_t)((f - J.carry_from) * 4);   // (chunks and histories are far below 4 GB)
+  int64_t f[kPremixWords];
+  bool live[kPremixWords], keep[kPremixWords];
+  uint32_t off[kPremixWords], coff[kPremixWords];   // byte offsets (chunks and histories are far below 4 GB)
+  Kahan4 acc[kPremixWords];
+#pragma unroll
+  for (int w = 0; w < kPremixWords; w++) {
+    f[w] = tile0 + (int64_t)(w * 64 + lane) * 4;
+    live[w] = f[w] < J.n;
+    keep[w] = live[w] && f[w] >= J.carry_from;
+    off[w] = live[w] ? (uint32_t)(f[w] * 4) : 0u;
+    coff[w] = (uint32_t)((f[w] - J.carry_from) * 4);
+    acc[w] = Kahan4{v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};
+  }
   // this wave's share of the terms: a multiple of kPremixAhead each
   const int per = ((J.nterms + kPremixWaves - 1) / kPremixWaves + kPremixAhead - 1) / kPremixAhead * kPremixAhead;
   const int t0 = min(J.nterms, wv * per), t1 = min(J.nterms, t0 + per);
-  Kahan4 acc{v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};
-  const bool carry_here = (J.flags & 2) && (int64_t)blockIdx.x * 256 + 256 > J.carry_from;   // (uniform)
+  const bool carry_here = (J.flags & 2) && tile0 + kPremixTile > J.carry_from;   // (uniform)
   if (J.flags & 1) {
-    if (carry_here) premix_stream<true, true>(J, terms, t0, t1, lane, off, live, keep, coff, acc);
-    else premix_stream<true, false>(J, terms, t0, t1, lane, off, live, keep, coff, acc);
+    if (carry_here) premix_stream<true, true>(J, terms, t0, t1, lane, off, keep, coff, acc);
+    else premix_stream<true, false>(J, terms, t0, t1, lane, off, keep, coff, acc);
   } else {
-    if (carry_here) premix_stream<false, true>(J, terms, t0, t1, lane, off, live, keep, coff, acc);
-    else premix_stream<false, false>(J, terms, t0, t1, lane, off, live, keep, coff, acc);
+    if (carry_here) premix_stream<false, true>(J, terms, t0, t1, lane, off, keep, coff, acc);
+    else premix_stream<false, false>(J, terms, t0, t1, lane, off, keep, coff, acc);
   }
   if (wv > 0) {
-    part[wv - 1][0][lane] = acc.s;
-    part[wv - 1][1][lane] = acc.c;
+#pragma unroll
+    for (int w = 0; w < kPremixWords; w++) {
+      part[wv - 1][0][w][lane] = acc[w].s;
+      part[wv - 1][1][w][lane] = acc[w].c;
+    }
   }
   __syncthreads();
   if (wv == 0) {
 #pragma unroll
-    for (int w = 0; w < kPremixWaves - 1; w++) {   // (a partial sum is s - c: add both parts)
-      acc.add(part[w][0][lane]);
-      acc.add(-part[w][1][lane]);
+    for (int w = 0; w < kPremixWords; w++) {
+#pragma unroll
+      for (int q = 0; q < kPremixWaves - 1; q++) {   // (a partial sum is s - c: add both parts)
+        acc[w].add(part[q][0][w][lane]);
+        acc[w].add(-part[q][1][w][lane]);
+      }
+      if (live[w]) stg4(J.out + f[w], acc[w].s);
     }
-    if (live) stg4(J.out + f, acc.s);
   }
 }
 const char* launch_coarse_premix(hipStream_t s, const PremixJob* jobs_dev, int njobs, const PremixTerm* terms_dev, int64_t max_n) {
   if (njobs <= 0 || max_n <= 0) return "";
-  const int64_t gx = (max_n + 255) / 256;
+  const int64_t gx = (max_n + kPremixTile - 1) / kPremixTile;
   if (gx > 0x7fffffff || max_n >= ((int64_t)1 << 29)) launch_fail("coarse pre-mix: chunk too long");
   for (int j0 = 0; j0 < njobs; j0 += 32768)
     hipLaunchKernelGGL(coarse_premix_kernel, dim3((unsigned)gx, std::min(32768, njobs - j0)), dim3(64 * kPremixWaves), 0, s, jobs_dev + j0, terms_dev);

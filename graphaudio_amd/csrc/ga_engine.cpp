@@ -20,6 +20,11 @@ void* Context::dalloc(size_t bytes) {
   devBytes += (int64_t)bytes;
   return p;
 }
+float* Context::dallocSkewed(size_t bytes, void** base, size_t* total) {
+  *total = bytes + 64 * 1024;
+  *base = dalloc(*total);
+  return (float*)((char*)*base + (size_t)(skewSeq++ % 64) * 1024);
+}
 void Context::dfree(void* p, size_t bytes) {
   if (!p) return;
   (void)hipFree(p);
@@ -67,7 +72,7 @@ Context::~Context() {
   } catch (...) {
   }
   for (auto& b : buffers)
-    if (b && b->dev) (void)hipFree(b->dev);
+    if (b && b->devBase) (void)hipFree(b->devBase);
   for (auto& g : groups) {
     if (g->histR) (void)hipFree(g->histR);
     if (g->histI) (void)hipFree(g->histI);
@@ -84,8 +89,8 @@ Context::~Context() {
     if (np && np->bHistR) (void)hipFree(np->bHistR);
     if (np && np->bHistI) (void)hipFree(np->bHistI);
     if (np && np->bOverlap) (void)hipFree(np->bOverlap);
-    if (np && np->dHist[0]) (void)hipFree(np->dHist[0]);
-    if (np && np->dHist[1]) (void)hipFree(np->dHist[1]);
+    if (np && np->dHistBase[0]) (void)hipFree(np->dHistBase[0]);
+    if (np && np->dHistBase[1]) (void)hipFree(np->dHistBase[1]);
     if (np && np->dTail[0]) (void)hipFree(np->dTail[0]);
     if (np && np->dTail[1]) (void)hipFree(np->dTail[1]);
     if (np && np->stWin[0]) (void)hipFree(np->stWin[0]);
@@ -118,6 +123,7 @@ Context::~Context() {
   if (coarseX.p) (void)hipFree(coarseX.p);
   if (coarseY.p) (void)hipFree(coarseY.p);
   if (coarseM.p) (void)hipFree(coarseM.p);
+  if (deferStage) (void)hipFree(deferStage);
   if (ilvDev) (void)hipFree(ilvDev);
   if (tables.p) (void)hipFree(tables.p);
   if (tablesHost) (void)hipHostFree(tablesHost);
@@ -205,7 +211,7 @@ void Context::collectGarbage() {
         synced = true;
       }
       PlayBuf& b = *buffers[id];
-      if (b.dev) dfree(b.dev, (size_t)b.stride * b.channels * sizeof(float));
+      if (b.devBase) dfree(b.devBase, b.devBytes);
       for (auto it = irCache.begin(); it != irCache.end();)   // spectra built from it stay with the convolvers that hold them
         it = it->first.first == id ? irCache.erase(it) : std::next(it);
       buffers[id].reset();
@@ -253,8 +259,14 @@ void Context::harvestProfile(bool wait) {
     pendingProf.pop_front();
   }
 }
+void Context::flushHandOver() {
+  for (const HandOver& h : pendingHandOver)
+    GA_HIP(hipMemcpyAsync(h.dst_host, h.src, sizeof(float) * (size_t)h.n, hipMemcpyDeviceToHost, stream));
+  pendingHandOver.clear();
+}
 void Context::synchronize() {
   GA_HIP(hipSetDevice(device));
+  flushHandOver();
   GA_HIP(hipStreamSynchronize(stream));
   waitHostCopies();
   harvestProfile(true);
@@ -413,9 +425,9 @@ void Context::releaseConvState(NodeS& n) {
   }
   if (n.dHist[0]) {
     if (stream) (void)hipStreamSynchronize(stream);
-    const size_t hb = (size_t)n.bInCh * (size_t)n.dHistLen * sizeof(float);
-    dfree(n.dHist[0], hb);
-    dfree(n.dHist[1], hb);
+    dfree(n.dHistBase[0], n.dHistBytes);
+    dfree(n.dHistBase[1], n.dHistBytes);
+    n.dHistBase[0] = n.dHistBase[1] = nullptr;
   }
   if (n.dTail[0]) {
     if (stream) (void)hipStreamSynchronize(stream);
@@ -565,8 +577,8 @@ void Context::assignConvPaths(const std::vector<int>& topo, int64_t chunkBlocks)
       ensureCoarseSpectra(*ir);
       nd.dHistLen = (int64_t)ir->coarseP * kCoarseBlock;
       const size_t hb = (size_t)nd.bInCh * (size_t)nd.dHistLen * sizeof(float);
-      nd.dHist[0] = (float*)dalloc(hb);
-      nd.dHist[1] = (float*)dalloc(hb);
+      nd.dHist[0] = dallocSkewed(hb, &nd.dHistBase[0], &nd.dHistBytes);
+      nd.dHist[1] = dallocSkewed(hb, &nd.dHistBase[1], &nd.dHistBytes);
       nd.dHistCur = 0;
       nd.dHistZero = true;   // (never read while the flag is set)
       nd.bShared = true;
@@ -909,7 +921,7 @@ std::vector<Context::TconvLaunch> Context::tconvPlan(int nblocks, int P) const {
     count[i]++;
     rem -= std::min(rem, sizes[i] - (P - 1));
   }
-  if (const char* e = getenv("GA_TCONV_PLAN")) {   // measurement only: "n1024,n2048,n4096" segment counts (must cover the chunk)
+  if (const char* e = expenv("GA_TCONV_PLAN")) {   // measurement only: "n1024,n2048,n4096" segment counts (must cover the chunk)
     int c0 = 0, c1 = 0, c2 = 0;
     if (sscanf(e, "%d,%d,%d", &c0, &c1, &c2) == 3 &&
         (long long)c0 * (1024 - (P - 1)) + (long long)c1 * (2048 - (P - 1)) + (long long)c2 * (4096 - (P - 1)) >= nblocks) {

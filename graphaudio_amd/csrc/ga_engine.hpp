@@ -90,7 +90,9 @@ struct PlayBuf {
   int64_t stride = 0;  // floats between channels on the device
   int sampleRate = 0;
   std::vector<std::vector<float>> host;
-  float* dev = nullptr;
+  float* dev = nullptr;   // first sample (inside the allocation `devBase`: Context::dallocSkewed)
+  void* devBase = nullptr;
+  size_t devBytes = 0;
   bool released = false;   // ga_buffer_release: the host no longer holds the buffer; storage goes when no node refers to it
 };
 
@@ -237,7 +239,9 @@ struct NodeS {
   bool bHistZero = true;
   // formulation D (convPath 4): the state of a node is the last coarseP x 8192 INPUT samples of every input channel (time
   // domain, double buffered: a chunk reads one copy and writes the other); overlap-save keeps nothing on the output side
-  float* dHist[2] = {nullptr, nullptr};   // [bInCh][dHistLen]
+  float* dHist[2] = {nullptr, nullptr};   // [bInCh][dHistLen]  (inside the allocations dHistBase: Context::dallocSkewed)
+  void* dHistBase[2] = {nullptr, nullptr};
+  size_t dHistBytes = 0;
   int64_t dHistLen = 0;
   int dHistCur = 0;
   bool dHistZero = true;
@@ -546,6 +550,12 @@ struct Context {
   void* dalloc(size_t bytes);
   void dfree(void* p, size_t bytes);
   void ensure(DevArena& a, size_t bytes);
+  // Rows that many workgroups walk side by side (the voices' sample buffers, their input histories): separate allocations
+  // start at multiples of 2 MiB, so the same offset of every row would sit on the same HBM channel and bank -- measured 5.0
+  // TB/s against 6.1 for the pre-mix kernel's access pattern (tools/proto/hbm_peak.hip).  Each row therefore starts 1 KiB
+  // further into its allocation than the one before (mod 64).  `*base` / `*total` are what dfree() takes.
+  float* dallocSkewed(size_t bytes, void** base, size_t* total);
+  unsigned skewSeq = 0;
 
   // command queue (AudioContextBase.cs:266-305)
   void executeOrPost(std::function<void()> cmd);
@@ -672,6 +682,16 @@ struct Context {
   std::vector<float*> busSlabs;
   // a render into device memory whose chunk covers whole blocks lets the destination mix straight into the caller's rows
   // (no copy of the bus afterwards): set by Context::render around runChunk, consulted where the destination's input is resolved
+  // Deferred hand-over (option "host_defer"): an ASYNCHRONOUS render whose rows are page-locked host memory leaves its bus in device
+  // staging rows, and the rows cross PCIe inside the NEXT chunk's first long kernel (extra one-term jobs of the pre-mix launch:
+  // their workgroups write over PCIe while the others stream HBM) instead of at the end of this chunk's last kernel, where
+  // nothing else runs.  Without a next chunk: plain copies on the stream, from ga_synchronize or whatever touches the stream next.
+  struct HandOver { const float* src; float* dst_dev; float* dst_host; int64_t n; };
+  std::vector<HandOver> pendingHandOver;
+  float* deferStage = nullptr;
+  size_t deferStageBytes = 0;
+  bool hostDefer = true;
+  void flushHandOver();
   float* busTarget[32] = {};
   bool hostDirect = true;   // option "host_direct": page-locked host rows are such a target too (0: always the copy kernels)
   struct SegCh { int64_t b0, b1; int ch; };

@@ -1869,12 +1869,12 @@ static void launch_biquad_pipe(hipStream_t s, const BiquadJob* jobs_dev, int njo
   constexpr int MAXJ = 4 * (16 / NSEC);
   // latency-bound: one wave per SIMD is the most the chip can use; more cascades than that share waves
   int jpw = std::min(MAXJ, std::max(1, (njobs + 1023) / 1024));
-  if (const char* e = getenv("GA_BQ_JPW")) jpw = std::min(MAXJ, std::max(1, atoi(e)));
+  if (const char* e = expenv("GA_BQ_JPW")) jpw = std::min(MAXJ, std::max(1, atoi(e)));
   hipLaunchKernelGGL(biquad_pipe_kernel<NSEC>, dim3((njobs + jpw - 1) / jpw), dim3(64), 0, s, jobs_dev, njobs, secs_dev, jpw);
 }
 void launch_biquad(hipStream_t s, const BiquadJob* jobs_dev, int njobs, const BiquadSection* secs_dev, int nsec) {
   if (njobs <= 0) return;
-  static const bool pipe = !getenv("GA_BQ_NOPIPE");
+  static const bool pipe = !expenv("GA_BQ_NOPIPE");
   if (pipe && nsec >= 2) {
     switch (nsec) {
       case 2: launch_biquad_pipe<2>(s, jobs_dev, njobs, secs_dev); return;
@@ -1890,7 +1890,7 @@ void launch_biquad(hipStream_t s, const BiquadJob* jobs_dev, int njobs, const Bi
   // spot -- 4 / 8 / 16 / 32 jobs per wave took 81 / 65 / 47 / 54 ms.  A wave issues one VALU instruction per ~4 cycles
   // however many lanes are busy, so fewer, fuller waves only pay once that many waves exist.
   int per = (njobs + 511) / 512;
-  if (const char* e = getenv("GA_BQ_JPW")) per = atoi(e);   // tuning override
+  if (const char* e = expenv("GA_BQ_JPW")) per = atoi(e);   // tuning override
   if (per <= 4) launch_biquad_jpw<4>(s, jobs_dev, njobs, secs_dev, nsec);
   else if (per <= 8) launch_biquad_jpw<8>(s, jobs_dev, njobs, secs_dev, nsec);
   else if (per <= 16) launch_biquad_jpw<16>(s, jobs_dev, njobs, secs_dev, nsec);

@@ -4,12 +4,21 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace ga {
 
 // A launcher that cannot serve its arguments (a planner bug, e.g. an FFT length without a kernel) reports it as an error
 // code through the C ABI (GA_ERR_INVALID_OPERATION): the library never aborts the host process.  Defined in ga_engine.cpp.
 [[noreturn]] void launch_fail(const char* what);
+
+// Measurement-only environment switches (kernel variant A/B tests, phase-removal experiments of tools/) exist only in builds made
+// with -DGA_EXPERIMENTS (tools/build_variant.sh): the shipped library reads no environment variable that changes what it computes.
+#ifdef GA_EXPERIMENTS
+inline const char* expenv(const char* name) { return getenv(name); }
+#else
+inline const char* expenv(const char*) { return nullptr; }
+#endif
 
 constexpr int kBlock = 128;  // AudioBuffer.FramesPerBlock (AudioBuffer.cs:10)
 constexpr int kBins = 129;   // complexCount for fftSize 256 (PartitionedConvolver.cs:40-41)
@@ -186,7 +195,7 @@ struct PremixJob {
   int term0, nterms;       // (no terms: zeros)
   int64_t n;               // multiple of 4
   int64_t carry_from;      // multiple of 4
-  int flags;               // bit 0: every `in` is 16-byte aligned ; bit 1: some term has a carry
+  int flags;               // bit 0: every `in` is 16-byte aligned ; bit 1: some term has a carry ; bit 2: hand-over copy to host rows
   int pad_;
 };
 const char* launch_coarse_premix(hipStream_t s, const PremixJob* jobs_dev, int njobs, const PremixTerm* terms_dev, int64_t max_n);

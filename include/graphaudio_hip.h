@@ -114,6 +114,8 @@ typedef struct ga_stats {
   char    stage_kernel[16][64]; /* name of the kernel (template instance) the stage's most recent launch ran, "" if none */
   int64_t coarse_premixed_signals; /* formulation D: (member input channel, chunk) pairs that were summed in the time domain in
                                       front of their group's transforms instead of being transformed one by one */
+  int64_t deferred_handovers;   /* asynchronous renders whose bus crossed PCIe inside the next chunk's pre-mix launch (option
+                                   "host_defer") instead of at the end of their own last kernel */
 } ga_stats;
 enum {
   GA_STAGE_OTHER = 0,        /* sources, biquads, gains, parameter curves, ... */

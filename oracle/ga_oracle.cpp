@@ -4,7 +4,7 @@
 // GraphAudio.Core), written from reading the C# sources: same pull-model traversal, same per-block
 // processing, float32 exactly where the reference is float32, double where it is double, same loop
 // and accumulation order, same silent-flag propagation, same block clock.  Every function cites the
-// reference file:line it follows.  Build flags (oracle/Makefile): -O2 -mavx2 -ffp-contract=off
+// reference file:line it follows.  Build flags (oracle/Makefile): -O3 -mavx2 -ffp-contract=off
 // -fno-fast-math, so no fused multiply-adds are introduced (the .NET JIT does not contract either).
 //
 // PARITY UNPINNED by the reference: the reference ships no tests, golden vectors or fixtures for this

@@ -1,0 +1,81 @@
+"""Asynchronous renders into page-locked host rows (include/graphaudio_hip.h "pipelined renders", option host_defer).
+
+An asynchronous render leaves its bus in device staging rows; the rows cross PCIe inside the next chunk's pre-mix launch (or, when
+that chunk has none, as copies in front of it; after the last chunk: from ga_synchronize).  Whatever route a step's bus takes it
+has to arrive, bit for bit what a blocking render of the same step produces -- also when consecutive steps write into the SAME
+rows (the benchmark's loop) and when renders of several chunks are in flight.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import torch
+
+from graphaudio_amd import OfflineAudioContext
+from tests import _graphs as G
+
+SR = 48000
+
+
+def _steps(builder, frames, steps, async_, pinned, same_rows=False, **opts):
+    ctx = OfflineAudioContext(SR)
+    for k, v in opts.items():
+        ctx.SetOption(k, v)
+    ch = builder(ctx)
+    if async_:
+        ctx.SetOption("async", 1)
+    keep, outs = [], []
+    for k in range(steps):
+        if pinned:
+            if not same_rows or not keep:
+                keep.append(torch.zeros((ch, frames), dtype=torch.float32).pin_memory())
+            a = keep[-1].numpy()
+        else:
+            a = np.zeros((ch, frames), np.float32)
+        ctx.Render(a, frames)
+        if same_rows:
+            ctx.Synchronize()
+            outs.append(a.copy())
+        else:
+            outs.append(a)
+    ctx.Synchronize()
+    st = ctx.GetStats()
+    outs = [o.copy() for o in outs]
+    ctx.Dispose()
+    return outs, st
+
+
+@pytest.mark.parametrize("shared", [True, False])   # a pre-mix launch per chunk to ride along with / none (copies in front)
+def test_deferred_hand_over_equals_blocking_renders(shared):
+    frames, steps = 128 * 300, 5
+    build = lambda c: G.config3_convolver(c, voices=12, taps=30000, frames=frames * steps, shared=shared)
+    ref, _ = _steps(build, frames, steps, async_=False, pinned=False, coarse_min_blocks=1)
+    got, st = _steps(build, frames, steps, async_=True, pinned=True, coarse_min_blocks=1)
+    assert (st["deferred_handovers"] == steps - 1) == shared   # rode along with the next chunk's pre-mix launch
+    for k in range(steps):
+        assert G.rms(ref[k]) > 1e-4
+        assert np.array_equal(ref[k], got[k]), k
+    off, st2 = _steps(build, frames, steps, async_=True, pinned=True, coarse_min_blocks=1, host_defer=0)
+    assert st2["deferred_handovers"] == 0
+    for k in range(steps):
+        assert np.array_equal(ref[k], off[k]), k
+
+
+def test_steps_that_reuse_the_same_rows():
+    frames, steps = 128 * 260, 4
+    build = lambda c: G.config3_convolver(c, voices=9, taps=20000, frames=frames * steps)
+    ref, _ = _steps(build, frames, steps, async_=False, pinned=False, coarse_min_blocks=1)
+    got, _ = _steps(build, frames, steps, async_=True, pinned=True, same_rows=True, coarse_min_blocks=1)
+    for k in range(steps):
+        assert np.array_equal(ref[k], got[k]), k
+
+
+def test_render_spanning_several_chunks_and_a_biquad_graph():
+    """chunks of 64 blocks: every chunk's hand-over rides with (or goes in front of) the next one; a graph without convolvers"""
+    frames = 128 * 300
+    for build in (lambda c: G.config3_convolver(c, voices=5, taps=20000, frames=frames), lambda c: G.config2_biquad(c, voices=16, frames=frames)):
+        ref, _ = _steps(build, frames, 2, async_=False, pinned=False, coarse_min_blocks=1, max_chunk_blocks=64)
+        got, _ = _steps(build, frames, 2, async_=True, pinned=True, coarse_min_blocks=1, max_chunk_blocks=64)
+        for k in range(2):
+            assert np.array_equal(ref[k], got[k]), k

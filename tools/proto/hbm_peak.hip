@@ -1,0 +1,187 @@
+// What HBM rate does this board give a kernel that does nothing else?  (the round-2 micro-benchmark
+// tools/proto/hbm_rw.hip kept ONE load in flight per thread and topped out at 4.85-5.0 TB/s copy; the guide quotes 6.29.)
+// Every thread keeps U independent 16-byte accesses in flight, the grid is a multiple of the resident workgroups, loads /
+// stores optionally non-temporal.  Patterns: read, write, copy (1:1), read 1 : write 2 (the forward transform's mix), and
+// "rows": the pre-mix kernel's pattern -- R rows of L bytes each, a workgroup sums one 1 KB x WORDS column range over all rows.
+//   hipcc --offload-arch=gfx950 -O3 -o tools/proto/hbm_peak tools/proto/hbm_peak.hip && tools/proto/hbm_peak
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) f4 gf4;
+
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void rd(const f4* __restrict p, size_t n, float* out) {
+  f4 s = f4{0, 0, 0, 0};
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = blockIdx.x * 256ull + threadIdx.x;
+  for (; i + (U - 1) * stride < n; i += U * stride) {
+    f4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) v[u] = NT ? __builtin_nontemporal_load((const gf4*)p + i + u * stride) : ((const gf4*)p)[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < U; u++) s += v[u];
+  }
+  for (; i < n; i += stride) s += p[i];
+  if (s.x + s.y + s.z + s.w == 12345.678f) out[0] = 1.f;
+}
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void wr(f4* __restrict p, size_t n, float v) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  const f4 x = f4{v, v + 1, v + 2, v + 3};
+  for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += stride) {
+    if (NT) __builtin_nontemporal_store(x, (gf4*)p + i);
+    else ((gf4*)p)[i] = x;
+  }
+}
+template <int U, bool NTL, bool NTS>
+__global__ __launch_bounds__(256) void cp(const f4* __restrict a, f4* __restrict b, size_t n) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = blockIdx.x * 256ull + threadIdx.x;
+  for (; i + (U - 1) * stride < n; i += U * stride) {
+    f4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) v[u] = NTL ? __builtin_nontemporal_load((const gf4*)a + i + u * stride) : ((const gf4*)a)[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (NTS) __builtin_nontemporal_store(v[u], (gf4*)b + i + u * stride);
+      else ((gf4*)b)[i + u * stride] = v[u];
+    }
+  }
+  for (; i < n; i += stride) b[i] = a[i];
+}
+// reads n words of a, writes 2 n words of b
+template <int U, bool NTS>
+__global__ __launch_bounds__(256) void mix12(const f4* __restrict a, f4* __restrict b, size_t n) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = blockIdx.x * 256ull + threadIdx.x;
+  for (; i + (U - 1) * stride < n; i += U * stride) {
+    f4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) v[u] = ((const gf4*)a)[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (NTS) {
+        __builtin_nontemporal_store(v[u], (gf4*)b + 2 * (i + u * stride));
+        __builtin_nontemporal_store(v[u] + 1.f, (gf4*)b + 2 * (i + u * stride) + 1);
+      } else {
+        ((gf4*)b)[2 * (i + u * stride)] = v[u];
+        ((gf4*)b)[2 * (i + u * stride) + 1] = v[u] + 1.f;
+      }
+    }
+  }
+}
+// the pre-mix pattern: `rows` rows of `rowlen16` words; workgroup x = column range of W x 64 words; its 4 waves take a quarter of the rows each
+// rows start `stride16` words apart plus a skew of (row % 64) * skew16 words (rows of separately allocated buffers start at 2 MB
+// multiples: the same offset of every row then sits on the same channel and bank)
+template <int U, int W>
+__global__ __launch_bounds__(256) void rows_sum(const f4* __restrict p, int rows, size_t rowlen16, f4* __restrict out, size_t stride16 = 0,
+                                                size_t skew16 = 0) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const size_t col = (size_t)blockIdx.x * 64 * W + lane;
+  if ((size_t)blockIdx.x * 64 * W >= rowlen16) return;
+  if (stride16) {
+    f4 s[W];
+#pragma unroll
+    for (int w = 0; w < W; w++) s[w] = f4{0, 0, 0, 0};
+    const int r0 = rows / 4 * wv, r1 = r0 + rows / 4;
+    for (int r = r0; r + U <= r1; r += U) {
+      f4 v[U][W];
+#pragma unroll
+      for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int w = 0; w < W; w++) v[u][w] = ((const gf4*)p)[(size_t)(r + u) * stride16 + (size_t)((r + u) & 63) * skew16 + col + 64 * w];
+#pragma unroll
+      for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int w = 0; w < W; w++) s[w] += v[u][w];
+    }
+    if (s[0].x == 12345.678f)
+      for (int w = 0; w < W; w++) out[col + 64 * w] = s[w];
+    return;
+  }
+  f4 s[W];
+#pragma unroll
+  for (int w = 0; w < W; w++) s[w] = f4{0, 0, 0, 0};
+  const int r0 = rows / 4 * wv, r1 = r0 + rows / 4;
+  for (int r = r0; r + U <= r1; r += U) {
+    f4 v[U][W];
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+      for (int w = 0; w < W; w++) v[u][w] = ((const gf4*)p)[(size_t)(r + u) * rowlen16 + col + 64 * w];
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+      for (int w = 0; w < W; w++) s[w] += v[u][w];
+  }
+  if (s[0].x == 12345.678f)
+    for (int w = 0; w < W; w++) out[col + 64 * w] = s[w];
+}
+
+static hipEvent_t e0, e1;
+template <class F>
+static double timeit(F f, int reps = 5) {
+  f();
+  double best = 1e30;
+  for (int r = 0; r < reps; r++) {
+    float ms;
+    (void)hipEventRecord(e0);
+    f();
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    best = ms < best ? ms : best;
+  }
+  return best;
+}
+int main() {
+  const size_t S = 2ull << 30, n = S / 16;
+  f4 *a, *b;
+  float* out;
+  (void)hipMalloc(&a, 2 * S);
+  (void)hipMalloc(&b, 2 * S);
+  (void)hipMalloc(&out, 64);
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  wr<1, false><<<4096, 256>>>(a, 2 * n, 0.37f);
+  wr<1, false><<<4096, 256>>>(b, 2 * n, 0.11f);
+  (void)hipDeviceSynchronize();
+  printf("bytes per launch: read / write 2 GiB, copy 2 + 2 GiB, mix 2 + 4 GiB; best of 5\n");
+  for (int grid : {1024, 2048, 4096, 8192, 16384}) {
+    printf("grid %5d | read  U1 %.2f  U4 %.2f  U8 %.2f  U8nt %.2f | write %.2f  nt %.2f | copy U1 %.2f  U4 %.2f  U4 nt-st %.2f  U4 nt-ld-st %.2f  U8 nt-st %.2f | "
+           "mix1:2 U4 %.2f  U4 nt-st %.2f  (TB/s)\n",
+           grid, S / (timeit([&] { rd<1, false><<<grid, 256>>>(a, n, out); }) * 1e9), S / (timeit([&] { rd<4, false><<<grid, 256>>>(a, n, out); }) * 1e9),
+           S / (timeit([&] { rd<8, false><<<grid, 256>>>(a, n, out); }) * 1e9), S / (timeit([&] { rd<8, true><<<grid, 256>>>(a, n, out); }) * 1e9),
+           S / (timeit([&] { wr<1, false><<<grid, 256>>>(b, n, 1.f); }) * 1e9), S / (timeit([&] { wr<1, true><<<grid, 256>>>(b, n, 1.f); }) * 1e9),
+           2 * S / (timeit([&] { cp<1, false, false><<<grid, 256>>>(a, b, n); }) * 1e9), 2 * S / (timeit([&] { cp<4, false, false><<<grid, 256>>>(a, b, n); }) * 1e9),
+           2 * S / (timeit([&] { cp<4, false, true><<<grid, 256>>>(a, b, n); }) * 1e9), 2 * S / (timeit([&] { cp<4, true, true><<<grid, 256>>>(a, b, n); }) * 1e9),
+           2 * S / (timeit([&] { cp<8, false, true><<<grid, 256>>>(a, b, n); }) * 1e9),
+           3 * S / (timeit([&] { mix12<4, false><<<grid, 256>>>(a, b, n); }) * 1e9), 3 * S / (timeit([&] { mix12<4, true><<<grid, 256>>>(a, b, n); }) * 1e9));
+  }
+  // the pre-mix pattern: 1024 rows of 480,000 floats (1.97 GB)
+  const int rows = 1024;
+  const size_t rowlen16 = 480000 / 4;
+  const double bytes = (double)rows * rowlen16 * 16;
+  printf("rows pattern (1024 rows x 480,000 floats): ");
+  printf("W1 U8 %.2f  ", bytes / (timeit([&] { rows_sum<8, 1><<<(unsigned)((rowlen16 + 63) / 64), 256>>>(a, rows, rowlen16, b); }) * 1e9));
+  printf("W2 U8 %.2f  ", bytes / (timeit([&] { rows_sum<8, 2><<<(unsigned)((rowlen16 + 127) / 128), 256>>>(a, rows, rowlen16, b); }) * 1e9));
+  printf("W4 U4 %.2f  ", bytes / (timeit([&] { rows_sum<4, 4><<<(unsigned)((rowlen16 + 255) / 256), 256>>>(a, rows, rowlen16, b); }) * 1e9));
+  printf("W4 U8 %.2f  ", bytes / (timeit([&] { rows_sum<8, 4><<<(unsigned)((rowlen16 + 255) / 256), 256>>>(a, rows, rowlen16, b); }) * 1e9));
+  printf("W8 U4 %.2f  (TB/s)\n", bytes / (timeit([&] { rows_sum<4, 8><<<(unsigned)((rowlen16 + 511) / 512), 256>>>(a, rows, rowlen16, b); }) * 1e9));
+  // rows at a stride of exactly 2 MiB (what 1024 separate allocations give), with and without a per-row skew
+  {
+    const size_t st16 = (2u << 20) / 16;
+    f4* big;
+    (void)hipMalloc(&big, (size_t)rows * (2u << 20) + (64u << 20));
+    wr<1, false><<<4096, 256>>>(big, ((size_t)rows * (2u << 20) + (64u << 20)) / 16, 0.5f);
+    (void)hipDeviceSynchronize();
+    printf("rows 2 MiB apart: ");
+    for (size_t skewB : {0, 256, 1024, 4096, 4352, 16384, 69632}) {
+      const size_t sk = skewB / 16;
+      printf("skew %zu B: %.2f  ", skewB, bytes / (timeit([&] { rows_sum<8, 1><<<(unsigned)((rowlen16 + 63) / 64), 256>>>(big, rows, rowlen16, b, st16, sk); }) * 1e9));
+    }
+    printf("(TB/s)\n");
+  }
+  return 0;
+}
