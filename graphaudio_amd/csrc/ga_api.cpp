@@ -365,8 +365,10 @@ int ga_set_option(ga_context* ctx, const char* key, double value) {
     else if (k == "coarse_carry") c.coarseCarry = value != 0;
     else if (k == "coarse_tail") c.coarseTail = value != 0;
     else if (k == "coarse_premix") c.coarsePremix = value != 0;
+    else if (k == "coarse_ext_history") c.coarseExtHist = value != 0;
     else if (k == "host_direct") c.hostDirect = value != 0;
     else if (k == "host_defer") c.hostDefer = value != 0;
+    else if (k == "comm_timeout_s") c.commTimeoutS = std::max(1.0, value);
     else if (k == "host_copy_stream") c.hostCopyStream = value != 0;
     else if (k == "coarse_min_blocks") c.coarseMinBlocks = std::max<int64_t>(1, (int64_t)value);
     else if (k == "debug_tconv_n2") c.debugTconvN2 = (int)value;   // tests only: plan the block-axis FFT with this (possibly unsupported) length
@@ -424,6 +426,7 @@ int ga_buffer_create(ga_context* ctx, const float* const* planar, int channels, 
     }
     GA_HIP(hipStreamSynchronize(c.stream));
     c.buffers.push_back(std::move(b));
+    c.bufVersion++;
     *out_id = (int)c.buffers.size() - 1;
   });
 }

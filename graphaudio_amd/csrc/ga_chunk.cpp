@@ -1443,6 +1443,22 @@ static const float* convChunkInput(Context& c, Exec& ex, const std::vector<Views
   return slab;
 }
 
+// the hist_len samples in front of the chunk of input channel `ch`: a span of a PlayableAudioBuffer, the node's own copy, or nothing yet
+static const float* coarseHistory(const NodeS& nd, int ch) {
+  if (ch < (int)nd.dHistExt.size() && nd.dHistExt[ch].first) return nd.dHistExt[ch].first;
+  return nd.dHistZero ? nullptr : nd.dHist[nd.dHistCur] + (size_t)ch * nd.dHistLen;
+}
+// If the last hist_len samples of this chunk's input are device memory that stays (a PlayableAudioBuffer played zero-copy), the
+// next chunk's history is that span and nothing has to be written; otherwise the span is forgotten and the caller copies.
+static bool coarseHistoryStays(Context& c, NodeS& nd, int ch, const float* in, int64_t frames) {
+  if ((int)nd.dHistExt.size() < nd.bInCh) nd.dHistExt.resize(nd.bInCh, {nullptr, -1});
+  const int64_t hl = nd.dHistLen;
+  int buf = -1;
+  if (c.coarseExtHist && in && frames >= hl) buf = c.persistentBuffer(in + (frames - hl), hl);
+  nd.dHistExt[ch] = buf >= 0 ? std::make_pair(in + (frames - hl), buf) : std::make_pair((const float*)nullptr, -1);
+  return buf >= 0;
+}
+
 // One convolver stage of a chunk in formulation D, planned in five passes (Context::chunkPlanConvolvers calls planCoarseStage).
 namespace {
 struct CoarseStage {
@@ -1537,10 +1553,12 @@ void CoarseStage::resolveInputs() {
     bool allSame = true;
     for (int ch = 1; ch < nd.bInCh; ch++) allSame = allSame && (chIn[ch] == chIn[0]);
     if (nd.bShared && !allSame) {   // the channels start to differ: every channel inherits the (so far common) history
-      if (!nd.dHistZero)
-        for (int ch = 1; ch < nd.bInCh; ch++)
-          GA_HIP(hipMemcpyAsync(nd.dHist[nd.dHistCur] + (size_t)ch * hl, nd.dHist[nd.dHistCur], (size_t)hl * sizeof(float),
-                                hipMemcpyDeviceToDevice, c.stream));
+      if (const float* h0 = coarseHistory(nd, 0))
+        for (int ch = 1; ch < nd.bInCh; ch++) {
+          GA_HIP(hipMemcpyAsync(nd.dHist[nd.dHistCur] + (size_t)ch * hl, h0, (size_t)hl * sizeof(float), hipMemcpyDeviceToDevice, c.stream));
+          if (ch < (int)nd.dHistExt.size()) nd.dHistExt[ch] = {nullptr, -1};
+        }
+      if (nd.dHistZero && coarseHistory(nd, 0)) nd.dHistZero = false;   // (the copies above are the channels' histories now)
       nd.bShared = false;
     }
   }
@@ -1645,10 +1663,12 @@ void CoarseStage::buildRows() {
       // a member of a pre-mixed group: nothing to transform for it; its samples join the group's sum and its own history of the
       // next chunk is written on the way (or by a copy job where that is not possible)
       for (int ch = 0; ch < nxr; ch++) {
-        const float* oldHist = nd.dHistZero ? nullptr : nd.dHist[nd.dHistCur] + (size_t)ch * hl;
+        const float* oldHist = coarseHistory(nd, ch);
         float* nextHist = nd.dHist[nd.dHistCur ^ 1] + (size_t)ch * hl;
         PremixTerm t{chIn[ch], nullptr};
-        if (c.coarseCarry && chIn[ch] && frames >= hl && ((uintptr_t)nextHist & 15) == 0) {
+        if (coarseHistoryStays(c, nd, ch, chIn[ch], frames)) {
+          // (the next chunk's history is a span of the member's sample buffer)
+        } else if (c.coarseCarry && chIn[ch] && frames >= hl && ((uintptr_t)nextHist & 15) == 0) {
           t.carry = nextHist;
           pmBytes += (double)hl * 4.0;
         } else {
@@ -1666,7 +1686,7 @@ void CoarseStage::buildRows() {
     int xFrame[32], xIndex[32];
     for (int ch = 0; ch < nxr; ch++) {
       CoarseXRow r;
-      const float* oldHist = nd.dHistZero ? nullptr : nd.dHist[nd.dHistCur] + (size_t)ch * hl;   // (kept up to date in every mode)
+      const float* oldHist = coarseHistory(nd, ch);   // (kept up to date in every mode)
       r.hist = carried ? nullptr : oldHist;
       r.in = chIn[ch];
       r.nvalid = frames;
@@ -1686,7 +1706,9 @@ void CoarseStage::buildRows() {
       float* nextHist = nd.dHist[nd.dHistCur ^ 1] + (size_t)ch * hl;
       r.carry = nullptr;
       r.carry_from = 0;
-      if (c.coarseCarry && r.in && frames >= hl && (((uintptr_t)r.in | (uintptr_t)nextHist) & 15) == 0) {
+      if (coarseHistoryStays(c, nd, ch, r.in, frames)) {
+        // (the next chunk's history is a span of the sample buffer the input aliases)
+      } else if (c.coarseCarry && r.in && frames >= hl && (((uintptr_t)r.in | (uintptr_t)nextHist) & 15) == 0) {
         r.carry = nextHist;
         r.carry_from = frames - hl;
         carryBytes[(int)xrows.size()] = (double)hl * 4.0;

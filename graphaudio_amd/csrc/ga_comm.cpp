@@ -6,12 +6,25 @@
 #include <cstring>
 #include <mutex>
 
+#include <chrono>
+#include <thread>
+
 #include "ga_engine.hpp"
+
+// RCCL is loaded with dlopen, so its declarations are restated below.  Where the header is present at build time the restated
+// constants and the by-value id are checked against it (a silent mismatch would corrupt the collective, not fail it).
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+static_assert(NCCL_UNIQUE_ID_BYTES == GA_COMM_ID_BYTES, "include/graphaudio_hip.h: GA_COMM_ID_BYTES != NCCL_UNIQUE_ID_BYTES");
+static_assert(sizeof(ncclUniqueId) == GA_COMM_ID_BYTES, "ncclUniqueId is passed by value as GA_COMM_ID_BYTES bytes");
+static_assert((int)ncclSuccess == 0 && (int)ncclInProgress == 7, "restated ncclResult_t values");
+static_assert((int)ncclFloat32 == 7 && (int)ncclSum == 0, "restated ncclDataType_t / ncclRedOp_t values");
+#endif
 
 namespace ga {
 
 namespace {
-// the few RCCL entry points used (rccl/rccl.h: NCCL_UNIQUE_ID_BYTES = 128, ncclFloat32 = 7, ncclSum = 0, ncclSuccess = 0)
+constexpr int kNcclSuccess = 0, kNcclInProgress = 7, kNcclFloat32 = 7, kNcclSum = 0;
 struct UniqueId {
   char internal[GA_COMM_ID_BYTES];
 };
@@ -21,6 +34,8 @@ struct Rccl {
   int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
   int (*Reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t) = nullptr;
+  int (*CommAbort)(void*) = nullptr;                 // (optional: older libraries)
+  int (*CommGetAsyncError)(void*, int*) = nullptr;   // (optional)
   const char* (*GetErrorString)(int) = nullptr;
   std::string error;
 };
@@ -41,6 +56,8 @@ Rccl& rccl() {
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
     r.Reduce = (decltype(r.Reduce))dlsym(r.lib, "ncclReduce");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+    r.CommAbort = (decltype(r.CommAbort))dlsym(r.lib, "ncclCommAbort");
+    r.CommGetAsyncError = (decltype(r.CommGetAsyncError))dlsym(r.lib, "ncclCommGetAsyncError");
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.Reduce || !r.GetErrorString) r.error = "RCCL library lacks an expected symbol";
   });
   return r;
@@ -80,13 +97,58 @@ void Context::commInit(const void* id, int nRanks, int rank) {
   commRank = rank;
 }
 
+// A rank that cannot take part in a collective its peers have already enqueued (its render failed) must not leave them waiting:
+// the communicator is aborted -- the peers' collectives then end with an error, which their commWait() turns into an error code.
+void Context::commAbort() {
+  if (!comm) return;
+  Rccl& r = rccl();
+  if (r.CommAbort) (void)r.CommAbort(comm);
+  else if (r.CommDestroy) (void)r.CommDestroy(comm);
+  comm = nullptr;
+  commDead = true;
+}
+
+// Wait for the stream of a context that has collectives in flight: a peer that died or aborted shows up as an asynchronous
+// error of the communicator (or, at worst, as the time limit of option "comm_timeout_s"), not as a wait that never ends.
+void Context::commWait() {
+  if (!comm) {
+    GA_HIP(hipStreamSynchronize(stream));
+    return;
+  }
+  Rccl& r = rccl();
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t q = hipStreamQuery(stream);
+    if (q == hipSuccess) return;
+    if (q != hipErrorNotReady) GA_HIP(q);
+    (void)hipGetLastError();
+    int async = kNcclSuccess;
+    if (r.CommGetAsyncError && r.CommGetAsyncError(comm, &async) == kNcclSuccess && async != kNcclSuccess && async != kNcclInProgress) {
+      const std::string what = r.GetErrorString ? r.GetErrorString(async) : "RCCL error";
+      commAbort();
+      fail(GA_ERR_DEVICE, "the communicator failed (a peer rank aborted or died): " + what);
+    }
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > commTimeoutS) {
+      commAbort();
+      fail(GA_ERR_DEVICE, "timed out waiting for the sharded render's collective (option comm_timeout_s)");
+    }
+    std::this_thread::sleep_for(std::chrono::microseconds(200));
+  }
+}
+
 void Context::commDestroy() {
   if (comm) {
-    if (stream) (void)hipStreamSynchronize(stream);
+    try {
+      if (stream) commWait();
+    } catch (...) {   // (commWait aborted the communicator)
+    }
+  }
+  if (comm) {
     Rccl& r = rccl();
     if (r.CommDestroy) (void)r.CommDestroy(comm);
     comm = nullptr;
   }
+  commDead = false;
   commRanks = 0;
   commRank = 0;
   if (reduceBuf) {
@@ -101,6 +163,7 @@ void Context::commDestroy() {
 // renders and reduces call k)
 void Context::renderReduce(float* const* out, int channels, int64_t frames, int64_t start, int root) {
   if (commRanks < 1) fail(GA_ERR_INVALID_OPERATION, "ga_comm_init has not been called on this context");
+  if (commDead) fail(GA_ERR_INVALID_OPERATION, "the communicator was aborted after an error; ga_comm_destroy and ga_comm_init again");
   if (root < 0 || root >= commRanks) fail(GA_ERR_OUT_OF_RANGE, "root");
   if (channels < 1 || channels > 32) fail(GA_ERR_OUT_OF_RANGE, "channelIndex");
   if (frames <= 0) fail(GA_ERR_OUT_OF_RANGE, "Frame count must be positive.");
@@ -130,10 +193,25 @@ void Context::renderReduce(float* const* out, int channels, int64_t frames, int6
     render(rows, channels, frames, 0, true);
     if (comm) {
       Rccl& r = rccl();
-      check(r, r.Reduce(reduceBuf, reduceBuf, (size_t)channels * frames, /*ncclFloat32*/ 7, /*ncclSum*/ 0, root, comm, stream), "ncclReduce");
+      check(r, r.Reduce(reduceBuf, reduceBuf, (size_t)channels * frames, kNcclFloat32, kNcclSum, root, comm, stream), "ncclReduce");
     }
     if (isRoot) {
-      if (callerAsync && ownStream && hostCopyStream) {
+      // page-locked rows of an asynchronous caller: the sum crosses PCIe inside the next step's pre-mix launch (Context::pendingHandOver)
+      float* devAlias[32];
+      bool locked = callerAsync && hostDefer && (frames % 4) == 0;
+      for (int ch = 0; ch < channels && locked; ch++) {
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, out[ch] + start) != hipSuccess || at.type != hipMemoryTypeHost || !at.devicePointer ||
+            (((uintptr_t)at.devicePointer) & 15)) {
+          (void)hipGetLastError();
+          locked = false;
+        } else {
+          devAlias[ch] = (float*)at.devicePointer;
+        }
+      }
+      if (locked) {
+        for (int ch = 0; ch < channels; ch++) pendingHandOver.push_back(HandOver{rows[ch], devAlias[ch], out[ch] + start, frames});
+      } else if (callerAsync && ownStream && hostCopyStream) {
         handOverToHost(rows, out, channels, start, frames);   // (leaves on the copy stream: ga_engine.hpp)
       } else {
         for (int ch = 0; ch < channels; ch++)
@@ -142,11 +220,13 @@ void Context::renderReduce(float* const* out, int channels, int64_t frames, int6
     }
   } catch (...) {
     asyncMode = callerAsync;
+    commAbort();   // the peers have (or will have) this step's collective on their streams: do not leave them waiting
     throw;
   }
   asyncMode = callerAsync;
   if (!callerAsync) {
-    GA_HIP(hipStreamSynchronize(stream));
+    flushHandOver();
+    commWait();
     harvestProfile(true);
   }
 }

@@ -25,6 +25,20 @@ float* Context::dallocSkewed(size_t bytes, void** base, size_t* total) {
   *base = dalloc(*total);
   return (float*)((char*)*base + (size_t)(skewSeq++ % 64) * 1024);
 }
+int Context::persistentBuffer(const float* p, int64_t n) {
+  if (!p || n <= 0) return -1;
+  if (bufSpansVersion != bufVersion) {
+    bufSpans.clear();
+    for (size_t i = 0; i < buffers.size(); i++)
+      if (buffers[i] && buffers[i]->dev) bufSpans.push_back(BufSpan{buffers[i]->dev, buffers[i]->dev + (size_t)buffers[i]->stride * buffers[i]->channels, (int)i});
+    std::sort(bufSpans.begin(), bufSpans.end(), [](const BufSpan& a, const BufSpan& b) { return a.lo < b.lo; });
+    bufSpansVersion = bufVersion;
+  }
+  auto it = std::upper_bound(bufSpans.begin(), bufSpans.end(), p, [](const float* q, const BufSpan& s) { return q < s.lo; });
+  if (it == bufSpans.begin()) return -1;
+  --it;
+  return (p >= it->lo && p + n <= it->hi) ? it->id : -1;
+}
 void Context::dfree(void* p, size_t bytes) {
   if (!p) return;
   (void)hipFree(p);
@@ -192,6 +206,8 @@ void Context::collectGarbage() {
       if (!np || np->disposed) continue;
       if (np->bufId >= 0 && np->bufId < (int)used.size()) used[np->bufId] = 1;
       if (np->irBuf >= 0 && np->irBuf < (int)used.size()) used[np->irBuf] = 1;
+      for (auto& e : np->dHistExt)   // a convolver's input history that is a span of the buffer (NodeS::dHistExt)
+        if (e.first && e.second >= 0 && e.second < (int)used.size()) used[e.second] = 1;
       if (np->type == GA_NODE_STREAM_SOURCE) {   // queued, current and processed (not yet handed back) buffers of a stream
         if (np->stCurrent >= 0 && np->stCurrent < (int)used.size()) used[np->stCurrent] = 1;
         for (int id : np->stQueued) if (id >= 0 && id < (int)used.size()) used[id] = 1;
@@ -212,6 +228,7 @@ void Context::collectGarbage() {
       }
       PlayBuf& b = *buffers[id];
       if (b.devBase) dfree(b.devBase, b.devBytes);
+      bufVersion++;
       for (auto it = irCache.begin(); it != irCache.end();)   // spectra built from it stay with the convolvers that hold them
         it = it->first.first == id ? irCache.erase(it) : std::next(it);
       buffers[id].reset();
@@ -267,7 +284,7 @@ void Context::flushHandOver() {
 void Context::synchronize() {
   GA_HIP(hipSetDevice(device));
   flushHandOver();
-  GA_HIP(hipStreamSynchronize(stream));
+  commWait();   // (= hipStreamSynchronize without a communicator)
   waitHostCopies();
   harvestProfile(true);
 }
@@ -439,6 +456,7 @@ void Context::releaseConvState(NodeS& n) {
   n.dTailSig = 0;
   n.dTailSeq = ~0ull - 1;
   n.dHist[0] = n.dHist[1] = nullptr;
+  n.dHistExt.clear();
   n.dHistLen = 0;
   n.dHistCur = 0;
   n.dHistZero = true;

@@ -239,6 +239,10 @@ struct NodeS {
   bool bHistZero = true;
   // formulation D (convPath 4): the state of a node is the last coarseP x 8192 INPUT samples of every input channel (time
   // domain, double buffered: a chunk reads one copy and writes the other); overlap-save keeps nothing on the output side
+  // ... unless the samples in front of the next chunk ARE device memory that stays: a source played without resampling hands its
+  // PlayableAudioBuffer itself to the convolver (zero-copy views), so the history of the next chunk is a span of that buffer --
+  // nothing is copied (dHistExt[ch] = {first sample of the span, buffer id}; the buffer is kept alive by Context::collectGarbage)
+  std::vector<std::pair<const float*, int>> dHistExt;
   float* dHist[2] = {nullptr, nullptr};   // [bInCh][dHistLen]  (inside the allocations dHistBase: Context::dallocSkewed)
   void* dHistBase[2] = {nullptr, nullptr};
   size_t dHistBytes = 0;
@@ -555,6 +559,13 @@ struct Context {
   // TB/s against 6.1 for the pre-mix kernel's access pattern (tools/proto/hbm_peak.hip).  Each row therefore starts 1 KiB
   // further into its allocation than the one before (mod 64).  `*base` / `*total` are what dfree() takes.
   float* dallocSkewed(size_t bytes, void** base, size_t* total);
+  // id of the live PlayableAudioBuffer whose device storage holds all of [p, p + n), -1 if none (a sorted table, rebuilt when buffers
+  // come or go: bufVersion)
+  int persistentBuffer(const float* p, int64_t n);
+  struct BufSpan { const float* lo; const float* hi; int id; };
+  std::vector<BufSpan> bufSpans;
+  uint64_t bufVersion = 1, bufSpansVersion = 0;
+  bool coarseExtHist = true;   // option "coarse_ext_history"
   unsigned skewSeq = 0;
 
   // command queue (AudioContextBase.cs:266-305)
@@ -674,8 +685,12 @@ struct Context {
   int commRanks = 0, commRank = 0;
   float* reduceBuf = nullptr;    // [channels][frames] contiguous
   size_t reduceBytes = 0;
+  bool commDead = false;         // aborted after a local failure or a failed / timed-out collective: ga_comm_destroy + ga_comm_init
+  double commTimeoutS = 120.0;   // option "comm_timeout_s"
   void commInit(const void* id, int nRanks, int rank);
   void commDestroy();
+  void commAbort();
+  void commWait();               // wait for the stream; a dead peer becomes an error code, not a hang
   void renderReduce(float* const* out, int channels, int64_t frames, int64_t start, int root);
 
   int64_t busCapFrames = 0;

@@ -8,15 +8,15 @@ set -e
 TAG=${1:-r02}; shift || true
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf /tmp/prof_stats /tmp/prof_f /tmp/prof_w
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o st -- python3 bench.py --no-cpu-baseline "$@" > gpurun_out/${TAG}_bench_under_rocprof.json 2> gpurun_out/${TAG}_stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o st -- python3 bench.py --no-cpu-baseline --no-variants "$@" > gpurun_out/${TAG}_bench_under_rocprof.json 2> gpurun_out/${TAG}_stats.err
 cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) gpurun_out/${TAG}_kernel_stats.csv
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/prof_f -o f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > gpurun_out/${TAG}_bench_pmc_pass.json 2> gpurun_out/${TAG}_f.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/prof_w -o w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > /dev/null 2> gpurun_out/${TAG}_w.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/prof_f -o f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants "$@" > gpurun_out/${TAG}_bench_pmc_pass.json 2> gpurun_out/${TAG}_f.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/prof_w -o w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants "$@" > /dev/null 2> gpurun_out/${TAG}_w.err
 python3 - "$TAG" <<'PY'
 import csv, glob, json, sys, collections
 tag = sys.argv[1]
 bench = json.loads(open(f"gpurun_out/{tag}_bench_under_rocprof.json").read().strip().splitlines()[-1])
-stage_of = {"coarse_fwd_kernel": "coarse_fwd", "coarse_mac_kernel": "coarse_mac", "coarse_sum_kernel": "coarse_mac", "coarse_inv_kernel": "coarse_inv", "coarse_hist_kernel": "coarse_hist",
+stage_of = {"coarse_premix_kernel": "coarse_premix", "coarse_fwd_kernel": "coarse_fwd", "coarse_mac_kernel": "coarse_mac", "coarse_sum_kernel": "coarse_mac", "coarse_inv_kernel": "coarse_inv", "coarse_hist_kernel": "coarse_hist",
             "mix_kernel": "mix", "rfft_fwd_b_kernel": "rfft_fwd", "hist_copy_b_kernel": "rfft_fwd", "tconv16_kernel": "mac", "irfft_ola_b_kernel": "rfft_inv"}
 raw = {}
 for name, d in (("FETCH_SIZE", "/tmp/prof_f"), ("WRITE_SIZE", "/tmp/prof_w")):

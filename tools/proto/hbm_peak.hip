@@ -119,6 +119,35 @@ __global__ __launch_bounds__(256) void rows_sum(const f4* __restrict p, int rows
     for (int w = 0; w < W; w++) out[col + 64 * w] = s[w];
 }
 
+// the same with row base pointers from a table: rows as SEPARATE allocations (what ga_buffer_create makes)
+template <int U>
+__global__ __launch_bounds__(256) void rows_ptr(const f4* const* __restrict tab, int rows, size_t rowlen16, f4* __restrict out) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const size_t col = (size_t)blockIdx.x * 64 + lane;
+  if ((size_t)blockIdx.x * 64 >= rowlen16) return;
+  f4 s = f4{0, 0, 0, 0};
+  const int r0 = rows / 4 * wv, r1 = r0 + rows / 4;
+  for (int r = r0; r + U <= r1; r += U) {
+    f4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) v[u] = ((const gf4*)tab[r + u])[col];
+#pragma unroll
+    for (int u = 0; u < U; u++) s += v[u];
+  }
+  if (s.x == 12345.678f) out[col] = s;
+}
+
+__global__ void fill_noise(f4* p, size_t n) {   // (audio is noise, not a constant: every bit toggles)
+  for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    unsigned h = (unsigned)i * 2654435761u;
+    f4 v;
+    h ^= h >> 15; h *= 2246822519u; v.x = (float)(int)h * 1e-10f;
+    h ^= h >> 13; h *= 3266489917u; v.y = (float)(int)h * 1e-10f;
+    h ^= h >> 16; h *= 2654435761u; v.z = (float)(int)h * 1e-10f;
+    h ^= h >> 15; h *= 2246822519u; v.w = (float)(int)h * 1e-10f;
+    p[i] = v;
+  }
+}
 static hipEvent_t e0, e1;
 template <class F>
 static double timeit(F f, int reps = 5) {
@@ -182,6 +211,44 @@ int main() {
       printf("skew %zu B: %.2f  ", skewB, bytes / (timeit([&] { rows_sum<8, 1><<<(unsigned)((rowlen16 + 63) / 64), 256>>>(big, rows, rowlen16, b, st16, sk); }) * 1e9));
     }
     printf("(TB/s)\n");
+  }
+  {
+    fill_noise<<<4096, 256>>>(a, 2 * n);
+    (void)hipDeviceSynchronize();
+    printf("rows pattern on NOISE data: W1 U8 %.2f  read U8nt grid 8192 %.2f (TB/s)\n",
+           bytes / (timeit([&] { rows_sum<8, 1><<<(unsigned)((rowlen16 + 63) / 64), 256>>>(a, rows, rowlen16, b); }) * 1e9),
+           S / (timeit([&] { rd<8, true><<<8192, 256>>>(a, n, out); }) * 1e9));
+  }
+  // 1024 separate allocations of one row each (+ 64 KB), rows starting (i % 64) x skew bytes into their allocation
+  for (size_t skewB : {0, 1024}) {
+    std::vector<const f4*> hp(rows);
+    std::vector<void*> bases(rows);
+    for (int r = 0; r < rows; r++) {
+      (void)hipMalloc(&bases[r], rowlen16 * 16 + 65536);
+      hp[r] = (const f4*)((char*)bases[r] + (size_t)(r % 64) * skewB);
+      wr<1, false><<<256, 256>>>((f4*)bases[r], (rowlen16 * 16 + 65536) / 16, 0.25f);
+    }
+    const f4** tab;
+    (void)hipMalloc(&tab, rows * sizeof(void*));
+    (void)hipMemcpy(tab, hp.data(), rows * sizeof(void*), hipMemcpyHostToDevice);
+    printf("1024 separate allocations, skew %zu B: %.2f TB/s (first bases %p %p %p)\n", skewB,
+           bytes / (timeit([&] { rows_ptr<8><<<(unsigned)((rowlen16 + 63) / 64), 256>>>(tab, rows, rowlen16, b); }) * 1e9), bases[0], bases[1], bases[2]);
+    for (int r = 0; r < rows; r++) (void)hipFree(bases[r]);
+    (void)hipFree(tab);
+  }
+  // ... and carved out of one arena at their natural stride (row bytes rounded up to 1 KB)
+  {
+    const size_t rb = (rowlen16 * 16 + 1023) / 1024 * 1024 + 1024;
+    void* arena;
+    (void)hipMalloc(&arena, rb * rows);
+    wr<1, false><<<4096, 256>>>((f4*)arena, rb * rows / 16, 0.25f);
+    std::vector<const f4*> hp(rows);
+    for (int r = 0; r < rows; r++) hp[r] = (const f4*)((char*)arena + rb * r);
+    const f4** tab;
+    (void)hipMalloc(&tab, rows * sizeof(void*));
+    (void)hipMemcpy(tab, hp.data(), rows * sizeof(void*), hipMemcpyHostToDevice);
+    printf("rows carved out of one arena (stride %zu B): %.2f TB/s\n", rb,
+           bytes / (timeit([&] { rows_ptr<8><<<(unsigned)((rowlen16 + 63) / 64), 256>>>(tab, rows, rowlen16, b); }) * 1e9));
   }
   return 0;
 }
