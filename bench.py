@@ -437,6 +437,7 @@ def main():
     ap.add_argument("--no-carry", action="store_true", help="formulation D: copy the input history with its own kernel instead of from the forward transforms (measurement)")
     ap.add_argument("--copy-stream", action="store_true", help="hand the bus to the host on a copy stream of its own (measurement)")
     ap.add_argument("--sync-steps", action="store_true", help="one blocking render per step (no host/device pipelining)")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="ga_set_option on the main context (measurements)")
     ap.add_argument("--library", default="", help="load this build of the library instead of the product (tools/build_variant.sh; measurements)")
     ap.add_argument("--force-dist", action="store_true", help="exercise the sharded-render path (ga_render_reduce) even with one rank")
     args = ap.parse_args()
@@ -503,6 +504,9 @@ def main():
         ctx.SetOption("host_direct", 0)
     if args.copy_stream:
         ctx.SetOption("host_copy_stream", 1)
+    for kv in args.opt:
+        k, v = kv.split("=", 1)
+        ctx.SetOption(k, float(v))
     check = not args.no_check and not args.no_profile
     xsum = np.zeros(frames, np.float64) if check and not args.private_ir else None
     build_graph(ctx, v1 - v0, v0, args.taps, frames, G, private=args.private_ir, xsum=xsum)

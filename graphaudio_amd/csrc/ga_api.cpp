@@ -368,6 +368,7 @@ int ga_set_option(ga_context* ctx, const char* key, double value) {
     else if (k == "coarse_ext_history") c.coarseExtHist = value != 0;
     else if (k == "host_direct") c.hostDirect = value != 0;
     else if (k == "host_defer") c.hostDefer = value != 0;
+    else if (k == "table_upload_kernel") c.tableUploadKernel = value != 0;
     else if (k == "comm_timeout_s") c.commTimeoutS = std::max(1.0, value);
     else if (k == "host_copy_stream") c.hostCopyStream = value != 0;
     else if (k == "coarse_min_blocks") c.coarseMinBlocks = std::max<int64_t>(1, (int64_t)value);

@@ -856,10 +856,33 @@ struct Exec {
   std::vector<ResampleBlock> traj;  // per-chunk trajectory table (all rates + custom tail blocks)
   bool mixAligned = true;
   // conv inputs: node -> slot -> per segment view
-  std::unordered_map<int, std::vector<Views>> convIn;
+  // conv inputs: node -> per segment views of its input channels (a dense table: one lookup per convolver and pass)
+  struct ConvInRow {   // the per-segment views of one node (a window of ConvIn::flat)
+    Views* p = nullptr;
+    size_t n = 0;
+    bool empty() const { return n == 0; }
+    size_t size() const { return n; }
+    Views& operator[](size_t i) const { return p[i]; }
+  };
+  struct ConvIn {
+    std::vector<int> slot;     // node id -> index of its row, -1 = the node's input was not resolved in this chunk
+    std::vector<Views> flat;   // [row][segment]
+    size_t nsegs = 1, used = 0;
+    bool has(int id) const { return id < (int)slot.size() && slot[id] >= 0; }
+    ConvInRow operator[](int id) {
+      if (id >= (int)slot.size()) slot.resize(id + 1, -1);
+      if (slot[id] < 0) {
+        slot[id] = (int)used++;
+        if (flat.size() < used * nsegs) flat.resize(std::max(used * nsegs, 2 * flat.size()));
+      }
+      return ConvInRow{flat.data() + (size_t)slot[id] * nsegs, nsegs};
+    }
+  } convIn;
 
   Exec(Context& c_, int64_t n_, std::vector<Segment>& s) : c(c_), n(n_), frames(n_ * kBlock), segs(s) {
     nodeSlab01.assign(c.nodes.size() * 2, nullptr);
+    convIn.slot.assign(c.nodes.size(), -1);
+    convIn.nsegs = std::max<size_t>(segs.size(), 1);
   }
 
   float* slabFor(std::unordered_map<uint64_t, float*>& m, uint64_t key) {
@@ -1373,6 +1396,19 @@ void Context::streamReplay(NodeS& s, int64_t nblocks, const std::vector<double>&
 // may receive the sum of the group as ONE term -- the leader's output -- and nothing from the other members.  What changes
 // is only the association of the float32 additions (the reference adds the members one by one in connection order).
 void Context::planCoarseFusion(const std::vector<int>& topo, const std::vector<Segment>& segs) {
+  // The grouping is a function of the graph, of the convolvers' formulations and impulse responses and of the segments' control
+  // state (who is a term of which input): while none of them moved since the previous chunk the leaders stand.
+  {
+    uint64_t key = hmix(graphVersion, (uint64_t)segs.size());
+    for (const Segment& sg : segs) key = hmix(key, sg.hash);
+    for (int id : topo) {
+      const NodeS& nd = *nodes[id];
+      if (nd.type == GA_NODE_CONVOLVER) key = hmix(hmix(key, ((uint64_t)id << 8) | (uint64_t)nd.convPath), (uint64_t)(uintptr_t)nd.ir.get());
+    }
+    if (fusionKeyValid && key == fusionKey) return;
+    fusionKey = key;
+    fusionKeyValid = true;
+  }
   std::vector<int> cand;
   for (int id : topo) {
     NodeS& nd = *nodes[id];
@@ -1416,7 +1452,7 @@ void Context::planCoarseFusion(const std::vector<int>& topo, const std::vector<S
 }
 
 // chunk-long view of input channel `c` of a convolver: the segment views when they agree, else a materialised copy
-static const float* convChunkInput(Context& c, Exec& ex, const std::vector<Views>& ci, int ch) {
+static const float* convChunkInput(Context& c, Exec& ex, const Exec::ConvInRow& ci, int ch) {
   const auto& segs = ex.segs;
   const float* stable = nullptr;
   bool same = true, first = true;
@@ -1486,9 +1522,10 @@ struct CoarseStage {
     int members = 0, nxr = 0, bInCh0 = 0, bSlots0 = 0;
     bool ts0 = false;
     int64_t hl0 = 0;
-    std::vector<PremixTerm> inTerms[32], histTerms[32];   // per input channel of the group
+    struct Terms { std::vector<PremixTerm> in[32], hist[32]; };   // per input channel of the group
+    std::unique_ptr<Terms> terms;                                 // (pre-mixed groups only)
   };
-  std::map<int, std::vector<const float*>> chInOf;   // node -> chunk-long views of its input channels
+  std::vector<Views> chInOf;   // [position in dNodes]: chunk-long views of the node's input channels
   std::vector<PremixJob> pmJobs;
   std::vector<PremixTerm> pmTerms;
   size_t pmUsed = 0;       // bytes of the pre-mix arena handed out
@@ -1532,11 +1569,13 @@ struct CoarseStage {
 };
 
 void CoarseStage::resolveInputs() {
-  for (int id : dNodes) {
+  chInOf.resize(dNodes.size());
+  for (size_t di = 0; di < dNodes.size(); di++) {
+    const int id = dNodes[di];
     NodeS& nd = *c.nodes[id];
     const int64_t hl = nd.dHistLen;
-    auto& ci = ex.convIn[id];
-    std::vector<const float*>& chIn = chInOf[id];
+    const Exec::ConvInRow ci = ex.convIn[id];
+    Views& chIn = chInOf[di];
     chIn.assign(nd.bInCh, nullptr);
     auto viewOf = [&](size_t si, int ch) { return (ci[si].empty() || ch >= (int)ci[si].size()) ? (const float*)nullptr : ci[si][ch]; };
     for (int ch = 0; ch < nd.bInCh; ch++) {
@@ -1647,7 +1686,8 @@ void CoarseStage::addPieces(NodeS& nd, int leader, int nxr, const int* xFrame, c
 }
 
 void CoarseStage::buildRows() {
-  for (int id : dNodes) {
+  for (size_t di = 0; di < dNodes.size(); di++) {
+    const int id = dNodes[di];
     NodeS& nd = *c.nodes[id];
     IrSpectra& ir = *nd.ir;
     const int P = ir.coarseP;
@@ -1655,7 +1695,7 @@ void CoarseStage::buildRows() {
     const int64_t hl = nd.dHistLen;
     GroupInfo& gi0 = groups[nd.dLeader >= 0 ? nd.dLeader : id];
     const bool carried = gi0.noHist;   // no windows in front of the chunk
-    const std::vector<const float*>& chIn = chInOf[id];
+    const Views& chIn = chInOf[di];
     const int nxr = nd.bShared ? 1 : nd.bInCh;
     c.stats.mac_flops_total += 8.0 * ir.P * kBins * (double)nd.bSlots * (double)n;
     c.stats.mac_bytes_total += ((double)ir.P * kBins * 8.0 + kBins * 8.0 + 512.0) * nd.bSlots * (double)n;
@@ -1676,8 +1716,9 @@ void CoarseStage::buildRows() {
           maxHist = std::max(maxHist, hl);
           histBytes += 2.0 * (double)hl * 4.0;
         }
-        gi0.inTerms[ch].push_back(t);
-        if (!carried) gi0.histTerms[ch].push_back(PremixTerm{oldHist, nullptr});
+        if (!gi0.terms) gi0.terms = std::make_unique<GroupInfo::Terms>();
+        gi0.terms->in[ch].push_back(t);
+        if (!carried) gi0.terms->hist[ch].push_back(PremixTerm{oldHist, nullptr});
       }
       nd.dHistCur ^= 1;
       nd.dHistZero = false;
@@ -1750,8 +1791,9 @@ void CoarseStage::buildRows() {
         pmMaxN = std::max(pmMaxN, len);
         pmBytes += (double)len * 4.0;
       };
-      if (!g.noHist) job(mixed, g.histTerms[ch], hl, hl);
-      job(mixed + hl, g.inTerms[ch], frames, std::max<int64_t>(0, frames - hl));
+      if (!g.terms) g.terms = std::make_unique<GroupInfo::Terms>();
+      if (!g.noHist) job(mixed, g.terms->hist[ch], hl, hl);
+      job(mixed + hl, g.terms->in[ch], frames, std::max<int64_t>(0, frames - hl));
       CoarseXRow r{};
       r.hist = g.noHist ? nullptr : mixed;
       r.in = mixed + hl;
@@ -3040,9 +3082,7 @@ void Context::chunkPlanNodes(ChunkRun& r, int d) {
           case GA_NODE_CONVOLVER: {
             auto iv = ex.resolveInput((int)si, ns, 0, false, nullptr);
             if (!nd.ir) break;  // no IR: cleared output (ConvolverNode.cs:107-119)
-            auto& ci = ex.convIn[ns.id];
-            if (ci.empty()) ci.assign(segs.size(), Views());
-            ci[si] = iv;
+            ex.convIn[ns.id][si] = iv;
             // formulation D: the outputs of a fused group are summed as spectra; the sum is the LEADER's output, the other
             // members hand their consumer a null (= contributes nothing) view (Context::planCoarseFusion)
             if (nd.convPath == 4 && nd.dLeader >= 0 && nd.dLeader != ns.id) break;
@@ -3093,7 +3133,7 @@ void Context::chunkPlanConvolvers(ChunkRun& r, int d) {
     for (int id : topo) {
       NodeS& nd = *nodes[id];
       if (nd.type != GA_NODE_CONVOLVER || !nd.ir || nd.depth != d) continue;
-      if (ex.convIn.find(id) == ex.convIn.end()) continue;
+      if (!ex.convIn.has(id)) continue;
       if (nd.convPath == 4) {
         dNodes.push_back(id);
         continue;
@@ -3116,7 +3156,7 @@ void Context::chunkPlanConvolvers(ChunkRun& r, int d) {
         const int idx = nd.convRows[slot].idx;
         // which input channel feeds this row: discrete -> slot ; true stereo -> L,L,R,R for h0,h1,h2,h3 (ConvolverNode.cs:127-151)
         const int inCh = nd.isTrueStereo ? (slot >> 1) : slot;
-        auto& ci = ex.convIn[ns_.first];
+        const Exec::ConvInRow ci = ex.convIn[ns_.first];
         const float* stable = nullptr;
         bool same = true, first = true;
         for (size_t si = 0; si < segs.size(); si++) {
@@ -3233,7 +3273,7 @@ void Context::chunkPlanConvolvers(ChunkRun& r, int d) {
       for (int id : bNodes) {
         NodeS& nd = *nodes[id];
         const int P = nd.ir->P, h = P - 1;
-        auto& ci = ex.convIn[id];
+        const Exec::ConvInRow ci = ex.convIn[id];
         // chunk-long input pointer of every input channel (stable view, or a materialised copy)
         chIn.assign(nd.bInCh, nullptr);
         for (int c = 0; c < nd.bInCh; c++) {
@@ -3514,12 +3554,13 @@ void Context::chunkExecute(ChunkRun& r) {
       GA_HIP(hipStreamSynchronize(stream));
       (void)hipHostFree(thost);
     }
-    thostBytes = tbytes + tbytes / 4 + 4096;
+    thostBytes = (tbytes + tbytes / 4 + 4096 + 15) & ~(size_t)15;
     GA_HIP(hipHostMalloc(&thost, thostBytes, hipHostMallocDefault));
   }
   ensure(tables, std::max(tablesHostBytes, tablesHostBBytes));
   std::memcpy(thost, ex.plan.host.data(), tbytes);
-  GA_HIP(hipMemcpyAsync(tables.p, thost, tbytes, hipMemcpyHostToDevice, stream));
+  if (tableUploadKernel) launch_table_upload(stream, tables.p, thost, tbytes);   // (staging and arena sizes are multiples of 16)
+  else GA_HIP(hipMemcpyAsync(tables.p, thost, tbytes, hipMemcpyHostToDevice, stream));
   uint8_t* base = (uint8_t*)tables.p;
 
   std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;

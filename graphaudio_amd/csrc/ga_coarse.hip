@@ -847,7 +847,10 @@ constexpr int kPremixAhead = GA_PREMIX_AHEAD, kPremixWaves = GA_PREMIX_WAVES;
 #ifndef GA_PREMIX_WORDS
 #define GA_PREMIX_WORDS 1   // 16-byte words per lane and term: a wave reads GA_PREMIX_WORDS KB in a row from a member before it moves on
 #endif
-constexpr int kPremixCopyWgs = 32;   // workgroups that carry one row of a hand-over across PCIe
+#ifndef GA_PREMIX_COPY_WGS
+#define GA_PREMIX_COPY_WGS 8
+#endif
+constexpr int kPremixCopyWgs = GA_PREMIX_COPY_WGS;   // workgroups that carry one row of a hand-over across PCIe
 constexpr int kPremixWords = GA_PREMIX_WORDS, kPremixTile = 256 * kPremixWords;   // frames per workgroup
 struct Kahan4 {
   v4f s, c;
@@ -1004,6 +1007,16 @@ void launch_coarse_hist(hipStream_t s, const CoarseHistJob* jobs_dev, int njobs,
   const int gx = (int)std::min<int64_t>((max_len / 4 + 255) / 256, 64);
   for (int j0 = 0; j0 < njobs; j0 += 32768)
     hipLaunchKernelGGL(coarse_hist_kernel, dim3(gx, std::min(32768, njobs - j0)), dim3(256), 0, s, jobs_dev + j0);
+}
+
+__global__ __launch_bounds__(256) void table_upload_kernel(v4f* __restrict dst, const v4f* __restrict src, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) ((GA_GLOBAL v4f*)dst)[i] = ((const GA_GLOBAL v4f*)src)[i];
+}
+void launch_table_upload(hipStream_t s, void* dst, const void* src_pinned, size_t bytes) {
+  const size_t n16 = (bytes + 15) / 16;
+  if (!n16) return;
+  const unsigned grid = (unsigned)std::min<size_t>((n16 + 255) / 256, 64);
+  hipLaunchKernelGGL(table_upload_kernel, dim3(grid), dim3(256), 0, s, (v4f*)dst, (const v4f*)src_pinned, n16);
 }
 
 }  // namespace ga

@@ -461,6 +461,7 @@ void Context::releaseConvState(NodeS& n) {
   n.dHistCur = 0;
   n.dHistZero = true;
   n.dLeader = -1;
+  fusionKeyValid = false;
   n.bHistR = n.bHistI = n.bOverlap = nullptr;
   n.bHistPlane = -1;
   n.convPath = 0;

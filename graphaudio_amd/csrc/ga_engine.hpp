@@ -518,6 +518,7 @@ struct Context {
   float* xPlane(int pair, int im) { return (float*)(pair == 0 ? planesB[im].p : planesBalt[im].p); }
   void flushPlaneHistories(int pair); // moves them to the nodes' private stores (before the pair is rewritten)
   DevArena tables;         // per-chunk job tables
+  bool tableUploadKernel = true;   // option "table_upload_kernel": the job tables reach the device by a kernel, not by the DMA engine
   void* tablesHost = nullptr;      // pinned staging of the job tables (buffer 0)
   size_t tablesHostBytes = 0;
   // option "async": render calls return after the work is enqueued (the host simulation and planning of the next call
@@ -640,6 +641,8 @@ struct Context {
   const float2* twiddles16pw();
   void ensureCoarseSpectra(IrSpectra& ir);
   void planCoarseFusion(const std::vector<int>& topo, const std::vector<Segment>& segs);
+  uint64_t fusionKey = 0;      // what the current dLeader assignment was derived from (planCoarseFusion)
+  bool fusionKeyValid = false;
   void aliasBusToLeader(ChunkRun& r);
   ConvRowRef addGroupRow(const std::shared_ptr<IrSpectra>& ir, int ch, int depth, int nodeId);
   void ensureGroupState(ConvGroup& g);

@@ -208,6 +208,10 @@ const char* launch_coarse_mac(hipStream_t s, const CoarseJob* jobs_dev, int njob
 const char* launch_coarse_inv(hipStream_t s, const CoarseOut* outs_dev, int nouts, int n_t, const int* ylist_dev, const float2* Y, int y_frames,
                        const float2* tw16, const float2* twab);
 void launch_coarse_hist(hipStream_t s, const CoarseHistJob* jobs_dev, int njobs, int64_t max_len);
+// A chunk's job tables, page-locked host memory -> device memory, by a kernel on the chunk's own stream: a copy by the DMA engine
+// in front of the first kernel costs two engine hand-overs (~ 20 us each way in the traces), a kernel in front of a kernel one
+// launch gap.  `bytes` is a multiple of 16; src is the device-visible address of hipHostMalloc'ed memory.
+void launch_table_upload(hipStream_t s, void* dst, const void* src_pinned, size_t bytes);
 
 // ---- graph plumbing kernels ------------------------------------------------------------------------
 // out[f0 + i] = ((0 + t0[f0+i]) + t1[f0+i]) + ...  in term order (AudioNodeInput.cs:118-132,182-244)
