@@ -423,6 +423,8 @@ def main():
     ap.add_argument("--no-variants", action="store_true", help="skip the per-voice / private-IR / config 5 variants of the default run")
     ap.add_argument("--no-check", action="store_true", help="skip the float64 check of the last timed step")
     ap.add_argument("--variant-steps", type=int, default=6)
+    ap.add_argument("--only-variant", choices=["per_voice_spectra", "private_ir", "config5_1gpu"], default="",
+                    help="measure just this variant (--steps / --warmup apply) and print ITS record: profiling runs (tools/collect_profiles.sh)")
     ap.add_argument("--baseline-blocks", type=int, default=375)
     ap.add_argument("--baseline-cores", type=int, default=0)
     ap.add_argument("--direct", action="store_true", help="direct (matrix-core) partition sum, formulation A")
@@ -451,6 +453,21 @@ def main():
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
 
     frames = int(round(args.seconds * SR)) // 128 * 128
+    if args.only_variant:
+        import torch
+        if args.library:
+            from graphaudio_amd import _capi
+            _capi.use_library(os.path.abspath(args.library))
+        from tests import _graphs as G
+        builds = {"per_voice_spectra": (lambda c: build_graph(c, args.voices, 0, args.taps, frames, G), 2, {"coarse_premix": 0}),
+                  "private_ir": (lambda c: build_graph(c, args.voices, 0, args.taps, frames, G, private=True), 2, {}),
+                  "config5_1gpu": (lambda c: build_config5(c, 512, 0, 32768, frames, G), 16, {})}
+        build, ch, opts = builds[args.only_variant]
+        for kv in args.opt:
+            k, v = kv.split("=", 1)
+            opts[k] = float(v)
+        print(json.dumps(run_variant(args.only_variant, torch, G, frames, args.steps, args.warmup, build, ch, opts, args.only_variant)))
+        return
     all_cores = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         all_cores = cpu_all_cores(args.voices, args.taps, args)   # before anything initialises the GPU in this process

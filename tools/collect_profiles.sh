@@ -12,7 +12,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o st --
 cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) gpurun_out/${TAG}_kernel_stats.csv
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/prof_f -o f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants "$@" > gpurun_out/${TAG}_bench_pmc_pass.json 2> gpurun_out/${TAG}_f.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/prof_w -o w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants "$@" > /dev/null 2> gpurun_out/${TAG}_w.err
-python3 - "$TAG" <<'PY'
+python3 - "$TAG" "$@" <<'PY'
 import csv, glob, json, sys, collections
 tag = sys.argv[1]
 bench = json.loads(open(f"gpurun_out/{tag}_bench_under_rocprof.json").read().strip().splitlines()[-1])
@@ -32,7 +32,7 @@ for r in csv.DictReader(open(f"gpurun_out/{tag}_kernel_stats.csv")):
     k = r["Name"].split("(")[0].replace("void ", "").split("<")[0].replace("ga::", "")
     s = stats.setdefault(k, {"calls": 0, "total_ns": 0.0})
     s["calls"] += int(r["Calls"]); s["total_ns"] += float(r["TotalDurationNs"])
-out = {"command": "python3 bench.py " + " ".join(sys.argv[2:]), "units": "FETCH_SIZE / WRITE_SIZE as rocprofv3 reports them: kilobytes (x1024 B) per dispatch",
+out = {"command": "python3 bench.py --no-cpu-baseline --no-variants " + " ".join(sys.argv[2:]), "units": "FETCH_SIZE / WRITE_SIZE as rocprofv3 reports them: kilobytes (x1024 B) per dispatch",
        "fetch_correction": "MI355X_MICROARCH.md, HBM: on gfx950 FETCH_SIZE reports exactly half the bytes of a wide coalesced streaming read (16 B/lane) -> x2; "
                            "other widths are uncalibrated (coarse_hist_kernel reads 4 B/lane, coarse_fwd_kernel 8 B/lane: see calibration column)",
        "kernels": {}}
