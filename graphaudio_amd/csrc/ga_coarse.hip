@@ -312,7 +312,10 @@ const char* launch_coarse_fwd(hipStream_t s, const CoarseXRow* rows_dev, int nro
 #endif
 constexpr int kMacWaves = GA_MAC_WAVES;      // waves per workgroup: each takes 1/kMacWaves of the job's coarse blocks
 constexpr int kMacThreads = 64 * kMacWaves;
-constexpr int kMacWavesPerSimd = kMacWaves / 2;   // two workgroups per CU (LDS), four SIMDs
+#ifndef GA_MAC_WGS_PER_CU
+#define GA_MAC_WGS_PER_CU 2
+#endif
+constexpr int kMacWavesPerSimd = kMacWaves * GA_MAC_WGS_PER_CU / 4;   // workgroups per CU (LDS) x waves, four SIMDs
 // (launches whose terms all share one impulse response take coarse_sum_kernel below instead)
 template <int CW, int TW, int PB>
 __global__ __launch_bounds__(kMacThreads, kMacWavesPerSimd) void coarse_mac_kernel(const CoarseJob* __restrict jobs, const CoarseTerm* __restrict terms,
@@ -353,10 +356,13 @@ __global__ __launch_bounds__(kMacThreads, kMacWavesPerSimd) void coarse_mac_kern
   auto issue_h = [&](const CoarseTerm& T, f2* hs) {   // P x CW rows of 512 bytes
     for (int pc0 = 2 * wv; pc0 < P * CW; pc0 += 2 * kMacWaves) {
       const int pc = pc0 + (lane >> 5), of = lane & 31;
-      if (pc < P * CW) {
-        const int p = pc / CW, c = pc % CW;
-        __builtin_amdgcn_global_load_lds(gptr(T.h[c] + (size_t)p * kCoarseBins + binoff + 2 * of), (lds_t)(hs + pc0 * 64), 16, 0, 0);
-      }
+      // the two rows' base addresses are wave-uniform (scalar loads of the term's descriptor: a per-lane descriptor load is a
+      // vector-memory instruction whose result the address needs at once -- a vmcnt(0) in the middle of the staging)
+      const int pA = pc0 / CW, cA = pc0 % CW, pB = (pc0 + 1) / CW, cB = (pc0 + 1) % CW;
+      const float2* rowA = T.h[cA] + (size_t)pA * kCoarseBins;
+      const float2* rowB = pc0 + 1 < P * CW ? T.h[cB] + (size_t)pB * kCoarseBins : rowA;
+      if (pc < P * CW)
+        __builtin_amdgcn_global_load_lds(gptr(((lane >> 5) ? rowB : rowA) + binoff + 2 * of), (lds_t)(hs + pc0 * 64), 16, 0, 0);
     }
   };
 
