@@ -40,6 +40,7 @@ internal static unsafe partial class GraphAudioHip
         public fixed byte stage_kernel[1024];    // [16][64] zero-terminated names
         public long coarse_premixed_signals;
         public long deferred_handovers;
+        public long biquad_split_cascades;
     }
 
     [LibraryImport(Lib, EntryPoint = "ga_strerror")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]

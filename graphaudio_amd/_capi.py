@@ -84,6 +84,7 @@ class Stats(C.Structure):
         ("stage_kernel", (C.c_char * 64) * 16),
         ("coarse_premixed_signals", C.c_int64),
         ("deferred_handovers", C.c_int64),
+        ("biquad_split_cascades", C.c_int64),
     ]
     STAGES = ("other", "mix", "rfft_fwd", "mac", "rfft_inv", "coarse_fwd", "coarse_mac", "coarse_inv", "coarse_hist", "coarse_section")
 

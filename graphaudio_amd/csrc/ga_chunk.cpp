@@ -842,6 +842,12 @@ struct Exec {
   std::vector<GainJob> gainJobs;
   std::vector<BiquadJob> bqJobs[kMaxBiquadSections + 1];  // by cascade length
   std::vector<BiquadSection> bqSecs;
+  // cascades split along time (ga_kernels.hpp, BiquadScanJob): pass A / pass B pieces by cascade length, the scans, A^K matrices
+  std::vector<BiquadScanJob> bqScans[kMaxBiquadSections + 1];          // by cascade length; all of one level share G and K
+  std::vector<const std::vector<float>*> bqMats[kMaxBiquadSections + 1];   // their A^K -> m_off once the table exists
+  int bqG = 0;
+  int64_t bqK = 0;
+  size_t bqZeroFrom = 0;   // Context::bqSplitUsed up to which the pieces' states are already covered by a zeroing launch
   std::vector<BiquadDynJob> bqDynJobs;
   std::vector<LoopJob> loopJobs;
   std::vector<ResampleJob> rsJobs;
@@ -1141,6 +1147,46 @@ struct Exec {
           });
         }
       }
+    }
+    if (bqG > 1) {   // cascades split along time: expand the pieces, zero their states, pass A, scan, pass B
+      const size_t soff = plan.putv(bqSecs);
+      hipStream_t st = c.stream;
+      Context* cp = &c;
+      const int G = bqG;
+      const int64_t K = bqK;
+      struct Grp { size_t off; int n, k; BiquadJob* pa; BiquadJob* pb; };
+      std::vector<Grp> grps;
+      for (int k = 1; k <= kMaxBiquadSections; k++) {
+        if (bqScans[k].empty()) continue;
+        for (size_t i = 0; i < bqScans[k].size(); i++) bqScans[k][i].m_off = (uint64_t)plan.putv(*bqMats[k][i]);
+        const int n = (int)bqScans[k].size();
+        // the expanded job tables live in the same blocks as the pieces' states (in chunks that fit a block)
+        const int per = (int)std::max<size_t>(1, Context::kBqSplitBlock / sizeof(BiquadJob) / (size_t)G);
+        for (int i0 = 0; i0 < n; i0 += per) {
+          const int m = std::min(per, n - i0);
+          std::vector<BiquadScanJob> part(bqScans[k].begin() + i0, bqScans[k].begin() + i0 + m);
+          BiquadJob* pa = (BiquadJob*)c.bqSplitAlloc((size_t)m * (G - 1) * sizeof(BiquadJob) / sizeof(float));
+          BiquadJob* pb = (BiquadJob*)c.bqSplitAlloc((size_t)m * G * sizeof(BiquadJob) / sizeof(float));
+          grps.push_back(Grp{plan.putv(part), m, k, pa, pb});
+        }
+      }
+      const size_t used0 = bqZeroFrom, used1 = c.bqSplitUsed;
+      bqZeroFrom = used1;
+      plan.add(LK_OTHER, [=](uint8_t* base) {
+        // zero states for pass A: the ranges of the blocks handed out since the previous level (the job tables in them are written next)
+        for (size_t b = used0 / Context::kBqSplitBlock; b * Context::kBqSplitBlock < used1; b++) {
+          const size_t lo = std::max(used0, b * Context::kBqSplitBlock), hi = std::min(used1, (b + 1) * Context::kBqSplitBlock);
+          if (hi > lo) GA_HIP(hipMemsetAsync((char*)cp->bqSplitBlocks[b] + lo % Context::kBqSplitBlock, 0, hi - lo, st));
+        }
+        for (const Grp& g : grps) launch_biquad_split_expand(st, (const BiquadScanJob*)(base + g.off), g.n, G, K, g.pa, g.pb);
+        for (const Grp& g : grps) launch_biquad_lanes(st, g.pa, g.n * (G - 1), (const BiquadSection*)(base + soff), g.k);
+        for (const Grp& g : grps) launch_biquad_scan(st, (const BiquadScanJob*)(base + g.off), g.n, G, (const BiquadSection*)(base + soff), base);
+        for (const Grp& g : grps) launch_biquad_lanes(st, g.pb, g.n * G, (const BiquadSection*)(base + soff), g.k);
+      });
+      for (auto& v : bqScans) v.clear();
+      for (auto& v : bqMats) v.clear();
+      bqG = 0;
+      bqK = 0;
     }
     if (!bqDynJobs.empty()) {
       size_t off = plan.putv(bqDynJobs);
@@ -2712,7 +2758,7 @@ void Context::chunkPlanNodes(ChunkRun& r, int d) {
         fuseAbs[a_.id] = b_.id;
         fuseLen[b_.id] = la_ + 1;
       }
-      int curLevel = -1;
+      int curLevel = -1, levelBqHeads = 0;
       for (size_t ti = 0; ti < todo.size(); ti++) {
         const NodeSeg* nsp = todo[ti];
         if (ti + 4 < todo.size()) {   // (the sweep is bound by cache misses on the node records)
@@ -2726,6 +2772,11 @@ void Context::chunkPlanNodes(ChunkRun& r, int d) {
         if (nd.level != curLevel) {
           ex.flushLevel();
           curLevel = nd.level;
+          levelBqHeads = 0;   // constant-coefficient cascade outputs of this level (all levels' biquad launches are separate)
+          for (size_t tj = ti; tj < todo.size() && nodes[todo[tj]->id]->level == curLevel; tj++) {
+            const NodeSeg& o = *todo[tj];
+            if (nodes[o.id]->type == GA_NODE_BIQUAD && o.bqActive && !o.bqDynamic && absorbedBy.get(o.id) < 0) levelBqHeads += std::max(o.outCh, 1);
+          }
         }
         auto& ov = ex.outViews[si][ns.id];
         ov.assign(nd.type == GA_NODE_CHANNEL_SPLITTER ? (int)nd.outputs.size() : std::max(ns.outCh, 1), nullptr);
@@ -3059,6 +3110,28 @@ void Context::chunkPlanNodes(ChunkRun& r, int d) {
               NodeS& cnd = *nodes[cn->id];
               ensureBiquadState(cnd);
             }
+            // pieces along time (ga_kernels.hpp, BiquadScanJob): as many as keep every lane of the chip busy, each >= 1024 frames;
+            // mode 1: only cascades whose float32 rounding noise is so small that a different rounding stays inside the budget
+            int G = 1;
+            float coefs[5 * kMaxBiquadSections];
+            if (biquadTimeSplit && nf >= biquadSplitMinFrames) {
+              const int64_t lanes = 64 * 1024, heads = std::max(levelBqHeads, 1);
+              G = (int)std::max<int64_t>(1, std::min<int64_t>({(lanes + heads - 1) / heads, nf / 1024, 256}));
+              int q = 0;
+              for (const NodeSeg* cn : chain) {
+                coefs[5 * q] = cn->b0; coefs[5 * q + 1] = cn->b1; coefs[5 * q + 2] = cn->b2; coefs[5 * q + 3] = cn->a1; coefs[5 * q + 4] = cn->a2;
+                q++;
+              }
+              if (biquadTimeSplit == 1 && biquadDeviation(coefs, (int)chain.size()) > biquadSplitMaxDeviation) G = 1;
+            }
+            int64_t K = G > 1 ? ((nf + G - 1) / G + 3) / 4 * 4 : nf;
+            if (G > 1) G = (int)((nf + K - 1) / K);
+            if (G > 1 && ex.bqG == 0) {
+              ex.bqG = G;
+              ex.bqK = K;
+            }
+            if (G > 1 && (G != ex.bqG || K != ex.bqK)) G = 1;   // (one cut per level: the pieces of a level are expanded by one launch)
+            const std::vector<float>* AK = G > 1 ? &biquadTransition(coefs, (int)chain.size(), K).M : nullptr;
             for (int ch = 0; ch < ns.outCh; ch++) {
               BiquadJob bj;
               bj.in = iv[ch] ? iv[ch] : zeros;
@@ -3067,6 +3140,7 @@ void Context::chunkPlanNodes(ChunkRun& r, int d) {
               bj.nsec = (int)chain.size();
               bj.f0 = f0;
               bj.n = nf;
+              bj.state = nullptr;
               for (const NodeSeg* cn : chain) {
                 BiquadSection sc;
                 sc.b0 = cn->b0; sc.b1 = cn->b1; sc.b2 = cn->b2; sc.a1 = cn->a1; sc.a2 = cn->a2;
@@ -3074,8 +3148,15 @@ void Context::chunkPlanNodes(ChunkRun& r, int d) {
                 sc.state = nodes[cn->id]->bqState + 2 * ch;
                 ex.bqSecs.push_back(sc);
               }
-              ex.bqJobs[bj.nsec].push_back(bj);
               ov[ch] = bj.out;
+              if (G <= 1) {
+                ex.bqJobs[bj.nsec].push_back(bj);
+                continue;
+              }
+              stats.biquad_split_cascades++;
+              float* scratch = bqSplitAlloc((size_t)(G - 1) * bj.nsec * 2);
+              ex.bqMats[bj.nsec].push_back(AK);
+              ex.bqScans[bj.nsec].push_back(BiquadScanJob{bj.in, bj.out, 0, scratch, bj.sec0, bj.nsec, f0, nf});
             }
             break;
           }
@@ -3712,6 +3793,7 @@ void Context::runChunkImpl(int64_t nblocks, float* const* /*unused*/) {
   chunkSimulate(r);
   chunkResources(r);
   r.tmRes = nowMs();
+  bqSplitUsed = 0;   // (the blocks are reused chunk after chunk: every use is ordered on the stream behind the previous one)
   r.ex = std::make_unique<Exec>(*this, r.n, r.segs);
   r.ex->outViews.resize(r.segs.size());
   r.ex->plan.host.resize(16);  // reserved header

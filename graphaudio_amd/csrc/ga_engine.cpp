@@ -25,6 +25,132 @@ float* Context::dallocSkewed(size_t bytes, void** base, size_t* total) {
   *base = dalloc(*total);
   return (float*)((char*)*base + (size_t)(skewSeq++ % 64) * 1024);
 }
+// Predicted RMS difference between two float32 evaluations of a cascade that round differently, for white input of unit variance.
+double Context::biquadDeviation(const float* coefs, int nsec) {
+  std::vector<float> key(coefs, coefs + 5 * nsec);
+  uint64_t h = 1469598103934665603ull;
+  for (float f : key) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    h = (h ^ u) * 1099511628211ull;
+  }
+  auto& bucket = bqDeviations[h];
+  for (auto& e : bucket)
+    if (e.first == key) return e.second;
+  double dev = 1.0;
+  // Rounding-noise model (white input): the rounding of section q's  w = x - a1 w1 - a2 w2  is an error of ~ 2^-24 / sqrt(3) |w|
+  // entering at that section's input; it reaches the output through sections q .. nsec-1.  With g_q = energy of the impulse response
+  // input -> w_q and t_q = energy of (input of section q -> output), the noise-to-signal ratio is eps^2 sum_q g_q t_q / energy of the
+  // whole cascade; two evaluations that round differently differ by sqrt(2) of that.
+  {
+    const int N = 1 << 14;
+    std::vector<double> sig(N, 0.0);
+    sig[0] = 1.0;
+    std::vector<std::vector<double>> wq(nsec);
+    for (int q = 0; q < nsec; q++) {   // impulse response of the first q sections + 1/A_q: the W of section q
+      const double b0 = coefs[5 * q], b1 = coefs[5 * q + 1], b2 = coefs[5 * q + 2], a1 = coefs[5 * q + 3], a2 = coefs[5 * q + 4];
+      wq[q].resize(N);
+      double w1 = 0, w2 = 0;
+      for (int i = 0; i < N; i++) {
+        const double w = sig[i] - a1 * w1 - a2 * w2;
+        wq[q][i] = w;
+        sig[i] = b0 * w + b1 * w1 + b2 * w2;
+        w2 = w1;
+        w1 = w;
+      }
+    }
+    double eOut = 0;
+    for (double v : sig) eOut += v * v;
+    double acc = 0;
+    for (int q = 0; q < nsec; q++) {
+      std::vector<double> tail(N, 0.0);
+      tail[0] = 1.0;
+      for (int r = q; r < nsec; r++) {
+        const double b0 = coefs[5 * r], b1 = coefs[5 * r + 1], b2 = coefs[5 * r + 2], a1 = coefs[5 * r + 3], a2 = coefs[5 * r + 4];
+        double w1 = 0, w2 = 0;
+        for (int i = 0; i < N; i++) {
+          const double w = tail[i] - a1 * w1 - a2 * w2;
+          tail[i] = b0 * w + b1 * w1 + b2 * w2;
+          w2 = w1;
+          w1 = w;
+        }
+      }
+      double g = 0, tt = 0;
+      for (int i = 0; i < N; i++) {
+        g += wq[q][i] * wq[q][i];
+        tt += tail[i] * tail[i];
+      }
+      acc += g * tt;
+    }
+    const double eps = 5.96e-8 / 1.7320508;
+    // absolute, for white input of unit variance; x 3: what the measured deviations are above this model (tests/test_gpu_biquad_split.py)
+    (void)eOut;
+    dev = 3.0 * std::sqrt(2.0 * eps * eps * acc);
+  }
+  bucket.push_back({std::move(key), dev});
+  return dev;
+}
+// A^K of a cascade's state recursion (state = W1, W2 of every section, direct form II as in BiQuadFilterNode.cs:137-141), float64.
+const Context::BqTransition& Context::biquadTransition(const float* coefs, int nsec, int64_t K) {
+  const int D = 2 * nsec;
+  std::vector<float> key(coefs, coefs + 5 * nsec);
+  key.push_back((float)K);
+  uint64_t h = 1469598103934665603ull;
+  for (float f : key) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    h = (h ^ u) * 1099511628211ull;
+  }
+  auto& bucket = bqTransitions[h];
+  for (auto& t : bucket)
+    if (t.key == key) return t;
+  // one step from the unit states with zero input gives the columns of A
+  std::vector<double> A((size_t)D * D, 0.0), R((size_t)D * D, 0.0), T((size_t)D * D);
+  for (int j = 0; j < D; j++) {
+    std::vector<double> st(D, 0.0);
+    st[j] = 1.0;
+    double x = 0.0;
+    for (int q = 0; q < nsec; q++) {
+      const double b0 = coefs[5 * q], b1 = coefs[5 * q + 1], b2 = coefs[5 * q + 2], a1 = coefs[5 * q + 3], a2 = coefs[5 * q + 4];
+      const double w1 = st[2 * q], w2 = st[2 * q + 1];
+      const double w = x - a1 * w1 - a2 * w2;
+      x = b0 * w + b1 * w1 + b2 * w2;
+      st[2 * q + 1] = w1;
+      st[2 * q] = w;
+    }
+    for (int r = 0; r < D; r++) A[(size_t)r * D + j] = st[r];
+  }
+  for (int i = 0; i < D; i++) R[(size_t)i * D + i] = 1.0;
+  auto mul = [&](std::vector<double>& out, const std::vector<double>& a, const std::vector<double>& b) {
+    for (int i = 0; i < D; i++)
+      for (int j = 0; j < D; j++) {
+        double acc = 0.0;
+        for (int k = 0; k < D; k++) acc += a[(size_t)i * D + k] * b[(size_t)k * D + j];
+        T[(size_t)i * D + j] = acc;
+      }
+    out = T;
+  };
+  for (int64_t e = K; e > 0; e >>= 1) {
+    if (e & 1) mul(R, R, A);
+    if (e > 1) mul(A, A, A);
+  }
+  BqTransition t;
+  t.key = std::move(key);
+  t.M.resize((size_t)D * D);
+  for (size_t i = 0; i < t.M.size(); i++) t.M[i] = (float)R[i];
+  bucket.push_back(std::move(t));
+  return bucket.back();
+}
+float* Context::bqSplitAlloc(size_t floats) {
+  const size_t bytes = (floats * sizeof(float) + 63) & ~(size_t)63;
+  if (bytes > kBqSplitBlock) fail(GA_ERR_INVALID_OPERATION, "internal: biquad split state larger than a block");
+  if (bqSplitUsed / kBqSplitBlock != (bqSplitUsed + bytes - 1) / kBqSplitBlock) bqSplitUsed = (bqSplitUsed / kBqSplitBlock + 1) * kBqSplitBlock;
+  const size_t blk = bqSplitUsed / kBqSplitBlock;
+  while (bqSplitBlocks.size() <= blk) bqSplitBlocks.push_back((float*)dalloc(kBqSplitBlock));
+  float* p = (float*)((char*)bqSplitBlocks[blk] + bqSplitUsed % kBqSplitBlock);
+  bqSplitUsed += bytes;
+  return p;
+}
 int Context::persistentBuffer(const float* p, int64_t n) {
   if (!p || n <= 0) return -1;
   if (bufSpansVersion != bufVersion) {
@@ -138,6 +264,7 @@ Context::~Context() {
   if (coarseY.p) (void)hipFree(coarseY.p);
   if (coarseM.p) (void)hipFree(coarseM.p);
   if (deferStage) (void)hipFree(deferStage);
+  for (float* p : bqSplitBlocks) (void)hipFree(p);
   if (ilvDev) (void)hipFree(ilvDev);
   if (tables.p) (void)hipFree(tables.p);
   if (tablesHost) (void)hipHostFree(tablesHost);

@@ -567,6 +567,25 @@ struct Context {
   std::vector<BufSpan> bufSpans;
   uint64_t bufVersion = 1, bufSpansVersion = 0;
   bool coarseExtHist = true;   // option "coarse_ext_history"
+  // constant-coefficient biquad cascades split along time (ga_kernels.hpp, BiquadScanJob): A^K per (coefficients, K), float64 on
+  // the host, remembered; the pieces' states live in blocks that are handed out per chunk and kept
+  int biquadTimeSplit = 1;            // option "biquad_time_split": 0 never, 1 where the predicted deviation is small (below), 2 always
+  int64_t biquadSplitMinFrames = 16384;   // option "biquad_split_min_frames": segments shorter than this stay one walk
+  // biquadDeviation: predicted RMS difference between two float32 evaluations of the cascade that round differently (the one walk
+  // and the split): rounding noise injected at every section's W, shaped by the rest of the cascade.  Direct form II at low cut-offs is the hard case (large W, cancelling output taps): e.g. the 100 Hz low shelf of
+  // config 4 carries ~1e-4 of such noise IN THE REFERENCE'S OWN ARITHMETIC, so no re-association can stay within 1e-5 of it.
+  struct BqTransition { std::vector<float> key; std::vector<float> M; };
+  std::unordered_map<uint64_t, std::vector<std::pair<std::vector<float>, double>>> bqDeviations;
+  double biquadDeviation(const float* coefs, int nsec);
+  std::unordered_map<uint64_t, std::vector<BqTransition>> bqTransitions;
+  const BqTransition& biquadTransition(const float* coefs, int nsec, int64_t K);   // coefs: [nsec][5] = b0 b1 b2 a1 a2
+  // mode 1 splits a cascade when that prediction (absolute, unit-variance white input) is below this: with audio at sigma <= 0.25
+  // a thousand such cascades summed incoherently stay within north_star's 1e-5
+  double biquadSplitMaxDeviation = 2.5e-6;   // option "biquad_split_max_deviation"
+  std::vector<float*> bqSplitBlocks;   // blocks of kBqSplitBlock bytes
+  size_t bqSplitUsed = 0;              // bytes handed out in the current chunk
+  static constexpr size_t kBqSplitBlock = (size_t)4 << 20;
+  float* bqSplitAlloc(size_t floats);
   unsigned skewSeq = 0;
 
   // command queue (AudioContextBase.cs:266-305)

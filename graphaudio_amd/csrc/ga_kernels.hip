@@ -1549,7 +1549,7 @@ __global__ __launch_bounds__(64) void biquad_kernel(const BiquadJob* __restrict 
   BiquadJob me{};
   if (have) me = jobs[myj];
   const float* inb = have ? me.in + me.f0 : nullptr;
-  float* outb = have ? me.out + me.f0 : nullptr;
+  float* outb = (have && me.out) ? me.out + me.f0 : nullptr;
   float b0[NSEC], b1[NSEC], b2[NSEC], a1[NSEC], a2[NSEC], w1[NSEC], w2[NSEC];
   float* st[NSEC];
 #pragma unroll
@@ -1559,9 +1559,9 @@ __global__ __launch_bounds__(64) void biquad_kernel(const BiquadJob* __restrict 
     if (have) {
       const BiquadSection sc = secs[me.sec0 + q];
       b0[q] = sc.b0; b1[q] = sc.b1; b2[q] = sc.b2; a1[q] = sc.a1; a2[q] = sc.a2;
-      st[q] = sc.state;
-      w1[q] = ldg1(sc.state);
-      w2[q] = ldg1(sc.state + 1);
+      st[q] = me.state ? me.state + 2 * q : sc.state;
+      w1[q] = ldg1(st[q]);
+      w2[q] = ldg1(st[q] + 1);
     }
   }
   const int64_t n = have ? me.n : 0;
@@ -1695,6 +1695,7 @@ __global__ __launch_bounds__(64) void biquad_kernel(const BiquadJob* __restrict 
     for (int r = 0; r < JPW; r++) {
       if (r < jcount) {
         float* q = (float*)bcast_ptr(outb, r);
+        if (!q) continue;   // (a state-only job: pass A of a cascade split along time)
         int64_t nr = __builtin_amdgcn_readlane((int)n, r);
 #pragma unroll
         for (int u = 0; u < TM; u++) {
@@ -1755,9 +1756,9 @@ __global__ __launch_bounds__(64) void biquad_pipe_kernel(const BiquadJob* __rest
   if (have) {
     const BiquadSection sc = secs[me.sec0 + q];
     b0 = sc.b0; b1 = sc.b1; b2 = sc.b2; a1 = sc.a1; a2 = sc.a2;
-    st = sc.state;
-    w1 = ldg1(sc.state);
-    w2 = ldg1(sc.state + 1);
+    st = me.state ? me.state + 2 * q : sc.state;
+    w1 = ldg1(st);
+    w2 = ldg1(st + 1);
   }
   const int64_t n = have ? me.n : 0;
   int64_t nmax = n;
@@ -1871,6 +1872,72 @@ static void launch_biquad_pipe(hipStream_t s, const BiquadJob* jobs_dev, int njo
   int jpw = std::min(MAXJ, std::max(1, (njobs + 1023) / 1024));
   if (const char* e = expenv("GA_BQ_JPW")) jpw = std::min(MAXJ, std::max(1, atoi(e)));
   hipLaunchKernelGGL(biquad_pipe_kernel<NSEC>, dim3((njobs + jpw - 1) / jpw), dim3(64), 0, s, jobs_dev, njobs, secs_dev, jpw);
+}
+void launch_biquad_lanes(hipStream_t s, const BiquadJob* jobs_dev, int njobs, const BiquadSection* secs_dev, int nsec) {
+  if (njobs <= 0) return;
+  if (njobs <= 16 * 1024) launch_biquad_jpw<32>(s, jobs_dev, njobs, secs_dev, nsec);   // (more, emptier waves while the chip has room)
+  else launch_biquad_jpw<64>(s, jobs_dev, njobs, secs_dev, nsec);
+}
+// the pieces of every cascade as jobs of the lane-per-cascade kernel: thread = (cascade, piece)
+__global__ __launch_bounds__(256) void biquad_split_expand_kernel(const BiquadScanJob* __restrict casc, int ncasc, int G, int64_t K,
+                                                                 BiquadJob* __restrict passA, BiquadJob* __restrict passB) {
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= ncasc * G) return;
+  const int j = v / G, l = v % G;
+  const BiquadScanJob C = casc[j];
+  BiquadJob b;
+  b.in = C.in;
+  b.out = C.out;
+  b.sec0 = C.sec0;
+  b.nsec = C.nsec;
+  b.f0 = C.f0 + (int64_t)l * K;
+  b.n = min(K, C.n - (int64_t)l * K);
+  b.state = l + 1 < G ? C.scratch + (size_t)l * C.nsec * 2 : nullptr;   // the last piece runs on the cascade's own state
+  passB[(size_t)j * G + l] = b;
+  if (l + 1 < G) {
+    b.out = nullptr;
+    passA[(size_t)j * (G - 1) + l] = b;
+  }
+}
+void launch_biquad_split_expand(hipStream_t s, const BiquadScanJob* casc_dev, int ncasc, int G, int64_t K, BiquadJob* passA, BiquadJob* passB) {
+  if (ncasc <= 0) return;
+  hipLaunchKernelGGL(biquad_split_expand_kernel, dim3((ncasc * G + 255) / 256), dim3(256), 0, s, casc_dev, ncasc, G, K, passA, passB);
+}
+// s_{l+1} = A^K s_l + z_l (float64 accumulation); one thread per cascade
+__global__ __launch_bounds__(64) void biquad_scan_kernel(const BiquadScanJob* __restrict jobs, int njobs, int G, const BiquadSection* __restrict secs,
+                                                        const uint8_t* __restrict tables) {
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  if (j >= njobs) return;
+  const BiquadScanJob J = jobs[j];
+  const int D = 2 * J.nsec;
+  const float* Mg = (const float*)(tables + J.m_off);
+  double cur[2 * kMaxBiquadSections], nxt[2 * kMaxBiquadSections];
+  for (int q = 0; q < J.nsec; q++) {
+    const float* st = secs[J.sec0 + q].state;
+    cur[2 * q] = ldg1(st);
+    cur[2 * q + 1] = ldg1(st + 1);
+  }
+  for (int l = 0; l + 1 < G; l++) {
+    float* sc = J.scratch + (size_t)l * D;
+    for (int r = 0; r < D; r++) {
+      double a = (double)ldg1(sc + r);   // z_l
+      for (int c = 0; c < D; c++) a += (double)ldg1(Mg + r * D + c) * cur[c];
+      nxt[r] = a;
+    }
+    for (int r = 0; r < D; r++) {
+      stg1(sc + r, (float)cur[r]);       // s_l: where pass B's piece l starts
+      cur[r] = (double)(float)nxt[r];    // (the state is float in the filter)
+    }
+  }
+  for (int q = 0; q < J.nsec; q++) {     // s_{G-1}: the last piece starts from (and ends in) the cascade's own state
+    float* st = secs[J.sec0 + q].state;
+    stg1(st, (float)cur[2 * q]);
+    stg1(st + 1, (float)cur[2 * q + 1]);
+  }
+}
+void launch_biquad_scan(hipStream_t s, const BiquadScanJob* jobs_dev, int njobs, int G, const BiquadSection* secs_dev, const uint8_t* tables) {
+  if (njobs <= 0) return;
+  hipLaunchKernelGGL(biquad_scan_kernel, dim3((njobs + 63) / 64), dim3(64), 0, s, jobs_dev, njobs, G, secs_dev, tables);
 }
 void launch_biquad(hipStream_t s, const BiquadJob* jobs_dev, int njobs, const BiquadSection* secs_dev, int nsec) {
   if (njobs <= 0) return;

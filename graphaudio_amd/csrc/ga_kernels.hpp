@@ -259,13 +259,38 @@ struct BiquadSection {
 };
 struct BiquadJob {
   const float* in;
-  float* out;
+  float* out;     // nullptr: the job only advances its state (pass A of a cascade split along time)
   int sec0;       // first section in the section table
   int nsec;
   int64_t f0;
   int64_t n;
+  float* state;   // nullptr: every section's own `state` ; else {W1, W2} of section q at state + 2 q (a piece of a split cascade)
 };
 void launch_biquad(hipStream_t s, const BiquadJob* jobs_dev, int njobs, const BiquadSection* secs_dev, int nsec);
+
+// ---- constant-coefficient cascades split ALONG TIME (option "biquad_time_split") ---------------------------------------
+// A cascade is a linear time-invariant system  s[n+1] = A s[n] + B x[n]  with the 2 x nsec direct-form-II values (W1, W2 of every
+// section) as its state, so a long segment need not be one serial walk: cut into G pieces of K frames,
+//   pass A   every piece but the last is run from the ZERO state, outputs dropped: its final state z_l          (G - 1 pieces in parallel)
+//   scan     s_0 = the cascade's state ; s_{l+1} = A^K s_l + z_l                                             (per cascade, G - 1 steps)
+//   pass B   every piece is run from its true initial state s_l and writes its outputs                        (G pieces in parallel)
+// Each pass is the per-sample arithmetic of BiQuadFilterNode.cs:137-138 (the lane-per-cascade kernel, biquad_kernel<NSEC, 64>);
+// A^K comes from the host (float64, repeated squaring).  What differs from the one-walk evaluation is the rounding of the
+// pieces' initial states (not bit-exact; tests/test_gpu_biquad_split.py measures it): twice the arithmetic, G times the lanes.
+struct BiquadScanJob {   // one cascade (node chain x channel) cut into G pieces of K frames (the last one shorter)
+  const float* in;
+  float* out;
+  uint64_t m_off;     // offset of A^K (row-major [2 nsec][2 nsec], float) in the chunk's table
+  float* scratch;     // [G - 1][nsec][2]: in: z_l of pass A ; out: s_l, where pass B's piece l starts
+  int sec0, nsec;     // the cascade's own sections (their `state` is the persistent state: in s_0, out s_{G-1})
+  int64_t f0, n;
+};
+// the pieces of `ncasc` cascades as BiquadJobs, written on the device (the host tables stay one record per cascade):
+// pass A: ncasc x (G - 1) state-only jobs ; pass B: ncasc x G jobs
+void launch_biquad_split_expand(hipStream_t s, const BiquadScanJob* casc_dev, int ncasc, int G, int64_t K, BiquadJob* passA, BiquadJob* passB);
+// lane-per-cascade kernel for any number of jobs (a job with out == nullptr only advances its state)
+void launch_biquad_lanes(hipStream_t s, const BiquadJob* jobs_dev, int njobs, const BiquadSection* secs_dev, int nsec);
+void launch_biquad_scan(hipStream_t s, const BiquadScanJob* casc_dev, int ncasc, int G, const BiquadSection* secs_dev, const uint8_t* tables);
 
 // BiQuadFilterNode with automated parameters (BiQuadFilterNode.cs:87-147): one lane per NODE walks block by block and
 // channel by channel exactly like the reference, refreshing the coefficients whenever the per-sample frequency / Q move

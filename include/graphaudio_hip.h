@@ -116,6 +116,7 @@ typedef struct ga_stats {
                                       front of their group's transforms instead of being transformed one by one */
   int64_t deferred_handovers;   /* asynchronous renders whose bus crossed PCIe inside the next chunk's pre-mix launch (option
                                    "host_defer") instead of at the end of their own last kernel */
+  int64_t biquad_split_cascades; /* (cascade x channel, segment) pairs evaluated in pieces along time (option "biquad_time_split") */
 } ga_stats;
 enum {
   GA_STAGE_OTHER = 0,        /* sources, biquads, gains, parameter curves, ... */

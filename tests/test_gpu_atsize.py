@@ -131,7 +131,7 @@ def test_config5_16_channel_32768_tap_private_irs(coarse):
 
 def test_config2_256_voices_bit_exact():
     frames = 375 * 128
-    ref, got = both(G.config2_biquad, frames, voices=256, frames=frames)
+    ref, got = both(G.config2_biquad, frames, options={"biquad_time_split": 0}, voices=256, frames=frames)   # (the one-walk evaluation)
     report("config 2, 256 voices -> lowpass -> gain -> mono mix, 375 blocks", ref, got)
     assert G.rms(ref) > 1e-3
     assert np.array_equal(ref, got)
@@ -139,7 +139,7 @@ def test_config2_256_voices_bit_exact():
 
 def test_config4_512_voice_shard():
     frames = 375 * 128
-    ref, got = both(G.config4_eq, frames, voices=512, frames=frames)
+    ref, got = both(G.config4_eq, frames, options={"biquad_time_split": 0}, voices=512, frames=frames)   # (split: tests/test_gpu_biquad_split.py)
     err, sig = report("config 4, 512 voices (resampler + 5-band EQ + gain automation), 375 blocks", ref, got)
     assert sig > 1e-4
     assert err <= 1e-6, err     # constant-coefficient cascades and the resampler are bit-exact; the gain curve is f64 on both sides
