@@ -91,14 +91,20 @@ int64_t Context::chunkLimit(int64_t) {
     {
       size_t freeB = 0, totalB = 0;
       if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
-        double perBlock = 0;
+        double perBlock = 0, fixedBytes = 0;   // what a chunk needs per block, and whatever its length
         int convRowsMax = 0;
         for (auto& g : groups) convRowsMax = std::max(convRowsMax, (int)((g->rows.size() + 127) / 128 * 128));
         perBlock += (double)convRowsMax * kBins * 4.0 * 4.0;
         for (auto& np : nodes)   // private-IR convolvers (formulations B / C): y rows + x rows in both plane pairs
           if (np->type == GA_NODE_CONVOLVER && np->ir && np->convPath == 4)
             // formulation D: X frames of the input channels + (at worst, nothing fused) Y frames of the slots: 64 KB per 8192 samples
+          {
             perBlock += (double)((np->isTrueStereo ? 2 : np->ir->nch) + (np->isTrueStereo ? 4 : np->ir->nch)) * 1024.0;
+            // ... and per input row the P' history windows in front of the chunk + the window behind it, per slot the P' blocks of a
+            // carried tail: 64 KB each, whatever the chunk's length (1 GB at 1024 voices x 8 partitions)
+            const double inCh = np->isTrueStereo ? 2 : np->ir->nch, slots = np->isTrueStereo ? 4 : np->ir->nch;
+            fixedBytes += (inCh * (np->ir->coarseP + 1) + slots * (double)kCoarseMaxP) * 65536.0;
+          }
           else if (np->type == GA_NODE_CONVOLVER && np->ir && np->convPath != 1)
             perBlock += (double)(np->ir->nch + 2 * (np->isTrueStereo ? 2 : np->ir->nch)) * kBins * 8.0;
         perBlock += ((double)nodes.size() * 2.0 + 64.0) * kBlock * 4.0;
@@ -108,7 +114,7 @@ int64_t Context::chunkLimit(int64_t) {
         budget += (double)(planesB[0].bytes + planesB[1].bytes + planesB[2].bytes + planesB[3].bytes + planesBalt[0].bytes + planesBalt[1].bytes);
         budget += (double)slabAll.size() * (double)slabFrames * 4.0;
         budget += (double)(coarseX.bytes + coarseY.bytes + coarseM.bytes);
-        int64_t byMem = (int64_t)(budget / std::max(perBlock, 1.0));
+        int64_t byMem = (int64_t)(std::max(budget - fixedBytes, 0.0) / std::max(perBlock, 1.0));
         limit = std::max<int64_t>(1, std::min<int64_t>(limit, byMem));
       }
     }
@@ -251,12 +257,10 @@ void Context::render(float* const* out, int channels, int64_t frameCount, int64_
         deferStage = (float*)dalloc(deferStageBytes);
       }
       for (int ch = 0; ch < channels; ch++) busTarget[ch] = (float*)((char*)deferStage + (size_t)ch * (deferStageBytes / 32));
-    } else {
-      flushHandOver();
-      if (direct)
-        for (int ch = 0; ch < channels; ch++) busTarget[ch] = tgt[ch];
+    } else if (direct) {
+      for (int ch = 0; ch < channels; ch++) busTarget[ch] = tgt[ch];
     }
-    runChunk(nblk, nullptr);   // (takes the previous chunk's pending hand-over with it)
+    runChunk(nblk, nullptr);   // (takes a pending hand-over with it: in its pre-mix launch, or as copies in front of everything else)
     if (defer)
       for (int ch = 0; ch < channels; ch++)
         pendingHandOver.push_back(HandOver{busTarget[ch], tgt[ch], out[ch] + startIndex + written, chunkBlocksDone * kBlock});

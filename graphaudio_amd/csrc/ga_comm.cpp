@@ -175,9 +175,9 @@ void Context::renderReduce(float* const* out, int channels, int64_t frames, int6
       if (!out[ch]) fail(GA_ERR_INVALID_ARGUMENT, "Channel buffer is null.");
   }
   GA_HIP(hipSetDevice(device));
-  flushHandOver();
   const size_t need_ = (size_t)channels * (size_t)frames * sizeof(float);
   if (reduceBytes < need_) {
+    flushHandOver();   // (a pending hand-over reads the buffer that is about to go)
     if (reduceBuf) {
       GA_HIP(hipStreamSynchronize(stream));
       dfree(reduceBuf, reduceBytes);
