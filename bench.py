@@ -431,7 +431,8 @@ def main():
     ap.add_argument("--no-coarse", action="store_true", help="formulation C (block-axis FFT) instead of D (coarse partitions)")
     ap.add_argument("--no-premix", action="store_true", help="formulation D without the time-domain pre-mix: every voice is transformed, the spectra are summed")
     ap.add_argument("--overlap", action="store_true", help="formulation D: forward and multiply-accumulate stages concurrently on two streams (measured slower)")
-    ap.add_argument("--profile-every", type=int, default=4, help="record the per-stage HIP events on every k-th chunk of the timed region")
+    ap.add_argument("--profile-every", type=int, default=8, help="record the per-stage HIP events on every k-th chunk of the timed region "
+                    "(a chunk that records them runs ~0.08 ms longer: every event is a barrier between two launches)")
     ap.add_argument("--no-profile", action="store_true", help="no per-stage HIP events (measurement of their cost; the roofline object is then empty)")
     ap.add_argument("--private-ir", action="store_true", help="every voice convolves with its own impulse response (general path; measurement, not the headline config)")
     ap.add_argument("--no-host-direct", action="store_true", help="copy the bus to the host with copy kernels instead of writing it from the last kernel (measurement)")
@@ -503,7 +504,10 @@ def main():
     ctx = OfflineAudioContext(SR, device=local_rank)
     ctx.SetOption("profile", 0 if args.no_profile else 1)
     # the events cost device time: only every k-th chunk records them (every chunk when the run is too short to sample)
-    ctx.SetOption("profile_every", args.profile_every if args.steps >= 2 * args.profile_every else 1)
+    pe = args.profile_every
+    while pe > 1 and args.steps < 2 * pe:
+        pe //= 2
+    ctx.SetOption("profile_every", pe)
     ctx.SetOption("max_chunk_blocks", 4096)
     if args.direct:
         ctx.SetOption("time_fft", 0)
