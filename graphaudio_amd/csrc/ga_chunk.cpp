@@ -1555,7 +1555,7 @@ struct CoarseStage {
     IrSpectra* ir;
     int leader;
     int ncol;
-    int irCh[4], outCh[4];
+    int irCh[16], outCh[16];
   };
   struct GroupInfo {   // a fused group (by leader), or a convolver on its own
     uint64_t sig = 1469598103934665603ull;
@@ -1572,6 +1572,7 @@ struct CoarseStage {
     std::unique_ptr<Terms> terms;                                 // (pre-mixed groups only)
   };
   std::vector<Views> chInOf;   // [position in dNodes]: chunk-long views of the node's input channels
+  std::vector<CoarseHandOver> fwdHandOver;   // a pending hand-over that rides in the first forward launch of this stage
   std::vector<PremixJob> pmJobs;
   std::vector<PremixTerm> pmTerms;
   size_t pmUsed = 0;       // bytes of the pre-mix arena handed out
@@ -1591,10 +1592,11 @@ struct CoarseStage {
   std::vector<CoarseTerm> terms;
   // launches: by column count (1, 2, 4) x (terms with their own impulse responses | one impulse response for all terms), and
   // by the group whose transforms complete the job's inputs.  Class index = 2 * column class + shared.
-  std::vector<CoarseJob> jobs[6][8];
-  int maxT[6] = {0, 0, 0, 0, 0, 0}, maxP[6] = {0, 0, 0, 0, 0, 0};
-  int pbOf[6] = {4, 4, 4, 4, 4, 4};   // largest of 4, 2, 1 dividing every job's partition count (the sweep's register block)
-  double macBytes[6][8] = {}, macFlops[6][8] = {};
+  static constexpr int kCwOf[4] = {1, 2, 4, 16};   // column classes of the multiply-accumulate launches
+  std::vector<CoarseJob> jobs[8][8];
+  int maxT[8] = {0, 0, 0, 0, 0, 0, 0, 0}, maxP[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int pbOf[8] = {4, 4, 4, 4, 4, 4, 4, 4};   // largest of 4, 2, 1 dividing every job's partition count (the sweep's register block)
+  double macBytes[8][8] = {}, macFlops[8][8] = {};
   double pmFlops = 0, invFlops = 0;
   std::map<std::pair<int, int>, std::vector<int>> outRows;   // (leader, channel) -> Y rows to sum
   int yNext = 0;
@@ -1710,9 +1712,13 @@ void CoarseStage::addPieces(NodeS& nd, int leader, int nxr, const int* xFrame, c
       cols[ncols][1] = nd.isTrueStereo ? (slot & 1) : slot;
       ncols++;
     }
+    // 16 columns of one signal at once where the group's terms have impulse responses of their own (the general kernel's 16-column
+    // instance: the signal's frames are staged once for all of them) and its double-buffered spectra fit the LDS (P' <= 4)
+    const GroupInfo& gi = groups[leader];
+    const bool wide = !gi.oneIr && ir.coarseP <= 4 && c.coarseWide;
     for (int c0 = 0; c0 < ncols;) {
       const int left = ncols - c0;
-      const int w = left >= 4 ? 4 : (left >= 2 ? 2 : 1);
+      const int w = (wide && left >= 16) ? 16 : (left >= 4 ? 4 : (left >= 2 ? 2 : 1));
       Piece pc{};
       pc.frame0 = xFrame[xc];
       pc.xrow = xIndex[xc];
@@ -1873,6 +1879,10 @@ void CoarseStage::buildRows() {
     pmJobs.insert(pmJobs.begin(), head.begin(), head.end());
     c.pendingHandOver.clear();
     c.stats.deferred_handovers++;
+  } else if (!c.pendingHandOver.empty() && !xrows.empty()) {   // no pre-mix launch: they ride in the stage's first forward launch
+    for (const Context::HandOver& h : c.pendingHandOver) fwdHandOver.push_back(CoarseHandOver{h.src, h.dst_dev, h.n});
+    c.pendingHandOver.clear();
+    c.stats.deferred_handovers++;
   }
   ex.flushLevel();   // (materialised inputs)
 }
@@ -1880,14 +1890,14 @@ void CoarseStage::buildRows() {
 void CoarseStage::buildJobs() {
   // ---- jobs: pieces with the same (leader, output channels, partitions) accumulate into the same Y rows ----
   struct Key {
-    int leader, P, ncol, out[4];
-    bool operator<(const Key& o) const {
-      return std::tie(leader, P, ncol, out[0], out[1], out[2], out[3]) < std::tie(o.leader, o.P, o.ncol, o.out[0], o.out[1], o.out[2], o.out[3]);
-    }
+    int leader, P, ncol;
+    std::array<int, 16> out;
+    bool operator<(const Key& o) const { return std::tie(leader, P, ncol, out) < std::tie(o.leader, o.P, o.ncol, o.out); }
   };
   std::map<Key, std::vector<const Piece*>> byKey;
   for (const Piece& pc : pieces) {
-    Key k{pc.leader, pc.P, pc.ncol, {-1, -1, -1, -1}};
+    Key k{pc.leader, pc.P, pc.ncol, {}};
+    k.out.fill(-1);
     for (int j = 0; j < pc.ncol; j++) k.out[j] = pc.outCh[j];
     byKey[k].push_back(&pc);
   }
@@ -1900,7 +1910,7 @@ void CoarseStage::buildJobs() {
   for (int g = 1; g <= G; g++) gBegin[g] = std::max(gBegin[g], gBegin[g - 1]);
   for (auto& kv : byKey) {
     const Key& k = kv.first;
-    const int cw = k.ncol, ci = cw == 1 ? 0 : (cw == 2 ? 1 : 2);
+    const int cw = k.ncol, ci = cw == 1 ? 0 : (cw == 2 ? 1 : (cw == 4 ? 2 : 3));
     const auto& pv = kv.second;
     for (size_t p0 = 0; p0 < pv.size(); p0 += kVoicesPerJob) {
       const size_t p1 = std::min(pv.size(), p0 + kVoicesPerJob);
@@ -1911,13 +1921,14 @@ void CoarseStage::buildJobs() {
         const Piece& pc = *pv[i];
         CoarseTerm t{};
         t.frame0 = pc.frame0 - (pc.u0 + (pc.P - 1));   // frame the window u = -(P - 1) would have (the kernels index from there)
-        for (int j = 0; j < 4; j++) t.h[j] = nullptr;
+        for (int j = 0; j < 16; j++) t.h[j] = nullptr;
         for (int j = 0; j < cw; j++) t.h[j] = pc.ir->coarse + (size_t)pc.irCh[j] * pc.P * kCoarseBins;
         if (i > p0)
           for (int j = 0; j < cw; j++) shared = shared && (t.h[j] == terms[term0].h[j]);
         terms.push_back(t);
         lastX = std::max(lastX, pc.xrow);
       }
+      if (cw == 16) shared = false;   // (the reduction kernel has no 16-column instance)
       const int grp = groupOf(lastX);
       const int yrow0 = yNext;
       yNext += cw;
@@ -2022,16 +2033,17 @@ void CoarseStage::enqueue() {
   const int G = this->G, yFrames = this->yFrames, invBlocks = this->invBlocks, nxAll = this->nxAll;
   const double invBytes = this->invBytes, histBytes = this->histBytes;
   const size_t xo = ex.plan.putv(xrows), ho = ex.plan.putv(hjobs), to = ex.plan.putv(terms), oo = ex.plan.putv(outs), yo = ex.plan.putv(ylist);
-  const size_t pjo = ex.plan.putv(pmJobs), pto = ex.plan.putv(pmTerms);
+  const size_t pjo = ex.plan.putv(pmJobs), pto = ex.plan.putv(pmTerms), fho = ex.plan.putv(fwdHandOver);
+  const int nfh = (int)fwdHandOver.size();
   const int npm = (int)pmJobs.size();
   const int64_t pmMaxN = this->pmMaxN;
   const double pmBytes = this->pmBytes, pmFlops = this->pmFlops, invFlops = this->invFlops;
   struct MacLaunch { size_t off; int nj, cw, mt, mp, pb, grp; bool ap; double bytes, flops; };
   std::vector<MacLaunch> macs;
   for (int g = 0; g < G; g++)
-    for (int i = 0; i < 6; i++) {
+    for (int i = 0; i < 8; i++) {
       if (jobs[i][g].empty()) continue;
-      macs.push_back(MacLaunch{ex.plan.putv(jobs[i][g]), (int)jobs[i][g].size(), 1 << (i >> 1), maxT[i], maxP[i], pbOf[i], g, (i & 1) == 0,
+      macs.push_back(MacLaunch{ex.plan.putv(jobs[i][g]), (int)jobs[i][g].size(), kCwOf[i >> 1], maxT[i], maxP[i], pbOf[i], g, (i & 1) == 0,
                                macBytes[i][g], macFlops[i][g]});
       c.stats.mac_launches += 1;
     }
@@ -2089,7 +2101,10 @@ void CoarseStage::enqueue() {
     for (int g = 0; g < G; g++) {
       const FwdLaunch& f = fwds[g];
       if (f.nx > 0)
-        timed(st, LK_CFWD, f.bytes, f.flops, [&] { return launch_coarse_fwd(st, (const CoarseXRow*)(base + xo) + f.x0, f.nx, f.maxFrames, f.run, X, twFwd, twab); });
+        timed(st, LK_CFWD, f.bytes, f.flops, [&] {
+          return launch_coarse_fwd(st, (const CoarseXRow*)(base + xo) + f.x0, f.nx, f.maxFrames, f.run, X, twFwd, twab,
+                                   (const CoarseHandOver*)(base + fho), g == 0 ? nfh : 0);
+        });
       if (G > 1) {
         GA_HIP(hipEventRecord(cp->dGroupEv[g], st));
         GA_HIP(hipStreamWaitEvent(s2, cp->dGroupEv[g], 0));

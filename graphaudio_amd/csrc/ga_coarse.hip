@@ -114,12 +114,31 @@ __device__ __forceinline__ void coarse_issue_half(const CoarseXRow& R, int hw, i
   }
 }
 
+constexpr int kHandOverWgs = 8;    // workgroups that carry one row of a hand-over across PCIe
 constexpr int kFwdPark = 4;         // values per thread parked in LDS across transform b (8 KB: what three workgroups per CU leave)
 constexpr int kFwdTw3 = 4 * 256;   // power twiddles of the last pass: W_4096^(j m), m = 1, 2, 4, 8 (ga_fft16.hpp, PW)
 // EXPERIMENT: the phase-removal timing variants of tools/coarse_exp.sh (run-time flags `exp_`); the product kernel has none
 template <bool EXPERIMENT>
 __global__ __launch_bounds__(256, 3) void coarse_fwd_kernel(const CoarseXRow* __restrict rows, int run, float2* __restrict X,
-                                                            const float2* __restrict twg, const float2* __restrict twab, int exp_) {
+                                                            const float2* __restrict twg, const float2* __restrict twab, int exp_,
+                                                            const CoarseHandOver* __restrict handover, int n_handover) {
+  if ((int)blockIdx.y < n_handover) {
+    // the previous chunk's bus on its way to the caller's page-locked rows (Context::pendingHandOver): a few long-lived workgroups
+    // per row write over PCIe while the rest of the launch transforms (chunks without a pre-mix launch to ride in)
+    const int nwg = min((int)gridDim.x, kHandOverWgs);
+    if ((int)blockIdx.x >= nwg) return;
+    const CoarseHandOver H = handover[blockIdx.y];
+    const GA_GLOBAL v4f* src = (const GA_GLOBAL v4f*)H.src;
+    GA_GLOBAL v4f* dst = (GA_GLOBAL v4f*)H.dst;
+    const int64_t nw = H.n / 4, step = (int64_t)nwg * 512;
+    for (int64_t i = (int64_t)blockIdx.x * 512 + threadIdx.x; i < nw; i += step) {
+      const int64_t i2 = i + 256;
+      const v4f a = src[i], b = i2 < nw ? src[i2] : a;
+      dst[i] = a;
+      if (i2 < nw) dst[i2] = b;
+    }
+    return;
+  }
   const int exp = EXPERIMENT ? exp_ : 0;
   using PL = R16Plan<CM>;
   extern __shared__ f2 clds[];
@@ -129,7 +148,7 @@ __global__ __launch_bounds__(256, 3) void coarse_fwd_kernel(const CoarseXRow* __
   f2* park = buf + CPAD;   // kFwdPark mirrored values of transform a per thread wait here while transform b runs (registers)
   const int t_ = threadIdx.x;
   for (int i = t_; i < PL::T2 + kFwdTw3; i += 256) clds[i] = f2{twg[i].x, twg[i].y};
-  const CoarseXRow R = rows[blockIdx.y];
+  const CoarseXRow R = rows[blockIdx.y - n_handover];
   const int w0 = blockIdx.x * run;
   const int w1 = min(R.n_frames, w0 + run);
   if (w0 >= w1) return;   // (uniform)
@@ -278,7 +297,7 @@ __global__ __launch_bounds__(256, 3) void coarse_fwd_kernel(const CoarseXRow* __
 }
 
 const char* launch_coarse_fwd(hipStream_t s, const CoarseXRow* rows_dev, int nrows, int max_frames, int run, float2* X, const float2* tw16,
-                              const float2* twab) {
+                              const float2* twab, const CoarseHandOver* handover_dev, int n_handover) {
   if (nrows <= 0 || max_frames <= 0) return "";
   using PL = R16Plan<CM>;
   const size_t lds = (size_t)(PL::T2 + kFwdTw3 + CPAD + kFwdPark * 256) * sizeof(float2);
@@ -288,8 +307,9 @@ const char* launch_coarse_fwd(hipStream_t s, const CoarseXRow* rows_dev, int nro
   lim[exp ? 1 : 0].raise((const void*)kern, lds, "cannot raise the dynamic LDS limit of the coarse forward transform");
   run = std::max(run, 1);
   for (int r0 = 0; r0 < nrows; r0 += 32768) {
-    dim3 grid((max_frames + run - 1) / run, std::min(32768, nrows - r0));
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, rows_dev + r0, run, X, tw16, twab, exp);
+    const int nh = r0 == 0 ? n_handover : 0;   // (the hand-over rows come first in the grid: their workgroups start at once)
+    dim3 grid((max_frames + run - 1) / run, std::min(32768, nrows - r0) + nh);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, rows_dev + r0, run, X, tw16, twab, exp, handover_dev, nh);
   }
   return "coarse_fwd_kernel";
 }
@@ -310,15 +330,16 @@ const char* launch_coarse_fwd(hipStream_t s, const CoarseXRow* rows_dev, int nro
 #ifndef GA_MAC_PB2
 #define GA_MAC_PB2 2      // partition block used for 2-column jobs whose partition count is a multiple of 4
 #endif
+constexpr int kMacWaves16 = 12;                               // the 16-column instance: 12 waves (three per SIMD: 168 registers each) ...
+constexpr int kMacTW16 = kCoarseJobBlocks(16) / kMacWaves16;   // ... x 3 blocks x 16 columns = 48 complex accumulators per lane
 constexpr int kMacWaves = GA_MAC_WAVES;      // waves per workgroup: each takes 1/kMacWaves of the job's coarse blocks
-constexpr int kMacThreads = 64 * kMacWaves;
 #ifndef GA_MAC_WGS_PER_CU
 #define GA_MAC_WGS_PER_CU 2
 #endif
 constexpr int kMacWavesPerSimd = kMacWaves * GA_MAC_WGS_PER_CU / 4;   // workgroups per CU (LDS) x waves, four SIMDs
 // (launches whose terms all share one impulse response take coarse_sum_kernel below instead)
-template <int CW, int TW, int PB>
-__global__ __launch_bounds__(kMacThreads, kMacWavesPerSimd) void coarse_mac_kernel(const CoarseJob* __restrict jobs, const CoarseTerm* __restrict terms,
+template <int CW, int TW, int PB, int WV>
+__global__ __launch_bounds__(64 * WV, WV == 8 ? kMacWavesPerSimd : WV / 4) void coarse_mac_kernel(const CoarseJob* __restrict jobs, const CoarseTerm* __restrict terms,
                                                                     const float2* __restrict X, float2* __restrict Y, int y_frames, int NFA,
                                                                     int exp) {
   extern __shared__ f2 mlds[];   // (ALL of the kernel's LDS is this one array: a second object beside a direct-to-LDS target costs a vmcnt(0) per read)
@@ -333,7 +354,7 @@ __global__ __launch_bounds__(kMacThreads, kMacWavesPerSimd) void coarse_mac_kern
   f2* xs1 = mlds + (size_t)NFA * 64;
   f2* hs0 = mlds + (size_t)2 * NFA * 64;
   f2* hs1 = hs0 + (size_t)P * CW * 64;       // only when the job's terms have different impulse responses
-  const int twr = (nT + kMacWaves - 1) / kMacWaves;   // coarse blocks per wave (<= TW)
+  const int twr = (nT + WV - 1) / WV;   // coarse blocks per wave (<= TW)
   const int t0w = wv * twr;
   const bool special = tile == 0;            // bin 0 of tile 0 is the packed pair of real bins
   const bool lane0 = special && lane == 0;
@@ -343,18 +364,18 @@ __global__ __launch_bounds__(kMacThreads, kMacWavesPerSimd) void coarse_mac_kern
   // no staging registers, no ds_write pass).  One wave instruction moves two consecutive 512-byte rows: the LDS image is
   // linear in the lane (destination = wave-uniform base + 16 lane), the source address is per lane.
   typedef __attribute__((address_space(3))) void* lds_t;
-  constexpr int XR = ((kMacWaves * TW + kCoarseMaxP) * 32 + kMacThreads - 1) / kMacThreads;  // instructions per wave that cover NF <= kMacWaves TW + P - 1 frames
+  constexpr int XR = ((WV * TW + kCoarseMaxP) * 32 + (64 * WV) - 1) / (64 * WV);  // instructions per wave that cover NF <= WV TW + P - 1 frames
   auto issue_x = [&](const CoarseTerm& T, f2* xs) {
 #pragma unroll
     for (int r = 0; r < XR; r++) {
-      const int fr0 = (kMacThreads / 32) * r + 2 * wv;   // (uniform)
+      const int fr0 = ((64 * WV) / 32) * r + 2 * wv;   // (uniform)
       const int fr = fr0 + (lane >> 5), of = lane & 31;
       if (fr >= fr_lo && fr <= fr_hi)
         __builtin_amdgcn_global_load_lds(gptr(X + (size_t)(T.frame0 + J.t0 + fr) * kCoarseBins + binoff + 2 * of), (lds_t)(xs + fr0 * 64), 16, 0, 0);
     }
   };
   auto issue_h = [&](const CoarseTerm& T, f2* hs) {   // P x CW rows of 512 bytes
-    for (int pc0 = 2 * wv; pc0 < P * CW; pc0 += 2 * kMacWaves) {
+    for (int pc0 = 2 * wv; pc0 < P * CW; pc0 += 2 * WV) {
       const int pc = pc0 + (lane >> 5), of = lane & 31;
       // the two rows' base addresses are wave-uniform (scalar loads of the term's descriptor: a per-lane descriptor load is a
       // vector-memory instruction whose result the address needs at once -- a vmcnt(0) in the middle of the staging)
@@ -374,7 +395,7 @@ __global__ __launch_bounds__(kMacThreads, kMacWavesPerSimd) void coarse_mac_kern
 
   const CoarseTerm* __restrict T = terms + J.term0;
   // windows that do not exist are zero rows in both buffers (no term ever writes them)
-  for (int idx = tid; idx < NF * 32; idx += kMacThreads) {
+  for (int idx = tid; idx < NF * 32; idx += (64 * WV)) {
     const int fr = idx >> 5;
     if (fr < fr_lo || fr > fr_hi) {
       *reinterpret_cast<v4f*>(xs0 + fr * 64 + 2 * (idx & 31)) = v4f{0.f, 0.f, 0.f, 0.f};
@@ -403,34 +424,49 @@ __global__ __launch_bounds__(kMacThreads, kMacWavesPerSimd) void coarse_mac_kern
         constexpr bool SP = decltype(sp)::value;
         constexpr int PBX = PB;
         for (int pb = 0; pb < P; pb += PBX) {
-          f2 hl[PBX][CW];
+          constexpr bool EARLY_H = CW <= 4;   // (16 columns: the spectra are read where they are used, or 32 more registers spill)
+          f2 hl[EARLY_H ? PBX : 1][EARLY_H ? CW : 1];
+          if constexpr (EARLY_H) {
 #pragma unroll
-          for (int j = 0; j < PBX; j++)
+            for (int j = 0; j < PBX; j++)
 #pragma unroll
-            for (int c = 0; c < CW; c++) hl[j][c] = hs[((pb + j) * CW + c) * 64 + lane];
+              for (int c = 0; c < CW; c++) hl[j][c] = hs[((pb + j) * CW + c) * 64 + lane];
+          }
           const f2* __restrict xb = xs + (t0w + (P - 1) - pb - (PBX - 1)) * 64 + lane;   // (pb + PBX - 1 <= P - 1: inside the buffer)
           f2 xv[TW + PBX - 1];
 #pragma unroll
           for (int q = 0; q < TW + PBX - 1; q++) xv[q] = xb[q * 64];
+          auto fma1 = [&](int tt, int c, f2 x, f2 h) {
+            if constexpr (!SP) {
+              acc[tt][c] = cfmap(x, h, acc[tt][c]);
+            } else {
+              const f2 gen = cfmap(x, h, acc[tt][c]);
+              const f2 pk = __builtin_elementwise_fma(x, h, acc[tt][c]);   // two real bins side by side
+              acc[tt][c] = lane0 ? pk : gen;
+            }
+          };
+          if constexpr (EARLY_H) {
 #pragma unroll
-          for (int j = 0; j < PBX; j++)
+            for (int j = 0; j < PBX; j++)
 #pragma unroll
-            for (int tt = 0; tt < TW; tt++)
+              for (int tt = 0; tt < TW; tt++)
+#pragma unroll
+                for (int c = 0; c < CW; c++) fma1(tt, c, xv[tt - j + (PBX - 1)], hl[j][c]);
+          } else {
+#pragma unroll
+            for (int j = 0; j < PBX; j++)
 #pragma unroll
               for (int c = 0; c < CW; c++) {
-                const f2 x = xv[tt - j + (PBX - 1)];
-                const f2 h = hl[j][c];
-                if constexpr (!SP) {
-                  acc[tt][c] = cfmap(x, h, acc[tt][c]);
-                } else {
-                  const f2 gen = cfmap(x, h, acc[tt][c]);
-                  const f2 pk = __builtin_elementwise_fma(x, h, acc[tt][c]);   // two real bins side by side
-                  acc[tt][c] = lane0 ? pk : gen;
-                }
+                const f2 h = hs[((pb + j) * CW + c) * 64 + lane];
+#pragma unroll
+                for (int tt = 0; tt < TW; tt++) fma1(tt, c, xv[tt - j + (PBX - 1)], h);
               }
+          }
         }
       };
-      if (special) sweep(std::true_type{});
+      // (the 16-column instance leaves the packed pair of real bins to coarse_mac_bin0_kernel: a second copy of a sweep with 48
+      // accumulators does not fit the registers)
+      if (special && CW != 16) sweep(std::true_type{});
       else sweep(std::false_type{});
     }
     __syncthreads();
@@ -618,29 +654,54 @@ static const char* launch_coarse_sum(hipStream_t s, const CoarseJob* jobs_dev, i
   return CW == 1 ? "coarse_sum_kernel<1>" : (CW == 2 ? "coarse_sum_kernel<2>" : "coarse_sum_kernel<4>");
 }
 
-template <int CW, int TW, int PB>
+// bin 0 of the packed spectra holds the two REAL bins (X[0], X[8192]): their products are element-wise.  The 16-column instance of
+// the general kernel computes a complex product there like everywhere else; this kernel writes the right value over it:
+// thread = (output block, column) of a job, Y[c][t][0] = sum over terms, partitions of X[t - p][0] (.) H_c[p][0].
+__global__ __launch_bounds__(256) void coarse_mac_bin0_kernel(const CoarseJob* __restrict jobs, const CoarseTerm* __restrict terms,
+                                                             const float2* __restrict X, float2* __restrict Y, int y_frames) {
+  const CoarseJob J = jobs[blockIdx.x];
+  const CoarseTerm* __restrict T = terms + J.term0;
+  const int P = J.P;
+  for (int idx = threadIdx.x; idx < J.n_t * 16; idx += 256) {
+    const int t = idx >> 4, c = idx & 15;
+    f2 acc = f2{0.f, 0.f};
+    for (int i = 0; i < J.n_terms; i++) {
+      const float2* __restrict h = T[i].h[c];
+      for (int p = 0; p < P; p++) {
+        const int u = J.t0 + t - p;   // window index
+        if (u < J.u_lo || u > J.u_hi) continue;
+        const v2f x = ldg2(X + (size_t)(T[i].frame0 + u + (P - 1)) * kCoarseBins);
+        const v2f hv = ldg2(h + (size_t)p * kCoarseBins);
+        acc = __builtin_elementwise_fma(f2{x.x, x.y}, f2{hv.x, hv.y}, acc);
+      }
+    }
+    stg2(Y + ((size_t)(J.yrow0 + c) * y_frames + J.t0 + t) * kCoarseBins, v2f{acc.x, acc.y});
+  }
+}
+
+template <int CW, int TW, int PB, int WV = kMacWaves>
 static const char* launch_coarse_mac_t(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
                                 int y_frames, int max_t, int maxP, bool any_private) {
   static const int exp = expenv("GA_COARSE_EXP") ? atoi(expenv("GA_COARSE_EXP")) : 0;   // timing experiments only
   // frames the sweep of the last active wave touches: t0w + TW + P - 1 with t0w = (active waves - 1) * ceil(n_t / waves)
   int NFA = 0;
   for (int nt = 1; nt <= max_t; nt++) {
-    const int twr = (nt + kMacWaves - 1) / kMacWaves, wl = (nt + twr - 1) / twr - 1;
+    const int twr = (nt + WV - 1) / WV, wl = (nt + twr - 1) / twr - 1;
     NFA = std::max(NFA, wl * twr + TW + maxP - 1);
   }
   const size_t lds = ((size_t)2 * NFA * 64 + (size_t)(any_private ? 2 : 1) * maxP * CW * 64) * sizeof(float2);
   if (lds > 160 * 1024) launch_fail("coarse multiply-accumulate: staging does not fit the LDS");
   static LdsLimit lim;
-  lim.raise((const void*)coarse_mac_kernel<CW, TW, PB>, lds, "cannot raise the dynamic LDS limit of the coarse multiply-accumulate");
+  lim.raise((const void*)coarse_mac_kernel<CW, TW, PB, WV>, lds, "cannot raise the dynamic LDS limit of the coarse multiply-accumulate");
   if (expenv("GA_COARSE_EXP")) {
     int occ = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, coarse_mac_kernel<CW, TW, PB>, kMacThreads, lds);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, coarse_mac_kernel<CW, TW, PB, WV>, 64 * WV, lds);
     fprintf(stderr, "[coarse_mac<%d,%d,%d>] lds %zu B, NFA %d, occupancy %d workgroups/CU, %d jobs\n", CW, TW, PB, lds, NFA, occ, njobs);
   }
   for (int j0 = 0; j0 < njobs; j0 += 32768)
-    hipLaunchKernelGGL((coarse_mac_kernel<CW, TW, PB>), dim3(kCoarseBins / 64, std::min(32768, njobs - j0)), dim3(kMacThreads), lds, s,
+    hipLaunchKernelGGL((coarse_mac_kernel<CW, TW, PB, WV>), dim3(kCoarseBins / 64, std::min(32768, njobs - j0)), dim3(64 * WV), lds, s,
                        jobs_dev + j0, terms_dev, X, Y, y_frames, NFA, exp >> 4);
-  static const std::string name = "coarse_mac_kernel<" + std::to_string(CW) + "," + std::to_string(TW) + "," + std::to_string(PB) + ">";
+  static const std::string name = "coarse_mac_kernel<" + std::to_string(CW) + "," + std::to_string(TW) + "," + std::to_string(PB) + "," + std::to_string(WV) + ">";
   return name.c_str();
 }
 // all jobs of one launch have the same column count `cw` (1, 2 or 4), at most `max_t` coarse blocks (<= kCoarseJobBlocks(cw))
@@ -648,7 +709,7 @@ static const char* launch_coarse_mac_t(hipStream_t s, const CoarseJob* jobs_dev,
 template <int CW>
 static const char* launch_coarse_mac_cw(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
                                  int y_frames, int max_t, int maxP, bool any_private, int pb) {
-  constexpr int TWL = CW <= 2 ? GA_MAC_TW : GA_MAC_TW / 2;   // accumulators: TW x CW complex values per lane
+  constexpr int TWL = CW <= 2 ? GA_MAC_TW : GA_MAC_TW4;   // accumulators: TW x CW complex values per lane
   if (!any_private) return launch_coarse_sum<CW>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP);   // (the planner cut these jobs for it)
   if (max_t <= 2 * kMacWaves) return launch_coarse_mac_t<CW, 2, 1>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
   if (pb >= 4 && (CW == 1 || (CW == 2 && GA_MAC_PB2 == 4))) return launch_coarse_mac_t<CW, TWL, 4>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
@@ -664,6 +725,14 @@ const char* launch_coarse_mac(hipStream_t s, const CoarseJob* jobs_dev, int njob
   if (cw == 1) return launch_coarse_mac_cw<1>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private, pb);
   if (cw == 2) return launch_coarse_mac_cw<2>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private, pb);
   if (cw == 4) return launch_coarse_mac_cw<4>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private, pb);
+  // all 16 columns of a source in one job (BASELINE.json configs[4]): 12 waves x 3 blocks x 16 columns, one workgroup per CU --
+  // the source's X frames are staged ONCE for its 16 columns (4-column jobs: four times) and its impulse-response spectra once per
+  // 36 blocks
+  if (cw == 16 && any_private) {
+    const char* name = launch_coarse_mac_t<16, kMacTW16, 1, kMacWaves16>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, true);
+    hipLaunchKernelGGL(coarse_mac_bin0_kernel, dim3(njobs), dim3(256), 0, s, jobs_dev, terms_dev, X, Y, y_frames);
+    return name;
+  }
   launch_fail("coarse multiply-accumulate: unsupported column count");
 }
 

@@ -124,8 +124,11 @@ constexpr int kCoarseMaxP = 16;      // partitions a job can slide over (impulse
 constexpr int kCoarseJobTerms = 32;   // terms (signals) whose products one multiply-accumulate job sums in registers
 // ... and one reduction job (coarse_sum_kernel: the terms share their impulse response): 8 waves x 9 (x 5) -- a 10 s chunk with its
 // carried tail is 59 + 8 output blocks
-constexpr int kCoarseSumJobBlocks(int columns) { return columns <= 2 ? 72 : 40; }
-constexpr int kCoarseJobBlocks(int columns) { return columns <= 2 ? 64 : 32; }   // coarse blocks one multiply-accumulate job covers: 8 waves x 8 (x 4)
+constexpr int kCoarseSumJobBlocks(int columns) { return columns <= 2 ? 72 : 40; }   // (1, 2, 4 columns)
+#ifndef GA_MAC_TW4
+#define GA_MAC_TW4 4   // coarse blocks per wave of the 4-column instance of the general multiply-accumulate kernel
+#endif
+constexpr int kCoarseJobBlocks(int columns) { return columns <= 2 ? 64 : (columns == 16 ? 36 : 8 * GA_MAC_TW4); }   // coarse blocks one multiply-accumulate job covers: 8 waves x 8 (x 4)
 // floating-point operations of one 16,384-point real transform as the kernels evaluate it: two complex radix-16 transforms of 4096
 // points (3 passes x 256 radix-16 butterflies of ~ 200 flops incl. twiddles, each) + the combine pass (~ 30 flops per bin quad pair)
 constexpr double kCoarseTransformFlops = 2.0 * 3.0 * 256.0 * 200.0 + 2048.0 * 60.0;
@@ -146,10 +149,15 @@ struct CoarseXRow {        // one transformed signal: a convolver input channel,
   float* carry;
   int64_t carry_from;      // multiple of 4
 };
+struct CoarseHandOver {    // a finished bus row on its way to page-locked host memory, carried by a few workgroups of a long launch
+  const float* src;        // device staging row
+  float* dst;              // device-visible address of the caller's row
+  int64_t n;               // frames (a multiple of 4; both pointers 16-byte aligned)
+};
 struct CoarseTerm {        // one (signal, impulse response) product feeding a job's accumulators
   int frame0;              // frame of window u = -(P - 1) of the signal
   int pad_;
-  const float2* h[4];      // per column: packed spectra [P][kCoarseBins] of the column's impulse-response channel
+  const float2* h[16];     // per column: packed spectra [P][kCoarseBins] of the column's impulse-response channel
 };
 struct CoarseJob {         // accumulators Y[yrow0 + c][t] = sum over terms sum_p X[t - p] H_c[p],  c < columns of the launch
   int term0, n_terms;
@@ -202,7 +210,7 @@ const char* launch_coarse_premix(hipStream_t s, const PremixJob* jobs_dev, int n
 // (the coarse launchers return the name of the kernel instance they ran: ga_stats.stage_kernel)
 // forward: tw16 = Context::twiddles16pw() ; inverse: tw16 = Context::twiddles16(4096) ; twab = [2][2049]: W_8192^k, W_16384^k
 const char* launch_coarse_fwd(hipStream_t s, const CoarseXRow* rows_dev, int nrows, int max_frames, int run, float2* X, const float2* tw16,
-                       const float2* twab);
+                       const float2* twab, const CoarseHandOver* handover_dev = nullptr, int n_handover = 0);
 const char* launch_coarse_mac(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
                        int y_frames, int cw, int max_t, int maxP, bool any_private, int pb);
 const char* launch_coarse_inv(hipStream_t s, const CoarseOut* outs_dev, int nouts, int n_t, const int* ylist_dev, const float2* Y, int y_frames,
