@@ -1572,6 +1572,7 @@ struct CoarseStage {
     std::unique_ptr<Terms> terms;                                 // (pre-mixed groups only)
   };
   std::vector<Views> chInOf;   // [position in dNodes]: chunk-long views of the node's input channels
+  bool wideStrided = true;   // every 16-column term's spectra are h[0] + c x P x kCoarseBins
   std::vector<CoarseHandOver> fwdHandOver;   // a pending hand-over that rides in the first forward launch of this stage
   std::vector<PremixJob> pmJobs;
   std::vector<PremixTerm> pmTerms;
@@ -1928,7 +1929,11 @@ void CoarseStage::buildJobs() {
         terms.push_back(t);
         lastX = std::max(lastX, pc.xrow);
       }
-      if (cw == 16) shared = false;   // (the reduction kernel has no 16-column instance)
+      if (cw == 16) {
+        shared = false;   // (the reduction kernel has no 16-column instance)
+        for (size_t i = term0; i < terms.size(); i++)   // the matrix-core kernel addresses the columns' spectra from h[0]
+          for (int j = 1; j < 16; j++) wideStrided = wideStrided && terms[i].h[j] == terms[i].h[0] + (size_t)j * k.P * kCoarseBins;
+      }
       const int grp = groupOf(lastX);
       const int yrow0 = yNext;
       yNext += cw;
@@ -2039,6 +2044,7 @@ void CoarseStage::enqueue() {
   const int64_t pmMaxN = this->pmMaxN;
   const double pmBytes = this->pmBytes, pmFlops = this->pmFlops, invFlops = this->invFlops;
   struct MacLaunch { size_t off; int nj, cw, mt, mp, pb, grp; bool ap; double bytes, flops; };
+  const bool matrixCores = c.coarseMfma && wideStrided;
   std::vector<MacLaunch> macs;
   for (int g = 0; g < G; g++)
     for (int i = 0; i < 8; i++) {
@@ -2112,7 +2118,8 @@ void CoarseStage::enqueue() {
       for (const MacLaunch& m : macs)
         if (m.grp == g)
           timed(s2, LK_CMAC, m.bytes, m.flops, [&] {
-            return launch_coarse_mac(s2, (const CoarseJob*)(base + m.off), m.nj, (const CoarseTerm*)(base + to), X, Y, yFrames, m.cw, m.mt, m.mp, m.ap, m.pb);
+            return launch_coarse_mac(s2, (const CoarseJob*)(base + m.off), m.nj, (const CoarseTerm*)(base + to), X, Y, yFrames, m.cw, m.mt, m.mp, m.ap, m.pb,
+                                     matrixCores);
           });
     }
     if (G > 1) {   // join: the inverse transforms (and the next chunk's forward transforms, which reuse X) wait for every job

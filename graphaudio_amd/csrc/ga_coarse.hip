@@ -331,7 +331,7 @@ const char* launch_coarse_fwd(hipStream_t s, const CoarseXRow* rows_dev, int nro
 #define GA_MAC_PB2 2      // partition block used for 2-column jobs whose partition count is a multiple of 4
 #endif
 constexpr int kMacWaves16 = 12;                               // the 16-column instance: 12 waves (three per SIMD: 168 registers each) ...
-constexpr int kMacTW16 = kCoarseJobBlocks(16) / kMacWaves16;   // ... x 3 blocks x 16 columns = 48 complex accumulators per lane
+constexpr int kMacTW16 = (kCoarseJobBlocks(16) + kMacWaves16 - 1) / kMacWaves16;   // ... x 3 blocks x 16 columns = 48 complex accumulators per lane
 constexpr int kMacWaves = GA_MAC_WAVES;      // waves per workgroup: each takes 1/kMacWaves of the job's coarse blocks
 #ifndef GA_MAC_WGS_PER_CU
 #define GA_MAC_WGS_PER_CU 2
@@ -679,6 +679,111 @@ __global__ __launch_bounds__(256) void coarse_mac_bin0_kernel(const CoarseJob* _
   }
 }
 
+// =====================================================================================================================
+//  16 columns on the MATRIX CORES.  For one bin the partition sum of a job is a small complex GEMM,
+//        Y[c][t] += sum over terms, p < 4 of  H_c[p] . X[t - p]          c < 16 columns, t < 32 blocks,
+//  i.e. per (bin, term) a [16 x 4] . [4 x 32] product: two v_mfma_f32_16x16x4_f32 tiles, four real MFMAs each (re += ar br,
+//  re += (-ai) bi, im += ar bi, im += ai br).  A = the term's spectra (lane l holds H_{c = l & 15}[p = l >> 4]), B = its frames in
+//  Toeplitz order (lane l holds X[t0 + (l & 15) - (l >> 4)]), D: lane l, register r = Y[c = 4 (l >> 4) + r][t = l & 15].  The
+//  operand reuse that the register-tiled VALU kernel has to buy with accumulators (3 blocks x 16 columns per lane, one LDS read
+//  per 6 packed fmas) is done by the hardware here: 3 LDS reads per 8 MFMAs (8192 real multiply-adds).
+//  Workgroup = (job, 64 bins), 8 waves, wave w owns bins 8 w .. 8 w + 7 and keeps their 2 x 2 x 4 accumulators over the job's
+//  terms.  A term's frames and spectra are staged global -> registers -> LDS with a row pitch of 65 complex values (a fragment
+//  read walks ROWS at a fixed bin: at the natural pitch of 64 every lane would hit the same bank), double buffered.  The results
+//  leave through the LDS as whole 512-byte rows.  Bin 0 of tile 0 (the packed pair of real bins) is put right by
+//  coarse_mac_bin0_kernel afterwards.
+// =====================================================================================================================
+typedef float f4v __attribute__((ext_vector_type(4)));
+constexpr int kMfThreads = 512, kMfFrames = kCoarseJobBlocks(16) + 3, kMfRows = kMfFrames + 64, kMfPitch = 65;
+constexpr int kMfXWords = kMfFrames * 32, kMfWords = kMfRows * 32, kMfPerThread = (kMfWords + kMfThreads - 1) / kMfThreads;
+constexpr size_t kMfLdsBytes = std::max<size_t>((size_t)2 * kMfRows * kMfPitch, (size_t)256 * kMfPitch) * sizeof(float2);
+__global__ __launch_bounds__(kMfThreads, 2) void coarse_mfma16_kernel(const CoarseJob* __restrict jobs, const CoarseTerm* __restrict terms,
+                                                                     const float2* __restrict X, float2* __restrict Y, int y_frames) {
+  extern __shared__ f2 mlds[];
+  const CoarseJob J = jobs[blockIdx.y];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int P = J.P, nT = J.n_t;
+  const size_t binoff = (size_t)blockIdx.x * 64;
+  const CoarseTerm* __restrict T = terms + J.term0;
+  // word k of this thread: idx = tid + 512 k ; rows 0 .. 34 = frames (frame f = window J.t0 + f - 3), rows 35 .. 98 = spectra (p, c)
+  auto fetch = [&](int i, v4f (&w)[kMfPerThread]) {
+    const int frame0 = T[i].frame0;                 // (scalar loads: the term index is uniform)
+    const float2* __restrict h0 = T[i].h[0];
+#pragma unroll
+    for (int k = 0; k < kMfPerThread; k++) {
+      const int idx = tid + kMfThreads * k, row = idx >> 5, of = idx & 31;
+      w[k] = v4f{0.f, 0.f, 0.f, 0.f};
+      if (idx < kMfXWords) {
+        const int u = J.t0 + row - 3;
+        if (row < nT + 3 && u >= J.u_lo && u <= J.u_hi) w[k] = ldg4(X + (size_t)(frame0 + u + (P - 1)) * kCoarseBins + binoff + 2 * of);
+      } else if (idx < kMfWords) {
+        const int r = row - kMfFrames, p = r >> 4, c = r & 15;
+        if (p < P) w[k] = ldg4(h0 + ((size_t)c * P + p) * kCoarseBins + binoff + 2 * of);
+      }
+    }
+  };
+  auto put = [&](f2* stage, const v4f (&w)[kMfPerThread]) {
+#pragma unroll
+    for (int k = 0; k < kMfPerThread; k++) {
+      const int idx = tid + kMfThreads * k, row = idx >> 5, of = idx & 31;
+      if (idx < kMfWords) {
+        stage[row * kMfPitch + 2 * of] = f2{w[k].x, w[k].y};
+        stage[row * kMfPitch + 2 * of + 1] = f2{w[k].z, w[k].w};
+      }
+    }
+  };
+  f4v accr[8][2], acci[8][2];
+#pragma unroll
+  for (int b = 0; b < 8; b++)
+#pragma unroll
+    for (int q = 0; q < 2; q++) accr[b][q] = acci[b][q] = f4v{0.f, 0.f, 0.f, 0.f};
+  v4f w[kMfPerThread];
+  fetch(0, w);
+  put(mlds, w);
+  __syncthreads();
+  const int arow = kMfFrames + lane;                              // A fragment: spectra row (p = lane >> 4, c = lane & 15)
+  const int brow = (lane & 15) - (lane >> 4) + 3;                 // B fragment of tile 0: frame of t = lane & 15, p = lane >> 4
+  for (int i = 0; i < J.n_terms; i++) {
+    const bool more = i + 1 < J.n_terms;
+    const f2* __restrict st = mlds + (size_t)(i & 1) * kMfRows * kMfPitch;
+    if (more) fetch(i + 1, w);   // (in flight during the MFMAs below)
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      const int bin = 8 * wv + b;
+      const f2 a = st[arow * kMfPitch + bin];
+      const f2 x0 = st[brow * kMfPitch + bin], x1 = st[(brow + 16) * kMfPitch + bin];
+      const float nai = -a.y;
+      accr[b][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x0.x, accr[b][0], 0, 0, 0);
+      acci[b][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x0.y, acci[b][0], 0, 0, 0);
+      accr[b][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x1.x, accr[b][1], 0, 0, 0);
+      acci[b][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x1.y, acci[b][1], 0, 0, 0);
+      accr[b][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(nai, x0.y, accr[b][0], 0, 0, 0);
+      acci[b][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x0.x, acci[b][0], 0, 0, 0);
+      accr[b][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(nai, x1.y, accr[b][1], 0, 0, 0);
+      acci[b][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x1.x, acci[b][1], 0, 0, 0);
+    }
+    if (more) put(mlds + (size_t)((i + 1) & 1) * kMfRows * kMfPitch, w);
+    __syncthreads();
+  }
+  // results: per tile of 16 blocks through the LDS ([row = c 16 + t][bin], pitch 65), then whole 512-byte rows to Y
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+#pragma unroll
+    for (int b = 0; b < 8; b++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) mlds[((4 * (lane >> 4) + r) * 16 + (lane & 15)) * kMfPitch + 8 * wv + b] = f2{accr[b][q][r], acci[b][q][r]};
+    __syncthreads();
+    for (int idx = tid; idx < 256 * 32; idx += kMfThreads) {
+      const int row = idx >> 5, of = idx & 31, c = row >> 4, t = 16 * q + (row & 15);
+      if (t < nT) {
+        const f2 v0 = mlds[row * kMfPitch + 2 * of], v1 = mlds[row * kMfPitch + 2 * of + 1];
+        stg4(Y + ((size_t)(J.yrow0 + c) * y_frames + J.t0 + t) * kCoarseBins + binoff + 2 * of, v4f{v0.x, v0.y, v1.x, v1.y});
+      }
+    }
+    __syncthreads();
+  }
+}
+
 template <int CW, int TW, int PB, int WV = kMacWaves>
 static const char* launch_coarse_mac_t(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
                                 int y_frames, int max_t, int maxP, bool any_private) {
@@ -717,7 +822,7 @@ static const char* launch_coarse_mac_cw(hipStream_t s, const CoarseJob* jobs_dev
   return launch_coarse_mac_t<CW, TWL, 1>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
 }
 const char* launch_coarse_mac(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
-                       int y_frames, int cw, int max_t, int maxP, bool any_private, int pb) {
+                       int y_frames, int cw, int max_t, int maxP, bool any_private, int pb, bool matrix_cores) {
   if (njobs <= 0) return "";
   if (max_t > (any_private ? kCoarseJobBlocks(cw) : kCoarseSumJobBlocks(cw))) launch_fail("coarse multiply-accumulate: too many coarse blocks in a job");
   if (const char* e = expenv("GA_COARSE_PB")) pb = std::min(pb, std::max(1, atoi(e)));   // measurements only
@@ -729,7 +834,17 @@ const char* launch_coarse_mac(hipStream_t s, const CoarseJob* jobs_dev, int njob
   // the source's X frames are staged ONCE for its 16 columns (4-column jobs: four times) and its impulse-response spectra once per
   // 36 blocks
   if (cw == 16 && any_private) {
-    const char* name = launch_coarse_mac_t<16, kMacTW16, 1, kMacWaves16>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, true);
+    const char* name;
+    if (matrix_cores && maxP <= 4 && max_t <= kCoarseJobBlocks(16)) {
+      static LdsLimit lim;
+      lim.raise((const void*)coarse_mfma16_kernel, kMfLdsBytes, "cannot raise the dynamic LDS limit of the matrix-core multiply-accumulate");
+      for (int j0 = 0; j0 < njobs; j0 += 32768)
+        hipLaunchKernelGGL(coarse_mfma16_kernel, dim3(kCoarseBins / 64, std::min(32768, njobs - j0)), dim3(kMfThreads), kMfLdsBytes, s, jobs_dev + j0,
+                           terms_dev, X, Y, y_frames);
+      name = "coarse_mfma16_kernel";
+    } else {
+      name = launch_coarse_mac_t<16, kMacTW16, 1, kMacWaves16>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, true);
+    }
     hipLaunchKernelGGL(coarse_mac_bin0_kernel, dim3(njobs), dim3(256), 0, s, jobs_dev, terms_dev, X, Y, y_frames);
     return name;
   }

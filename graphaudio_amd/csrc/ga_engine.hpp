@@ -567,6 +567,7 @@ struct Context {
   std::vector<BufSpan> bufSpans;
   uint64_t bufVersion = 1, bufSpansVersion = 0;
   bool coarseExtHist = true;   // option "coarse_ext_history"
+  bool coarseMfma = true;      // option "coarse_mfma": 16-column jobs on the matrix cores (coarse_mfma16_kernel); 0 = the register-tiled instance
   bool coarseWide = true;      // option "coarse_wide": 16-column multiply-accumulate jobs for multi-channel private impulse responses
   // constant-coefficient biquad cascades split along time (ga_kernels.hpp, BiquadScanJob): A^K per (coefficients, K), float64 on
   // the host, remembered; the pieces' states live in blocks that are handed out per chunk and kept

@@ -128,7 +128,7 @@ constexpr int kCoarseSumJobBlocks(int columns) { return columns <= 2 ? 72 : 40; 
 #ifndef GA_MAC_TW4
 #define GA_MAC_TW4 4   // coarse blocks per wave of the 4-column instance of the general multiply-accumulate kernel
 #endif
-constexpr int kCoarseJobBlocks(int columns) { return columns <= 2 ? 64 : (columns == 16 ? 36 : 8 * GA_MAC_TW4); }   // coarse blocks one multiply-accumulate job covers: 8 waves x 8 (x 4)
+constexpr int kCoarseJobBlocks(int columns) { return columns <= 2 ? 64 : (columns == 16 ? 32 : 8 * GA_MAC_TW4); }   // coarse blocks one multiply-accumulate job covers: 8 waves x 8 (x 4)
 // floating-point operations of one 16,384-point real transform as the kernels evaluate it: two complex radix-16 transforms of 4096
 // points (3 passes x 256 radix-16 butterflies of ~ 200 flops incl. twiddles, each) + the combine pass (~ 30 flops per bin quad pair)
 constexpr double kCoarseTransformFlops = 2.0 * 3.0 * 256.0 * 200.0 + 2048.0 * 60.0;
@@ -211,8 +211,10 @@ const char* launch_coarse_premix(hipStream_t s, const PremixJob* jobs_dev, int n
 // forward: tw16 = Context::twiddles16pw() ; inverse: tw16 = Context::twiddles16(4096) ; twab = [2][2049]: W_8192^k, W_16384^k
 const char* launch_coarse_fwd(hipStream_t s, const CoarseXRow* rows_dev, int nrows, int max_frames, int run, float2* X, const float2* tw16,
                        const float2* twab, const CoarseHandOver* handover_dev = nullptr, int n_handover = 0);
+// matrix_cores (16-column jobs with at most 4 partitions whose columns' spectra are h[0] + c x P x kCoarseBins): the per-bin complex
+// GEMM  Y[c][t] += sum_p H_c[p] X[t - p]  on v_mfma_f32_16x16x4_f32 (coarse_mfma16_kernel)
 const char* launch_coarse_mac(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
-                       int y_frames, int cw, int max_t, int maxP, bool any_private, int pb);
+                       int y_frames, int cw, int max_t, int maxP, bool any_private, int pb, bool matrix_cores = false);
 const char* launch_coarse_inv(hipStream_t s, const CoarseOut* outs_dev, int nouts, int n_t, const int* ylist_dev, const float2* Y, int y_frames,
                        const float2* tw16, const float2* twab);
 void launch_coarse_hist(hipStream_t s, const CoarseHistJob* jobs_dev, int njobs, int64_t max_len);
