@@ -661,22 +661,33 @@ __global__ __launch_bounds__(256) void coarse_mac_bin0_kernel(const CoarseJob* _
                                                              const float2* __restrict X, float2* __restrict Y, int y_frames) {
   const CoarseJob J = jobs[blockIdx.x];
   const CoarseTerm* __restrict T = terms + J.term0;
-  const int P = J.P;
-  for (int idx = threadIdx.x; idx < J.n_t * 16; idx += 256) {
-    const int t = idx >> 4, c = idx & 15;
-    f2 acc = f2{0.f, 0.f};
-    for (int i = 0; i < J.n_terms; i++) {
-      const float2* __restrict h = T[i].h[c];
-      for (int p = 0; p < P; p++) {
-        const int u = J.t0 + t - p;   // window index
-        if (u < J.u_lo || u > J.u_hi) continue;
-        const v2f x = ldg2(X + (size_t)(T[i].frame0 + u + (P - 1)) * kCoarseBins);
-        const v2f hv = ldg2(h + (size_t)p * kCoarseBins);
-        acc = __builtin_elementwise_fma(f2{x.x, x.y}, f2{hv.x, hv.y}, acc);
+  const int P = J.P;   // (<= kCoarseMaxP)
+  const int idx = blockIdx.y * 256 + threadIdx.x;
+  if (idx >= J.n_t * 16) return;
+  const int t = idx >> 4, c = idx & 15;
+  // partitions whose window exists: u = J.t0 + t - p in [u_lo, u_hi]
+  const int p_lo = max(0, J.t0 + t - J.u_hi), p_hi = min(P - 1, J.t0 + t - J.u_lo);
+  f2 acc = f2{0.f, 0.f};
+  for (int i = 0; i < J.n_terms; i++) {   // (all loads of a term are independent: the partitions' loop is unrolled by four)
+    const float2* __restrict h = T[i].h[c];
+    const float2* __restrict x = X + (size_t)(T[i].frame0 + J.t0 + t + (P - 1)) * kCoarseBins;   // window u = J.t0 + t - p sits p frames back
+    int p = p_lo;
+    for (; p + 3 <= p_hi; p += 4) {
+      v2f xv[4], hv[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        xv[q] = ldg2(x - (size_t)(p + q) * kCoarseBins);
+        hv[q] = ldg2(h + (size_t)(p + q) * kCoarseBins);
       }
+#pragma unroll
+      for (int q = 0; q < 4; q++) acc = __builtin_elementwise_fma(f2{xv[q].x, xv[q].y}, f2{hv[q].x, hv[q].y}, acc);
     }
-    stg2(Y + ((size_t)(J.yrow0 + c) * y_frames + J.t0 + t) * kCoarseBins, v2f{acc.x, acc.y});
+    for (; p <= p_hi; p++) {
+      const v2f xv = ldg2(x - (size_t)p * kCoarseBins), hv = ldg2(h + (size_t)p * kCoarseBins);
+      acc = __builtin_elementwise_fma(f2{xv.x, xv.y}, f2{hv.x, hv.y}, acc);
+    }
   }
+  stg2(Y + ((size_t)(J.yrow0 + c) * y_frames + J.t0 + t) * kCoarseBins, v2f{acc.x, acc.y});
 }
 
 // =====================================================================================================================
@@ -845,7 +856,7 @@ const char* launch_coarse_mac(hipStream_t s, const CoarseJob* jobs_dev, int njob
     } else {
       name = launch_coarse_mac_t<16, kMacTW16, 1, kMacWaves16>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, true);
     }
-    hipLaunchKernelGGL(coarse_mac_bin0_kernel, dim3(njobs), dim3(256), 0, s, jobs_dev, terms_dev, X, Y, y_frames);
+    hipLaunchKernelGGL(coarse_mac_bin0_kernel, dim3(njobs, (kCoarseJobBlocks(16) * 16 + 255) / 256), dim3(256), 0, s, jobs_dev, terms_dev, X, Y, y_frames);
     return name;
   }
   launch_fail("coarse multiply-accumulate: unsupported column count");
