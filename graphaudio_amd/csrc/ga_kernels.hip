@@ -1970,8 +1970,11 @@ __device__ void biquad_update_coefficients(int type, float frequency, float q, f
                                            float& b2, float& a1, float& a2) {   // BiQuadFilterNode.cs:149-258
   const float PI = 3.14159274f;
   float w0 = 2.f * PI * frequency / sample_rate;
-  float cosW0 = cosf(w0);
-  float sinW0 = sinf(w0);
+  // The reference's MathF.Cos / MathF.Sin are the C library's, which evaluate in double and round once; the device library's
+  // single-precision versions are 1-2 ulp off that, which a resonant section amplifies ~fs/(pi*f/Q) times.  Evaluating in
+  // double here lands on the same float except when the true value sits within ~1e-9 of a rounding boundary.
+  float cosW0 = (float)cos((double)w0);
+  float sinW0 = (float)sin((double)w0);
   float alpha = sinW0 / (2.f * q);
   float a0, A1, A2, B0, B1, B2;
   switch (type) {
@@ -1981,12 +1984,12 @@ __device__ void biquad_update_coefficients(int type, float frequency, float q, f
     case 3: B0 = 1.f; B1 = -2.f * cosW0; B2 = 1.f; a0 = 1.f + alpha; A1 = -2.f * cosW0; A2 = 1.f - alpha; break;
     case 4: B0 = 1.f - alpha; B1 = -2.f * cosW0; B2 = 1.f + alpha; a0 = 1.f + alpha; A1 = -2.f * cosW0; A2 = 1.f - alpha; break;
     case 5: {
-      float A = powf(10.f, gain / 40.f);
+      float A = (float)pow(10.0, (double)(gain / 40.f));
       B0 = 1.f + alpha * A; B1 = -2.f * cosW0; B2 = 1.f - alpha * A; a0 = 1.f + alpha / A; A1 = -2.f * cosW0; A2 = 1.f - alpha / A;
       break;
     }
     case 6: {
-      float A = powf(10.f, gain / 40.f);
+      float A = (float)pow(10.0, (double)(gain / 40.f));
       float beta = sqrtf(A) / q;
       B0 = A * ((A + 1.f) - (A - 1.f) * cosW0 + beta * sinW0);
       B1 = 2.f * A * ((A - 1.f) - (A + 1.f) * cosW0);
@@ -1997,7 +2000,7 @@ __device__ void biquad_update_coefficients(int type, float frequency, float q, f
       break;
     }
     case 7: {
-      float A = powf(10.f, gain / 40.f);
+      float A = (float)pow(10.0, (double)(gain / 40.f));
       float beta = sqrtf(A) / q;
       B0 = A * ((A + 1.f) + (A - 1.f) * cosW0 + beta * sinW0);
       B1 = -2.f * A * ((A - 1.f) + (A + 1.f) * cosW0);
@@ -2445,8 +2448,9 @@ void launch_delay(hipStream_t s, const DelayJob* jobs_dev, int njobs, int64_t ma
 __device__ __forceinline__ void pan_gains(float pan, int stereo, float& gl, float& gr) {   // :94-98 / :129-133
   const float PIf = 3.14159265358979323846f;
   const float x = stereo ? (pan <= 0.0f ? pan + 1.0f : pan) : (pan + 1.0f) * 0.5f;
-  gl = cosf(x * PIf / 2.0f);
-  gr = sinf(x * PIf / 2.0f);
+  const float a = x * PIf / 2.0f;
+  gl = (float)cos((double)a);   // rounded once from double, as the C library's cosf / sinf behind MathF are
+  gr = (float)sin((double)a);
 }
 __global__ __launch_bounds__(64) void stereo_panner_dynamic_kernel(const PanDynJob* __restrict jobs) {
   __shared__ float chg_pan[64];

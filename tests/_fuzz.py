@@ -291,7 +291,8 @@ def run_random_session(ctx, seed, frames=128 * 48, max_piece=128 * 9, keep=None)
             cands += [(n, n.Frequency if isinstance(n, OscillatorNode) else n.Offset, 50.0 if isinstance(n, OscillatorNode) else 0.2)
                       for n in h.get("scheduled", []) if id(n) not in dead]
             if cands:
-                _, prm, depth = cands[int(rng.integers(0, len(cands)))]
+                tgt_node, prm, depth = cands[int(rng.integers(0, len(cands)))]
+                detail.append((type(tgt_node).__name__, nid(tgt_node), depth))
                 lfo = AudioBufferSourceNode(ctx)
                 lfo.Buffer = PlayableAudioBuffer.FromMonoArray((rng.standard_normal(700) * depth).astype(np.float32), SR)
                 lfo.Loop = True
@@ -322,6 +323,7 @@ def run_random_session(ctx, seed, frames=128 * 48, max_piece=128 * 9, keep=None)
         elif kind == "osc":
             o = pick(h.get("scheduled", []))
             if o is not None:
+                detail.append((type(o).__name__, nid(o)))
                 if isinstance(o, OscillatorNode):
                     if rng.random() < 0.5: o.Type = OscillatorType(int(rng.integers(0, 4)))
                     else: o.Frequency.Value = float(rng.uniform(20, 8000))
