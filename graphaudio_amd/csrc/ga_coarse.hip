@@ -36,6 +36,7 @@
 #include <atomic>
 #include <string>
 #include <type_traits>
+#include <utility>
 #include <cstdio>
 #include <cstdlib>
 
@@ -75,6 +76,31 @@ __device__ __forceinline__ f2 cfmap(f2 a, f2 b, f2 acc) {
   asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(t) : "v"(a), "v"(b), "v"(acc));
   asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
   return r;
+}
+
+// 8-byte LDS reads that STAY `ds_read_b64`.  The compiler merges two reads off one base register into `ds_read2st64_b64`, which
+// the LDS serves as two accesses of four 16-lane groups each -- 8 LDS cycles for 1 KB, where two `ds_read_b64` take 2 + 2
+// (MI355X_MICROARCH.md, LDS table: 128 vs 256 B/clk/CU).  The sliding sweeps below read 13 values per 64 packed fmas and wave;
+// merged, that is ~70 % of the LDS pipe's cycles next to a VALU that wants every issue slot.  Reads issued here are invisible
+// to the compiler's wait-count pass: lds_wait_all() must follow before the first use.
+template <int OFF>
+__device__ __forceinline__ f2 lds_rd_b64(unsigned addr) {
+  f2 r;
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+  return r;
+}
+template <int STRIDE, int... Q>
+__device__ __forceinline__ void lds_rd_seq(f2* dst, unsigned addr, std::integer_sequence<int, Q...>) {
+  ((dst[Q] = lds_rd_b64<Q * STRIDE>(addr)), ...);
+}
+template <int N>
+__device__ __forceinline__ void lds_pin(f2* v) {   // values of asm reads: usable only after the wait (volatile asms keep their order)
+#pragma unroll
+  for (int i = 0; i < N; i++) asm volatile("" : "+v"(v[i]));
+}
+__device__ __forceinline__ void lds_wait_all() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned lds_addr(const f2* p) {
+  return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) f2*)p;
 }
 
 // =====================================================================================================================
@@ -328,18 +354,19 @@ const char* launch_coarse_fwd(hipStream_t s, const CoarseXRow* rows_dev, int nro
 #define GA_MAC_TW 8
 #endif
 #ifndef GA_MAC_PB2
-#define GA_MAC_PB2 2      // partition block used for 2-column jobs whose partition count is a multiple of 4
+#define GA_MAC_PB2 4      // partition block used for 2-column jobs whose partition count is a multiple of 4 (2: 1.54 ms, 4: 1.49 ms at 1024 private stereo IRs)
 #endif
 constexpr int kMacWaves16 = 12;                               // the 16-column instance: 12 waves (three per SIMD: 168 registers each) ...
 constexpr int kMacTW16 = (kCoarseJobBlocks(16) + kMacWaves16 - 1) / kMacWaves16;   // ... x 3 blocks x 16 columns = 48 complex accumulators per lane
 constexpr int kMacWaves = GA_MAC_WAVES;      // waves per workgroup: each takes 1/kMacWaves of the job's coarse blocks
-#ifndef GA_MAC_WGS_PER_CU
-#define GA_MAC_WGS_PER_CU 2
-#endif
-constexpr int kMacWavesPerSimd = kMacWaves * GA_MAC_WGS_PER_CU / 4;   // workgroups per CU (LDS) x waves, four SIMDs
+// Workgroups per CU the register budget is set for.  Jobs of 1 or 2 columns span up to 64 coarse blocks: 2 x 71 frames x 512 B of
+// double-buffered staging (72.7 KB) + the spectra leave room for ONE workgroup per CU whatever the partition count (measured:
+// hipOccupancyMaxActiveBlocksPerMultiprocessor = 1 at 89 KB), so those instances take the 256 registers two waves per SIMD may
+// have (the operand prefetch of the sweep needs 130); 4-column jobs span 32 blocks (72 KB at 8 partitions): two per CU, 128.
+constexpr int kMacWavesPerSimd(int cw) { return kMacWaves * (cw >= 4 ? 2 : 1) / 4; }
 // (launches whose terms all share one impulse response take coarse_sum_kernel below instead)
 template <int CW, int TW, int PB, int WV>
-__global__ __launch_bounds__(64 * WV, WV == 8 ? kMacWavesPerSimd : WV / 4) void coarse_mac_kernel(const CoarseJob* __restrict jobs, const CoarseTerm* __restrict terms,
+__global__ __launch_bounds__(64 * WV, WV == 8 ? kMacWavesPerSimd(CW) : WV / 4) void coarse_mac_kernel(const CoarseJob* __restrict jobs, const CoarseTerm* __restrict terms,
                                                                     const float2* __restrict X, float2* __restrict Y, int y_frames, int NFA,
                                                                     int exp) {
   extern __shared__ f2 mlds[];   // (ALL of the kernel's LDS is this one array: a second object beside a direct-to-LDS target costs a vmcnt(0) per read)
@@ -422,37 +449,57 @@ __global__ __launch_bounds__(64 * WV, WV == 8 ? kMacWavesPerSimd : WV / 4) void 
       // flag inside the unrolled body the compiler evaluates both products for every tile.
       auto sweep = [&](auto sp) {
         constexpr bool SP = decltype(sp)::value;
-        constexpr int PBX = PB;
-        for (int pb = 0; pb < P; pb += PBX) {
-          constexpr bool EARLY_H = CW <= 4;   // (16 columns: the spectra are read where they are used, or 32 more registers spill)
-          f2 hl[EARLY_H ? PBX : 1][EARLY_H ? CW : 1];
-          if constexpr (EARLY_H) {
-#pragma unroll
-            for (int j = 0; j < PBX; j++)
-#pragma unroll
-              for (int c = 0; c < CW; c++) hl[j][c] = hs[((pb + j) * CW + c) * 64 + lane];
+        constexpr int PBX = PB, NX = TW + PBX - 1, NH = PBX * CW;
+        constexpr bool EARLY_H = CW <= 4;   // (16 columns: the spectra are read where they are used, or 32 more registers spill)
+        auto fma1 = [&](int tt, int c, f2 x, f2 h) {
+          if constexpr (!SP) {
+            acc[tt][c] = cfmap(x, h, acc[tt][c]);
+          } else {
+            const f2 gen = cfmap(x, h, acc[tt][c]);
+            const f2 pk = __builtin_elementwise_fma(x, h, acc[tt][c]);   // two real bins side by side
+            acc[tt][c] = lane0 ? pk : gen;
           }
-          const f2* __restrict xb = xs + (t0w + (P - 1) - pb - (PBX - 1)) * 64 + lane;   // (pb + PBX - 1 <= P - 1: inside the buffer)
-          f2 xv[TW + PBX - 1];
-#pragma unroll
-          for (int q = 0; q < TW + PBX - 1; q++) xv[q] = xb[q * 64];
-          auto fma1 = [&](int tt, int c, f2 x, f2 h) {
-            if constexpr (!SP) {
-              acc[tt][c] = cfmap(x, h, acc[tt][c]);
-            } else {
-              const f2 gen = cfmap(x, h, acc[tt][c]);
-              const f2 pk = __builtin_elementwise_fma(x, h, acc[tt][c]);   // two real bins side by side
-              acc[tt][c] = lane0 ? pk : gen;
-            }
+        };
+        if constexpr (EARLY_H) {
+          // One LDS latency per TERM, not per block of partitions: the operands of block b + 1 (NH spectra values, NX frames: rows
+          // 512 bytes apart, plain ds_read_b64 -- see lds_rd_b64) are requested before the fmas of block b are issued and waited
+          // for after them.  With the one workgroup per CU the double-buffered staging leaves room for (two waves per SIMD) a
+          // wave that waits for the LDS at every block idles the VALU a third of the time.
+          f2 hA[NH], xA[NX], hB[NH], xB[NX];
+          auto fetch = [&](int pb, f2* h, f2* x) {
+            lds_rd_seq<512>(h, lds_addr(hs + pb * CW * 64 + lane), std::make_integer_sequence<int, NH>{});
+            lds_rd_seq<512>(x, lds_addr(xs + (t0w + (P - 1) - pb - (PBX - 1)) * 64 + lane), std::make_integer_sequence<int, NX>{});   // (pb + PBX - 1 <= P - 1: inside the buffer)
           };
-          if constexpr (EARLY_H) {
+          auto arrive = [&](f2* h, f2* x) {
+            lds_wait_all();
+            lds_pin<NH>(h);
+            lds_pin<NX>(x);
+          };
+          auto fmas = [&](const f2* h, const f2* x) {
 #pragma unroll
             for (int j = 0; j < PBX; j++)
 #pragma unroll
               for (int tt = 0; tt < TW; tt++)
 #pragma unroll
-                for (int c = 0; c < CW; c++) fma1(tt, c, xv[tt - j + (PBX - 1)], hl[j][c]);
-          } else {
+                for (int c = 0; c < CW; c++) fma1(tt, c, x[tt - j + (PBX - 1)], h[j * CW + c]);
+          };
+          fetch(0, hA, xA);
+          for (int pb = 0; pb < P; pb += 2 * PBX) {
+            arrive(hA, xA);
+            const bool second = pb + PBX < P;
+            if (second) fetch(pb + PBX, hB, xB);
+            fmas(hA, xA);
+            if (!second) break;
+            arrive(hB, xB);
+            if (pb + 2 * PBX < P) fetch(pb + 2 * PBX, hA, xA);
+            fmas(hB, xB);
+          }
+        } else {
+          for (int pb = 0; pb < P; pb += PBX) {
+            const f2* __restrict xb = xs + (t0w + (P - 1) - pb - (PBX - 1)) * 64 + lane;
+            f2 xv[NX];
+#pragma unroll
+            for (int q = 0; q < NX; q++) xv[q] = xb[q * 64];
 #pragma unroll
             for (int j = 0; j < PBX; j++)
 #pragma unroll
@@ -469,7 +516,7 @@ __global__ __launch_bounds__(64 * WV, WV == 8 ? kMacWavesPerSimd : WV / 4) void 
       if (special && CW != 16) sweep(std::true_type{});
       else sweep(std::false_type{});
     }
-    __syncthreads();
+    if (!(exp & 8)) __syncthreads();
   }
 #pragma unroll
   for (int tt = 0; tt < TW; tt++) {

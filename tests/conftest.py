@@ -19,3 +19,22 @@ except Exception:  # torch is optional for everything else
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """The figures the at-size tests measured (tests/_report.py), printed with -q too and written next to the GPU run's other
+    outputs when that directory exists."""
+    from tests._report import FIGURES
+    if not FIGURES:
+        return
+    terminalreporter.section("parity figures measured by this run")
+    for line in FIGURES:
+        terminalreporter.write_line(line)
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        try:
+            import json
+            with open(os.path.join(out_dir, "parity_figures.json"), "w") as f:
+                json.dump(FIGURES, f, indent=1)
+        except OSError:
+            pass

@@ -21,6 +21,7 @@ from graphaudio_amd import (AudioBufferSourceNode, ConvolverNode, GainNode, Inva
                             PlayableAudioBuffer)
 from tests import _graphs as G
 from tests._oracle import OracleContext
+from tests._report import note
 
 SR = 48000
 TOL_RMS = 1e-5
@@ -41,7 +42,7 @@ def both(builder, nrender, options=None, **kw):
 
 def report(name, ref, got):
     err, sig = G.rms(ref - got), G.rms(ref)
-    print(f"[atsize] {name}: bus rms {sig:.4e}  abs rms err {err:.3e}  relative {err / sig:.3e}")
+    note(f"[atsize] {name}: bus rms {sig:.4e}  abs rms err {err:.3e}  relative {err / sig:.3e}")
     return err, sig
 
 
@@ -174,7 +175,7 @@ def test_more_than_65535_jobs_in_one_level():
         outs.append(G.render(ctx, 1, frames))
         if mk is OfflineAudioContext:
             st = ctx.GetStats()
-            print("[atsize] many-jobs graph:", st["segments"], "segments,", st["kernel_launches"], "launches")
+            note(f"[atsize] many-jobs graph: {st['segments']} segments, {st['kernel_launches']} launches")
         ctx.Dispose()
     ref, got = outs
     assert G.rms(ref) > 1e-3

@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 from graphaudio_amd import AudioBufferSourceNode, BiQuadFilterNode, FilterType, GainNode, OfflineAudioContext, PlayableAudioBuffer
 from tests import _graphs as G
 from tests._oracle import OracleContext
+from tests._report import note
 
 SR = 48000
 
@@ -44,7 +45,7 @@ def test_config2_split_against_the_oracle_and_bit_exact_without():
     assert np.array_equal(ref, one) and st1["biquad_split_cascades"] == 0
     assert st["biquad_split_cascades"] == 256    # default mode: every one of these low-passes is inside the predicted-deviation bound
     err, sig = G.rms(ref - got), G.rms(ref)
-    print(f"[biquad split] config 2, 256 voices: {st['biquad_split_cascades']} cascades split; bus rms {sig:.4f}, vs oracle abs rms {err:.3e} "
+    note(f"[biquad split] config 2, 256 voices: {st['biquad_split_cascades']} cascades split; bus rms {sig:.4f}, vs oracle abs rms {err:.3e} "
           f"(relative {err / sig:.3e})")
     assert err <= 1e-6 and err / sig < 2e-6
 
@@ -64,7 +65,7 @@ def test_config4_equaliser_is_not_split_by_default_and_why():
     forced, st2 = _render(OfflineAudioContext, build, frames, biquad_time_split=2)
     assert st2["biquad_split_cascades"] > 0
     err, sig = G.rms(ref - forced), G.rms(ref)
-    print(f"[biquad split] config 4, {voices} voices x 5 sections, split forced: bus rms {sig:.4f}, vs oracle abs rms {err:.3e} (relative {err / sig:.3e})")
+    note(f"[biquad split] config 4, {voices} voices x 5 sections, split forced: bus rms {sig:.4f}, vs oracle abs rms {err:.3e} (relative {err / sig:.3e})")
     assert err / sig < 1e-3   # noise level of the arithmetic, not an error of the split (next test: measured against float64)
 
 
@@ -107,7 +108,7 @@ def test_hard_filters_default_mode_stays_with_the_oracle_forced_mode_stays_at_no
     forced, st = _render(OfflineAudioContext, build, frames, biquad_time_split=2)
     assert st["biquad_split_cascades"] == len(HARD)
     sig = G.rms(ref)
-    print(f"[biquad split] hard filters: bus rms {sig:.4f}; default mode splits {st_auto['biquad_split_cascades']} of {len(HARD)}: vs oracle "
+    note(f"[biquad split] hard filters: bus rms {sig:.4f}; default mode splits {st_auto['biquad_split_cascades']} of {len(HARD)}: vs oracle "
           f"{G.rms(ref - auto):.3e}; forced: vs oracle {G.rms(ref - forced):.3e}")
     assert 0 < st_auto["biquad_split_cascades"] < len(HARD)
     assert G.rms(ref - auto) <= 1e-5

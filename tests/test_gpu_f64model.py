@@ -21,6 +21,7 @@ pytestmark = pytest.mark.gpu
 from graphaudio_amd import OfflineAudioContext
 from tests import _f64model as M
 from tests import _graphs as G
+from tests._report import note
 
 SR = 48000
 TOL = 1e-5
@@ -36,7 +37,7 @@ def _config3_truth(frames):
 
 def _check(name, got, truth, rel=2e-6):
     err, sig = M.rms(got - truth), M.rms(truth)
-    print(f"[f64] {name}: bus rms {sig:.4f}  abs rms err {err:.3e}  relative {err / sig:.3e}")
+    note(f"[f64] {name}: bus rms {sig:.4f}  abs rms err {err:.3e}  relative {err / sig:.3e}")
     assert err <= TOL, (name, err)
     assert err / sig < rel, (name, err / sig)
     return err, sig

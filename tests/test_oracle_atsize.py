@@ -17,6 +17,7 @@ import numpy as np
 from tests import _f64model as M
 from tests import _graphs as G
 from tests._oracle import OracleContext
+from tests._report import note
 
 SR = 48000
 
@@ -32,7 +33,7 @@ def test_oracle_config3_1024_voices_65536_taps_against_float64_convolution():
     err, sig = M.rms(got - truth), M.rms(truth)
     last = slice((blocks - 8) * 128, None)          # the blocks in which all 512 partitions are live
     err_last, sig_last = M.rms(got[:, last] - truth[:, last]), M.rms(truth[:, last])
-    print(f"[oracle vs f64] config 3, 1024 voices x 65,536 taps, {blocks} blocks: bus rms {sig:.4f}, abs rms err {err:.3e} "
+    note(f"[oracle vs f64] config 3, 1024 voices x 65,536 taps, {blocks} blocks: bus rms {sig:.4f}, abs rms err {err:.3e} "
           f"(relative {err / sig:.3e}); last 8 blocks: bus {sig_last:.4f}, err {err_last:.3e}")
     assert sig_last > 2.0                           # sigma ~ 2.6 once the tail has built up
     assert err <= 1e-5 and err_last <= 1e-5         # north_star's tolerance, absolute
@@ -48,7 +49,7 @@ def test_oracle_config5_64_source_shard_against_float64_convolution():
     o.Dispose()
     truth = M.config5(64, 32768, frames)
     err, sig = M.rms(got - truth), M.rms(truth)
-    print(f"[oracle vs f64] config 5 shard, 64 sources x 16 ch x 32,768 taps, {blocks} blocks: bus rms {sig:.4f}, abs rms err {err:.3e} "
+    note(f"[oracle vs f64] config 5 shard, 64 sources x 16 ch x 32,768 taps, {blocks} blocks: bus rms {sig:.4f}, abs rms err {err:.3e} "
           f"(relative {err / sig:.3e})")
     assert got.shape[0] == 16 and sig > 0.2
     assert err <= 1e-5

@@ -1,0 +1,65 @@
+// How fast can the multiply-accumulate kernel's READ PATTERN go, with nothing else in the kernel?  A workgroup = (tile of 64
+// bins, job of 8 voices); per voice it reads F frames x 512 bytes (its tile's slice of every frame's 64 KB spectrum) + 16
+// rows x 512 bytes of the voice's impulse-response spectra.  Layout A (the product's): frames are 64 KB apart.  Layout B:
+// a tile's frames contiguous ([row][tile][frame][64 bins]).  Layout C: groups of 8 tiles ([row][tile / 8][frame][8 x 64 bins]).
+//   hipcc --offload-arch=gfx950 -O3 -o tools/proto/xread_probe tools/proto/xread_probe.hip && tools/proto/xread_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) f4 gf4;
+constexpr int F = 66, TILES = 128, VOICES = 1024, TW = 8;
+template <int LAYOUT, int U>
+__global__ __launch_bounds__(256) void probe(const f4* __restrict x, float* out) {
+  const int tile = blockIdx.x, job = blockIdx.y;
+  const int sub = threadIdx.x >> 5, l = threadIdx.x & 31;   // 8 frames per pass, 32 lanes x 16 B = 512 B
+  f4 s = f4{0, 0, 0, 0};
+  for (int v = 0; v < TW; v++) {
+    const size_t row = (size_t)job * TW + v;
+    for (int f0 = 0; f0 < F; f0 += 8 * U) {
+      f4 r[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        int f = f0 + 8 * u + sub;
+        if (f >= F) f = F - 1;
+        size_t w;   // in 16-byte words
+        if (LAYOUT == 0) w = ((row * F + f) * TILES + tile) * 32 + l;
+        else if (LAYOUT == 1) w = ((row * TILES + tile) * F + f) * 32 + l;
+        else w = (((row * (TILES / 8) + tile / 8) * F + f) * 8 + (tile & 7)) * 32 + l;
+        r[u] = ((const gf4*)x)[w];
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) s += r[u];
+    }
+  }
+  if (s.x + s.y + s.z + s.w == 12345.678f) out[0] = 1.f;
+}
+template <int LAYOUT, int U>
+void run(const f4* x, float* out, const char* name) {
+  hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+  float best = 1e9, sum = 0; const int reps = 10;
+  for (int r = -2; r < reps; r++) {
+    (void)hipEventRecord(a);
+    hipLaunchKernelGGL((probe<LAYOUT, U>), dim3(TILES, VOICES / TW), dim3(256), 0, 0, x, out);
+    (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+    float ms; (void)hipEventElapsedTime(&ms, a, b);
+    if (r >= 0) { sum += ms; best = ms < best ? ms : best; }
+  }
+  const double gb = (double)VOICES * F * TILES * 512 / 1e9;
+  printf("%-46s U=%d  avg %.3f ms  %.0f GB/s   best %.0f GB/s\n", name, U, sum / reps, gb / (sum / reps * 1e-3), gb / (best * 1e-3));
+}
+int main() {
+  const size_t bytes = (size_t)VOICES * F * TILES * 512;
+  f4* x; float* out;
+  if (hipMalloc(&x, bytes) != hipSuccess || hipMalloc(&out, 64) != hipSuccess) return 1;
+  (void)hipMemset(x, 0, bytes);
+  printf("%.2f GB of spectra, %d x %d workgroups\n", bytes / 1e9, TILES, VOICES / TW);
+  run<0, 1>(x, out, "A: frames 64 KB apart (product)");
+  run<0, 3>(x, out, "A: frames 64 KB apart (product)");
+  run<0, 9>(x, out, "A: frames 64 KB apart (product)");
+  run<1, 1>(x, out, "B: a tile's frames contiguous");
+  run<1, 3>(x, out, "B: a tile's frames contiguous");
+  run<1, 9>(x, out, "B: a tile's frames contiguous");
+  run<2, 3>(x, out, "C: 8 tiles x frame (4 KB pieces on the write side)");
+  run<2, 9>(x, out, "C: 8 tiles x frame (4 KB pieces on the write side)");
+  return 0;
+}
