@@ -13,12 +13,18 @@ __global__ __launch_bounds__(BLK) void k(float* out, int iters, float seed, long
   const int l = threadIdx.x;
   if (iters < 0) dyn_lds[l] = seed;
   const long long c0 = clock64();
-  if constexpr (MODE == 4) {
+  if constexpr (MODE == 4 || MODE == 5) {
     // the sweep's shape: 4 x 2 accumulators, 8 partitions, sliding window of 11 frames, 16 spectra -- all in registers
     f2 acc[4][2], h[8][2], xv[11];
     for (int i = 0; i < 8; i++) { acc[i >> 1][i & 1] = f2{seed * i, seed + i}; }
     for (int i = 0; i < 16; i++) h[i >> 1][i & 1] = f2{1.f + 1e-7f * i, 1e-7f * l};
     for (int i = 0; i < 11; i++) xv[i] = f2{seed + l + i, seed - i};
+    if constexpr (MODE == 5) {   // noise in [-1, 1): audio spectra, not constants
+      auto rnd = [&](unsigned k) { unsigned h = (k * 2654435761u) ^ (l * 40503u) ^ (blockIdx.x * 69069u); h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; return (float)(int)h * 4.6566e-10f; };
+      for (int i = 0; i < 8; i++) acc[i >> 1][i & 1] = f2{rnd(i), rnd(100 + i)};
+      for (int i = 0; i < 16; i++) h[i >> 1][i & 1] = f2{rnd(200 + i), rnd(300 + i)};
+      for (int i = 0; i < 11; i++) xv[i] = f2{rnd(400 + i), rnd(500 + i)};
+    }
     for (int it = 0; it < iters; it++) {
 #pragma unroll
       for (int rep = 0; rep < 2; rep++)
@@ -152,6 +158,7 @@ int main() {
     run<0>("v_pk_fma_f32 plain", 64.0 * 64, w, 128);            // 64 pairs x 64 lanes
     run<1>("v_pk_fma_f32 complex pair (op_sel)", 64.0 * 64, w, 128);
     run<4>("complex pair, sweep-shaped registers", 128.0 * 64, w, 256);
+    run<5>("the same on noise operands", 128.0 * 64, w, 256);
     run<2>("v_fma_f32 x4", 64.0 * 64, w, 256);
     run<3>("v_mfma_f32_4x4x1 (pair = 128 cmac)", 32.0 * 128, w, 64);   // 64 mfma = 32 pairs
   }
