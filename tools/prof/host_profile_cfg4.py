@@ -8,7 +8,7 @@ from graphaudio_amd import OfflineAudioContext
 from tests import _graphs as G
 voices = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 pieces = int(sys.argv[2]) if len(sys.argv) > 2 else 60
-frames = 128 * 64
+frames = 128 * (int(sys.argv[3]) if len(sys.argv) > 3 else 64)
 ctx = OfflineAudioContext(48000)
 ch = G.config4_eq(ctx, voices=voices, frames=frames * pieces)
 out = np.zeros((ch, frames), np.float32)
