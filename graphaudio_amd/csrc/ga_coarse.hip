@@ -752,42 +752,51 @@ __global__ __launch_bounds__(256) void coarse_mac_bin0_kernel(const CoarseJob* _
 //  coarse_mac_bin0_kernel afterwards.
 // =====================================================================================================================
 typedef float f4v __attribute__((ext_vector_type(4)));
-constexpr int kMfThreads = 512, kMfFrames = kCoarseJobBlocks(16) + 3, kMfRows = kMfFrames + 64, kMfPitch = 65;
-constexpr int kMfXWords = kMfFrames * 32, kMfWords = kMfRows * 32, kMfPerThread = (kMfWords + kMfThreads - 1) / kMfThreads;
-constexpr size_t kMfLdsBytes = std::max<size_t>((size_t)2 * kMfRows * kMfPitch, (size_t)256 * kMfPitch) * sizeof(float2);
+constexpr int kMfThreads = 512, kMfFrames = kCoarseJobBlocks(16) + 3, kMfRows = kMfFrames + 64, kMfPitch = 65;   // (pitch of the result tile)
+constexpr size_t kMfLdsBytes = std::max<size_t>((size_t)2 * kMfRows * 64, (size_t)256 * kMfPitch) * sizeof(float2);
+// LDS image of a term: 35 frame rows + 64 spectra rows of 64 bins, 512 bytes apart, written by global_load_lds (no staging registers,
+// no ds_write pass after the MFMAs).  A fragment read walks ROWS at a fixed bin -- at this pitch every lane on one bank -- and a
+// direct-to-LDS load cannot pad rows (its image is linear in the lane), so the swizzle is applied on the GLOBAL side: slot s of row r
+// receives the row's 16-byte word s ^ (r & 31).  32 consecutive rows at one bin then fall on 16 different bank pairs: 2-way, on 3
+// reads per 8 MFMAs.
+__device__ __forceinline__ int mf_slot(int row, int bin) { return row * 64 + ((((bin >> 1) ^ row) & 31) << 1) + (bin & 1); }
 __global__ __launch_bounds__(kMfThreads, 2) void coarse_mfma16_kernel(const CoarseJob* __restrict jobs, const CoarseTerm* __restrict terms,
                                                                      const float2* __restrict X, float2* __restrict Y, int y_frames) {
   extern __shared__ f2 mlds[];
+  typedef __attribute__((address_space(3))) void* lds_t;
   const CoarseJob J = jobs[blockIdx.y];
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int P = J.P, nT = J.n_t;
   const size_t binoff = (size_t)blockIdx.x * 64;
   const CoarseTerm* __restrict T = terms + J.term0;
-  // word k of this thread: idx = tid + 512 k ; rows 0 .. 34 = frames (frame f = window J.t0 + f - 3), rows 35 .. 98 = spectra (p, c)
-  auto fetch = [&](int i, v4f (&w)[kMfPerThread]) {
+  // rows 0 .. 34 = frames (row f = window J.t0 + f - 3), rows 35 .. 98 = spectra (p = r >> 4, c = r & 15); rows that do not exist
+  // (windows outside the signal, partitions >= P) are zero in both buffers and never loaded
+  auto live = [&](int row) {
+    if (row < kMfFrames) {
+      const int u = J.t0 + row - 3;
+      return row < nT + 3 && u >= J.u_lo && u <= J.u_hi;
+    }
+    return row < kMfRows && ((row - kMfFrames) >> 4) < P;
+  };
+  f2* st0 = mlds;
+  f2* st1 = mlds + (size_t)kMfRows * 64;
+  for (int idx = tid; idx < kMfRows * 32; idx += kMfThreads) {
+    const int row = idx >> 5;
+    if (!live(row)) {
+      *reinterpret_cast<v4f*>(st0 + row * 64 + 2 * (idx & 31)) = v4f{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<v4f*>(st1 + row * 64 + 2 * (idx & 31)) = v4f{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  auto issue = [&](int i, f2* stage) {   // one wave instruction = two consecutive rows (1 KB, linear in the lane)
     const int frame0 = T[i].frame0;                 // (scalar loads: the term index is uniform)
     const float2* __restrict h0 = T[i].h[0];
 #pragma unroll
-    for (int k = 0; k < kMfPerThread; k++) {
-      const int idx = tid + kMfThreads * k, row = idx >> 5, of = idx & 31;
-      w[k] = v4f{0.f, 0.f, 0.f, 0.f};
-      if (idx < kMfXWords) {
-        const int u = J.t0 + row - 3;
-        if (row < nT + 3 && u >= J.u_lo && u <= J.u_hi) w[k] = ldg4(X + (size_t)(frame0 + u + (P - 1)) * kCoarseBins + binoff + 2 * of);
-      } else if (idx < kMfWords) {
-        const int r = row - kMfFrames, p = r >> 4, c = r & 15;
-        if (p < P) w[k] = ldg4(h0 + ((size_t)c * P + p) * kCoarseBins + binoff + 2 * of);
-      }
-    }
-  };
-  auto put = [&](f2* stage, const v4f (&w)[kMfPerThread]) {
-#pragma unroll
-    for (int k = 0; k < kMfPerThread; k++) {
-      const int idx = tid + kMfThreads * k, row = idx >> 5, of = idx & 31;
-      if (idx < kMfWords) {
-        stage[row * kMfPitch + 2 * of] = f2{w[k].x, w[k].y};
-        stage[row * kMfPitch + 2 * of + 1] = f2{w[k].z, w[k].w};
-      }
+    for (int k = 0; k < (kMfRows + 15) / 16; k++) {
+      const int r0 = 16 * k + 2 * wv, row = r0 + (lane >> 5);
+      const int sw = ((lane & 31) ^ row) & 31;      // the word of the row this lane fetches into slot (lane & 31)
+      const float2* src = row < kMfFrames ? X + (size_t)(frame0 + J.t0 + row - 3 + (P - 1)) * kCoarseBins
+                                          : h0 + ((size_t)((row - kMfFrames) & 15) * P + ((row - kMfFrames) >> 4)) * kCoarseBins;
+      if (live(row)) __builtin_amdgcn_global_load_lds(gptr(src + binoff + 2 * sw), (lds_t)(stage + r0 * 64), 16, 0, 0);
     }
   };
   f4v accr[8][2], acci[8][2];
@@ -795,21 +804,18 @@ __global__ __launch_bounds__(kMfThreads, 2) void coarse_mfma16_kernel(const Coar
   for (int b = 0; b < 8; b++)
 #pragma unroll
     for (int q = 0; q < 2; q++) accr[b][q] = acci[b][q] = f4v{0.f, 0.f, 0.f, 0.f};
-  v4f w[kMfPerThread];
-  fetch(0, w);
-  put(mlds, w);
-  __syncthreads();
+  issue(0, st0);
+  __syncthreads();   // (waits for the workgroup's direct-to-LDS loads: the barrier's fence includes vmcnt(0))
   const int arow = kMfFrames + lane;                              // A fragment: spectra row (p = lane >> 4, c = lane & 15)
   const int brow = (lane & 15) - (lane >> 4) + 3;                 // B fragment of tile 0: frame of t = lane & 15, p = lane >> 4
   for (int i = 0; i < J.n_terms; i++) {
-    const bool more = i + 1 < J.n_terms;
-    const f2* __restrict st = mlds + (size_t)(i & 1) * kMfRows * kMfPitch;
-    if (more) fetch(i + 1, w);   // (in flight during the MFMAs below)
+    const f2* __restrict st = (i & 1) ? st1 : st0;
+    if (i + 1 < J.n_terms) issue(i + 1, (i & 1) ? st0 : st1);   // lands during the MFMAs below (its last readers passed the barrier)
 #pragma unroll
     for (int b = 0; b < 8; b++) {
       const int bin = 8 * wv + b;
-      const f2 a = st[arow * kMfPitch + bin];
-      const f2 x0 = st[brow * kMfPitch + bin], x1 = st[(brow + 16) * kMfPitch + bin];
+      const f2 a = st[mf_slot(arow, bin)];
+      const f2 x0 = st[mf_slot(brow, bin)], x1 = st[mf_slot(brow + 16, bin)];
       const float nai = -a.y;
       accr[b][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x0.x, accr[b][0], 0, 0, 0);
       acci[b][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x0.y, acci[b][0], 0, 0, 0);
@@ -820,7 +826,6 @@ __global__ __launch_bounds__(kMfThreads, 2) void coarse_mfma16_kernel(const Coar
       accr[b][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(nai, x1.y, accr[b][1], 0, 0, 0);
       acci[b][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x1.x, acci[b][1], 0, 0, 0);
     }
-    if (more) put(mlds + (size_t)((i + 1) & 1) * kMfRows * kMfPitch, w);
     __syncthreads();
   }
   // results: per tile of 16 blocks through the LDS ([row = c 16 + t][bin], pitch 65), then whole 512-byte rows to Y
