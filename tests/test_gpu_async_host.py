@@ -63,6 +63,23 @@ def test_deferred_hand_over_equals_blocking_renders(shared):
         assert np.array_equal(ref[k], off[k]), k
 
 
+def test_sixteen_channel_bus():
+    """config 5's shape: the 16-channel bus of step k (31 MB per 10 s at full size) crosses PCIe inside step k + 1's forward launch,
+    whichever multiply-accumulate kernel the stage uses.  (Tried in round 3: carrying it in the matrix-core launch instead -- the
+    forward stage drops 1.01 -> 0.65 ms, the multiply-accumulate stage grows 1.60 -> 2.14: its copy workgroups each hold a CU's LDS.)"""
+    frames, steps = 128 * 320, 4
+    build = lambda c: G.config5_ambisonic(c, sources=5, taps=32768, frames=frames * steps)
+    for opts in ({}, {"coarse_mfma": 0}, {"coarse_wide": 0}):   # (different kernels round differently: a blocking reference per route)
+        ref, _ = _steps(build, frames, steps, async_=False, pinned=False, coarse_min_blocks=1, **opts)
+        got, st = _steps(build, frames, steps, async_=True, pinned=True, coarse_min_blocks=1, **opts)
+        assert st["deferred_handovers"] == steps - 1
+        for k in range(steps):
+            assert G.rms(ref[k]) > 1e-5
+            assert np.array_equal(ref[k], got[k]), (opts, k)
+        kernels = " ".join(st["stage_kernel"]) if isinstance(st.get("stage_kernel"), (list, tuple)) else str(st.get("stage_kernel"))
+        assert ("mfma16" in kernels) == (not opts), (opts, kernels)
+
+
 def test_steps_that_reuse_the_same_rows():
     frames, steps = 128 * 260, 4
     build = lambda c: G.config3_convolver(c, voices=9, taps=20000, frames=frames * steps)
