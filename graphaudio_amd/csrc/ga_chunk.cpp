@@ -1958,8 +1958,10 @@ void CoarseStage::buildJobs() {
         maxP[cj] = std::max(maxP[cj], k.P);
         while (k.P % pbOf[cj]) pbOf[cj] >>= 1;
         const int fread = std::max(0, std::min(jb_.u_hi, t0 + jb_.n_t - 1) - std::max(jb_.u_lo, t0 - (k.P - 1)) + 1);   // frames that exist
+        // (the spectra of the terms are necessary bytes ONCE: the block ranges of one group of terms are neighbours in the grid and
+        // the second range finds them in the L2 -- PMC: profiles/r03_config5_pmc_hbm_traffic.json)
         macBytes[cj][grp] += (double)jb_.n_terms * fread * kCoarseBins * 8.0 +
-                             (double)(shared ? 1 : jb_.n_terms) * k.P * cw * kCoarseBins * 8.0 + (double)cw * jb_.n_t * kCoarseBins * 8.0;
+                             (t0 == 0 ? (double)(shared ? 1 : jb_.n_terms) * k.P * cw * kCoarseBins * 8.0 : 0.0) + (double)cw * jb_.n_t * kCoarseBins * 8.0;
         // complex multiply-adds (8 flops): every term's products in the general kernel; in the reduction the terms' frames are
         // added up first (2 flops per complex value) and the sum is multiplied once
         macFlops[cj][grp] += shared ? ((double)jb_.n_terms * fread * 2.0 + (double)k.P * jb_.n_t * cw * 8.0) * kCoarseBins

@@ -16,7 +16,7 @@ python3 - "$TAG" "$@" <<'PY'
 import csv, glob, json, sys, collections
 tag = sys.argv[1]
 bench = json.loads(open(f"gpurun_out/{tag}_bench_under_rocprof.json").read().strip().splitlines()[-1])
-stage_of = {"coarse_premix_kernel": "coarse_premix", "coarse_fwd_kernel": "coarse_fwd", "coarse_mac_kernel": "coarse_mac", "coarse_sum_kernel": "coarse_mac", "coarse_inv_kernel": "coarse_inv", "coarse_hist_kernel": "coarse_hist",
+stage_of = {"coarse_premix_kernel": "coarse_premix", "coarse_fwd_kernel": "coarse_fwd", "coarse_mac_kernel": "coarse_mac", "coarse_mfma16_kernel": "coarse_mac", "coarse_sum_kernel": "coarse_mac", "coarse_inv_kernel": "coarse_inv", "coarse_hist_kernel": "coarse_hist",
             "mix_kernel": "mix", "rfft_fwd_b_kernel": "rfft_fwd", "hist_copy_b_kernel": "rfft_fwd", "tconv16_kernel": "mac", "irfft_ola_b_kernel": "rfft_inv"}
 raw = {}
 for name, d in (("FETCH_SIZE", "/tmp/prof_f"), ("WRITE_SIZE", "/tmp/prof_w")):
