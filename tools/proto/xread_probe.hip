@@ -47,6 +47,44 @@ void run(const f4* x, float* out, const char* name) {
   const double gb = (double)VOICES * F * TILES * 512 / 1e9;
   printf("%-46s U=%d  avg %.3f ms  %.0f GB/s   best %.0f GB/s\n", name, U, sum / reps, gb / (sum / reps * 1e-3), gb / (best * 1e-3));
 }
+// 512 threads: 16 frames per pass, U passes in flight, `tw` terms per job
+template <int U>
+__global__ __launch_bounds__(512) void probe2(const f4* __restrict x, float* out, int tw) {
+  extern __shared__ float dummy[];
+  const int tile = blockIdx.x, job = blockIdx.y;
+  const int sub = threadIdx.x >> 5, l = threadIdx.x & 31;
+  f4 s = f4{0, 0, 0, 0};
+  for (int v = 0; v < tw; v++) {
+    const size_t row = (size_t)job * tw + v;
+    for (int f0 = 0; f0 < F; f0 += 16 * U) {
+      f4 r[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        int f = f0 + 16 * u + sub;
+        if (f >= F) f = F - 1;
+        r[u] = ((const gf4*)x)[((row * F + f) * TILES + tile) * 32 + l];
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) s += r[u];
+    }
+  }
+  if (s.x + s.y + s.z + s.w == 12345.678f) { out[0] = 1.f; dummy[0] = 1.f; }
+}
+template <int U>
+void run2(const f4* x, float* out, int tw, size_t lds, const char* name) {
+  hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+  (void)hipFuncSetAttribute((const void*)probe2<U>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  float sum = 0; const int reps = 10;
+  for (int r = -2; r < reps; r++) {
+    (void)hipEventRecord(a);
+    hipLaunchKernelGGL((probe2<U>), dim3(TILES, VOICES / tw), dim3(512), lds, 0, x, out, tw);
+    (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+    float ms; (void)hipEventElapsedTime(&ms, a, b);
+    if (r >= 0) sum += ms;
+  }
+  const double gb = (double)VOICES * F * TILES * 512 / 1e9;
+  printf("%-46s U=%d  avg %.3f ms  %.0f GB/s\n", name, U, sum / reps, gb / (sum / reps * 1e-3));
+}
 int main() {
   const size_t bytes = (size_t)VOICES * F * TILES * 512;
   f4* x; float* out;
@@ -61,5 +99,10 @@ int main() {
   run<1, 9>(x, out, "B: a tile's frames contiguous");
   run<2, 3>(x, out, "C: 8 tiles x frame (4 KB pieces on the write side)");
   run<2, 9>(x, out, "C: 8 tiles x frame (4 KB pieces on the write side)");
+  // the reduction kernel's shape: 512 threads, 32 terms per job, two workgroups per CU (forced with 70 KB of LDS)
+  run2<4>(x, out, 32, 70 * 1024, "A, 512 threads, 32 terms/job, 2 wg/CU");
+  run2<2>(x, out, 32, 70 * 1024, "A, 512 threads, 32 terms/job, 2 wg/CU");
+  run2<4>(x, out, 32, 0, "A, 512 threads, 32 terms/job, 4 wg/CU");
+  run2<4>(x, out, 8, 70 * 1024, "A, 512 threads, 8 terms/job, 2 wg/CU");
   return 0;
 }
