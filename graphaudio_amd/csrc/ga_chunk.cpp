@@ -2699,6 +2699,413 @@ void Context::ensureBiquadState(NodeS& bn) {
     bqUsed += per;
   }
 
+// ---- pass 6, per node type -------------------------------------------------------------------------------------------------
+// dense tables indexed by node id, validated by a per-(stage, segment) stamp: no hashing on the per-node path
+struct DenseSeg {
+  std::vector<uint32_t>& st; std::vector<const NodeSeg*>& v; uint32_t e;
+  const NodeSeg* find(int id) const { return st[id] == e ? v[id] : nullptr; }
+};
+struct DenseInt {
+  std::vector<uint32_t>& st; std::vector<int>& v; uint32_t e; int def;
+  int get(int id) const { return st[id] == e ? v[id] : def; }
+};
+// one node of one segment being planned: what the per-type planners below share with Context::chunkPlanNodes
+struct NodePlanCtx {
+  ChunkRun& r; Exec& ex; size_t si; const Segment& sg; int64_t f0, nf, nb;
+  const NodeSeg& ns; NodeS& nd; Views& ov;
+  const DenseSeg& segNode; const DenseInt& absorbedBy; int levelBqHeads;
+};
+
+// ConstantSourceNode.Process (ConstantSourceNode.cs:76-141)
+void Context::planConstantSource(NodePlanCtx& k) {
+  Exec& ex = k.ex; const size_t si = k.si; const Segment& sg = k.sg; const NodeSeg& ns = k.ns; NodeS& nd = k.nd; Views& ov = k.ov;
+  const int64_t f0 = k.f0, nf = k.nf, nb = k.nb; (void)si; (void)sg; (void)nb; (void)nd; (void)f0; (void)nf;
+  if (ns.srcPhase != SRC_PLAY) return;
+  ConstJob cj;
+  cj.curve = ex.paramView((int)si, ns, 0);
+  cj.out = ex.nodeOut(ns.id, 0);
+  cj.value = nd.params[0].value;
+  cj.pad_ = 0;
+  cj.f0 = f0;
+  cj.n = nf;
+  cj.lo = nd.schedLo;
+  cj.hi = nd.schedHi;
+  ex.constJobs.push_back(cj);
+  ov[0] = cj.out;
+}
+
+// OscillatorNode.Process (OscillatorNode.cs:91-196)
+void Context::planOscillator(NodePlanCtx& k) {
+  Exec& ex = k.ex; const size_t si = k.si; const Segment& sg = k.sg; const NodeSeg& ns = k.ns; NodeS& nd = k.nd; Views& ov = k.ov;
+  const int64_t f0 = k.f0, nf = k.nf, nb = k.nb; (void)si; (void)sg; (void)nb; (void)nd; (void)f0; (void)nf;
+  if (ns.srcPhase != SRC_PLAY) return;
+  OscJob oj;
+  oj.curve = ex.paramView((int)si, ns, 0);
+  oj.out = ex.nodeOut(ns.id, 0);
+  oj.phase = nd.oscPhase;
+  oj.value = nd.params[0].value;
+  oj.type = nd.oscType;
+  oj.sample_rate = sampleRate;
+  oj.pad_ = 0;
+  oj.f0 = f0;
+  oj.n = nf;
+  oj.lo = nd.schedLo;
+  oj.hi = nd.schedHi;
+  ex.oscJobs.push_back(oj);
+  ov[0] = oj.out;
+}
+
+// DelayNode.Process (DelayNode.cs:43-100): the segment's input appended to the rings, then a gather
+void Context::planDelay(NodePlanCtx& k) {
+  Exec& ex = k.ex; const size_t si = k.si; const Segment& sg = k.sg; const NodeSeg& ns = k.ns; NodeS& nd = k.nd; Views& ov = k.ov;
+  const int64_t f0 = k.f0, nf = k.nf, nb = k.nb; (void)si; (void)sg; (void)nb; (void)nd; (void)f0; (void)nf;
+  const int ch = ns.ins[0].bufCh;
+  const int maxD = nd.maxDelaySamples;
+  const size_t pitch = (size_t)maxD + (size_t)nd.delayCap;
+  if (!nd.delayLoaded) {   // history of the previous chunks in front of every ring's line
+    nd.delayLoaded = true;
+    std::fill(nd.delayW.begin(), nd.delayW.end(), 0);
+    float* line = nd.delayLine;
+    float* hist = nd.delayHist;
+    const int rings = nd.delayHistRings;
+    hipStream_t st = stream;
+    ex.plan.add(LK_OTHER, [=](uint8_t*) {
+      GA_HIP(hipMemcpy2DAsync(line, pitch * 4, hist, (size_t)maxD * 4, (size_t)maxD * 4, rings, hipMemcpyDeviceToDevice, st));
+    });
+  }
+  // append this segment's input to the rings that are processed (a ring beyond the input's channel count does not
+  // move, DelayNode.cs:62-94), then gather
+  Views iv;
+  if (!ns.ins[0].silent) iv = ex.resolveInput((int)si, ns, 0, false, nullptr);
+  const float* delayCurve = ex.paramView((int)si, ns, 0);
+  for (int cch = 0; cch < ch; cch++) {
+    float* base = nd.delayLine + (size_t)cch * pitch + maxD + nd.delayW[cch] - f0;   // base[f] = input sample of frame f
+    MixJob mj;
+    mj.out = base;
+    mj.term0 = (int)ex.terms.size();
+    const float* v = (!ns.ins[0].silent && cch < (int)iv.size()) ? iv[cch] : nullptr;
+    mj.nterms = v ? 1 : 0;
+    mj.f0 = f0;
+    mj.n = nf;
+    if (v) {
+      ex.terms.push_back(v);
+      ex.noteAlign(v, f0);
+    }
+    ex.noteAlign(base, f0);
+    ex.mixJobs.push_back(mj);
+    DelayJob dj;
+    dj.line = base;
+    dj.curve = delayCurve;
+    dj.out = ex.nodeOut(ns.id, cch);
+    dj.value = nd.params[0].value;
+    dj.sample_rate = sampleRate;
+    dj.max_delay = maxD;
+    dj.pad_ = 0;
+    dj.f0 = f0;
+    dj.n = nf;
+    ex.delayJobs.push_back(dj);
+    nd.delayW[cch] += nf;
+    if (ns.delayAudible) ov[cch] = dj.out;   // a buffer still flagged silent is skipped by every consumer
+  }
+}
+
+// StereoPannerNode.Process (StereoPannerNode.cs:36-153)
+void Context::planStereoPanner(NodePlanCtx& k) {
+  Exec& ex = k.ex; const size_t si = k.si; const Segment& sg = k.sg; const NodeSeg& ns = k.ns; NodeS& nd = k.nd; Views& ov = k.ov;
+  const int64_t f0 = k.f0, nf = k.nf, nb = k.nb; (void)si; (void)sg; (void)nb; (void)nd; (void)f0; (void)nf;
+  if (ns.ins[0].silent) return;   // cleared 2-channel output (:49-54)
+  auto iv = ex.resolveInput((int)si, ns, 0, false, nullptr);
+  if (ns.panDyn) {
+    if (!nd.panDev) nd.panDev = (PanState*)dalloc(64);
+    PanDynJob dj;
+    dj.in_l = iv[0] ? iv[0] : zeros;
+    dj.in_r = ns.panMode == 2 ? (iv[1] ? iv[1] : zeros) : nullptr;
+    dj.out_l = ex.nodeOut(ns.id, 0);
+    dj.out_r = ex.nodeOut(ns.id, 1);
+    dj.curve = ex.paramView((int)si, ns, 0);
+    dj.state = nd.panDev;
+    dj.init_state = PanState{nd.panLast, nd.panGL, nd.panGR, 0.f};
+    dj.init = nd.panOnDevice ? 0 : 1;   // the host-tracked state is handed over once
+    nd.panOnDevice = true;
+    dj.stereo = ns.panMode == 2 ? 1 : 0;
+    dj.f0 = f0;
+    dj.n = nf;
+    ex.panDynJobs.push_back(dj);
+    ov[0] = dj.out_l;
+    ov[1] = dj.out_r;
+    return;
+  }
+  PanJob pj;
+  pj.in_l = iv[0] ? iv[0] : zeros;
+  pj.in_r = ns.panMode == 2 ? (iv[1] ? iv[1] : zeros) : nullptr;
+  pj.out_l = ex.nodeOut(ns.id, 0);
+  pj.out_r = ex.nodeOut(ns.id, 1);
+  pj.gain_l = ns.panGL;
+  pj.gain_r = ns.panGR;
+  pj.pan = ns.pan;
+  pj.stereo = ns.panMode == 2 ? 1 : 0;
+  pj.f0 = f0;
+  pj.n = nf;
+  ex.panJobs.push_back(pj);
+  ov[0] = pj.out_l;
+  ov[1] = pj.out_r;
+}
+
+// AudioBufferSourceNode.Process (AudioBufferSourceNode.cs:150-260): zero-copy windows, loop walks, resampler jobs, general replay
+void Context::planBufferSource(NodePlanCtx& k) {
+  Exec& ex = k.ex; const size_t si = k.si; const Segment& sg = k.sg; const NodeSeg& ns = k.ns; NodeS& nd = k.nd; Views& ov = k.ov;
+  const int64_t f0 = k.f0, nf = k.nf, nb = k.nb; (void)si; (void)sg; (void)nb; (void)nd; (void)f0; (void)nf;
+  const std::vector<int>& srcIds = k.r.srcIds; const std::vector<SrcPlanOut>& srcPlans = k.r.srcPlans;
+  if (ns.srcPhase != SRC_PLAY) return;  // silent: ZERO views
+  PlayBuf& pb = *buffers[ns.srcBuf];
+  SrcGeom g = sourceGeom(*this, nd, pb);
+  if (nd.gsr) {  // general replay: one host-made descriptor per block
+    if (!nd.gsrUploaded) {
+      nd.gsrDevOff = ex.plan.putv(nd.gsrBlocks);
+      nd.gsrUploaded = true;
+    }
+    for (int ch = 0; ch < pb.channels; ch++) {
+      GsrJob gj;
+      gj.buf = pb.dev + (size_t)ch * pb.stride;
+      gj.out = ex.nodeOut(ns.id, ch);
+      gj.desc_off = nd.gsrDevOff + (uint64_t)ns.srcBlk * sizeof(GsrBlock);
+      gj.b0 = sg.b0;
+      gj.nblocks = nb;
+      gj.loop_start = g.loopStartFrame;
+      gj.loop_end = g.loopEndFrame;
+      gj.loop = nd.loop ? 1 : 0;
+      gj.pad_ = 0;
+      ex.gsrJobs.push_back(gj);
+      ov[ch] = gj.out;
+    }
+  } else if (g.effectiveRate == 1.0 && (ns.srcPos < 0 || (nd.loop ? g.loopEndFrame : ns.srcPos + nf) > pb.length)) {
+    fail(GA_ERR_DEVICE, "internal: source window beyond the buffer");
+  } else if (g.effectiveRate == 1.0 && !nd.loop) {
+    // zero-copy: the node's output for these blocks IS the buffer (AudioBufferSourceNode.cs:186-222)
+    for (int ch = 0; ch < pb.channels; ch++) ov[ch] = pb.dev + (size_t)ch * pb.stride + ns.srcPos - f0;
+  } else if (g.effectiveRate == 1.0 && ns.srcPos < g.loopEndFrame && ns.srcPos + nf <= g.loopEndFrame) {
+    // looping, but these blocks do not reach the loop end: still a plain window of the buffer (zero-copy)
+    for (int ch = 0; ch < pb.channels; ch++) ov[ch] = pb.dev + (size_t)ch * pb.stride + ns.srcPos - f0;
+  } else if (g.effectiveRate == 1.0) {
+    for (int ch = 0; ch < pb.channels; ch++) {
+      LoopJob lj;
+      lj.buf = pb.dev + (size_t)ch * pb.stride;
+      lj.out = ex.nodeOut(ns.id, ch);
+      lj.pos0 = ns.srcPos;  // map() below handles positions beyond loopEnd
+      lj.loop_start = g.loopStartFrame;
+      lj.loop_end = g.loopEndFrame;
+      lj.f0 = f0;
+      lj.n = nf;
+      ex.loopJobs.push_back(lj);
+      ov[ch] = lj.out;
+    }
+  } else {
+    Resampler& rs = resamplerFor(*this, g.effectiveRate);
+    if (rs.devOffset < 0) {
+      rs.devOffset = (int)ex.traj.size();
+      ex.traj.insert(ex.traj.end(), rs.blocks.begin(), rs.blocks.end());
+    }
+    int64_t avail = g.durationEndFrame - nd.rsStartPos;
+    // a partial block (input ran out) is its own one-block segment with a custom trajectory entry
+    int traj0 = rs.devOffset + (int)ns.srcBlk;
+    for (size_t k = 0; k < srcIds.size(); k++)
+      if (srcIds[k] == ns.id && srcPlans[k].partialBlock == sg.b0) {
+        ResampleBlock rb = rs.blocks[ns.srcBlk];
+        rb.produced = srcPlans[k].partialProduced;
+        traj0 = (int)ex.traj.size();
+        ex.traj.push_back(rb);
+      }
+    {  // host-side bound of the device reads of this job: a wrong plan must be an error, not a GPU fault
+      const bool partial = ex.traj[traj0].produced != kBlock;
+      if (nd.rsStartPos < 0 || avail < 0 || nd.rsStartPos + avail > pb.length ||
+          (!partial && rs.blocks[ns.srcBlk + nb].consumed > avail))
+        fail(GA_ERR_DEVICE, "internal: resampler job reads beyond the source buffer");
+    }
+    for (int ch = 0; ch < pb.channels; ch++) {
+      ResampleJob rj;
+      rj.buf = pb.dev + (size_t)ch * pb.stride;
+      rj.out = ex.nodeOut(ns.id, ch);
+      rj.start_pos = nd.rsStartPos;
+      rj.avail = avail;
+      rj.traj0 = traj0;
+      rj.rate = g.effectiveRate;
+      rj.b0 = sg.b0;
+      rj.nblocks = nb;
+      ex.rsJobs.push_back(rj);
+      ov[ch] = rj.out;
+    }
+  }
+}
+
+// AudioStreamSourceNodeBase.Process (AudioStreamSourceNodeBase.cs:132-301), replayed by the host (streamReplay)
+void Context::planStreamSource(NodePlanCtx& k) {
+  Exec& ex = k.ex; const size_t si = k.si; const Segment& sg = k.sg; const NodeSeg& ns = k.ns; NodeS& nd = k.nd; Views& ov = k.ov;
+  const int64_t f0 = k.f0, nf = k.nf, nb = k.nb; (void)si; (void)sg; (void)nb; (void)nd; (void)f0; (void)nf;
+  if (ns.outSilent) return;   // ProduceSilence / nothing rendered: cleared buffer
+  if (!nd.stUploaded) {
+    nd.stBlocksOff = ex.plan.putv(nd.stBlocks);
+    nd.stPiecesOff = ex.plan.putv(nd.stPieces);
+    nd.stSegsOff = ex.plan.putv(nd.stSegs);
+    nd.stUploaded = true;
+  }
+  if (!nd.stWin[0]) {
+    nd.stWin[0] = (float*)dalloc(32 * 4 * sizeof(float));
+    nd.stWin[1] = (float*)dalloc(32 * 4 * sizeof(float));
+    GA_HIP(hipMemsetAsync(nd.stWin[0], 0, 32 * 4 * sizeof(float), stream));
+    GA_HIP(hipMemsetAsync(nd.stWin[1], 0, 32 * 4 * sizeof(float), stream));
+  }
+  for (int ch = 0; ch < ns.outCh && ch < 32; ch++) {
+    StreamJob sj{};
+    sj.out = ex.nodeOut(ns.id, ch);
+    sj.win_in = nd.stWin[nd.stWinCur] + 4 * ch;
+    sj.win_out = nd.stFed ? nd.stWin[nd.stWinCur ^ 1] + 4 * ch : nullptr;   // every job of the chunk writes the same end state
+    sj.blocks_off = nd.stBlocksOff;
+    sj.pieces_off = nd.stPiecesOff;
+    sj.segs_off = nd.stSegsOff;
+    sj.b0 = sg.b0;
+    sj.nblocks = nb;
+    for (int k = 0; k < 4; k++) {
+      sj.wend[k] = nd.stWend[k];
+      sj.wend_seg[k] = nd.stWendSeg[k];
+    }
+    sj.ch = ch;
+    ex.streamJobs.push_back(sj);
+    ov[ch] = sj.out;
+  }
+}
+
+// GainNode.Process (GainNode.cs:36-80)
+void Context::planGain(NodePlanCtx& k) {
+  Exec& ex = k.ex; const size_t si = k.si; const Segment& sg = k.sg; const NodeSeg& ns = k.ns; NodeS& nd = k.nd; Views& ov = k.ov;
+  const int64_t f0 = k.f0, nf = k.nf, nb = k.nb; (void)si; (void)sg; (void)nb; (void)nd; (void)f0; (void)nf;
+  const float* gmod = nullptr;   // audio-rate modulation of gain: mixed to 1 channel (AudioParam.cs:68-70,123-135)
+  if (!ns.pins.empty() && !ns.pins[0].silent) gmod = ex.resolveInSeg((int)si, ns.id, -1, ns.pins[0], false, nullptr)[0];
+  auto iv = ex.resolveInput((int)si, ns, 0, false, nullptr);
+  if (ns.ins[0].silent) return;  // cleared output (GainNode.cs:41-46)
+  for (int ch = 0; ch < ns.outCh; ch++) {
+    if (!iv[ch]) continue;
+    GainJob gj;
+    gj.in = iv[ch];
+    gj.out = ex.nodeOut(ns.id, ch);
+    gj.curve = nd.params[0].curve;
+    gj.mod = gmod;
+    gj.vmin = nd.params[0].minv;
+    gj.vmax = nd.params[0].maxv;
+    gj.gain = nd.params[0].value;
+    gj.f0 = f0;
+    gj.n = nf;
+    ex.gainJobs.push_back(gj);
+    ov[ch] = gj.out;
+  }
+}
+
+// BiQuadFilterNode.Process (BiQuadFilterNode.cs:96-143): automated parameters, fused constant-coefficient cascades, cascades split along time
+void Context::planBiquad(NodePlanCtx& k) {
+  Exec& ex = k.ex; const size_t si = k.si; const Segment& sg = k.sg; const NodeSeg& ns = k.ns; NodeS& nd = k.nd; Views& ov = k.ov;
+  const int64_t f0 = k.f0, nf = k.nf, nb = k.nb; (void)si; (void)sg; (void)nb; (void)nd; (void)f0; (void)nf;
+  const DenseSeg& segNode = k.segNode; const DenseInt& absorbedBy = k.absorbedBy; const int levelBqHeads = k.levelBqHeads;
+  if (!ns.bqActive) {  // silent input: cleared output, state frozen (BiQuadFilterNode.cs:103-108)
+    ex.resolveInput((int)si, ns, 0, false, nullptr);
+    return;
+  }
+  if (ns.bqDynamic) {  // automated parameters: per-sample coefficient refresh on the device
+    auto iv = ex.resolveInput((int)si, ns, 0, false, nullptr);
+    ensureBiquadState(nd);
+    BiquadDynJob dj{};
+    for (int ch = 0; ch < ns.outCh && ch < 32; ch++) {
+      dj.in[ch] = iv[ch];
+      dj.out[ch] = ex.nodeOut(ns.id, ch);
+      ov[ch] = dj.out[ch];
+    }
+    dj.fcurve = ex.paramView((int)si, ns, 0);
+    dj.qcurve = ex.paramView((int)si, ns, 1);
+    dj.gcurve = ex.paramView((int)si, ns, 2);
+    dj.fval = nd.params[0].value;
+    dj.qval = nd.params[1].value;
+    dj.gval = nd.params[2].value;
+    dj.channels = ns.outCh;
+    dj.filter_type = nd.filterType;
+    dj.nyquist = sampleRate / 2.f;
+    dj.sample_rate = (float)sampleRate;
+    dj.state = nd.bqDyn;
+    dj.b0 = sg.b0;
+    dj.nblocks = nb;
+    if (!nd.coefOnDevice) {  // hand the host-side coefficient state (constant-parameter runs) to the device once
+      BiquadDynState init{};
+      init.b0 = nd.b0; init.b1 = nd.b1; init.b2 = nd.b2; init.a1 = nd.a1; init.a2 = nd.a2;
+      init.dirty = nd.coefDirty ? 1 : 0;
+      GA_HIP(hipMemcpyAsync(nd.bqDyn, &init, 24, hipMemcpyHostToDevice, stream));
+      GA_HIP(hipStreamSynchronize(stream));
+      nd.coefOnDevice = true;
+    }
+    ex.bqDynJobs.push_back(dj);
+    return;
+  }
+  if (absorbedBy.get(ns.id) >= 0) return;  // evaluated inside the cascade job of a downstream biquad
+  // chain head ... this node: biquads connected output -> single input with equal channel counts
+  SmallVec<const NodeSeg*, kMaxBiquadSections> chain{&ns};
+  while (true) {
+    const NodeSeg* h = chain.front();
+    if (h->ins[0].terms.size() != 1) break;
+    int up = h->ins[0].terms[0].node;
+    if (absorbedBy.get(up) != h->id) break;
+    chain.insert_front(segNode.find(up));
+  }
+  auto iv = ex.resolveInput((int)si, *chain.front(), 0, false, nullptr);
+  for (const NodeSeg* cn : chain) {
+    NodeS& cnd = *nodes[cn->id];
+    ensureBiquadState(cnd);
+  }
+  // pieces along time (ga_kernels.hpp, BiquadScanJob): as many as keep every lane of the chip busy, each >= 1024 frames;
+  // mode 1: only cascades whose float32 rounding noise is so small that a different rounding stays inside the budget
+  int G = 1;
+  float coefs[5 * kMaxBiquadSections];
+  if (biquadTimeSplit && nf >= biquadSplitMinFrames) {
+    const int64_t lanes = 64 * 1024, heads = std::max(levelBqHeads, 1);
+    G = (int)std::max<int64_t>(1, std::min<int64_t>({(lanes + heads - 1) / heads, nf / 1024, 256}));
+    int q = 0;
+    for (const NodeSeg* cn : chain) {
+      coefs[5 * q] = cn->b0; coefs[5 * q + 1] = cn->b1; coefs[5 * q + 2] = cn->b2; coefs[5 * q + 3] = cn->a1; coefs[5 * q + 4] = cn->a2;
+      q++;
+    }
+    if (biquadTimeSplit == 1 && biquadDeviation(coefs, (int)chain.size()) > biquadSplitMaxDeviation) G = 1;
+  }
+  int64_t K = G > 1 ? ((nf + G - 1) / G + 3) / 4 * 4 : nf;
+  if (G > 1) G = (int)((nf + K - 1) / K);
+  if (G > 1 && ex.bqG == 0) {
+    ex.bqG = G;
+    ex.bqK = K;
+  }
+  if (G > 1 && (G != ex.bqG || K != ex.bqK)) G = 1;   // (one cut per level: the pieces of a level are expanded by one launch)
+  const std::vector<float>* AK = G > 1 ? &biquadTransition(coefs, (int)chain.size(), K).M : nullptr;
+  for (int ch = 0; ch < ns.outCh; ch++) {
+    BiquadJob bj;
+    bj.in = iv[ch] ? iv[ch] : zeros;
+    bj.out = ex.nodeOut(ns.id, ch);
+    bj.sec0 = (int)ex.bqSecs.size();
+    bj.nsec = (int)chain.size();
+    bj.f0 = f0;
+    bj.n = nf;
+    bj.state = nullptr;
+    for (const NodeSeg* cn : chain) {
+      BiquadSection sc;
+      sc.b0 = cn->b0; sc.b1 = cn->b1; sc.b2 = cn->b2; sc.a1 = cn->a1; sc.a2 = cn->a2;
+      sc.pad_ = 0.f;
+      sc.state = nodes[cn->id]->bqState + 2 * ch;
+      ex.bqSecs.push_back(sc);
+    }
+    ov[ch] = bj.out;
+    if (G <= 1) {
+      ex.bqJobs[bj.nsec].push_back(bj);
+      continue;
+    }
+    stats.biquad_split_cascades++;
+    float* scratch = bqSplitAlloc((size_t)(G - 1) * bj.nsec * 2);
+    ex.bqMats[bj.nsec].push_back(AK);
+    ex.bqScans[bj.nsec].push_back(BiquadScanJob{bj.in, bj.out, 0, scratch, bj.sec0, bj.nsec, f0, nf});
+  }
+}
+
 // pass 6 (per convolver depth d): every segment, level by level -- node launches are batched per (level, type)
 void Context::chunkPlanNodes(ChunkRun& r, int d) {
   Context& c_ = *this; (void)c_;
@@ -2750,14 +3157,7 @@ void Context::chunkPlanNodes(ChunkRun& r, int d) {
         fuseLen.assign(nodes.size(), 0);
       }
       const uint32_t stamp = ++fuseEpoch;
-      struct DenseSeg {
-        std::vector<uint32_t>& st; std::vector<const NodeSeg*>& v; uint32_t e;
-        const NodeSeg* find(int id) const { return st[id] == e ? v[id] : nullptr; }
-      } segNode{fuseStamp, fuseSeg, stamp};
-      struct DenseInt {
-        std::vector<uint32_t>& st; std::vector<int>& v; uint32_t e; int def;
-        int get(int id) const { return st[id] == e ? v[id] : def; }
-      };
+      DenseSeg segNode{fuseStamp, fuseSeg, stamp};
       for (const NodeSeg* nsp : todo) {
         fuseStamp[nsp->id] = stamp;
         fuseSeg[nsp->id] = nsp;
@@ -2804,6 +3204,7 @@ void Context::chunkPlanNodes(ChunkRun& r, int d) {
         }
         auto& ov = ex.outViews[si][ns.id];
         ov.assign(nd.type == GA_NODE_CHANNEL_SPLITTER ? (int)nd.outputs.size() : std::max(ns.outCh, 1), nullptr);
+        NodePlanCtx k{r, ex, si, sg, f0, nf, nb, ns, nd, ov, segNode, absorbedBy, levelBqHeads};
         switch (nd.type) {
           case GA_NODE_CHANNEL_SPLITTER: {   // zero-copy: output o IS channel o of the mixed input
             if (!ns.outMask) break;
@@ -2820,370 +3221,14 @@ void Context::chunkPlanNodes(ChunkRun& r, int d) {
             }
             break;
           }
-          case GA_NODE_CONSTANT_SOURCE: {
-            if (ns.srcPhase != SRC_PLAY) break;
-            ConstJob cj;
-            cj.curve = ex.paramView((int)si, ns, 0);
-            cj.out = ex.nodeOut(ns.id, 0);
-            cj.value = nd.params[0].value;
-            cj.pad_ = 0;
-            cj.f0 = f0;
-            cj.n = nf;
-            cj.lo = nd.schedLo;
-            cj.hi = nd.schedHi;
-            ex.constJobs.push_back(cj);
-            ov[0] = cj.out;
-            break;
-          }
-          case GA_NODE_OSCILLATOR: {
-            if (ns.srcPhase != SRC_PLAY) break;
-            OscJob oj;
-            oj.curve = ex.paramView((int)si, ns, 0);
-            oj.out = ex.nodeOut(ns.id, 0);
-            oj.phase = nd.oscPhase;
-            oj.value = nd.params[0].value;
-            oj.type = nd.oscType;
-            oj.sample_rate = sampleRate;
-            oj.pad_ = 0;
-            oj.f0 = f0;
-            oj.n = nf;
-            oj.lo = nd.schedLo;
-            oj.hi = nd.schedHi;
-            ex.oscJobs.push_back(oj);
-            ov[0] = oj.out;
-            break;
-          }
-          case GA_NODE_DELAY: {
-            const int ch = ns.ins[0].bufCh;
-            const int maxD = nd.maxDelaySamples;
-            const size_t pitch = (size_t)maxD + (size_t)nd.delayCap;
-            if (!nd.delayLoaded) {   // history of the previous chunks in front of every ring's line
-              nd.delayLoaded = true;
-              std::fill(nd.delayW.begin(), nd.delayW.end(), 0);
-              float* line = nd.delayLine;
-              float* hist = nd.delayHist;
-              const int rings = nd.delayHistRings;
-              hipStream_t st = stream;
-              ex.plan.add(LK_OTHER, [=](uint8_t*) {
-                GA_HIP(hipMemcpy2DAsync(line, pitch * 4, hist, (size_t)maxD * 4, (size_t)maxD * 4, rings, hipMemcpyDeviceToDevice, st));
-              });
-            }
-            // append this segment's input to the rings that are processed (a ring beyond the input's channel count does not
-            // move, DelayNode.cs:62-94), then gather
-            Views iv;
-            if (!ns.ins[0].silent) iv = ex.resolveInput((int)si, ns, 0, false, nullptr);
-            const float* delayCurve = ex.paramView((int)si, ns, 0);
-            for (int cch = 0; cch < ch; cch++) {
-              float* base = nd.delayLine + (size_t)cch * pitch + maxD + nd.delayW[cch] - f0;   // base[f] = input sample of frame f
-              MixJob mj;
-              mj.out = base;
-              mj.term0 = (int)ex.terms.size();
-              const float* v = (!ns.ins[0].silent && cch < (int)iv.size()) ? iv[cch] : nullptr;
-              mj.nterms = v ? 1 : 0;
-              mj.f0 = f0;
-              mj.n = nf;
-              if (v) {
-                ex.terms.push_back(v);
-                ex.noteAlign(v, f0);
-              }
-              ex.noteAlign(base, f0);
-              ex.mixJobs.push_back(mj);
-              DelayJob dj;
-              dj.line = base;
-              dj.curve = delayCurve;
-              dj.out = ex.nodeOut(ns.id, cch);
-              dj.value = nd.params[0].value;
-              dj.sample_rate = sampleRate;
-              dj.max_delay = maxD;
-              dj.pad_ = 0;
-              dj.f0 = f0;
-              dj.n = nf;
-              ex.delayJobs.push_back(dj);
-              nd.delayW[cch] += nf;
-              if (ns.delayAudible) ov[cch] = dj.out;   // a buffer still flagged silent is skipped by every consumer
-            }
-            break;
-          }
-          case GA_NODE_STEREO_PANNER: {
-            if (ns.ins[0].silent) break;   // cleared 2-channel output (:49-54)
-            auto iv = ex.resolveInput((int)si, ns, 0, false, nullptr);
-            if (ns.panDyn) {
-              if (!nd.panDev) nd.panDev = (PanState*)dalloc(64);
-              PanDynJob dj;
-              dj.in_l = iv[0] ? iv[0] : zeros;
-              dj.in_r = ns.panMode == 2 ? (iv[1] ? iv[1] : zeros) : nullptr;
-              dj.out_l = ex.nodeOut(ns.id, 0);
-              dj.out_r = ex.nodeOut(ns.id, 1);
-              dj.curve = ex.paramView((int)si, ns, 0);
-              dj.state = nd.panDev;
-              dj.init_state = PanState{nd.panLast, nd.panGL, nd.panGR, 0.f};
-              dj.init = nd.panOnDevice ? 0 : 1;   // the host-tracked state is handed over once
-              nd.panOnDevice = true;
-              dj.stereo = ns.panMode == 2 ? 1 : 0;
-              dj.f0 = f0;
-              dj.n = nf;
-              ex.panDynJobs.push_back(dj);
-              ov[0] = dj.out_l;
-              ov[1] = dj.out_r;
-              break;
-            }
-            PanJob pj;
-            pj.in_l = iv[0] ? iv[0] : zeros;
-            pj.in_r = ns.panMode == 2 ? (iv[1] ? iv[1] : zeros) : nullptr;
-            pj.out_l = ex.nodeOut(ns.id, 0);
-            pj.out_r = ex.nodeOut(ns.id, 1);
-            pj.gain_l = ns.panGL;
-            pj.gain_r = ns.panGR;
-            pj.pan = ns.pan;
-            pj.stereo = ns.panMode == 2 ? 1 : 0;
-            pj.f0 = f0;
-            pj.n = nf;
-            ex.panJobs.push_back(pj);
-            ov[0] = pj.out_l;
-            ov[1] = pj.out_r;
-            break;
-          }
-          case GA_NODE_BUFFER_SOURCE: {
-            if (ns.srcPhase != SRC_PLAY) break;  // silent: ZERO views
-            PlayBuf& pb = *buffers[ns.srcBuf];
-            SrcGeom g = sourceGeom(*this, nd, pb);
-            if (nd.gsr) {  // general replay: one host-made descriptor per block
-              if (!nd.gsrUploaded) {
-                nd.gsrDevOff = ex.plan.putv(nd.gsrBlocks);
-                nd.gsrUploaded = true;
-              }
-              for (int ch = 0; ch < pb.channels; ch++) {
-                GsrJob gj;
-                gj.buf = pb.dev + (size_t)ch * pb.stride;
-                gj.out = ex.nodeOut(ns.id, ch);
-                gj.desc_off = nd.gsrDevOff + (uint64_t)ns.srcBlk * sizeof(GsrBlock);
-                gj.b0 = sg.b0;
-                gj.nblocks = nb;
-                gj.loop_start = g.loopStartFrame;
-                gj.loop_end = g.loopEndFrame;
-                gj.loop = nd.loop ? 1 : 0;
-                gj.pad_ = 0;
-                ex.gsrJobs.push_back(gj);
-                ov[ch] = gj.out;
-              }
-            } else if (g.effectiveRate == 1.0 && (ns.srcPos < 0 || (nd.loop ? g.loopEndFrame : ns.srcPos + nf) > pb.length)) {
-              fail(GA_ERR_DEVICE, "internal: source window beyond the buffer");
-            } else if (g.effectiveRate == 1.0 && !nd.loop) {
-              // zero-copy: the node's output for these blocks IS the buffer (AudioBufferSourceNode.cs:186-222)
-              for (int ch = 0; ch < pb.channels; ch++) ov[ch] = pb.dev + (size_t)ch * pb.stride + ns.srcPos - f0;
-            } else if (g.effectiveRate == 1.0 && ns.srcPos < g.loopEndFrame && ns.srcPos + nf <= g.loopEndFrame) {
-              // looping, but these blocks do not reach the loop end: still a plain window of the buffer (zero-copy)
-              for (int ch = 0; ch < pb.channels; ch++) ov[ch] = pb.dev + (size_t)ch * pb.stride + ns.srcPos - f0;
-            } else if (g.effectiveRate == 1.0) {
-              for (int ch = 0; ch < pb.channels; ch++) {
-                LoopJob lj;
-                lj.buf = pb.dev + (size_t)ch * pb.stride;
-                lj.out = ex.nodeOut(ns.id, ch);
-                lj.pos0 = ns.srcPos;  // map() below handles positions beyond loopEnd
-                lj.loop_start = g.loopStartFrame;
-                lj.loop_end = g.loopEndFrame;
-                lj.f0 = f0;
-                lj.n = nf;
-                ex.loopJobs.push_back(lj);
-                ov[ch] = lj.out;
-              }
-            } else {
-              Resampler& rs = resamplerFor(*this, g.effectiveRate);
-              if (rs.devOffset < 0) {
-                rs.devOffset = (int)ex.traj.size();
-                ex.traj.insert(ex.traj.end(), rs.blocks.begin(), rs.blocks.end());
-              }
-              int64_t avail = g.durationEndFrame - nd.rsStartPos;
-              // a partial block (input ran out) is its own one-block segment with a custom trajectory entry
-              int traj0 = rs.devOffset + (int)ns.srcBlk;
-              for (size_t k = 0; k < srcIds.size(); k++)
-                if (srcIds[k] == ns.id && srcPlans[k].partialBlock == sg.b0) {
-                  ResampleBlock rb = rs.blocks[ns.srcBlk];
-                  rb.produced = srcPlans[k].partialProduced;
-                  traj0 = (int)ex.traj.size();
-                  ex.traj.push_back(rb);
-                }
-              {  // host-side bound of the device reads of this job: a wrong plan must be an error, not a GPU fault
-                const bool partial = ex.traj[traj0].produced != kBlock;
-                if (nd.rsStartPos < 0 || avail < 0 || nd.rsStartPos + avail > pb.length ||
-                    (!partial && rs.blocks[ns.srcBlk + nb].consumed > avail))
-                  fail(GA_ERR_DEVICE, "internal: resampler job reads beyond the source buffer");
-              }
-              for (int ch = 0; ch < pb.channels; ch++) {
-                ResampleJob rj;
-                rj.buf = pb.dev + (size_t)ch * pb.stride;
-                rj.out = ex.nodeOut(ns.id, ch);
-                rj.start_pos = nd.rsStartPos;
-                rj.avail = avail;
-                rj.traj0 = traj0;
-                rj.rate = g.effectiveRate;
-                rj.b0 = sg.b0;
-                rj.nblocks = nb;
-                ex.rsJobs.push_back(rj);
-                ov[ch] = rj.out;
-              }
-            }
-            break;
-          }
-          case GA_NODE_STREAM_SOURCE: {
-            if (ns.outSilent) break;   // ProduceSilence / nothing rendered: cleared buffer
-            if (!nd.stUploaded) {
-              nd.stBlocksOff = ex.plan.putv(nd.stBlocks);
-              nd.stPiecesOff = ex.plan.putv(nd.stPieces);
-              nd.stSegsOff = ex.plan.putv(nd.stSegs);
-              nd.stUploaded = true;
-            }
-            if (!nd.stWin[0]) {
-              nd.stWin[0] = (float*)dalloc(32 * 4 * sizeof(float));
-              nd.stWin[1] = (float*)dalloc(32 * 4 * sizeof(float));
-              GA_HIP(hipMemsetAsync(nd.stWin[0], 0, 32 * 4 * sizeof(float), stream));
-              GA_HIP(hipMemsetAsync(nd.stWin[1], 0, 32 * 4 * sizeof(float), stream));
-            }
-            for (int ch = 0; ch < ns.outCh && ch < 32; ch++) {
-              StreamJob sj{};
-              sj.out = ex.nodeOut(ns.id, ch);
-              sj.win_in = nd.stWin[nd.stWinCur] + 4 * ch;
-              sj.win_out = nd.stFed ? nd.stWin[nd.stWinCur ^ 1] + 4 * ch : nullptr;   // every job of the chunk writes the same end state
-              sj.blocks_off = nd.stBlocksOff;
-              sj.pieces_off = nd.stPiecesOff;
-              sj.segs_off = nd.stSegsOff;
-              sj.b0 = sg.b0;
-              sj.nblocks = nb;
-              for (int k = 0; k < 4; k++) {
-                sj.wend[k] = nd.stWend[k];
-                sj.wend_seg[k] = nd.stWendSeg[k];
-              }
-              sj.ch = ch;
-              ex.streamJobs.push_back(sj);
-              ov[ch] = sj.out;
-            }
-            break;
-          }
-          case GA_NODE_GAIN: {
-            const float* gmod = nullptr;   // audio-rate modulation of gain: mixed to 1 channel (AudioParam.cs:68-70,123-135)
-            if (!ns.pins.empty() && !ns.pins[0].silent) gmod = ex.resolveInSeg((int)si, ns.id, -1, ns.pins[0], false, nullptr)[0];
-            auto iv = ex.resolveInput((int)si, ns, 0, false, nullptr);
-            if (ns.ins[0].silent) break;  // cleared output (GainNode.cs:41-46)
-            for (int ch = 0; ch < ns.outCh; ch++) {
-              if (!iv[ch]) continue;
-              GainJob gj;
-              gj.in = iv[ch];
-              gj.out = ex.nodeOut(ns.id, ch);
-              gj.curve = nd.params[0].curve;
-              gj.mod = gmod;
-              gj.vmin = nd.params[0].minv;
-              gj.vmax = nd.params[0].maxv;
-              gj.gain = nd.params[0].value;
-              gj.f0 = f0;
-              gj.n = nf;
-              ex.gainJobs.push_back(gj);
-              ov[ch] = gj.out;
-            }
-            break;
-          }
-          case GA_NODE_BIQUAD: {
-            if (!ns.bqActive) {  // silent input: cleared output, state frozen (BiQuadFilterNode.cs:103-108)
-              ex.resolveInput((int)si, ns, 0, false, nullptr);
-              break;
-            }
-            if (ns.bqDynamic) {  // automated parameters: per-sample coefficient refresh on the device
-              auto iv = ex.resolveInput((int)si, ns, 0, false, nullptr);
-              ensureBiquadState(nd);
-              BiquadDynJob dj{};
-              for (int ch = 0; ch < ns.outCh && ch < 32; ch++) {
-                dj.in[ch] = iv[ch];
-                dj.out[ch] = ex.nodeOut(ns.id, ch);
-                ov[ch] = dj.out[ch];
-              }
-              dj.fcurve = ex.paramView((int)si, ns, 0);
-              dj.qcurve = ex.paramView((int)si, ns, 1);
-              dj.gcurve = ex.paramView((int)si, ns, 2);
-              dj.fval = nd.params[0].value;
-              dj.qval = nd.params[1].value;
-              dj.gval = nd.params[2].value;
-              dj.channels = ns.outCh;
-              dj.filter_type = nd.filterType;
-              dj.nyquist = sampleRate / 2.f;
-              dj.sample_rate = (float)sampleRate;
-              dj.state = nd.bqDyn;
-              dj.b0 = sg.b0;
-              dj.nblocks = nb;
-              if (!nd.coefOnDevice) {  // hand the host-side coefficient state (constant-parameter runs) to the device once
-                BiquadDynState init{};
-                init.b0 = nd.b0; init.b1 = nd.b1; init.b2 = nd.b2; init.a1 = nd.a1; init.a2 = nd.a2;
-                init.dirty = nd.coefDirty ? 1 : 0;
-                GA_HIP(hipMemcpyAsync(nd.bqDyn, &init, 24, hipMemcpyHostToDevice, stream));
-                GA_HIP(hipStreamSynchronize(stream));
-                nd.coefOnDevice = true;
-              }
-              ex.bqDynJobs.push_back(dj);
-              break;
-            }
-            if (absorbedBy.get(ns.id) >= 0) break;  // evaluated inside the cascade job of a downstream biquad
-            // chain head ... this node: biquads connected output -> single input with equal channel counts
-            SmallVec<const NodeSeg*, kMaxBiquadSections> chain{&ns};
-            while (true) {
-              const NodeSeg* h = chain.front();
-              if (h->ins[0].terms.size() != 1) break;
-              int up = h->ins[0].terms[0].node;
-              if (absorbedBy.get(up) != h->id) break;
-              chain.insert_front(segNode.find(up));
-            }
-            auto iv = ex.resolveInput((int)si, *chain.front(), 0, false, nullptr);
-            for (const NodeSeg* cn : chain) {
-              NodeS& cnd = *nodes[cn->id];
-              ensureBiquadState(cnd);
-            }
-            // pieces along time (ga_kernels.hpp, BiquadScanJob): as many as keep every lane of the chip busy, each >= 1024 frames;
-            // mode 1: only cascades whose float32 rounding noise is so small that a different rounding stays inside the budget
-            int G = 1;
-            float coefs[5 * kMaxBiquadSections];
-            if (biquadTimeSplit && nf >= biquadSplitMinFrames) {
-              const int64_t lanes = 64 * 1024, heads = std::max(levelBqHeads, 1);
-              G = (int)std::max<int64_t>(1, std::min<int64_t>({(lanes + heads - 1) / heads, nf / 1024, 256}));
-              int q = 0;
-              for (const NodeSeg* cn : chain) {
-                coefs[5 * q] = cn->b0; coefs[5 * q + 1] = cn->b1; coefs[5 * q + 2] = cn->b2; coefs[5 * q + 3] = cn->a1; coefs[5 * q + 4] = cn->a2;
-                q++;
-              }
-              if (biquadTimeSplit == 1 && biquadDeviation(coefs, (int)chain.size()) > biquadSplitMaxDeviation) G = 1;
-            }
-            int64_t K = G > 1 ? ((nf + G - 1) / G + 3) / 4 * 4 : nf;
-            if (G > 1) G = (int)((nf + K - 1) / K);
-            if (G > 1 && ex.bqG == 0) {
-              ex.bqG = G;
-              ex.bqK = K;
-            }
-            if (G > 1 && (G != ex.bqG || K != ex.bqK)) G = 1;   // (one cut per level: the pieces of a level are expanded by one launch)
-            const std::vector<float>* AK = G > 1 ? &biquadTransition(coefs, (int)chain.size(), K).M : nullptr;
-            for (int ch = 0; ch < ns.outCh; ch++) {
-              BiquadJob bj;
-              bj.in = iv[ch] ? iv[ch] : zeros;
-              bj.out = ex.nodeOut(ns.id, ch);
-              bj.sec0 = (int)ex.bqSecs.size();
-              bj.nsec = (int)chain.size();
-              bj.f0 = f0;
-              bj.n = nf;
-              bj.state = nullptr;
-              for (const NodeSeg* cn : chain) {
-                BiquadSection sc;
-                sc.b0 = cn->b0; sc.b1 = cn->b1; sc.b2 = cn->b2; sc.a1 = cn->a1; sc.a2 = cn->a2;
-                sc.pad_ = 0.f;
-                sc.state = nodes[cn->id]->bqState + 2 * ch;
-                ex.bqSecs.push_back(sc);
-              }
-              ov[ch] = bj.out;
-              if (G <= 1) {
-                ex.bqJobs[bj.nsec].push_back(bj);
-                continue;
-              }
-              stats.biquad_split_cascades++;
-              float* scratch = bqSplitAlloc((size_t)(G - 1) * bj.nsec * 2);
-              ex.bqMats[bj.nsec].push_back(AK);
-              ex.bqScans[bj.nsec].push_back(BiquadScanJob{bj.in, bj.out, 0, scratch, bj.sec0, bj.nsec, f0, nf});
-            }
-            break;
-          }
+          case GA_NODE_CONSTANT_SOURCE: planConstantSource(k); break;
+          case GA_NODE_OSCILLATOR: planOscillator(k); break;
+          case GA_NODE_DELAY: planDelay(k); break;
+          case GA_NODE_STEREO_PANNER: planStereoPanner(k); break;
+          case GA_NODE_BUFFER_SOURCE: planBufferSource(k); break;
+          case GA_NODE_STREAM_SOURCE: planStreamSource(k); break;
+          case GA_NODE_GAIN: planGain(k); break;
+          case GA_NODE_BIQUAD: planBiquad(k); break;
           case GA_NODE_CONVOLVER: {
             auto iv = ex.resolveInput((int)si, ns, 0, false, nullptr);
             if (!nd.ir) break;  // no IR: cleared output (ConvolverNode.cs:107-119)

@@ -473,6 +473,7 @@ struct Resampler {  // host replay of CubicResampler's position recurrence (Cubi
 };
 
 struct ChunkRun;   // ga_chunk.cpp
+struct NodePlanCtx;   // ga_chunk.cpp
 
 struct Context {
   int sampleRate;
@@ -691,6 +692,14 @@ struct Context {
   void chunkParamCurves(ChunkRun& r);
   void chunkConvScratch(ChunkRun& r);
   void chunkPlanNodes(ChunkRun& r, int depth);
+  void planConstantSource(NodePlanCtx& k);   // (chunkPlanNodes, one per node type)
+  void planOscillator(NodePlanCtx& k);
+  void planDelay(NodePlanCtx& k);
+  void planStereoPanner(NodePlanCtx& k);
+  void planBufferSource(NodePlanCtx& k);
+  void planStreamSource(NodePlanCtx& k);
+  void planGain(NodePlanCtx& k);
+  void planBiquad(NodePlanCtx& k);
   void chunkPlanConvolvers(ChunkRun& r, int depth);
   void chunkDelayCommit(ChunkRun& r);
   void chunkExecute(ChunkRun& r);
