@@ -3253,6 +3253,387 @@ void Context::chunkPlanNodes(ChunkRun& r, int d) {
     }
 }
 
+// what the passes of Context::chunkPlanConvolvers share (one convolver depth of one chunk)
+struct ConvGroupLess {   // ordered by (IR buffer, IR channel) so groups fed by the same inputs are adjacent
+  bool operator()(const ConvGroup* a, const ConvGroup* b) const {
+    if (a->ir.get() != b->ir.get()) return a->ir.get() < b->ir.get();
+    if (a->irCh != b->irCh) return a->irCh < b->irCh;
+    return a->depth < b->depth;
+  }
+};
+struct ConvPlanCtx {
+  std::map<ConvGroup*, std::vector<std::pair<int, int>>, ConvGroupLess> active;   // group -> (node, slot)
+  std::vector<const float*> prevIns;
+  int prevP = -1, prevRp = -1, prevRows = -1;
+  std::vector<int> bNodes, dNodes;
+  std::unordered_map<int, std::array<float*, 4>> tsTemps;   // true-stereo temp outputs per node
+};
+
+// formulation A: convolvers that share an impulse-response channel run as one group per (impulse response, channel) -- the
+// banded-Toeplitz matrix-core kernel or the block-axis transforms over all their rows (PartitionedConvolver.cs:104-223)
+void Context::planConvolversShared(ChunkRun& r, int d, ConvPlanCtx& k) {
+  Context& c_ = *this; (void)c_;
+  std::vector<int>& topo = r.topo;
+  int& maxDepth = r.maxDepth; int& maxLevel = r.maxLevel; (void)maxDepth; (void)maxLevel;
+  int64_t& n = r.n; (void)n;
+  std::vector<double>& bt = r.bt; (void)bt;
+  std::vector<int>& srcIds = r.srcIds; (void)srcIds;
+  std::vector<SrcPlanOut>& srcPlans = r.srcPlans; (void)srcPlans;
+  std::vector<Segment>& segs = r.segs; (void)segs;
+  const int64_t frames = r.n * kBlock; (void)frames;
+  int& bHistMax = r.bHistMax; (void)bHistMax;
+  Exec& ex = *r.ex;
+  (void)d; (void)topo;
+  auto& active = k.active; auto& tsTemps = k.tsTemps; auto& prevIns = k.prevIns; int& prevP = k.prevP; int& prevRp = k.prevRp; int& prevRows = k.prevRows;
+  for (auto& kv : active) {
+    ConvGroup& g = *kv.first;
+    const int P = g.P, hist = P - 1;
+    const int nrows = (int)g.rows.size();
+    std::vector<ConvRowIO> rio(nrows, ConvRowIO{nullptr, nullptr});
+    for (auto& ns_ : kv.second) {
+      NodeS& nd = *nodes[ns_.first];
+      const int slot = ns_.second;
+      const int idx = nd.convRows[slot].idx;
+      // which input channel feeds this row: discrete -> slot ; true stereo -> L,L,R,R for h0,h1,h2,h3 (ConvolverNode.cs:127-151)
+      const int inCh = nd.isTrueStereo ? (slot >> 1) : slot;
+      const Exec::ConvInRow ci = ex.convIn[ns_.first];
+      const float* stable = nullptr;
+      bool same = true, first = true;
+      for (size_t si = 0; si < segs.size(); si++) {
+        const float* v = (ci[si].empty() || inCh >= (int)ci[si].size()) ? nullptr : ci[si][inCh];
+        if (first) { stable = v; first = false; } else if (v != stable) same = false;
+      }
+      const float* in = stable;
+      if (!same) {  // materialise: per segment copy / zero fill into a row slab
+        float* slab = getSlab(*this);
+        for (size_t si = 0; si < segs.size(); si++) {
+          const float* v = (ci[si].empty() || inCh >= (int)ci[si].size()) ? nullptr : ci[si][inCh];
+          MixJob mj;
+          mj.out = slab;
+          mj.term0 = (int)ex.terms.size();
+          mj.nterms = v ? 1 : 0;
+          mj.f0 = segs[si].b0 * kBlock;
+          mj.n = (segs[si].b1 - segs[si].b0) * kBlock;
+          if (v) {
+            ex.terms.push_back(v);
+            ex.noteAlign(v, mj.f0);
+          }
+          ex.mixJobs.push_back(mj);
+        }
+        in = slab;
+      }
+      float* out;
+      if (nd.isTrueStereo) {
+        out = getSlab(*this);  // temp1 / temp2, summed below (ConvolverNode.cs:137-143)
+      } else {
+        out = ex.nodeOut(ns_.first, slot);
+      }
+      rio[idx] = ConvRowIO{in, out};
+      if (nd.isTrueStereo) {
+        auto it = tsTemps.find(ns_.first);
+        if (it == tsTemps.end()) it = tsTemps.emplace(ns_.first, std::array<float*, 4>{nullptr, nullptr, nullptr, nullptr}).first;
+        it->second[slot] = out;
+      }
+    }
+    ex.flushLevel();
+    const int rp = g.rp;
+    const int ty = (int)roundup(n, 64);
+    const int tx = ty + P + 128;
+    ConvPlanes pl{(float*)planes[0].p, (float*)planes[1].p, (float*)planes[2].p, (float*)planes[3].p, tx, ty, rp};
+    size_t rioOff = ex.plan.putv(rio);
+    hipStream_t st = stream;
+    Twiddles tw{w128, w256};
+    const int nn = (int)n;
+    float* hR = g.histR;
+    float* hI = g.histI;
+    const bool hz = g.histZero;
+    const float* hr = g.ir->hr + (size_t)g.irCh * kBins * P;
+    const float* hi = g.ir->hi + (size_t)g.irCh * kBins * P;
+    float* ovIn = g.overlap[g.ovCur];
+    float* ovOut = g.overlap[g.ovCur ^ 1];
+    g.ovCur ^= 1;
+    g.histZero = false;
+    // forward spectra depend only on the inputs: a group fed by exactly the same signals as the previous one (e.g. the
+    // channels of one stereo IR behind mono voices) reuses the X rows that are still in the scratch planes
+    std::vector<const float*> ins(nrows);
+    for (int r = 0; r < nrows; r++) ins[r] = rio[r].in;
+    const bool skipFwd = (prevP == P && prevRp == rp && prevRows == nrows && prevIns == ins);
+    prevIns = ins;
+    prevP = P;
+    prevRp = rp;
+    prevRows = nrows;
+    ex.plan.add(LK_FFT, [=](uint8_t* base) {
+      // frequency-domain delay line of the previous chunk(s) in front of this chunk's spectra
+      if (hist > 0) {
+        launch_plane_copy(st, pl.xr, tx, 0, hz ? nullptr : hR, hist, 0, hist, rp);
+        launch_plane_copy(st, pl.xi, tx, 0, hz ? nullptr : hI, hist, 0, hist, rp);
+      }
+      // rows beyond this chunk that the banded MAC may touch for its (discarded) padded outputs
+      int tail = std::min(tx - (hist + nn), 256);
+      launch_plane_copy(st, pl.xr, tx, hist + nn, nullptr, 0, 0, tail, rp);
+      launch_plane_copy(st, pl.xi, tx, hist + nn, nullptr, 0, 0, tail, rp);
+      if (!skipFwd) launch_rfft_fwd(st, (const ConvRowIO*)(base + rioOff), nrows, nn, hist, pl, tw);
+    });
+    ex.plan.add(LK_MAC, [=](uint8_t*) { launch_spectral_mac_shared(st, pl, hr, hi, P, nn, nrows); });
+    ex.plan.add(LK_FFT, [=](uint8_t* base) {
+      launch_irfft_ola(st, (const ConvRowIO*)(base + rioOff), nrows, nn, pl, ovIn, ovOut, tw);
+      if (hist > 0) {  // keep the last P-1 spectra for the next chunk (the FDL, PartitionedConvolver.cs:122-128)
+        launch_plane_copy(st, hR, hist, 0, pl.xr, tx, nn, hist, rp);
+        launch_plane_copy(st, hI, hist, 0, pl.xi, tx, nn, hist, rp);
+      }
+    });
+    stats.mac_flops_total += 8.0 * P * kBins * (double)kv.second.size() * (double)n;
+    // streaming-formulation bytes: per channel-instance per block FDL read + write + input, IR once per block per channel
+    stats.mac_bytes_total += ((double)P * kBins * 8.0 + kBins * 8.0 + 512.0) * (double)kv.second.size() * (double)n +
+                             (double)P * kBins * 8.0 * (double)n;
+    stats.mac_launches += 1;
+  }
+}
+
+// formulations B / C: nodes with an impulse response of their own (per-node planes; block-axis FFT segments or the direct sum)
+void Context::planConvolversPrivate(ChunkRun& r, int d, ConvPlanCtx& k) {
+  Context& c_ = *this; (void)c_;
+  std::vector<int>& topo = r.topo;
+  int& maxDepth = r.maxDepth; int& maxLevel = r.maxLevel; (void)maxDepth; (void)maxLevel;
+  int64_t& n = r.n; (void)n;
+  std::vector<double>& bt = r.bt; (void)bt;
+  std::vector<int>& srcIds = r.srcIds; (void)srcIds;
+  std::vector<SrcPlanOut>& srcPlans = r.srcPlans; (void)srcPlans;
+  std::vector<Segment>& segs = r.segs; (void)segs;
+  const int64_t frames = r.n * kBlock; (void)frames;
+  int& bHistMax = r.bHistMax; (void)bHistMax;
+  Exec& ex = *r.ex;
+  (void)d; (void)topo;
+  const std::vector<int>& bNodes = k.bNodes; auto& tsTemps = k.tsTemps;
+  const int hist = (int)roundup(bHistMax, 4);   // plane time origin, 16-byte aligned rows
+  const int txb = hist + (int)roundup(n, 16) + 16, tyb = (int)roundup(n, 256);
+  // rows of this depth start after the rows of the depths before it: a node's spectra stay intact for the next chunk
+  const size_t rowX0 = bRowX, rowY0 = bRowY;
+  ConvPlanesB plb{xPlane(bPairWrite, 0) + rowX0 * kBins * txb, xPlane(bPairWrite, 1) + rowX0 * kBins * txb,
+                  (float*)planesB[2].p + rowY0 * kBins * tyb, (float*)planesB[3].p + rowY0 * kBins * tyb, txb, tyb};
+  std::vector<ConvRowIO> xrows, yrows;
+  std::vector<ConvSetB> sets;
+  std::map<int, std::vector<ConvSetC>> setsC;   // by P: launches per distinct segment length
+  struct SetTaps { IrSpectra* ir; int slot[16]; };
+  std::map<int, std::vector<SetTaps>> setsCTaps;   // which taps spectra each column of a set needs (filled per FFT length)
+  std::vector<HistJobB> restore;
+  std::vector<const float*> ovIn;
+  std::vector<float*> ovOut;
+  double flops = 0;
+  std::vector<const float*> chIn;   // (scratch vectors live outside the node loop: a thousand convolvers per chunk)
+  std::vector<float*> slotOut;
+  std::vector<int> cols;
+  for (int id : bNodes) {
+    NodeS& nd = *nodes[id];
+    const int P = nd.ir->P, h = P - 1;
+    const Exec::ConvInRow ci = ex.convIn[id];
+    // chunk-long input pointer of every input channel (stable view, or a materialised copy)
+    chIn.assign(nd.bInCh, nullptr);
+    for (int c = 0; c < nd.bInCh; c++) {
+      const float* stable = nullptr;
+      bool same = true, first = true;
+      for (size_t si = 0; si < segs.size(); si++) {
+        const float* v = (ci[si].empty() || c >= (int)ci[si].size()) ? nullptr : ci[si][c];
+        if (first) { stable = v; first = false; } else if (v != stable) same = false;
+      }
+      if (same) {
+        chIn[c] = stable;
+      } else {
+        float* slab = getSlab(*this);
+        for (size_t si = 0; si < segs.size(); si++) {
+          const float* v = (ci[si].empty() || c >= (int)ci[si].size()) ? nullptr : ci[si][c];
+          MixJob mj;
+          mj.out = slab;
+          mj.term0 = (int)ex.terms.size();
+          mj.nterms = v ? 1 : 0;
+          mj.f0 = segs[si].b0 * kBlock;
+          mj.n = (segs[si].b1 - segs[si].b0) * kBlock;
+          if (v) {
+            ex.terms.push_back(v);
+            ex.noteAlign(v, mj.f0);
+          }
+          ex.mixJobs.push_back(mj);
+        }
+        chIn[c] = slab;
+      }
+    }
+    bool allSame = true;
+    for (int c = 1; c < nd.bInCh; c++) allSame = allSame && (chIn[c] == chIn[0]);
+    const size_t hstride = (size_t)kBins * std::max(h, 1);
+    if (nd.bShared && !allSame) {
+      // the channels start to differ: every channel inherits the (so far common) history of channel 0
+      if (!nd.bHistZero && h > 0 && nd.bHistPlane < 0)   // (a plane-resident shared row is simply read by every channel)
+        for (int c = 1; c < nd.bInCh; c++) {
+          GA_HIP(hipMemcpyAsync(nd.bHistR + c * hstride, nd.bHistR, hstride * 4, hipMemcpyDeviceToDevice, stream));
+          GA_HIP(hipMemcpyAsync(nd.bHistI + c * hstride, nd.bHistI, hstride * 4, hipMemcpyDeviceToDevice, stream));
+        }
+      nd.bShared = false;
+    }
+    const int nxr = nd.bShared ? 1 : nd.bInCh;
+    const int x0 = (int)xrows.size();
+    for (int c = 0; c < nxr; c++) {
+      const int xi = x0 + c;
+      xrows.push_back(ConvRowIO{chIn[c], nullptr});
+      float* xr_row = plb.xr + (size_t)xi * kBins * txb;
+      float* xi_row = plb.xi + (size_t)xi * kBins * txb;
+      // [0, hist - h) zeros, [hist - h, hist) this channel's history, rows after the chunk zero (K padding reads them)
+      if (hist - h > 0) {
+        restore.push_back(HistJobB{xr_row, nullptr, txb, 0, hist - h, 0});
+        restore.push_back(HistJobB{xi_row, nullptr, txb, 0, hist - h, 0});
+      }
+      if (h > 0) {
+        const float *srcR = nullptr, *srcI = nullptr;
+        int sstride = h;
+        if (nd.bHistZero) {
+        } else if (nd.bHistPlane >= 0) {   // the previous chunk's x planes (never the pair being written: flushed above)
+          const size_t off = (size_t)(nd.bHistRow + (nd.bHistNx == 1 ? 0 : c)) * kBins * nd.bHistTxb + nd.bHistOff;
+          srcR = xPlane(nd.bHistPlane, 0) + off;
+          srcI = xPlane(nd.bHistPlane, 1) + off;
+          sstride = nd.bHistTxb;
+        } else {
+          srcR = nd.bHistR + c * hstride;
+          srcI = nd.bHistI + c * hstride;
+        }
+        restore.push_back(HistJobB{xr_row + (hist - h), srcR, txb, sstride, h, 0});
+        restore.push_back(HistJobB{xi_row + (hist - h), srcI, txb, sstride, h, 0});
+      }
+      const int tailn = txb - (hist + (int)n);
+      restore.push_back(HistJobB{xr_row + hist + (int)n, nullptr, txb, 0, tailn, 0});
+      restore.push_back(HistJobB{xi_row + hist + (int)n, nullptr, txb, 0, tailn, 0});
+    }
+    // slots: discrete -> slot c reads input c, IR channel c ; true stereo -> (L,h0) (L,h1) (R,h2) (R,h3)
+    slotOut.assign(nd.bSlots, nullptr);
+    for (int slot = 0; slot < nd.bSlots; slot++) {
+      if (nd.isTrueStereo) {
+        float* tmp = getSlab(*this);
+        slotOut[slot] = tmp;
+        auto it = tsTemps.find(id);
+        if (it == tsTemps.end()) it = tsTemps.emplace(id, std::array<float*, 4>{nullptr, nullptr, nullptr, nullptr}).first;
+        it->second[slot] = tmp;
+      } else {
+        slotOut[slot] = ex.nodeOut(id, slot);
+      }
+    }
+    // sets: columns grouped by the x-row they read, at most 16 per set, y rows consecutive per set
+    for (int xc = 0; xc < nxr; xc++) {
+      cols.clear();
+      for (int slot = 0; slot < nd.bSlots; slot++) {
+        int inc = nd.isTrueStereo ? (slot >> 1) : slot;
+        if (nd.bShared || inc == xc) cols.push_back(slot);
+      }
+      for (size_t c0 = 0; c0 < cols.size(); c0 += 16) {
+        ConvSetB st{};
+        st.x = x0 + xc;
+        st.y0 = (int)yrows.size();
+        st.ncol = (int)std::min<size_t>(16, cols.size() - c0);
+        st.P = P;
+        ConvSetC sc{};
+        sc.x = st.x;
+        sc.y0 = st.y0;
+        sc.ncol = st.ncol;
+        sc.P = P;
+        for (int j = 0; j < st.ncol; j++) {
+          int slot = cols[c0 + j];
+          st.hr[j] = nd.ir->hr + (size_t)slot * kBins * P;   // slot index == IR channel index in both modes
+          st.hi[j] = nd.ir->hi + (size_t)slot * kBins * P;
+          sc.hs[j] = nullptr;   // per FFT length, below
+          yrows.push_back(ConvRowIO{nullptr, slotOut[slot]});
+          ovIn.push_back(nd.bOverlap + ((size_t)slot * 2 + nd.bOvCur) * kBlock);
+          ovOut.push_back(nd.bOverlap + ((size_t)slot * 2 + (nd.bOvCur ^ 1)) * kBlock);
+        }
+        if (nd.convPath == 3) {
+          SetTaps tp{nd.ir.get(), {}};
+          for (int j = 0; j < st.ncol; j++) tp.slot[j] = cols[c0 + j];
+          setsC[P].push_back(sc);
+          setsCTaps[P].push_back(tp);
+        } else {
+          sets.push_back(st);
+        }
+      }
+    }
+    nd.bOvCur ^= 1;
+    nd.bHistZero = false;
+    if (h > 0) {   // the history of the next chunk: the last h spectra of these rows
+      if (nd.bHistPlane == bPairWrite) fail(GA_ERR_DEVICE, "internal: convolver history lives in the planes being written");
+      nd.bHistPlane = bPairWrite;
+      nd.bHistRow = (int)rowX0 + x0;
+      nd.bHistNx = nxr;
+      nd.bHistOff = hist + (int)n - h;
+      nd.bHistTxb = txb;
+      bResidents[bPairWrite].push_back(id);
+    }
+    flops += 8.0 * P * kBins * (double)nd.bSlots * (double)n;
+  }
+  bRowX += xrows.size();
+  bRowY += yrows.size();
+  bPairCur = bPairWrite;
+  ex.flushLevel();
+  size_t xo = ex.plan.putv(xrows), yo = ex.plan.putv(yrows), so = ex.plan.putv(sets), ro = ex.plan.putv(restore),
+         oi = ex.plan.putv(ovIn), oo = ex.plan.putv(ovOut);
+  const int nx = (int)xrows.size(), ny = (int)yrows.size(), ns_ = (int)sets.size(), nr = (int)restore.size();
+  hipStream_t st = stream;
+  Twiddles tw{w128, w256};
+  const int nn = (int)n;
+  const int maxn = std::max(hist, txb - hist - nn);
+  const bool f64 = fft64;
+  ex.plan.add(LK_FFT, [=](uint8_t* base) {
+    launch_hist_copy_b(st, (const HistJobB*)(base + ro), nr, std::max(maxn, 1));
+    launch_rfft_fwd_b(st, (const ConvRowIO*)(base + xo), nx, nn, hist, plb, tw, f64);
+  });
+  if (ns_ > 0) ex.plan.add(LK_MAC, [=](uint8_t* base) { launch_spectral_mac_b(st, (const ConvSetB*)(base + so), ns_, nn, hist, plb); });
+  for (auto& kv : setsC) {
+    const int Pc = kv.first;
+    static const char* r16env = expenv("GA_TCONV_RADIX16");   // A/B switches for measurements
+    static const char* planenv = expenv("GA_TCONV_MIXED");
+    const bool r16 = r16env ? atoi(r16env) != 0 : useRadix16;
+    std::vector<TconvLaunch> tplan;
+    if (debugTconvN2 > 0) {   // tests: a length no kernel exists for must come back as an error code, not abort the host
+      const int Lc = std::max(1, debugTconvN2 - (Pc - 1));
+      tplan.push_back(TconvLaunch{debugTconvN2, 0, (nn + Lc - 1) / Lc});
+    } else if (r16 && !(planenv && atoi(planenv) == 0)) {
+      tplan = tconvPlan(nn, Pc);
+    } else {   // one FFT length for the whole chunk
+      const int N2 = tapFftSize(Pc), Lc = N2 - (Pc - 1);
+      tplan.push_back(TconvLaunch{N2, 0, (nn + Lc - 1) / Lc});
+    }
+    const std::vector<SetTaps>& taps = setsCTaps[Pc];
+    for (const TconvLaunch& tl : tplan) {
+      std::vector<ConvSetC> sv = kv.second;
+      for (size_t i = 0; i < sv.size(); i++) {
+        const float2* hsp = ensureTapSpectra(*taps[i].ir, tl.N2);
+        for (int j = 0; j < sv[i].ncol; j++) sv[i].hs[j] = hsp + (size_t)taps[i].slot[j] * kBins * tl.N2;
+      }
+      size_t co = ex.plan.putv(sv);
+      const int nc = (int)sv.size();
+      const int N2 = tl.N2, tbase = tl.tbase, nseg = tl.nseg;
+      const float2* twc = r16 ? twiddles16(N2) : twiddlesC(N2);
+      ex.plan.add(LK_MAC, [=](uint8_t* base) {
+        if (r16) launch_tconv16(st, (const ConvSetC*)(base + co), nc, nn, hist, plb, N2, twc, nseg, tbase);
+        else launch_tconv(st, (const ConvSetC*)(base + co), nc, nn, hist, plb, N2, twc, nseg);
+      });
+    }
+  }
+  ex.plan.add(LK_FFT, [=](uint8_t* base) {
+    launch_irfft_ola_b(st, (const ConvRowIO*)(base + yo), ny, nn, plb, (const float* const*)(base + oi), (float* const*)(base + oo), tw, f64);
+  });
+  stats.mac_flops_total += flops;
+  // streaming-formulation bytes: per channel-instance per block FDL read + write + input; every distinct
+  // IR channel is counted once per block however many nodes share it
+  {
+    std::map<std::pair<IrSpectra*, int>, int> distinct;
+    double bytes = 0;
+    for (int id : bNodes) {
+      NodeS& nd = *nodes[id];
+      const int P = nd.ir->P;
+      bytes += ((double)P * kBins * 8.0 + kBins * 8.0 + 512.0) * nd.bSlots * (double)n;
+      for (int sl = 0; sl < nd.bSlots; sl++) distinct[{nd.ir.get(), sl}] = P;
+    }
+    for (auto& kv : distinct) bytes += (double)kv.second * kBins * 8.0 * (double)n;
+    stats.mac_bytes_total += bytes;
+  }
+  stats.mac_launches += 1;
+}
+
 // pass 7 (per convolver depth d): the convolvers whose inputs are complete, once per chunk over all blocks
 void Context::chunkPlanConvolvers(ChunkRun& r, int d) {
   Context& c_ = *this; (void)c_;
@@ -3268,18 +3649,10 @@ void Context::chunkPlanConvolvers(ChunkRun& r, int d) {
   Exec& ex = *r.ex;
     // ---- convolvers whose inputs are complete (depth d): once per chunk over all blocks ----
     // group -> (node, slot); ordered by (IR buffer, IR channel) so groups fed by the same inputs are adjacent
-    struct GroupLess {
-      bool operator()(const ConvGroup* a, const ConvGroup* b) const {
-        if (a->ir.get() != b->ir.get()) return a->ir.get() < b->ir.get();
-        if (a->irCh != b->irCh) return a->irCh < b->irCh;
-        return a->depth < b->depth;
-      }
-    };
-    std::map<ConvGroup*, std::vector<std::pair<int, int>>, GroupLess> active;
-    std::vector<const float*> prevIns;
-    int prevP = -1, prevRp = -1, prevRows = -1;
-    std::vector<int> bNodes;  // formulation B / C nodes of this depth
-    std::vector<int> dNodes;  // formulation D nodes of this depth
+    ConvPlanCtx k;
+    auto& active = k.active;
+    std::vector<int>& bNodes = k.bNodes;  // formulation B / C nodes of this depth
+    std::vector<int>& dNodes = k.dNodes;  // formulation D nodes of this depth
     for (int id : topo) {
       NodeS& nd = *nodes[id];
       if (nd.type != GA_NODE_CONVOLVER || !nd.ir || nd.depth != d) continue;
@@ -3294,342 +3667,12 @@ void Context::chunkPlanConvolvers(ChunkRun& r, int d) {
       }
       for (int slot = 0; slot < (int)nd.convRows.size(); slot++) active[nd.convRows[slot].group].push_back({id, slot});
     }
-    std::unordered_map<int, std::array<float*, 4>> tsTemps;  // true-stereo temp outputs per node
-    for (auto& kv : active) {
-      ConvGroup& g = *kv.first;
-      const int P = g.P, hist = P - 1;
-      const int nrows = (int)g.rows.size();
-      std::vector<ConvRowIO> rio(nrows, ConvRowIO{nullptr, nullptr});
-      for (auto& ns_ : kv.second) {
-        NodeS& nd = *nodes[ns_.first];
-        const int slot = ns_.second;
-        const int idx = nd.convRows[slot].idx;
-        // which input channel feeds this row: discrete -> slot ; true stereo -> L,L,R,R for h0,h1,h2,h3 (ConvolverNode.cs:127-151)
-        const int inCh = nd.isTrueStereo ? (slot >> 1) : slot;
-        const Exec::ConvInRow ci = ex.convIn[ns_.first];
-        const float* stable = nullptr;
-        bool same = true, first = true;
-        for (size_t si = 0; si < segs.size(); si++) {
-          const float* v = (ci[si].empty() || inCh >= (int)ci[si].size()) ? nullptr : ci[si][inCh];
-          if (first) { stable = v; first = false; } else if (v != stable) same = false;
-        }
-        const float* in = stable;
-        if (!same) {  // materialise: per segment copy / zero fill into a row slab
-          float* slab = getSlab(*this);
-          for (size_t si = 0; si < segs.size(); si++) {
-            const float* v = (ci[si].empty() || inCh >= (int)ci[si].size()) ? nullptr : ci[si][inCh];
-            MixJob mj;
-            mj.out = slab;
-            mj.term0 = (int)ex.terms.size();
-            mj.nterms = v ? 1 : 0;
-            mj.f0 = segs[si].b0 * kBlock;
-            mj.n = (segs[si].b1 - segs[si].b0) * kBlock;
-            if (v) {
-              ex.terms.push_back(v);
-              ex.noteAlign(v, mj.f0);
-            }
-            ex.mixJobs.push_back(mj);
-          }
-          in = slab;
-        }
-        float* out;
-        if (nd.isTrueStereo) {
-          out = getSlab(*this);  // temp1 / temp2, summed below (ConvolverNode.cs:137-143)
-        } else {
-          out = ex.nodeOut(ns_.first, slot);
-        }
-        rio[idx] = ConvRowIO{in, out};
-        if (nd.isTrueStereo) {
-          auto it = tsTemps.find(ns_.first);
-          if (it == tsTemps.end()) it = tsTemps.emplace(ns_.first, std::array<float*, 4>{nullptr, nullptr, nullptr, nullptr}).first;
-          it->second[slot] = out;
-        }
-      }
-      ex.flushLevel();
-      const int rp = g.rp;
-      const int ty = (int)roundup(n, 64);
-      const int tx = ty + P + 128;
-      ConvPlanes pl{(float*)planes[0].p, (float*)planes[1].p, (float*)planes[2].p, (float*)planes[3].p, tx, ty, rp};
-      size_t rioOff = ex.plan.putv(rio);
-      hipStream_t st = stream;
-      Twiddles tw{w128, w256};
-      const int nn = (int)n;
-      float* hR = g.histR;
-      float* hI = g.histI;
-      const bool hz = g.histZero;
-      const float* hr = g.ir->hr + (size_t)g.irCh * kBins * P;
-      const float* hi = g.ir->hi + (size_t)g.irCh * kBins * P;
-      float* ovIn = g.overlap[g.ovCur];
-      float* ovOut = g.overlap[g.ovCur ^ 1];
-      g.ovCur ^= 1;
-      g.histZero = false;
-      // forward spectra depend only on the inputs: a group fed by exactly the same signals as the previous one (e.g. the
-      // channels of one stereo IR behind mono voices) reuses the X rows that are still in the scratch planes
-      std::vector<const float*> ins(nrows);
-      for (int r = 0; r < nrows; r++) ins[r] = rio[r].in;
-      const bool skipFwd = (prevP == P && prevRp == rp && prevRows == nrows && prevIns == ins);
-      prevIns = ins;
-      prevP = P;
-      prevRp = rp;
-      prevRows = nrows;
-      ex.plan.add(LK_FFT, [=](uint8_t* base) {
-        // frequency-domain delay line of the previous chunk(s) in front of this chunk's spectra
-        if (hist > 0) {
-          launch_plane_copy(st, pl.xr, tx, 0, hz ? nullptr : hR, hist, 0, hist, rp);
-          launch_plane_copy(st, pl.xi, tx, 0, hz ? nullptr : hI, hist, 0, hist, rp);
-        }
-        // rows beyond this chunk that the banded MAC may touch for its (discarded) padded outputs
-        int tail = std::min(tx - (hist + nn), 256);
-        launch_plane_copy(st, pl.xr, tx, hist + nn, nullptr, 0, 0, tail, rp);
-        launch_plane_copy(st, pl.xi, tx, hist + nn, nullptr, 0, 0, tail, rp);
-        if (!skipFwd) launch_rfft_fwd(st, (const ConvRowIO*)(base + rioOff), nrows, nn, hist, pl, tw);
-      });
-      ex.plan.add(LK_MAC, [=](uint8_t*) { launch_spectral_mac_shared(st, pl, hr, hi, P, nn, nrows); });
-      ex.plan.add(LK_FFT, [=](uint8_t* base) {
-        launch_irfft_ola(st, (const ConvRowIO*)(base + rioOff), nrows, nn, pl, ovIn, ovOut, tw);
-        if (hist > 0) {  // keep the last P-1 spectra for the next chunk (the FDL, PartitionedConvolver.cs:122-128)
-          launch_plane_copy(st, hR, hist, 0, pl.xr, tx, nn, hist, rp);
-          launch_plane_copy(st, hI, hist, 0, pl.xi, tx, nn, hist, rp);
-        }
-      });
-      stats.mac_flops_total += 8.0 * P * kBins * (double)kv.second.size() * (double)n;
-      // streaming-formulation bytes: per channel-instance per block FDL read + write + input, IR once per block per channel
-      stats.mac_bytes_total += ((double)P * kBins * 8.0 + kBins * 8.0 + 512.0) * (double)kv.second.size() * (double)n +
-                               (double)P * kBins * 8.0 * (double)n;
-      stats.mac_launches += 1;
-    }
+    if (!active.empty()) planConvolversShared(r, d, k);
     // ---- formulation D: coarse partitions, consumer sums fused in the frequency domain ----
     if (!dNodes.empty()) planCoarseStage(*this, ex, dNodes, n);
-    // ---- formulation B: nodes with a private impulse response ----
-    if (!bNodes.empty()) {
-      const int hist = (int)roundup(bHistMax, 4);   // plane time origin, 16-byte aligned rows
-      const int txb = hist + (int)roundup(n, 16) + 16, tyb = (int)roundup(n, 256);
-      // rows of this depth start after the rows of the depths before it: a node's spectra stay intact for the next chunk
-      const size_t rowX0 = bRowX, rowY0 = bRowY;
-      ConvPlanesB plb{xPlane(bPairWrite, 0) + rowX0 * kBins * txb, xPlane(bPairWrite, 1) + rowX0 * kBins * txb,
-                      (float*)planesB[2].p + rowY0 * kBins * tyb, (float*)planesB[3].p + rowY0 * kBins * tyb, txb, tyb};
-      std::vector<ConvRowIO> xrows, yrows;
-      std::vector<ConvSetB> sets;
-      std::map<int, std::vector<ConvSetC>> setsC;   // by P: launches per distinct segment length
-      struct SetTaps { IrSpectra* ir; int slot[16]; };
-      std::map<int, std::vector<SetTaps>> setsCTaps;   // which taps spectra each column of a set needs (filled per FFT length)
-      std::vector<HistJobB> restore;
-      std::vector<const float*> ovIn;
-      std::vector<float*> ovOut;
-      double flops = 0;
-      std::vector<const float*> chIn;   // (scratch vectors live outside the node loop: a thousand convolvers per chunk)
-      std::vector<float*> slotOut;
-      std::vector<int> cols;
-      for (int id : bNodes) {
-        NodeS& nd = *nodes[id];
-        const int P = nd.ir->P, h = P - 1;
-        const Exec::ConvInRow ci = ex.convIn[id];
-        // chunk-long input pointer of every input channel (stable view, or a materialised copy)
-        chIn.assign(nd.bInCh, nullptr);
-        for (int c = 0; c < nd.bInCh; c++) {
-          const float* stable = nullptr;
-          bool same = true, first = true;
-          for (size_t si = 0; si < segs.size(); si++) {
-            const float* v = (ci[si].empty() || c >= (int)ci[si].size()) ? nullptr : ci[si][c];
-            if (first) { stable = v; first = false; } else if (v != stable) same = false;
-          }
-          if (same) {
-            chIn[c] = stable;
-          } else {
-            float* slab = getSlab(*this);
-            for (size_t si = 0; si < segs.size(); si++) {
-              const float* v = (ci[si].empty() || c >= (int)ci[si].size()) ? nullptr : ci[si][c];
-              MixJob mj;
-              mj.out = slab;
-              mj.term0 = (int)ex.terms.size();
-              mj.nterms = v ? 1 : 0;
-              mj.f0 = segs[si].b0 * kBlock;
-              mj.n = (segs[si].b1 - segs[si].b0) * kBlock;
-              if (v) {
-                ex.terms.push_back(v);
-                ex.noteAlign(v, mj.f0);
-              }
-              ex.mixJobs.push_back(mj);
-            }
-            chIn[c] = slab;
-          }
-        }
-        bool allSame = true;
-        for (int c = 1; c < nd.bInCh; c++) allSame = allSame && (chIn[c] == chIn[0]);
-        const size_t hstride = (size_t)kBins * std::max(h, 1);
-        if (nd.bShared && !allSame) {
-          // the channels start to differ: every channel inherits the (so far common) history of channel 0
-          if (!nd.bHistZero && h > 0 && nd.bHistPlane < 0)   // (a plane-resident shared row is simply read by every channel)
-            for (int c = 1; c < nd.bInCh; c++) {
-              GA_HIP(hipMemcpyAsync(nd.bHistR + c * hstride, nd.bHistR, hstride * 4, hipMemcpyDeviceToDevice, stream));
-              GA_HIP(hipMemcpyAsync(nd.bHistI + c * hstride, nd.bHistI, hstride * 4, hipMemcpyDeviceToDevice, stream));
-            }
-          nd.bShared = false;
-        }
-        const int nxr = nd.bShared ? 1 : nd.bInCh;
-        const int x0 = (int)xrows.size();
-        for (int c = 0; c < nxr; c++) {
-          const int xi = x0 + c;
-          xrows.push_back(ConvRowIO{chIn[c], nullptr});
-          float* xr_row = plb.xr + (size_t)xi * kBins * txb;
-          float* xi_row = plb.xi + (size_t)xi * kBins * txb;
-          // [0, hist - h) zeros, [hist - h, hist) this channel's history, rows after the chunk zero (K padding reads them)
-          if (hist - h > 0) {
-            restore.push_back(HistJobB{xr_row, nullptr, txb, 0, hist - h, 0});
-            restore.push_back(HistJobB{xi_row, nullptr, txb, 0, hist - h, 0});
-          }
-          if (h > 0) {
-            const float *srcR = nullptr, *srcI = nullptr;
-            int sstride = h;
-            if (nd.bHistZero) {
-            } else if (nd.bHistPlane >= 0) {   // the previous chunk's x planes (never the pair being written: flushed above)
-              const size_t off = (size_t)(nd.bHistRow + (nd.bHistNx == 1 ? 0 : c)) * kBins * nd.bHistTxb + nd.bHistOff;
-              srcR = xPlane(nd.bHistPlane, 0) + off;
-              srcI = xPlane(nd.bHistPlane, 1) + off;
-              sstride = nd.bHistTxb;
-            } else {
-              srcR = nd.bHistR + c * hstride;
-              srcI = nd.bHistI + c * hstride;
-            }
-            restore.push_back(HistJobB{xr_row + (hist - h), srcR, txb, sstride, h, 0});
-            restore.push_back(HistJobB{xi_row + (hist - h), srcI, txb, sstride, h, 0});
-          }
-          const int tailn = txb - (hist + (int)n);
-          restore.push_back(HistJobB{xr_row + hist + (int)n, nullptr, txb, 0, tailn, 0});
-          restore.push_back(HistJobB{xi_row + hist + (int)n, nullptr, txb, 0, tailn, 0});
-        }
-        // slots: discrete -> slot c reads input c, IR channel c ; true stereo -> (L,h0) (L,h1) (R,h2) (R,h3)
-        slotOut.assign(nd.bSlots, nullptr);
-        for (int slot = 0; slot < nd.bSlots; slot++) {
-          if (nd.isTrueStereo) {
-            float* tmp = getSlab(*this);
-            slotOut[slot] = tmp;
-            auto it = tsTemps.find(id);
-            if (it == tsTemps.end()) it = tsTemps.emplace(id, std::array<float*, 4>{nullptr, nullptr, nullptr, nullptr}).first;
-            it->second[slot] = tmp;
-          } else {
-            slotOut[slot] = ex.nodeOut(id, slot);
-          }
-        }
-        // sets: columns grouped by the x-row they read, at most 16 per set, y rows consecutive per set
-        for (int xc = 0; xc < nxr; xc++) {
-          cols.clear();
-          for (int slot = 0; slot < nd.bSlots; slot++) {
-            int inc = nd.isTrueStereo ? (slot >> 1) : slot;
-            if (nd.bShared || inc == xc) cols.push_back(slot);
-          }
-          for (size_t c0 = 0; c0 < cols.size(); c0 += 16) {
-            ConvSetB st{};
-            st.x = x0 + xc;
-            st.y0 = (int)yrows.size();
-            st.ncol = (int)std::min<size_t>(16, cols.size() - c0);
-            st.P = P;
-            ConvSetC sc{};
-            sc.x = st.x;
-            sc.y0 = st.y0;
-            sc.ncol = st.ncol;
-            sc.P = P;
-            for (int j = 0; j < st.ncol; j++) {
-              int slot = cols[c0 + j];
-              st.hr[j] = nd.ir->hr + (size_t)slot * kBins * P;   // slot index == IR channel index in both modes
-              st.hi[j] = nd.ir->hi + (size_t)slot * kBins * P;
-              sc.hs[j] = nullptr;   // per FFT length, below
-              yrows.push_back(ConvRowIO{nullptr, slotOut[slot]});
-              ovIn.push_back(nd.bOverlap + ((size_t)slot * 2 + nd.bOvCur) * kBlock);
-              ovOut.push_back(nd.bOverlap + ((size_t)slot * 2 + (nd.bOvCur ^ 1)) * kBlock);
-            }
-            if (nd.convPath == 3) {
-              SetTaps tp{nd.ir.get(), {}};
-              for (int j = 0; j < st.ncol; j++) tp.slot[j] = cols[c0 + j];
-              setsC[P].push_back(sc);
-              setsCTaps[P].push_back(tp);
-            } else {
-              sets.push_back(st);
-            }
-          }
-        }
-        nd.bOvCur ^= 1;
-        nd.bHistZero = false;
-        if (h > 0) {   // the history of the next chunk: the last h spectra of these rows
-          if (nd.bHistPlane == bPairWrite) fail(GA_ERR_DEVICE, "internal: convolver history lives in the planes being written");
-          nd.bHistPlane = bPairWrite;
-          nd.bHistRow = (int)rowX0 + x0;
-          nd.bHistNx = nxr;
-          nd.bHistOff = hist + (int)n - h;
-          nd.bHistTxb = txb;
-          bResidents[bPairWrite].push_back(id);
-        }
-        flops += 8.0 * P * kBins * (double)nd.bSlots * (double)n;
-      }
-      bRowX += xrows.size();
-      bRowY += yrows.size();
-      bPairCur = bPairWrite;
-      ex.flushLevel();
-      size_t xo = ex.plan.putv(xrows), yo = ex.plan.putv(yrows), so = ex.plan.putv(sets), ro = ex.plan.putv(restore),
-             oi = ex.plan.putv(ovIn), oo = ex.plan.putv(ovOut);
-      const int nx = (int)xrows.size(), ny = (int)yrows.size(), ns_ = (int)sets.size(), nr = (int)restore.size();
-      hipStream_t st = stream;
-      Twiddles tw{w128, w256};
-      const int nn = (int)n;
-      const int maxn = std::max(hist, txb - hist - nn);
-      const bool f64 = fft64;
-      ex.plan.add(LK_FFT, [=](uint8_t* base) {
-        launch_hist_copy_b(st, (const HistJobB*)(base + ro), nr, std::max(maxn, 1));
-        launch_rfft_fwd_b(st, (const ConvRowIO*)(base + xo), nx, nn, hist, plb, tw, f64);
-      });
-      if (ns_ > 0) ex.plan.add(LK_MAC, [=](uint8_t* base) { launch_spectral_mac_b(st, (const ConvSetB*)(base + so), ns_, nn, hist, plb); });
-      for (auto& kv : setsC) {
-        const int Pc = kv.first;
-        static const char* r16env = expenv("GA_TCONV_RADIX16");   // A/B switches for measurements
-        static const char* planenv = expenv("GA_TCONV_MIXED");
-        const bool r16 = r16env ? atoi(r16env) != 0 : useRadix16;
-        std::vector<TconvLaunch> tplan;
-        if (debugTconvN2 > 0) {   // tests: a length no kernel exists for must come back as an error code, not abort the host
-          const int Lc = std::max(1, debugTconvN2 - (Pc - 1));
-          tplan.push_back(TconvLaunch{debugTconvN2, 0, (nn + Lc - 1) / Lc});
-        } else if (r16 && !(planenv && atoi(planenv) == 0)) {
-          tplan = tconvPlan(nn, Pc);
-        } else {   // one FFT length for the whole chunk
-          const int N2 = tapFftSize(Pc), Lc = N2 - (Pc - 1);
-          tplan.push_back(TconvLaunch{N2, 0, (nn + Lc - 1) / Lc});
-        }
-        const std::vector<SetTaps>& taps = setsCTaps[Pc];
-        for (const TconvLaunch& tl : tplan) {
-          std::vector<ConvSetC> sv = kv.second;
-          for (size_t i = 0; i < sv.size(); i++) {
-            const float2* hsp = ensureTapSpectra(*taps[i].ir, tl.N2);
-            for (int j = 0; j < sv[i].ncol; j++) sv[i].hs[j] = hsp + (size_t)taps[i].slot[j] * kBins * tl.N2;
-          }
-          size_t co = ex.plan.putv(sv);
-          const int nc = (int)sv.size();
-          const int N2 = tl.N2, tbase = tl.tbase, nseg = tl.nseg;
-          const float2* twc = r16 ? twiddles16(N2) : twiddlesC(N2);
-          ex.plan.add(LK_MAC, [=](uint8_t* base) {
-            if (r16) launch_tconv16(st, (const ConvSetC*)(base + co), nc, nn, hist, plb, N2, twc, nseg, tbase);
-            else launch_tconv(st, (const ConvSetC*)(base + co), nc, nn, hist, plb, N2, twc, nseg);
-          });
-        }
-      }
-      ex.plan.add(LK_FFT, [=](uint8_t* base) {
-        launch_irfft_ola_b(st, (const ConvRowIO*)(base + yo), ny, nn, plb, (const float* const*)(base + oi), (float* const*)(base + oo), tw, f64);
-      });
-      stats.mac_flops_total += flops;
-      // streaming-formulation bytes: per channel-instance per block FDL read + write + input; every distinct
-      // IR channel is counted once per block however many nodes share it
-      {
-        std::map<std::pair<IrSpectra*, int>, int> distinct;
-        double bytes = 0;
-        for (int id : bNodes) {
-          NodeS& nd = *nodes[id];
-          const int P = nd.ir->P;
-          bytes += ((double)P * kBins * 8.0 + kBins * 8.0 + 512.0) * nd.bSlots * (double)n;
-          for (int sl = 0; sl < nd.bSlots; sl++) distinct[{nd.ir.get(), sl}] = P;
-        }
-        for (auto& kv : distinct) bytes += (double)kv.second * kBins * 8.0 * (double)n;
-        stats.mac_bytes_total += bytes;
-      }
-      stats.mac_launches += 1;
-    }
+    // ---- formulations B / C: nodes with a private impulse response ----
+    if (!bNodes.empty()) planConvolversPrivate(r, d, k);
+    auto& tsTemps = k.tsTemps;
     // true stereo: outL = conv0(L) + conv2(R) ; outR = conv1(L) + conv3(R)  (ConvolverNode.cs:127-144)
     for (auto& kv : tsTemps) {
       hipStream_t st = stream;

@@ -474,6 +474,7 @@ struct Resampler {  // host replay of CubicResampler's position recurrence (Cubi
 
 struct ChunkRun;   // ga_chunk.cpp
 struct NodePlanCtx;   // ga_chunk.cpp
+struct ConvPlanCtx;   // ga_chunk.cpp
 
 struct Context {
   int sampleRate;
@@ -701,6 +702,8 @@ struct Context {
   void planGain(NodePlanCtx& k);
   void planBiquad(NodePlanCtx& k);
   void chunkPlanConvolvers(ChunkRun& r, int depth);
+  void planConvolversShared(ChunkRun& r, int depth, ConvPlanCtx& k);    // formulation A groups
+  void planConvolversPrivate(ChunkRun& r, int depth, ConvPlanCtx& k);   // formulations B / C
   void chunkDelayCommit(ChunkRun& r);
   void chunkExecute(ChunkRun& r);
   void chunkCommit(ChunkRun& r);
