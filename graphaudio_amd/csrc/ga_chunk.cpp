@@ -2982,8 +2982,15 @@ void Context::planGain(NodePlanCtx& k) {
   if (!ns.pins.empty() && !ns.pins[0].silent) gmod = ex.resolveInSeg((int)si, ns.id, -1, ns.pins[0], false, nullptr)[0];
   auto iv = ex.resolveInput((int)si, ns, 0, false, nullptr);
   if (ns.ins[0].silent) return;  // cleared output (GainNode.cs:41-46)
+  // a constant gain of exactly 1 (every GainNode's default: buses, splits and merges of effect chains) multiplies nothing:
+  // x * 1.0f == x bit for bit, so the output IS the (mixed) input -- no launch, no pass over the samples
+  const bool unity = !gmod && !nd.params[0].curve && nd.params[0].value == 1.0f && gainPassThrough;
   for (int ch = 0; ch < ns.outCh; ch++) {
     if (!iv[ch]) continue;
+    if (unity) {
+      ov[ch] = iv[ch];
+      continue;
+    }
     GainJob gj;
     gj.in = iv[ch];
     gj.out = ex.nodeOut(ns.id, ch);

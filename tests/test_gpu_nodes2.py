@@ -379,3 +379,72 @@ def test_audio_rate_modulation_of_oscillator_panner_delay_biquad_and_offset():
     # integer boundary
     assert err <= 5e-4 * G.rms(ref), (err, G.rms(ref))
     assert np.mean(np.abs(ref - got) > 1e-4) < 5e-3
+
+
+def test_unity_gains_hand_their_input_on():
+    """A GainNode whose gain is the constant 1 (the default: buses, the splits and merges of effect chains) is not evaluated --
+    its output IS its input, bit for bit what `x * 1.0f` gives.  Behind looping / late-starting / stopped sources (views that change
+    from segment to segment), in front of a convolver, a biquad, a delay and a panner, chained, fanned out, with channel
+    conversion at its input; a gain that is automated, modulated or set to 1 only later is evaluated as before."""
+    from graphaudio_amd import ConvolverNode, DelayNode
+    frames = 128 * 40
+
+    def build(ctx):
+        rng = np.random.default_rng(5)
+        hold = []
+        ir = PlayableAudioBuffer.FromChannelArrays([(rng.standard_normal(700) * 0.1).astype(np.float32) for _ in range(2)], SR)
+        bus = GainNode(ctx)                      # unity bus with several inputs: the mix is the output
+        bus.Connect(ctx.Destination)
+        for v in range(6):
+            s = AudioBufferSourceNode(ctx)
+            nch = 1 + v % 2
+            s.Buffer = PlayableAudioBuffer.FromChannelArrays([(rng.standard_normal(128 * 9 + 37 * v) * 0.2).astype(np.float32) for _ in range(nch)], SR)
+            s.Loop = v % 3 != 1
+            u1, u2 = GainNode(ctx), GainNode(ctx)   # two unity gains in a row
+            s.Connect(u1)
+            u1.Connect(u2)
+            tail = u2
+            if v == 0:
+                cv = ConvolverNode(ctx); cv.Buffer = ir; tail.Connect(cv); tail = cv
+            elif v == 1:
+                bq = BiQuadFilterNode(ctx); bq.Frequency.Value = 900.0; tail.Connect(bq); tail = bq
+            elif v == 2:
+                dl = DelayNode(ctx, 0.05); dl.DelayTime.Value = 0.004; tail.Connect(dl); tail = dl
+            elif v == 3:
+                pn = StereoPannerNode(ctx); pn.Pan.Value = -0.3; tail.Connect(pn); tail = pn
+            elif v == 4:
+                u2.Inputs[0].SetChannelCount(2)       # channel conversion in front of a unity gain
+                g = GainNode(ctx); g.Gain.SetValueAtTime(1.0, 0.0); g.Gain.LinearRampToValueAtTime(0.2, 0.08); tail.Connect(g); tail = g
+            else:
+                g = GainNode(ctx)                     # unity value, but modulated at audio rate: evaluated
+                lfo = OscillatorNode(ctx); lfo.Frequency.Value = 7.0
+                lg = GainNode(ctx); lg.Gain.Value = 0.25
+                lfo.Connect(lg); lg.Connect(g.Gain); lfo.Start()
+                tail.Connect(g); tail = g
+                hold += [lfo, lg]
+            tail.Connect(bus)
+            if v % 2:
+                tail.Connect(ctx.Destination)         # fan-out of a view
+            s.Start(0.0 if v % 2 == 0 else 0.013 * v)
+            if v == 2:
+                s.Stop(0.07)
+            hold += [s, u1, u2, tail]
+        return hold
+
+    for chunk in (0, 7):
+        ref, got = pair(build, 2, frames, pieces=[128 * 13, 128 * 5], chunk=chunk)
+        assert G.rms(ref) > 1e-3
+        assert G.rms(ref - got) <= 2e-6 * max(G.rms(ref), 1.0), (chunk, G.rms(ref - got))
+    # the same graph with the option off evaluates every gain: same result, more launches
+    stats = []
+    for opt in (1, 0):
+        ctx = OfflineAudioContext(SR)
+        ctx.SetOption("gain_pass_through", opt)
+        ctx.Destination.SetChannelCount(2)
+        hold = build(ctx)
+        out = np.zeros((2, frames), np.float32)
+        ctx.Render(out, frames)
+        stats.append((out, ctx.GetStats()["kernel_launches"]))
+        ctx.Dispose()
+    assert np.array_equal(stats[0][0], stats[1][0])
+    assert stats[0][1] < stats[1][1]
