@@ -368,6 +368,7 @@ int ga_set_option(ga_context* ctx, const char* key, double value) {
     else if (k == "coarse_overlap") c.coarseOverlap = value != 0;
     else if (k == "coarse_carry") c.coarseCarry = value != 0;
     else if (k == "coarse_tail") c.coarseTail = value != 0;
+    else if (k == "coarse_tail_private") c.coarseTailPrivate = value != 0;
     else if (k == "coarse_premix") c.coarsePremix = value != 0;
     else if (k == "coarse_ext_history") c.coarseExtHist = value != 0;
     else if (k == "coarse_wide") c.coarseWide = value != 0;

@@ -1687,11 +1687,13 @@ void CoarseStage::classifyGroups() {
     for (auto& kv : groups) {
       NodeS& ld = *c.nodes[kv.first];
       // a tail costs P' more inverse transforms per output channel and chunk and saves P' - 2 forward transforms per input row:
-      // worth it for sums of many signals, not for a convolver on its own; and the P' more output blocks are nearly free only
-      // in the reduction kernel (one impulse response for the whole group) -- the general kernel would multiply through them
+      // worth it for sums of many signals, not for a convolver on its own.  The P' more output blocks are nearly free in the
+      // reduction kernel (one impulse response for the whole group); the general kernel skips the partition blocks whose windows
+      // lie behind the chunk (all zero), so a group of private impulse responses multiplies exactly the products it would have
+      // multiplied with the histories in front (option "coarse_tail_private")
       kv.second.premix = c.coarsePremix && kv.second.members >= 2 && kv.second.oneIr && kv.second.uniform && kv.second.nxr <= 32;
       // (a pre-mixed group always keeps its tail: reading every member's history again would cost members x (P' - 1) blocks)
-      kv.second.tail = tails && kv.second.oneIr &&
+      kv.second.tail = tails && (kv.second.oneIr || c.coarseTailPrivate) &&
                        (kv.second.premix || (int64_t)kv.second.nIn * (kv.second.maxP - 2) >= (int64_t)kv.second.nOut * kv.second.maxP);
       kv.second.carried = kv.second.tail && ld.dTail[0] && ld.dTailSeq + 1 == c.chunkSeq && ld.dTailSig == kv.second.sig &&
                           ld.dTailLen == (int64_t)(kv.second.maxP + 1) * kCoarseBlock;

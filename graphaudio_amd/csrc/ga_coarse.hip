@@ -351,7 +351,7 @@ const char* launch_coarse_fwd(hipStream_t s, const CoarseXRow* rows_dev, int nro
 #define GA_MAC_WAVES 8
 #endif
 #ifndef GA_MAC_TW
-#define GA_MAC_TW 8
+#define GA_MAC_TW 9      // coarse blocks per wave of a 1- or 2-column job (8 waves x 9 = kCoarseJobBlocks(2))
 #endif
 #ifndef GA_MAC_PB2
 #define GA_MAC_PB2 4      // partition block used for 2-column jobs whose partition count is a multiple of 4 (2: 1.54 ms, 4: 1.49 ms at 1024 private stereo IRs)
@@ -483,16 +483,22 @@ __global__ __launch_bounds__(64 * WV, WV == 8 ? kMacWavesPerSimd(CW) : WV / 4) v
 #pragma unroll
                 for (int c = 0; c < CW; c++) fma1(tt, c, x[tt - j + (PBX - 1)], h[j * CW + c]);
           };
-          fetch(0, hA, xA);
-          for (int pb = 0; pb < P; pb += 2 * PBX) {
-            arrive(hA, xA);
-            const bool second = pb + PBX < P;
-            if (second) fetch(pb + PBX, hB, xB);
-            fmas(hA, xA);
-            if (!second) break;
-            arrive(hB, xB);
-            if (pb + 2 * PBX < P) fetch(pb + 2 * PBX, hA, xA);
-            fmas(hB, xB);
+          // partition blocks whose windows u = J.t0 + t0w + tt - p all lie outside [u_lo, u_hi] multiply zero rows: skipped.  (The
+          // blocks behind the chunk's end of a group that carries its tail, the first blocks of a signal without history.)
+          const int tw0 = J.t0 + t0w;
+          const int pbLo = max(0, (tw0 - (PBX - 1) - J.u_hi + PBX - 1) / PBX * PBX), pbHi = min(P, tw0 + TW - J.u_lo);
+          if (pbLo < pbHi) {
+            fetch(pbLo, hA, xA);
+            for (int pb = pbLo; pb < pbHi; pb += 2 * PBX) {
+              arrive(hA, xA);
+              const bool second = pb + PBX < pbHi;
+              if (second) fetch(pb + PBX, hB, xB);
+              fmas(hA, xA);
+              if (!second) break;
+              arrive(hB, xB);
+              if (pb + 2 * PBX < pbHi) fetch(pb + 2 * PBX, hA, xA);
+              fmas(hB, xB);
+            }
           }
         } else {
           for (int pb = 0; pb < P; pb += PBX) {
@@ -874,15 +880,25 @@ static const char* launch_coarse_mac_t(hipStream_t s, const CoarseJob* jobs_dev,
 }
 // all jobs of one launch have the same column count `cw` (1, 2 or 4), at most `max_t` coarse blocks (<= kCoarseJobBlocks(cw))
 // and partition counts that are multiples of `pb` (1, 2 or 4: the register block of the sweep)
-template <int CW>
-static const char* launch_coarse_mac_cw(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
+template <int CW, int TWL>   // TWL = coarse blocks per wave: accumulators TWL x CW complex values per lane
+static const char* launch_coarse_mac_tw(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
                                  int y_frames, int max_t, int maxP, bool any_private, int pb) {
-  constexpr int TWL = CW <= 2 ? GA_MAC_TW : GA_MAC_TW4;   // accumulators: TW x CW complex values per lane
-  if (!any_private) return launch_coarse_sum<CW>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP);   // (the planner cut these jobs for it)
-  if (max_t <= 2 * kMacWaves) return launch_coarse_mac_t<CW, 2, 1>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
   if (pb >= 4 && (CW == 1 || (CW == 2 && GA_MAC_PB2 == 4))) return launch_coarse_mac_t<CW, TWL, 4>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
   if (pb >= 2) return launch_coarse_mac_t<CW, TWL, 2>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
   return launch_coarse_mac_t<CW, TWL, 1>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
+}
+template <int CW>
+static const char* launch_coarse_mac_cw(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
+                                 int y_frames, int max_t, int maxP, bool any_private, int pb) {
+  if (!any_private) return launch_coarse_sum<CW>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP);   // (the planner cut these jobs for it)
+  if (max_t <= 2 * kMacWaves) return launch_coarse_mac_t<CW, 2, 1>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private);
+  if constexpr (CW <= 2) {
+    // 9 blocks per wave only where a job needs them (a 10 s chunk + its carried tail = 67 blocks): the sweep computes all TWL blocks
+    if (max_t <= 8 * kMacWaves) return launch_coarse_mac_tw<CW, 8>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private, pb);
+    return launch_coarse_mac_tw<CW, GA_MAC_TW>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private, pb);
+  } else {
+    return launch_coarse_mac_tw<CW, GA_MAC_TW4>(s, jobs_dev, njobs, terms_dev, X, Y, y_frames, max_t, maxP, any_private, pb);
+  }
 }
 const char* launch_coarse_mac(hipStream_t s, const CoarseJob* jobs_dev, int njobs, const CoarseTerm* terms_dev, const float2* X, float2* Y,
                        int y_frames, int cw, int max_t, int maxP, bool any_private, int pb, bool matrix_cores) {

@@ -642,6 +642,7 @@ struct Context {
   hipEvent_t dJoinEv = nullptr;
   bool coarseOverlap = false;
   bool coarseTail = true;    // option "coarse_tail": outputs carry their tails from chunk to chunk (0: input histories only)
+  bool coarseTailPrivate = true;   // option "coarse_tail_private": also groups whose members have impulse responses of their own
   bool coarseCarry = true;   // option "coarse_carry": the forward kernel writes the next chunk's history (0: always the copy kernel)
   bool coarsePremix = true;  // option "coarse_premix": fused groups on ONE impulse response are summed in the time domain, in front of
                              // one set of transforms (0: every member is transformed, the spectra are summed -- coarse_sum_kernel)

@@ -128,7 +128,7 @@ constexpr int kCoarseSumJobBlocks(int columns) { return columns <= 2 ? 72 : 40; 
 #ifndef GA_MAC_TW4
 #define GA_MAC_TW4 4   // coarse blocks per wave of the 4-column instance of the general multiply-accumulate kernel
 #endif
-constexpr int kCoarseJobBlocks(int columns) { return columns <= 2 ? 64 : (columns == 16 ? 32 : 8 * GA_MAC_TW4); }   // coarse blocks one multiply-accumulate job covers: 8 waves x 8 (x 4)
+constexpr int kCoarseJobBlocks(int columns) { return columns <= 2 ? 72 : (columns == 16 ? 32 : 8 * GA_MAC_TW4); }   // coarse blocks one multiply-accumulate job covers: 8 waves x 9 (x 4) -- a 10 s chunk (59 blocks) + the 8 blocks of its carried tail in ONE job
 // floating-point operations of one 16,384-point real transform as the kernels evaluate it: two complex radix-16 transforms of 4096
 // points (3 passes x 256 radix-16 butterflies of ~ 200 flops incl. twiddles, each) + the combine pass (~ 30 flops per bin quad pair)
 constexpr double kCoarseTransformFlops = 2.0 * 3.0 * 256.0 * 200.0 + 2048.0 * 60.0;

@@ -94,23 +94,27 @@ def test_config3_all_1024_voices_second_call_from_the_carried_tails():
     assert err / sig < 2e-6
 
 
-def test_config3_256_voices_with_private_impulse_responses_in_two_calls():
+@pytest.mark.parametrize("tail_private", [1, 0])
+def test_config3_256_voices_with_private_impulse_responses_in_two_calls(tail_private):
     """the general multiply-accumulate kernel at scale (8 jobs of 32 terms, every term its own 65,536-tap stereo IR), rendered in
-    two calls so that the second one starts from the input histories (private impulse responses carry no output tails)"""
+    two calls: the second one starts from the carried output tails (default since round 3: the kernel skips the partition blocks
+    behind the chunk's end) or, with `coarse_tail_private = 0`, from the input histories"""
     frames = 375 * 128
     outs = []
     for mk in (OracleContext, OfflineAudioContext):
         ctx = mk(SR)
+        if mk is OfflineAudioContext:
+            ctx.SetOption("coarse_tail_private", tail_private)
         G.config3_convolver(ctx, voices=256, taps=65536, frames=frames, shared=False)
         out = np.zeros((2, frames), np.float32)
         ctx.Render(out, 260 * 128, 0)
         ctx.Render(out, frames - 260 * 128, 260 * 128)
         if mk is OfflineAudioContext:
             st = ctx.GetStats()
-            assert st["stage_launches"][5] > 0 and st["coarse_carried_outputs"] == 0
+            assert st["stage_launches"][5] > 0 and st["coarse_carried_outputs"] == (2 if tail_private else 0)
         outs.append(out)
         ctx.Dispose()
-    err, sig = report("config 3 variant, 256 voices x private 65,536-tap stereo IRs, 260 + 115 blocks", outs[0], outs[1])
+    err, sig = report(f"config 3 variant, 256 voices x private 65,536-tap stereo IRs, 260 + 115 blocks, tails carried: {tail_private}", outs[0], outs[1])
     assert err <= TOL_RMS, err
     assert err / sig < 2e-6
 

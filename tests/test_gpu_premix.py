@@ -197,7 +197,8 @@ def test_group_behind_gains_and_into_a_bus():
             s = AudioBufferSourceNode(ctx)
             s.Buffer = PlayableAudioBuffer.FromMonoArray(G.voice(v, frames + 256), SR)
             g = GainNode(ctx)
-            g.Gain.Value = 0.3 + 0.1 * v
+            g.Gain.Value = 0.25 + 0.1 * v   # (none of them 1: a unity gain hands the source's buffer view on, and a group whose
+                                            #  members mix buffer views and slabs is not pre-mixed -- covered below)
             cv = ConvolverNode(ctx)
             cv.Buffer = ir
             s.Connect(g).Connect(cv).Connect(bus)
@@ -205,3 +206,25 @@ def test_group_behind_gains_and_into_a_bus():
         return 2
 
     three_way(build, frames, [128 * 100, 128 * 200])
+
+
+def test_members_behind_unity_and_other_gains_are_summed_as_spectra():
+    """one member's gain is exactly 1 (its convolver reads the source's buffer view, the others read slabs): the group is not uniform,
+    so it is not pre-mixed -- every member is transformed and the spectra are summed; same result"""
+    frames = 128 * 300
+
+    def build(ctx):
+        ir = PlayableAudioBuffer.FromChannelArrays([G.synth_ir(c, 25000) for c in range(2)], SR)
+        ctx.Destination.SetChannelCount(2)
+        for v in range(6):
+            s = AudioBufferSourceNode(ctx)
+            s.Buffer = PlayableAudioBuffer.FromMonoArray(G.voice(v, frames + 256), SR)
+            g = GainNode(ctx)
+            g.Gain.Value = 1.0 if v == 2 else 0.4 + 0.1 * v
+            cv = ConvolverNode(ctx)
+            cv.Buffer = ir
+            s.Connect(g).Connect(cv).Connect(ctx.Destination)
+            s.Start()
+        return 2
+
+    three_way(build, frames, [128 * 100, 128 * 200], expect_premix=False)
