@@ -1690,7 +1690,7 @@ void CoarseStage::classifyGroups() {
       // worth it for sums of many signals, not for a convolver on its own.  The P' more output blocks are nearly free in the
       // reduction kernel (one impulse response for the whole group); the general kernel skips the partition blocks whose windows
       // lie behind the chunk (all zero), so a group of private impulse responses multiplies exactly the products it would have
-      // multiplied with the histories in front (option "coarse_tail_private")
+      // multiplied with the histories in front -- but measured it does not pay (ga_engine.hpp): option "coarse_tail_private", off
       kv.second.premix = c.coarsePremix && kv.second.members >= 2 && kv.second.oneIr && kv.second.uniform && kv.second.nxr <= 32;
       // (a pre-mixed group always keeps its tail: reading every member's history again would cost members x (P' - 1) blocks)
       kv.second.tail = tails && (kv.second.oneIr || c.coarseTailPrivate) &&

@@ -20,7 +20,8 @@ REGRESSION_SEEDS = [215, 219, 357, 430, 459, 749, 1232, 1273, 1476, 2550, 2577, 
 # coarse = 1: convolvers with more than 64 partitions are forced onto formulation D (coarse partitions) even though the pieces are
 # short -- every piece re-transforms the input history, which is exactly the state handling to stress
 # 2: formulation D without carried output tails (input histories only); 3: D without the time-domain pre-mix of shared-IR groups
-@pytest.mark.parametrize("coarse", [0, 1, 2, 3])
+# 4: D with carried tails also for groups of private impulse responses (option coarse_tail_private, off by default)
+@pytest.mark.parametrize("coarse", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("seed", list(range(120)) + REGRESSION_SEEDS)
 def test_random_graph_matches_oracle(seed, coarse):
     frames = 128 * 36
@@ -40,6 +41,7 @@ def test_random_graph_matches_oracle(seed, coarse):
     h.SetOption("coarse_min_blocks", 1 if coarse else 1 << 30)
     h.SetOption("coarse_tail", 0 if coarse == 2 else 1)
     h.SetOption("coarse_premix", 0 if coarse == 3 else 1)
+    h.SetOption("coarse_tail_private", 1 if coarse == 4 else 0)
     build_random_graph(h, seed, frames)
     got = np.zeros_like(ref)
     pos = 0
@@ -66,12 +68,13 @@ def _session_pair(seed, chunk=11, coarse=0):
     h.SetOption("coarse_min_blocks", 1 if coarse else 1 << 30)
     h.SetOption("coarse_tail", 0 if coarse == 2 else 1)
     h.SetOption("coarse_premix", 0 if coarse == 3 else 1)
+    h.SetOption("coarse_tail_private", 1 if coarse == 4 else 0)
     got, got_log = run_random_session(h, seed)
     return ref, ref_log, got, got_log
 
 
 # 2850: a shared-IR convolver taken out of the graph for 17 blocks and plugged back (its delay line has to freeze)
-@pytest.mark.parametrize("coarse", [0, 1, 2, 3])   # 2: D without carried tails; 3: D without the time-domain pre-mix
+@pytest.mark.parametrize("coarse", [0, 1, 2, 3, 4])   # 2: D without carried tails; 3: D without the time-domain pre-mix; 4: tails for private IRs too
 # 2573: a ramp on a biquad's frequency -- the per-block coefficients are evaluated on the device, where cos / sin / pow have to be
 #       rounded once from double like the C library's cosf / sinf / powf behind MathF (7.9e-6 -> 2.7e-9)
 @pytest.mark.parametrize("seed", list(range(60)) + [2850, 2573])

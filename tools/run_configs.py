@@ -13,6 +13,9 @@ seconds = float(sys.argv[2]) if len(sys.argv) > 2 else 10.0
 frames = int(seconds * SR) // 128 * 128
 ctx = OfflineAudioContext(SR)
 ctx.SetOption("profile", 1)
+for kv in os.environ.get("GA_OPTS", "").split(","):   # e.g. GA_OPTS=coarse_tail_private=0,async=1
+    if "=" in kv:
+        ctx.SetOption(kv.split("=")[0], float(kv.split("=")[1]))
 t0 = time.time()
 if which == "2":
     ch = G.config2_biquad(ctx, voices=256, frames=frames + 256)
