@@ -513,3 +513,19 @@ def test_group_changes_between_chunks_fall_back_to_the_histories():
     check(ref, got)
     h.Dispose()
     o.Dispose()
+
+
+@pytest.mark.parametrize("taps", [8193, 12000, 20000, 32768, 40000])
+@pytest.mark.parametrize("mfma", [1, 0])
+def test_sixteen_column_jobs_at_every_partition_count(taps, mfma):
+    """16-channel private impulse responses (config 5's shape) with P' = 2, 2, 3, 4 partitions on the matrix-core kernel (rows of
+    partitions that do not exist are zero rows of its LDS image, never loaded) and P' = 5 on the register-tiled 16-column kernel;
+    rendered in uneven pieces so that jobs start with and without windows in front; `coarse_mfma = 0`: the register-tiled kernel
+    for all of them."""
+    frames = 128 * 520
+    ref, got, st = pair(lambda c: G.config5_ambisonic(c, sources=3, taps=taps, frames=frames), frames, pieces=[128 * 70, 128 * 333, 128 * 117],
+                        coarse_mfma=mfma)
+    assert used_coarse(st)
+    kernels = " ".join(st["stage_kernel"])
+    assert ("mfma16" in kernels) == (mfma == 1 and taps <= 32768), kernels
+    check(ref, got)
