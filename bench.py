@@ -319,6 +319,27 @@ def roofline_of(stages):
     return r
 
 
+def attach_pmc_traffic(roof, profile_json):
+    """`traffic` of the roofline object: HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/
+    (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes of this command, FETCH_SIZE x 2 on gfx950: tools/collect_profiles.sh).
+    bench.py cannot collect counters itself; the committed figure is attached only when it is for the same kernel moving the same
+    necessary bytes (within 2 %), and the line says where it comes from.  Nothing under profiles/ is needed to run the bench."""
+    try:
+        if not roof or not os.path.exists(profile_json):
+            return roof
+        prof = json.load(open(profile_json))
+        for name, k in prof.get("kernels", {}).items():
+            nec = k.get("necessary_gb_per_launch (stage, planner)")
+            if name.split("<")[0] in roof["kernel"] and nec and abs(nec * 1e9 / roof["necessary_bytes_per_launch"] - 1.0) < 0.02 and k.get("pmc_total_x2_gb"):
+                roof["traffic"] = k["pmc_total_x2_gb"] * 1e9
+                roof["traffic_source"] = (os.path.relpath(profile_json, ROOT) + ": rocprofv3 --pmc FETCH_SIZE (x 2: gfx950 correction) + WRITE_SIZE, "
+                                          "separate passes of `" + str(prof.get("command", "bench.py")).strip() + "`, bytes per launch")
+                break
+    except Exception:   # a missing or malformed profile never fails the bench
+        pass
+    return roof
+
+
 def timed_steps(ctx, step, sync, steps, warmup):
     for _ in range(warmup):
         step()
@@ -404,7 +425,9 @@ def run_variant(name, torch, G, frames, steps, warmup, build, channels, options,
     rec = {"description": describe, "ms_per_step": dt / steps * 1e3, "frames_per_s": frames * steps / dt, "steps": steps, "warmup": warmup,
            "frames_per_step": frames, "host_issue_ms_per_step": t_enq / steps * 1e3,
            "device_ms_per_step": (st1["device_ms_total"] - st0["device_ms_total"]) * per_step,
-           "roofline": roofline_of(stages), "stages": stages, "whole_step": whole, "setup_s": t_build}
+           "roofline": attach_pmc_traffic(roofline_of(stages), os.path.join(ROOT, "profiles", {"per_voice_spectra": "r03_per_voice", "private_ir": "r03_private_ir",
+                                                                                                   "config5_1gpu": "r03_config5"}.get(name, "none") + "_pmc_hbm_traffic.json")),
+           "stages": stages, "whole_step": whole, "setup_s": t_build}
     if truth is not None:
         ref = truth()
         err, sig = M.rms(out - ref), M.rms(ref)
@@ -609,7 +632,7 @@ def main():
             "host_issue_ms_per_step": t_enq / args.steps * 1e3,
             "device_ms_per_step": dev_ms,
             "profiled_chunks": nprof,
-            "roofline": roofline_of(stages),
+            "roofline": attach_pmc_traffic(roofline_of(stages), os.path.join(ROOT, "profiles", "r03_cfg3_pmc_hbm_traffic.json")),
             "stages": stages,
             "whole_step": whole,
             "streaming_formulation": {"bytes_per_step": stream_bytes, "tb_per_s_if_streamed": stream_bytes / (dt / args.steps) / 1e12,
