@@ -12,6 +12,8 @@ def build_random_graph(ctx, seed, frames, keep=None, handles=None):
     """Sources -> random chains (gain / biquad / convolver) -> optional shared bus nodes -> destination."""
     rng = np.random.default_rng(seed)
     rng2 = np.random.default_rng(seed + 7777)   # later additions draw from their own stream: old seeds keep their graphs
+    rng3 = np.random.default_rng(seed + 31337)  # round 3: unity gains (handed on without a kernel) -- seeds >= 20000 only
+    unity = seed >= 20000
     dest_ch = int(rng.choice([1, 2, 2, 4]))
     ctx.Destination.SetChannelCount(dest_ch)
     if rng.random() < 0.3:
@@ -23,6 +25,8 @@ def build_random_graph(ctx, seed, frames, keep=None, handles=None):
     for _ in range(int(rng.integers(0, 3))):
         g = GainNode(ctx)
         g.Gain.Value = float(rng.uniform(0.3, 1.0))
+        if unity and rng3.random() < 0.4:
+            g.Gain.Value = 1.0
         if rng.random() < 0.5:
             g.Inputs[0].SetChannelCount(int(rng.choice([1, 2])))
         if rng.random() < 0.3:
@@ -65,6 +69,8 @@ def build_random_graph(ctx, seed, frames, keep=None, handles=None):
             if kind == "gain":
                 n = GainNode(ctx)
                 n.Gain.Value = float(rng.uniform(0.2, 1.2))
+                if unity and rng3.random() < 0.5:
+                    n.Gain.Value = 1.0
             elif kind == "gain_auto":
                 n = GainNode(ctx)
                 n.Gain.SetValueAtTime(float(rng.uniform(0, 1)), 0.0)

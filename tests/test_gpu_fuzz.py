@@ -22,7 +22,8 @@ REGRESSION_SEEDS = [215, 219, 357, 430, 459, 749, 1232, 1273, 1476, 2550, 2577, 
 # 2: formulation D without carried output tails (input histories only); 3: D without the time-domain pre-mix of shared-IR groups
 # 4: D with carried tails also for groups of private impulse responses (option coarse_tail_private, off by default)
 @pytest.mark.parametrize("coarse", [0, 1, 2, 3, 4])
-@pytest.mark.parametrize("seed", list(range(120)) + REGRESSION_SEEDS)
+# seeds >= 20000: graphs with GainNodes at exactly 1 (buses and chain gains: their input views are handed on, no kernel)
+@pytest.mark.parametrize("seed", list(range(120)) + REGRESSION_SEEDS + list(range(20000, 20024)))
 def test_random_graph_matches_oracle(seed, coarse):
     frames = 128 * 36
     o = OracleContext(48000)
@@ -77,7 +78,7 @@ def _session_pair(seed, chunk=11, coarse=0):
 @pytest.mark.parametrize("coarse", [0, 1, 2, 3, 4])   # 2: D without carried tails; 3: D without the time-domain pre-mix; 4: tails for private IRs too
 # 2573: a ramp on a biquad's frequency -- the per-block coefficients are evaluated on the device, where cos / sin / pow have to be
 #       rounded once from double like the C library's cosf / sinf / powf behind MathF (7.9e-6 -> 2.7e-9)
-@pytest.mark.parametrize("seed", list(range(60)) + [2850, 2573])
+@pytest.mark.parametrize("seed", list(range(60)) + [2850, 2573] + list(range(20000, 20012)))
 def test_random_edit_session_matches_oracle(seed, coarse):
     """The graph is edited between render pieces (parameter writes, automation, stop, new voices, dispose, rewiring,
     impulse-response swaps, audio-rate modulation, channel settings): same output and the same exceptions."""
