@@ -373,6 +373,7 @@ int ga_set_option(ga_context* ctx, const char* key, double value) {
     else if (k == "coarse_ext_history") c.coarseExtHist = value != 0;
     else if (k == "coarse_wide") c.coarseWide = value != 0;
     else if (k == "gain_pass_through") c.gainPassThrough = value != 0;
+    else if (k == "gain_fold") c.gainFold = value != 0;
     else if (k == "coarse_mfma") c.coarseMfma = value != 0;
     else if (k == "biquad_time_split") c.biquadTimeSplit = (int)std::min(2.0, std::max(0.0, value));
     else if (k == "biquad_split_max_deviation") c.biquadSplitMaxDeviation = std::max(0.0, value);

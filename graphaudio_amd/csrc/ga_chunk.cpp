@@ -837,6 +837,24 @@ struct Exec {
   std::vector<std::vector<Views>> outViews;  // [segment][node][channel]
   // per (level) batch tables
   std::vector<const float*> terms;
+  // constant GainNodes folded into their consumer's mix (option "gain_fold"): the node hands its input views on and records its
+  // gain per segment; the consumer's mix / down-mix job multiplies the term first -- fl(x * g), then the add, exactly the values
+  // GainNode.Process (GainNode.cs:48-58) + AudioNodeInput.MixBuffer produce, without a pass over the samples in between
+  std::vector<float> termGains;                  // parallel to `terms` (missing entries = 1)
+  bool anyTermGain = false;                      // this level has a term with a gain != 1
+  std::vector<std::vector<float>> outScale;      // [segment][node]: allocated for a segment when its first gain is folded
+  float scaleOf(int si, int node) const { return (si < (int)outScale.size() && !outScale[si].empty()) ? outScale[si][node] : 1.f; }
+  void setScale(int si, int node, float g) {
+    if ((int)outScale.size() <= si) outScale.resize(si + 1);
+    if (outScale[si].empty()) outScale[si].assign(c.nodes.size(), 1.f);
+    outScale[si][node] = g;
+  }
+  void pushTerm(const float* p, float g) {
+    termGains.resize(terms.size(), 1.f);
+    terms.push_back(p);
+    termGains.push_back(g);
+    if (g != 1.f) anyTermGain = true;
+  }
   std::vector<MixJob> mixJobs;
   std::vector<DownmixJob> dmJobs;
   std::vector<GainJob> gainJobs;
@@ -925,9 +943,11 @@ struct Exec {
     const Segment& sg = segs[si];
     const int dstCh = is.bufCh;
     const int64_t f0 = sg.b0 * kBlock, nf = (sg.b1 - sg.b0) * kBlock;
-    SmallVec<SmallVec<const float*, 2>, 4> lists((size_t)dstCh);
+    struct Tm { const float* p; float g; };
+    SmallVec<SmallVec<Tm, 2>, 4> lists((size_t)dstCh);
     for (const TermS& t : is.terms) {
       const auto& uvAll = outViews[si][t.node];
+      const float g = scaleOf(si, t.node);   // (a folded constant GainNode: its views are its INPUT's, to be multiplied here)
       // a ChannelSplitterNode keeps one mono view per OUTPUT; every other node has one output with t.ch channels
       Views uvOne;
       if (c.nodes[t.node]->type == GA_NODE_CHANNEL_SPLITTER) uvOne.assign(1, t.out < (int)uvAll.size() ? uvAll[t.out] : nullptr);
@@ -935,10 +955,10 @@ struct Exec {
       const int srcCh = t.ch;
       if (srcCh == dstCh) {
         for (int ch = 0; ch < dstCh; ch++)
-          if (uv[ch]) lists[ch].push_back(uv[ch]);
+          if (uv[ch]) lists[ch].push_back(Tm{uv[ch], g});
       } else if (srcCh == 1 && dstCh > 1) {
         if (uv[0])
-          for (int ch = 0; ch < dstCh; ch++) lists[ch].push_back(uv[0]);
+          for (int ch = 0; ch < dstCh; ch++) lists[ch].push_back(Tm{uv[0], g});
       } else if (srcCh > 1 && dstCh == 1) {
         // (sum over channels) * 1/sqrt(N), AudioNodeInput.cs:214-228
         bool anyCh = false;
@@ -951,13 +971,13 @@ struct Exec {
         dj.scale = 1.0f / std::sqrt((float)srcCh);
         dj.f0 = f0;
         dj.n = nf;
-        for (int ch = 0; ch < srcCh; ch++) terms.push_back(uv[ch] ? uv[ch] : c.zeros);
+        for (int ch = 0; ch < srcCh; ch++) pushTerm(uv[ch] ? uv[ch] : c.zeros, g);
         dmJobs.push_back(dj);
-        lists[0].push_back(dj.out);
+        lists[0].push_back(Tm{dj.out, 1.f});
       } else {
         int m = std::min(srcCh, dstCh);
         for (int ch = 0; ch < m; ch++)
-          if (uv[ch]) lists[ch].push_back(uv[ch]);
+          if (uv[ch]) lists[ch].push_back(Tm{uv[ch], g});
       }
     }
     Views views((size_t)dstCh, nullptr);
@@ -965,14 +985,14 @@ struct Exec {
       auto& l = lists[ch];
       if (!force) {
         if (l.empty()) continue;
-        if (l.size() == 1) {
-          views[ch] = l[0];
+        if (l.size() == 1 && l[0].g == 1.f) {
+          views[ch] = l[0].p;
           continue;
         }
       }
       float* out = forcedSlabs ? forcedSlabs[ch] : inMixed(nodeId, i + 64, ch);
       if (!out) continue;
-      if (l.size() == 1 && l[0] == out) {   // the only term was produced in place (Context::aliasBusToLeader)
+      if (l.size() == 1 && l[0].p == out && l[0].g == 1.f) {   // the only term was produced in place (Context::aliasBusToLeader)
         views[ch] = out;
         continue;
       }
@@ -982,9 +1002,9 @@ struct Exec {
       mj.nterms = (int)l.size();
       mj.f0 = f0;
       mj.n = nf;
-      for (const float* p : l) {
-        terms.push_back(p);
-        noteAlign(p, f0);
+      for (const Tm& tm : l) {
+        pushTerm(tm.p, tm.g);
+        noteAlign(tm.p, f0);
       }
       noteAlign(out, f0);
       mixJobs.push_back(mj);
@@ -1019,6 +1039,9 @@ struct Exec {
   void flushLevel() {
     // order: down-mix -> mix -> sources -> gain -> biquad (everything in one level is independent)
     size_t termsOff = plan.putv(terms);
+    termGains.resize(terms.size(), 1.f);
+    const bool scaled = anyTermGain;
+    const size_t gainsOff = scaled ? plan.putv(termGains) : 0;
     if (!dmJobs.empty()) {
       size_t off = plan.putv(dmJobs);
       int nj = (int)dmJobs.size();
@@ -1026,7 +1049,7 @@ struct Exec {
       for (auto& j : dmJobs) mx = std::max(mx, j.n);
       hipStream_t st = c.stream;
       plan.add(LK_OTHER, [=](uint8_t* base) {
-        launch_downmix(st, (const DownmixJob*)(base + off), nj, (const float* const*)(base + termsOff), mx);
+        launch_downmix(st, (const DownmixJob*)(base + off), nj, (const float* const*)(base + termsOff), mx, scaled ? (const float*)(base + gainsOff) : nullptr);
       });
     }
     if (!mixJobs.empty()) {
@@ -1039,7 +1062,7 @@ struct Exec {
       double mixBytes = 0;
       for (auto& j : mixJobs) mixBytes += 4.0 * (double)(j.nterms + 1) * (double)j.n;
       plan.add(LK_MIX, [=](uint8_t* base) {
-        launch_mix(st, (const MixJob*)(base + off), nj, (const float* const*)(base + termsOff), mx, v4);
+        launch_mix(st, (const MixJob*)(base + off), nj, (const float* const*)(base + termsOff), mx, v4, scaled ? (const float*)(base + gainsOff) : nullptr);
       }, mixBytes);
     }
     if (!pmodJobs.empty()) {   // after the mixes (the modulation inputs), before the nodes that read the parameter
@@ -1196,6 +1219,8 @@ struct Exec {
     }
     bqDynJobs.clear();
     terms.clear();
+    termGains.clear();
+    anyTermGain = false;
     mixJobs.clear();
     dmJobs.clear();
     gainJobs.clear();
@@ -2777,24 +2802,28 @@ void Context::planDelay(NodePlanCtx& k) {
   }
   // append this segment's input to the rings that are processed (a ring beyond the input's channel count does not
   // move, DelayNode.cs:62-94), then gather
-  Views iv;
-  if (!ns.ins[0].silent) iv = ex.resolveInput((int)si, ns, 0, false, nullptr);
+  // The input is mixed STRAIGHT into the rings (the rings are the forced targets of the input's mix, like the destination's bus):
+  // a second job that copies a mixed slab into the ring would sit in the same launch as the mix that produces the slab -- no
+  // order between them (until round 3 a DelayNode with two connections, or behind a folded GainNode, read a half-written slab).
+  SmallVec<float*, 4> ring((size_t)std::max(ch, 1), nullptr);
+  for (int cch = 0; cch < ch; cch++) ring[cch] = nd.delayLine + (size_t)cch * pitch + maxD + nd.delayW[cch] - f0;   // ring[c][f] = input sample of frame f
+  if (!ns.ins[0].silent) {
+    ex.resolveInput((int)si, ns, 0, true, ring.data());
+  } else {
+    for (int cch = 0; cch < ch; cch++) {   // zeros
+      MixJob mj;
+      mj.out = ring[cch];
+      mj.term0 = (int)ex.terms.size();
+      mj.nterms = 0;
+      mj.f0 = f0;
+      mj.n = nf;
+      ex.noteAlign(ring[cch], f0);
+      ex.mixJobs.push_back(mj);
+    }
+  }
   const float* delayCurve = ex.paramView((int)si, ns, 0);
   for (int cch = 0; cch < ch; cch++) {
-    float* base = nd.delayLine + (size_t)cch * pitch + maxD + nd.delayW[cch] - f0;   // base[f] = input sample of frame f
-    MixJob mj;
-    mj.out = base;
-    mj.term0 = (int)ex.terms.size();
-    const float* v = (!ns.ins[0].silent && cch < (int)iv.size()) ? iv[cch] : nullptr;
-    mj.nterms = v ? 1 : 0;
-    mj.f0 = f0;
-    mj.n = nf;
-    if (v) {
-      ex.terms.push_back(v);
-      ex.noteAlign(v, f0);
-    }
-    ex.noteAlign(base, f0);
-    ex.mixJobs.push_back(mj);
+    float* base = ring[cch];
     DelayJob dj;
     dj.line = base;
     dj.curve = delayCurve;
@@ -2986,10 +3015,14 @@ void Context::planGain(NodePlanCtx& k) {
   if (ns.ins[0].silent) return;  // cleared output (GainNode.cs:41-46)
   // a constant gain of exactly 1 (every GainNode's default: buses, splits and merges of effect chains) multiplies nothing:
   // x * 1.0f == x bit for bit, so the output IS the (mixed) input -- no launch, no pass over the samples
-  const bool unity = !gmod && !nd.params[0].curve && nd.params[0].value == 1.0f && gainPassThrough;
+  const bool constant = !gmod && !nd.params[0].curve;
+  const bool unity = constant && nd.params[0].value == 1.0f && gainPassThrough;
+  // any other constant gain with ONE consumer connection: the consumer's mix multiplies (Exec::scaleOf) -- no pass of its own
+  const bool fold = constant && !unity && gainFold && nd.outputs.size() == 1 && nd.outputs[0].connectedInputs.size() == 1;
+  if (fold) ex.setScale((int)si, ns.id, nd.params[0].value);
   for (int ch = 0; ch < ns.outCh; ch++) {
     if (!iv[ch]) continue;
-    if (unity) {
+    if (unity || fold) {
       ov[ch] = iv[ch];
       continue;
     }

@@ -571,6 +571,7 @@ struct Context {
   bool coarseExtHist = true;   // option "coarse_ext_history"
   bool coarseMfma = true;      // option "coarse_mfma": 16-column jobs on the matrix cores (coarse_mfma16_kernel); 0 = the register-tiled instance
   bool coarseWide = true;      // option "coarse_wide": 16-column multiply-accumulate jobs for multi-channel private impulse responses
+  bool gainFold = true;        // option "gain_fold": a GainNode with any other constant gain and one consumer is multiplied inside the consumer's mix
   bool gainPassThrough = true; // option "gain_pass_through": a GainNode with a constant gain of exactly 1 hands its input views on (no kernel)
   // constant-coefficient biquad cascades split along time (ga_kernels.hpp, BiquadScanJob): A^K per (coefficients, K), float64 on
   // the host, remembered; the pieces' states live in blocks that are handed out per chunk and kept

@@ -1444,11 +1444,25 @@ void launch_pair_sum(hipStream_t s, float* out, const float* a, const float* b, 
 //  Mix (AudioNodeInput.Pull / MixBuffer, AudioNodeInput.cs:100-244): sequential float32 sum in connection order,
 //  starting from the cleared buffer (0 + t0 + t1 + ...), one thread per 1 or 4 frames.
 // =====================================================================================================
-template <int VEC>
-__global__ __launch_bounds__(256) void mix_kernel(const MixJob* __restrict jobs, const float* const* __restrict terms) {
+template <int VEC, bool SCALED>
+__global__ __launch_bounds__(256) void mix_kernel(const MixJob* __restrict jobs, const float* const* __restrict terms, const float* __restrict gains) {
   const MixJob job = jobs[blockIdx.y];
   const int64_t nv = (job.n + VEC - 1) / VEC;
   const float* const* __restrict tp = terms + job.term0;
+  const float* __restrict gp = SCALED ? gains + job.term0 : nullptr;   // SCALED: term j contributes fl(x * gain[j]) -- a folded constant GainNode
+  if (SCALED && job.nterms == 1) {   // a gain on its own: out = in * g, as gain_kernel writes it (no 0 + in front)
+    const float g = gp[0];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+      const int64_t f = job.f0 + i * VEC;
+      if (VEC == 4) {
+        const v4f v = ldg4(tp[0] + f);
+        stg4(job.out + f, v4f{v.x * g, v.y * g, v.z * g, v.w * g});
+      } else {
+        gptr(job.out)[f] = ldg1(tp[0] + f) * g;
+      }
+    }
+    return;
+  }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t f = job.f0 + i * VEC;
     if (VEC == 4) {
@@ -1459,6 +1473,13 @@ __global__ __launch_bounds__(256) void mix_kernel(const MixJob* __restrict jobs,
         v4f v1 = ldg4(tp[j + 1] + f);
         v4f v2 = ldg4(tp[j + 2] + f);
         v4f v3 = ldg4(tp[j + 3] + f);
+        if (SCALED) {   // (products rounded on their own: -ffp-contract=off, no fma with the add below)
+          const float g0 = gp[j], g1 = gp[j + 1], g2 = gp[j + 2], g3 = gp[j + 3];
+          v0 = v4f{v0.x * g0, v0.y * g0, v0.z * g0, v0.w * g0};
+          v1 = v4f{v1.x * g1, v1.y * g1, v1.z * g1, v1.w * g1};
+          v2 = v4f{v2.x * g2, v2.y * g2, v2.z * g2, v2.w * g2};
+          v3 = v4f{v3.x * g3, v3.y * g3, v3.z * g3, v3.w * g3};
+        }
         acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
         acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
         acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
@@ -1466,40 +1487,60 @@ __global__ __launch_bounds__(256) void mix_kernel(const MixJob* __restrict jobs,
       }
       for (; j < job.nterms; j++) {
         v4f v = ldg4(tp[j] + f);
+        if (SCALED) {
+          const float g = gp[j];
+          v = v4f{v.x * g, v.y * g, v.z * g, v.w * g};
+        }
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
       }
       stg4(job.out + f, v4f{acc.x, acc.y, acc.z, acc.w});
     } else {
       float acc = 0.f;
-      for (int j = 0; j < job.nterms; j++) acc += ldg1(tp[j] + f);
+      for (int j = 0; j < job.nterms; j++) {
+        float v = ldg1(tp[j] + f);
+        if (SCALED) v = v * gp[j];
+        acc += v;
+      }
       gptr(job.out)[f] = acc;
     }
   }
 }
-void launch_mix(hipStream_t s, const MixJob* jobs_dev, int njobs, const float* const* terms_dev, int64_t max_n, bool vec4) {
+void launch_mix(hipStream_t s, const MixJob* jobs_dev, int njobs, const float* const* terms_dev, int64_t max_n, bool vec4, const float* gains_dev) {
   if (njobs <= 0 || max_n <= 0) return;
   int64_t nv = vec4 ? (max_n + 3) / 4 : max_n;
   int gx = (int)std::min<int64_t>((nv + 255) / 256, 2048);
-  if (vec4)
-    GA_LAUNCH_JOBS(mix_kernel<4>, gx, 256, jobs_dev, njobs, terms_dev);
-  else
-    GA_LAUNCH_JOBS(mix_kernel<1>, gx, 256, jobs_dev, njobs, terms_dev);
+  if (gains_dev) {
+    if (vec4)
+      GA_LAUNCH_JOBS((mix_kernel<4, true>), gx, 256, jobs_dev, njobs, terms_dev, gains_dev);
+    else
+      GA_LAUNCH_JOBS((mix_kernel<1, true>), gx, 256, jobs_dev, njobs, terms_dev, gains_dev);
+  } else if (vec4) {
+    GA_LAUNCH_JOBS((mix_kernel<4, false>), gx, 256, jobs_dev, njobs, terms_dev, gains_dev);
+  } else {
+    GA_LAUNCH_JOBS((mix_kernel<1, false>), gx, 256, jobs_dev, njobs, terms_dev, gains_dev);
+  }
 }
 
-__global__ __launch_bounds__(256) void downmix_kernel(const DownmixJob* __restrict jobs, const float* const* __restrict terms) {
+template <bool SCALED>
+__global__ __launch_bounds__(256) void downmix_kernel(const DownmixJob* __restrict jobs, const float* const* __restrict terms, const float* __restrict gains) {
   const DownmixJob job = jobs[blockIdx.y];
   const float* const* __restrict tp = terms + job.term0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < job.n; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t f = job.f0 + i;
     float sum = 0.f;
-    for (int ch = 0; ch < job.nch; ch++) sum += ldg1(tp[ch] + f);   // AudioNodeInput.cs:221-226
+    for (int ch = 0; ch < job.nch; ch++) {   // AudioNodeInput.cs:221-226
+      float v = ldg1(tp[ch] + f);
+      if (SCALED) v = v * gains[job.term0 + ch];
+      sum += v;
+    }
     gptr(job.out)[f] = sum * job.scale;
   }
 }
-void launch_downmix(hipStream_t s, const DownmixJob* jobs_dev, int njobs, const float* const* terms_dev, int64_t max_n) {
+void launch_downmix(hipStream_t s, const DownmixJob* jobs_dev, int njobs, const float* const* terms_dev, int64_t max_n, const float* gains_dev) {
   if (njobs <= 0 || max_n <= 0) return;
   int gx = (int)std::min<int64_t>((max_n + 255) / 256, 2048);
-  GA_LAUNCH_JOBS(downmix_kernel, gx, 256, jobs_dev, njobs, terms_dev);
+  if (gains_dev) GA_LAUNCH_JOBS(downmix_kernel<true>, gx, 256, jobs_dev, njobs, terms_dev, gains_dev);
+  else GA_LAUNCH_JOBS(downmix_kernel<false>, gx, 256, jobs_dev, njobs, terms_dev, gains_dev);
 }
 
 // ---- GainNode (GainNode.cs:48-58) ---------------------------------------------------------------------

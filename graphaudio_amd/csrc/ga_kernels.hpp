@@ -232,7 +232,8 @@ struct MixJob {
   int64_t f0;     // first chunk frame
   int64_t n;      // frames
 };
-void launch_mix(hipStream_t s, const MixJob* jobs_dev, int njobs, const float* const* terms_dev, int64_t max_n, bool vec4);
+// gains_dev (may be null): one factor per entry of the term table -- term j contributes fl(term[j][f] * gain[j]) (a folded constant GainNode)
+void launch_mix(hipStream_t s, const MixJob* jobs_dev, int njobs, const float* const* terms_dev, int64_t max_n, bool vec4, const float* gains_dev = nullptr);
 
 // down-mix N -> 1: out[f] = (sum_ch in[ch][f]) * scale   (AudioNodeInput.cs:214-228); 'ins' index the term table
 struct DownmixJob {
@@ -243,7 +244,7 @@ struct DownmixJob {
   int64_t f0;
   int64_t n;
 };
-void launch_downmix(hipStream_t s, const DownmixJob* jobs_dev, int njobs, const float* const* terms_dev, int64_t max_n);
+void launch_downmix(hipStream_t s, const DownmixJob* jobs_dev, int njobs, const float* const* terms_dev, int64_t max_n, const float* gains_dev = nullptr);
 
 // out = in * gain  (GainNode.cs:48-58); curve != nullptr -> per-sample a-rate values, else constant
 struct GainJob {

@@ -440,6 +440,7 @@ def test_unity_gains_hand_their_input_on():
     for opt in (1, 0):
         ctx = OfflineAudioContext(SR)
         ctx.SetOption("gain_pass_through", opt)
+        ctx.SetOption("gain_fold", opt)          # (a unity gain that is not handed on would be folded as a constant one)
         ctx.Destination.SetChannelCount(2)
         hold = build(ctx)
         out = np.zeros((2, frames), np.float32)
@@ -448,3 +449,106 @@ def test_unity_gains_hand_their_input_on():
         ctx.Dispose()
     assert np.array_equal(stats[0][0], stats[1][0])
     assert stats[0][1] < stats[1][1]
+
+
+def test_delay_with_a_mixed_input_and_behind_constant_gains():
+    """A DelayNode whose input has to be mixed (two connections, a channel conversion, a folded constant GainNode in front): the mix
+    lands straight in the delay rings.  (Until round 3 the mixed slab was copied into the ring by a job of the SAME launch as the mix
+    that produced it -- unordered -- and such a delay rendered garbage; the fuzz graphs only ever chained ONE node into a delay.)"""
+    from graphaudio_amd import DelayNode
+    frames = 128 * 34
+
+    def build(ctx):
+        rng = np.random.default_rng(11)
+        hold = []
+
+        def src(nch, when):
+            s = AudioBufferSourceNode(ctx)
+            s.Buffer = PlayableAudioBuffer.FromChannelArrays([(rng.standard_normal(frames + 300) * 0.2).astype(np.float32) for _ in range(nch)], SR)
+            s.Start(when)
+            hold.append(s)
+            return s
+
+        d1 = DelayNode(ctx, 0.05); d1.DelayTime.Value = 0.004          # two mono sources, the second starting later
+        src(1, 0.0).Connect(d1); src(1, 0.013).Connect(d1)
+        d2 = DelayNode(ctx, 0.05); d2.DelayTime.Value = 0.0021         # mono + stereo: up-mix inside the delay's input
+        src(1, 0.0).Connect(d2); src(2, 0.006).Connect(d2)
+        d3 = DelayNode(ctx, 0.05); d3.DelayTime.Value = 0.0033         # a constant gain in front (folded into the ring's mix)
+        g3 = GainNode(ctx); g3.Gain.Value = 0.7
+        src(1, 0.002).Connect(g3); g3.Connect(d3)
+        d4 = DelayNode(ctx, 0.05)                                      # two gains into one delay, automated delay time
+        d4.DelayTime.SetValueAtTime(0.001, 0.0); d4.DelayTime.LinearRampToValueAtTime(0.008, 0.06)
+        for k in range(2):
+            g = GainNode(ctx); g.Gain.Value = 0.4 + 0.3 * k
+            src(1 + k, 0.004 * k).Connect(g); g.Connect(d4); hold.append(g)
+        d5 = DelayNode(ctx, 0.05); d5.DelayTime.Value = 0.002          # a delay feeding a delay
+        d1.Connect(d5)
+        for d in (d1, d2, d3, d4, d5):
+            d.Connect(ctx.Destination)
+        return hold + [d1, d2, d3, d4, d5, g3]
+
+    for chunk in (0, 5):
+        ref, got = pair(build, 2, frames, pieces=[128 * 9, 128 * 14], chunk=chunk)
+        assert G.rms(ref) > 1e-2
+        assert np.array_equal(ref, got), (chunk, G.rms(ref - got))
+
+
+def test_constant_gains_are_folded_into_the_consumers_mix():
+    """A GainNode with a constant gain and one consumer is not evaluated on its own: the consumer's mix (or down-mix, or the
+    ring of a delay, or the single-term copy in front of a biquad / convolver / panner) multiplies the term -- fl(x * g), then the
+    add: the reference's values bit for bit.  Voices -> volume gains -> bus gain -> master gain -> destination, with a stereo voice
+    into a mono bus (down-mix of a folded term), a mono voice into a stereo bus (up-mix), chained constant gains, a gain with two
+    consumers (evaluated: not folded), one automated gain."""
+    frames = 128 * 30
+
+    def build(ctx):
+        rng = np.random.default_rng(23)
+        hold = []
+        master = GainNode(ctx); master.Gain.Value = 0.8
+        master.Connect(ctx.Destination)
+        stereo_bus = GainNode(ctx); stereo_bus.Gain.Value = 0.9
+        mono_bus = GainNode(ctx); mono_bus.Gain.Value = 0.6
+        mono_bus.Inputs[0].SetChannelCount(1)
+        from graphaudio_amd import ChannelCountMode
+        mono_bus.Inputs[0].SetChannelCountMode(ChannelCountMode.Explicit)
+        stereo_bus.Connect(master); mono_bus.Connect(master)
+        for v in range(7):
+            s = AudioBufferSourceNode(ctx)
+            nch = 1 + (v % 2)
+            s.Buffer = PlayableAudioBuffer.FromChannelArrays([(rng.standard_normal(frames + 200) * 0.2).astype(np.float32) for _ in range(nch)], SR)
+            vol = GainNode(ctx); vol.Gain.Value = 0.3 + 0.09 * v
+            s.Connect(vol)
+            tail = vol
+            if v == 2:
+                trim = GainNode(ctx); trim.Gain.Value = 1.7; tail.Connect(trim); tail = trim; hold.append(trim)      # chained
+            if v == 3:
+                vol.Gain.SetValueAtTime(0.2, 0.0); vol.Gain.LinearRampToValueAtTime(0.9, 0.05)                       # automated: evaluated
+            tail.Connect(stereo_bus if v % 3 else mono_bus)
+            if v == 4:
+                tail.Connect(ctx.Destination)                                                                         # two consumers: evaluated
+            if v == 5:
+                bq = BiQuadFilterNode(ctx); bq.Frequency.Value = 1500.0; tail.Disconnect(); tail.Connect(bq); bq.Connect(stereo_bus); hold.append(bq)
+            s.Start(0.0 if v % 2 else 0.009)
+            hold += [s, vol]
+        return hold + [master, stereo_bus, mono_bus]
+
+    results = {}
+    for fold in (1, 0):
+        outs = []
+        for mk in (OracleContext, OfflineAudioContext):
+            ctx = mk(SR)
+            ctx.Destination.SetChannelCount(2)
+            if mk is OfflineAudioContext:
+                ctx.SetOption("gain_fold", fold)
+                ctx.SetOption("max_chunk_blocks", 7)
+            hold = build(ctx)
+            out = np.zeros((2, frames), np.float32)
+            ctx.Render(out, 128 * 11)
+            ctx.Render(out, frames - 128 * 11, 128 * 11)
+            if mk is OfflineAudioContext:
+                results[fold] = ctx.GetStats()["kernel_launches"]
+            outs.append(out)
+            ctx.Dispose()
+        assert G.rms(outs[0]) > 1e-2
+        assert np.array_equal(outs[0], outs[1]), (fold, G.rms(outs[0] - outs[1]))
+    assert results[1] < results[0]

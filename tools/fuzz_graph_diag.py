@@ -15,6 +15,8 @@ for seed in [int(x) for x in sys.argv[1:]]:
     for name, opts in (("default (D forced)", {"coarse_min_blocks": 1}), ("no D", {"coarse_min_blocks": 1 << 30}),
                        ("no D, fft64", {"coarse_min_blocks": 1 << 30, "fft64": 1}),
                        ("D, no pass-through", {"coarse_min_blocks": 1, "gain_pass_through": 0}),
+                       ("no D, no gain folding", {"coarse_min_blocks": 1 << 30, "gain_fold": 0}),
+                       ("no D, one chunk", {"coarse_min_blocks": 1 << 30, "max_chunk_blocks": 4096}),
                        ("D, no biquad split", {"coarse_min_blocks": 1, "biquad_time_split": 0}),
                        ("D, no premix / ext hist / private tails", {"coarse_min_blocks": 1, "coarse_premix": 0, "coarse_ext_history": 0, "coarse_tail_private": 0}),
                        ("one chunk", {"coarse_min_blocks": 1, "max_chunk_blocks": 4096})):
