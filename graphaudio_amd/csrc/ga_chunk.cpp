@@ -534,6 +534,7 @@ struct Sim {
   Segment* cur = nullptr;
   int64_t brel = 0;
   std::vector<int64_t>* extraBreaks = nullptr;   // chunk-relative blocks at which a node asks to be evaluated again
+  const std::vector<double>* blockTimes = nullptr;   // accumulated block clock of the chunk (chunk-relative block -> time)
 
   int computeOutputChannelCount(InputS& in) {  // AudioNodeInput.cs:140-168
     switch (in.mode) {
@@ -774,7 +775,37 @@ struct Sim {
           d = std::min(std::max(d, 0), maxD);
           dmin = dmax = d;
         }
-        if (!n_.delayAudible && dmax > 0) {
+        // A delay time on a timeline (no audio-rate modulation): the host evaluates the same per-sample curve the device does
+        // (param_value_at at blockTime + i / sampleRate, DelayNode.cs:66,86) and tests every frame of this block.  With the
+        // [1, maxDelay] bound used for modulated delay times the output would be flagged non-silent the moment its INPUT becomes
+        // audible -- blocks before the delayed audio arrives -- and a consumer whose state was frozen by silence (a biquad with a
+        // second connection that ended earlier) would wake up too early.  While audio is on its way the node is evaluated again
+        // block by block.
+        const bool timelineOnly = !n_.params[0].events.empty() && ns.pinSilent(0) && blockTimes && brel < (int64_t)blockTimes->size();
+        if (!n_.delayAudible && timelineOnly) {
+          const ParamS& pd = n_.params[0];
+          const double t0 = (*blockTimes)[brel], dts = 1.0 / c.sampleRate;
+          bool pending = false;
+          for (int r = 0; r < ch && !n_.delayAudible; r++) {
+            auto& m = model[r];
+            for (auto& run : m.runs)
+              if (run.second == OPEN || run.second + maxD >= m.pos) pending = true;
+            if (m.runs.empty()) continue;
+            for (int i = 0; i < kBlock && !n_.delayAudible; i++) {
+              const float dtv = param_value_at(pd.events.data(), (int)pd.events.size(), pd.value, pd.arate ? t0 + i * dts : t0);
+              int d = (int)(dtv * (float)c.sampleRate);
+              d = std::min(std::max(d, 0), maxD);
+              if (d == 0) continue;   // (reads nothing: delay_kernel writes 0)
+              const int64_t q = m.pos + i - d;
+              for (auto& run : m.runs)
+                if (q >= run.first && (run.second == OPEN || q < run.second)) {
+                  n_.delayAudible = true;
+                  break;
+                }
+            }
+          }
+          if (!n_.delayAudible && pending && extraBreaks) extraBreaks->push_back(brel + 1);
+        } else if (!n_.delayAudible && dmax > 0) {
           dmin = std::max(dmin, 1);
           int64_t nextFlip = OPEN;
           for (int r = 0; r < ch && !n_.delayAudible; r++) {
@@ -2373,6 +2404,7 @@ void Context::chunkSimulate(ChunkRun& r) {
   Sim sim{*this, n};
   std::vector<int64_t> extraBreaks;
   sim.extraBreaks = &extraBreaks;
+  sim.blockTimes = &bt;
   int minDestCh = 32;
   {
     int64_t b = 0;

@@ -34,6 +34,7 @@ def build_random_graph(ctx, seed, frames, keep=None, handles=None):
         g.Connect(ctx.Destination)
         buses.append(g)
     nvoices = int(rng.integers(2, 10))
+    earlier_nodes = []
     for v in range(nvoices):
         nch = int(rng.choice([1, 1, 2]))
         src_sr = int(rng.choice([SR, SR, 44100]))
@@ -62,6 +63,7 @@ def build_random_graph(ctx, seed, frames, keep=None, handles=None):
             if rng2.random() < 0.6:
                 s.PlaybackRate.LinearRampToValueAtTime(float(rng2.uniform(0.5, 2.0)), float(rng2.uniform(frames / SR * 0.5, frames / SR)))
         node = s
+        chain_of_voice = [s]
         if handles is not None:
             handles.setdefault("sources", []).append(s)
         for _ in range(int(rng.integers(0, 4))):
@@ -103,6 +105,7 @@ def build_random_graph(ctx, seed, frames, keep=None, handles=None):
                 n.Inputs[0].SetChannelCountMode(ChannelCountMode(int(rng.integers(0, 3))))
             node.Connect(n)
             node = n
+            chain_of_voice.append(n)
             if handles is not None:
                 handles.setdefault(type(n).__name__, []).append(n)
         # the remaining pure-Core nodes (drawn from rng2: the graphs of old seeds keep their shape and gain a tail)
@@ -137,6 +140,16 @@ def build_random_graph(ctx, seed, frames, keep=None, handles=None):
                 if rng2.random() < 0.8:
                     sp.Connect(mg, o, int(rng2.integers(0, mg._input_count)))
             node = mg
+        if node is not chain_of_voice[-1]:
+            chain_of_voice.append(node)   # the panner / delay / merger appended above
+        # seeds >= 20000: a second connection into a node of this chain from a node of an EARLIER voice (no cycle: voices are
+        # ordered) -- inputs that have to be mixed in front of biquads, convolvers, delays, panners, mergers, not only in front of gains
+        if unity and earlier_nodes and len(chain_of_voice) > 1 and rng3.random() < 0.5:
+            frm = earlier_nodes[int(rng3.integers(0, len(earlier_nodes)))]
+            to = chain_of_voice[1 + int(rng3.integers(0, len(chain_of_voice) - 1))]
+            if not isinstance(frm, (ChannelSplitterNode,)) and not isinstance(to, ChannelMergerNode):
+                frm.Connect(to)
+        earlier_nodes.extend(chain_of_voice)
         target = buses[int(rng.integers(0, len(buses)))] if buses and rng.random() < 0.6 else ctx.Destination
         live = keep is None or v in keep  # (minimiser hook: unconnected voices are never pulled)
         if live:
