@@ -571,7 +571,7 @@ struct Sim {
     int outCh = computeOutputChannelCount(in);
     in.dirty = false;
     in.bufCh = outCh;
-    bool mixed = false;
+    bool mixed = false, allZero = true;
     for (size_t k = 0; k < in.connected.size(); k++) {
       Conn cn = in.connected[k];
       if (k + 2 < in.connected.size()) __builtin_prefetch(c.nodes[in.connected[k + 2].node].get());   // (tens of thousands of nodes: the walk is bound by cache misses)
@@ -580,11 +580,13 @@ struct Sim {
       if (o.bufCh != 0 && !o.silent) {
         is.terms.push_back(TermS{cn.node, cn.out, o.bufCh});
         mixed = true;
+        allZero = allZero && o.zero;
       }
     }
     in.silent = !mixed;
     is.bufCh = in.bufCh;
     is.silent = in.silent;
+    is.zero = mixed && allZero;
   }
 
   void evalNode(int id) {  // AudioNode.ProcessInternal, Nodes/AudioNode.cs:152-183
@@ -630,10 +632,13 @@ struct Sim {
       case GA_NODE_GAIN:  // GainNode.cs:29-61
         n_.outputs[0].bufCh = ns.ins[0].bufCh;
         n_.outputs[0].silent = ns.ins[0].silent;
+        n_.outputs[0].zero = ns.ins[0].zero;   // (0 * g = 0 for every finite gain; a NaN gain is not worth a special case here)
         break;
       case GA_NODE_BIQUAD: {  // BiQuadFilterNode.cs:87-147
         n_.outputs[0].bufCh = ns.ins[0].bufCh;
         n_.outputs[0].silent = ns.ins[0].silent;
+        if (!ns.ins[0].silent && !ns.ins[0].zero) n_.everFed = true;
+        n_.outputs[0].zero = ns.ins[0].zero && !n_.everFed;   // zero input AND zero state
         ns.bqDynamic = !n_.params[0].events.empty() || !n_.params[1].events.empty() || !n_.params[2].events.empty() ||
                        !ns.pinSilent(0) || !ns.pinSilent(1) || !ns.pinSilent(2);   // a modulated parameter moves per sample
         if (!ns.ins[0].silent && ns.bqDynamic) {
@@ -658,9 +663,12 @@ struct Sim {
         if (!n_.ir) {
           n_.outputs[0].bufCh = ns.ins[0].bufCh;
           n_.outputs[0].silent = true;
+          n_.outputs[0].zero = false;
         } else {
           n_.outputs[0].bufCh = n_.effectiveOutCh;
           n_.outputs[0].silent = false;  // MarkAsNonSilent even for silent input (:153)
+          if (!ns.ins[0].silent && !ns.ins[0].zero) n_.everFed = true;
+          n_.outputs[0].zero = !n_.everFed;   // nothing has reached the input yet: the flagged-non-silent output is exact zeros
         }
         break;
       case GA_NODE_BUFFER_SOURCE: {
@@ -720,6 +728,7 @@ struct Sim {
       case GA_NODE_STEREO_PANNER: {  // StereoPannerNode.cs:36-74
         n_.outputs[0].bufCh = 2;
         n_.outputs[0].silent = ns.ins[0].silent;
+        n_.outputs[0].zero = ns.ins[0].zero;
         ns.panMode = ns.ins[0].bufCh == 1 ? 1 : 2;
         if (!ns.ins[0].silent && (!n_.params[0].events.empty() || !ns.pinSilent(0))) {
           ns.panDyn = true;   // gains follow the a-rate curve on the device (stereo_panner_dynamic_kernel)
@@ -757,7 +766,7 @@ struct Sim {
         if ((int)model.size() < std::max(ch, 2)) model.resize(std::max(ch, 2));   // EnsureChannelCount (:102-113)
         for (int r = 0; r < (int)model.size(); r++) {
           auto& m = model[r];
-          const bool writesAudio = r < ch && !in.silent;
+          const bool writesAudio = r < ch && !in.silent && !in.zero;   // (exact zeros never raise the output flag)
           if (writesAudio && !m.open) {
             m.runs.push_back({m.pos, OPEN});
             m.open = true;

@@ -82,6 +82,10 @@ struct OutputS {
   std::vector<InRef> connectedInputs;
   int bufCh = 0;  // AudioNodeOutput.Buffer channel count; 0 = null (owner not processed yet)
   bool silent = true;
+  // flagged non-silent, but every sample is an exact zero: a ConvolverNode marks its output non-silent from its first block
+  // (ConvolverNode.cs:153) while nothing has reached its input yet; nodes without state of their own pass the property on.  Only a
+  // DelayNode asks: its output flag is raised by the first non-ZERO sample (DelayNode.cs:72,92), which such an input never delivers.
+  bool zero = false;
 };
 
 struct PlayBuf {
@@ -249,6 +253,7 @@ struct NodeS {
   int64_t dHistLen = 0;
   int dHistCur = 0;
   bool dHistZero = true;
+  bool everFed = false;   // (control plane) a non-silent, not-known-zero block has reached this node's input: its state / tail may be non-zero
   // ... and the LEADER of a fused group (or a convolver on its own) carries, per output channel, what the input so far adds to
   // the samples behind the last chunk's end (ga_chunk.cpp, planCoarseStage): valid for the next chunk only, and only while the
   // group's signature is the same; the input histories above stay the authoritative state
@@ -400,6 +405,7 @@ struct TermS {
 struct InSeg {
   int bufCh = 0;
   bool silent = true;
+  bool zero = false;   // non-silent, but every contributing buffer is known to hold exact zeros (OutputS::zero)
   SmallVec<TermS, 2> terms;  // non-silent contributors in connection order
 };
 struct NodeSeg {
