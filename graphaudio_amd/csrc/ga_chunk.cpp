@@ -640,7 +640,9 @@ struct Sim {
         if (!ns.ins[0].silent && !ns.ins[0].zero) n_.everFed = true;
         n_.outputs[0].zero = ns.ins[0].zero && !n_.everFed;   // zero input AND zero state
         ns.bqDynamic = !n_.params[0].events.empty() || !n_.params[1].events.empty() || !n_.params[2].events.empty() ||
-                       !ns.pinSilent(0) || !ns.pinSilent(1) || !ns.pinSilent(2);   // a modulated parameter moves per sample
+                       !ns.pinSilent(0) || !ns.pinSilent(1) || !ns.pinSilent(2) ||   // a modulated parameter moves per sample
+                       n_.bqDynChunk;   // (went dynamic earlier in this chunk: the coefficient state lives on the device until the chunk ends)
+        if (ns.bqDynamic && !ns.ins[0].silent) n_.bqDynChunk = true;
         if (!ns.ins[0].silent && ns.bqDynamic) {
           ns.bqActive = true;   // coefficients are refreshed per sample on the device
         } else if (!ns.ins[0].silent) {
@@ -730,7 +732,8 @@ struct Sim {
         n_.outputs[0].silent = ns.ins[0].silent;
         n_.outputs[0].zero = ns.ins[0].zero;
         ns.panMode = ns.ins[0].bufCh == 1 ? 1 : 2;
-        if (!ns.ins[0].silent && (!n_.params[0].events.empty() || !ns.pinSilent(0))) {
+        if (!ns.ins[0].silent && (!n_.params[0].events.empty() || !ns.pinSilent(0) || n_.panDynChunk)) {
+          n_.panDynChunk = true;
           ns.panDyn = true;   // gains follow the a-rate curve on the device (stereo_panner_dynamic_kernel)
         } else if (!ns.ins[0].silent) {
           float pan = std::min(std::max(n_.params[0].value, -1.0f), 1.0f);
@@ -2331,6 +2334,8 @@ void Context::chunkTopology(ChunkRun& r) {
     maxDepth = std::max(maxDepth, nodes[id]->depth);
     maxLevel = std::max(maxLevel, nodes[id]->level);
     NodeS& nd = *nodes[id];
+    if (nd.type == GA_NODE_STEREO_PANNER) nd.panDynChunk = false;
+    if (nd.type == GA_NODE_BIQUAD) nd.bqDynChunk = false;
     if (nd.type == GA_NODE_STEREO_PANNER && nd.panOnDevice && nd.params[0].events.empty()) {
       PanState tmp;   // back to a constant pan: the gains the automated run left on the device are the node's state
       GA_HIP(hipStreamSynchronize(stream));
@@ -2897,6 +2902,8 @@ void Context::planStereoPanner(NodePlanCtx& k) {
     dj.curve = ex.paramView((int)si, ns, 0);
     dj.state = nd.panDev;
     dj.init_state = PanState{nd.panLast, nd.panGL, nd.panGR, 0.f};
+    dj.value = nd.params[0].value;
+    dj.pad_ = 0;
     dj.init = nd.panOnDevice ? 0 : 1;   // the host-tracked state is handed over once
     nd.panOnDevice = true;
     dj.stereo = ns.panMode == 2 ? 1 : 0;

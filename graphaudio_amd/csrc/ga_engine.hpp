@@ -190,6 +190,9 @@ struct NodeS {
   float panLast = std::nanf(""), panGL = 0.5f, panGR = 0.5f;
   PanState* panDev = nullptr;      // device copy of the three, authoritative while pan is automated (panOnDevice)
   bool panOnDevice = false;
+  bool bqDynChunk = false;         // the same for a biquad whose parameter modulation falls silent inside a chunk (coefficient state on the device)
+  bool panDynChunk = false;        // (control plane) evaluated by the dynamic kernel in an earlier segment of THIS chunk: the gains in force live on the
+                                   // device until the chunk ends, so the rest of the chunk stays on that kernel (a modulation input that falls silent)
   // DelayNode (DelayNode.cs:13-15)
   int maxDelaySamples = 0;
   int delayCh = 0;                 // channels of `_outputBuffer` (re-rented, i.e. silent again, when the count changes)

@@ -2502,7 +2502,7 @@ __global__ __launch_bounds__(64) void stereo_panner_dynamic_kernel(const PanDynJ
   const GA_GLOBAL float* psrc = (const GA_GLOBAL float*)job.state;   // {last_pan, gain_l, gain_r, pad}
   PanState st = job.init ? job.init_state : PanState{psrc[0], psrc[1], psrc[2], psrc[3]};
   const int64_t nblk = job.n / kBlock;
-  auto panAt = [&](int64_t f) { return fminf(fmaxf(gptr(job.curve)[f], -1.0f), 1.0f); };   // Math.Clamp(panValues[i], -1, 1)
+  auto panAt = [&](int64_t f) { return fminf(fmaxf(job.curve ? gptr(job.curve)[f] : job.value, -1.0f), 1.0f); };   // Math.Clamp(panValues[i], -1, 1)
   for (int64_t g0 = 0; g0 < nblk; g0 += 64) {
     const int nb = (int)min<int64_t>(64, nblk - g0);
     const int64_t fb = job.f0 + (g0 + lane) * kBlock;

@@ -539,11 +539,13 @@ struct PanDynJob {
   const float* in_r;     // null on the mono path
   float* out_l;
   float* out_r;
-  const float* curve;    // a-rate pan curve (chunk-frame indexed)
+  const float* curve;    // a-rate pan curve (chunk-frame indexed); null: the constant `value` (a modulation input that fell silent)
   PanState* state;       // device-resident (_lastPan, _lastGainL, _lastGainR); read at the start unless `init`, written at the end
   PanState init_state;   // host-tracked state handed over when the node turns dynamic
   int init;
   int stereo;
+  float value;           // Pan.Value, used where `curve` is null
+  int pad_;
   int64_t f0, n;         // multiples of 128
 };
 void launch_stereo_panner_dynamic(hipStream_t s, const PanDynJob* jobs_dev, int njobs);

@@ -35,6 +35,9 @@ def build_random_graph(ctx, seed, frames, keep=None, handles=None):
         buses.append(g)
     nvoices = int(rng.integers(2, 10))
     earlier_nodes = []
+    voice_chains = []
+    rng4 = np.random.default_rng(seed + 4242)   # seeds >= 30000: signals of one chain into PARAMETERS of a later one, scheduled sources into chains
+    wild = seed >= 30000
     for v in range(nvoices):
         nch = int(rng.choice([1, 1, 2]))
         src_sr = int(rng.choice([SR, SR, 44100]))
@@ -150,6 +153,7 @@ def build_random_graph(ctx, seed, frames, keep=None, handles=None):
             if not isinstance(frm, (ChannelSplitterNode,)) and not isinstance(to, ChannelMergerNode):
                 frm.Connect(to)
         earlier_nodes.extend(chain_of_voice)
+        voice_chains.append(chain_of_voice)
         target = buses[int(rng.integers(0, len(buses)))] if buses and rng.random() < 0.6 else ctx.Destination
         live = keep is None or v in keep  # (minimiser hook: unconnected voices are never pulled)
         if live:
@@ -182,6 +186,12 @@ def build_random_graph(ctx, seed, frames, keep=None, handles=None):
         g.Gain.Value = float(rng2.uniform(0.05, 0.3))
         o.Connect(g)
         g.Connect(buses[0] if buses and rng2.random() < 0.5 else ctx.Destination)
+        if wild and voice_chains and rng4.random() < 0.6:   # the oscillator / constant also feeds a node inside a voice chain
+            chain = voice_chains[int(rng4.integers(0, len(voice_chains)))]
+            if len(chain) > 1:
+                to = chain[1 + int(rng4.integers(0, len(chain) - 1))]
+                if not isinstance(to, ChannelMergerNode):
+                    g.Connect(to)
         when = float(rng2.uniform(0, frames / SR * 0.5))
         if rng2.random() < 0.4:
             o.Start(when, 0.0, float(rng2.uniform(0.001, frames / SR * 0.6)))
@@ -192,6 +202,29 @@ def build_random_graph(ctx, seed, frames, keep=None, handles=None):
         if handles is not None:
             handles.setdefault("scheduled", []).append(o)
             handles.setdefault("GainNode", []).append(g)
+    # seeds >= 30000: audio-rate modulation of a parameter of voice j by a signal of voice i < j (through a depth gain)
+    if wild:
+        for j in range(1, len(voice_chains)):
+            if rng4.random() >= 0.35:
+                continue
+            targets = []
+            for n in voice_chains[j][1:]:
+                if isinstance(n, GainNode): targets.append((n.Gain, 0.3))
+                elif isinstance(n, BiQuadFilterNode): targets.append((n.Frequency, 300.0))
+                elif isinstance(n, DelayNode): targets.append((n.DelayTime, 0.003))
+                elif isinstance(n, StereoPannerNode): targets.append((n.Pan, 0.5))
+            i = int(rng4.integers(0, j))
+            srcs = [n for n in voice_chains[i] if not isinstance(n, ChannelSplitterNode)]
+            if not targets or not srcs:
+                continue
+            prm, depth = targets[int(rng4.integers(0, len(targets)))]
+            frm = srcs[int(rng4.integers(0, len(srcs)))]
+            dg = GainNode(ctx)
+            dg.Gain.Value = float(depth * rng4.uniform(0.3, 2.0))
+            frm.Connect(dg)
+            dg.Connect(prm)
+            if handles is not None:
+                handles.setdefault("mod_gains", []).append(dg)
     if handles is not None:
         handles.update(buses=buses, shared_ir=shared_ir)
     return dest_ch

@@ -17,7 +17,9 @@ from tests._oracle import OracleContext
 REGRESSION_SEEDS = [215, 219, 357, 430, 459, 749, 1232, 1273, 1476, 2550, 2577, 2916, 3371, 1186, 1763, 3027, 3639, 4787,
                     # round 3 (connections between voice chains): a delay fed by a convolver that has not seen input yet (flagged non-silent,
                     # exact zeros) is one of two connections of a biquad whose other source ended -- the delay's output flag
-                    20256, 22316]
+                    20256, 22316,
+                    # a panner whose pan modulation falls silent inside a chunk (seeds >= 30000: chain signals into parameters of later chains)
+                    30941] + list(range(30000, 30012))
 
 
 # coarse = 1: convolvers with more than 64 partitions are forced onto formulation D (coarse partitions) even though the pieces are

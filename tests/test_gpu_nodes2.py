@@ -552,3 +552,34 @@ def test_constant_gains_are_folded_into_the_consumers_mix():
         assert G.rms(outs[0]) > 1e-2
         assert np.array_equal(outs[0], outs[1]), (fold, G.rms(outs[0] - outs[1]))
     assert results[1] < results[0]
+
+
+def test_parameter_modulation_that_falls_silent_inside_a_chunk():
+    """The signal that modulates a panner's pan / a biquad's frequency ends (its source runs out) in the middle of a chunk: the node has
+    been evaluated by its per-sample kernel, whose gains / coefficients live on the device -- the rest of the chunk has to stay on that
+    kernel (with the constant parameter value), not fall back to the host-tracked state of the chunk's start.  (Found by the round-3
+    generator, seed 30941: a panner modulated by a voice whose 882-frame source, played at 3.7 x, ends after two blocks.)"""
+    frames = 128 * 20
+
+    def build(ctx):
+        rng = np.random.default_rng(17)
+        hold = []
+        carrier = AudioBufferSourceNode(ctx)
+        carrier.Buffer = PlayableAudioBuffer.FromMonoArray((rng.standard_normal(frames + 64) * 0.2).astype(np.float32), SR)
+        short = AudioBufferSourceNode(ctx)                        # the modulator: ends after ~2.6 blocks
+        short.Buffer = PlayableAudioBuffer.FromMonoArray((rng.standard_normal(333) * 0.5).astype(np.float32), SR)
+        pn = StereoPannerNode(ctx); pn.Pan.Value = 0.15
+        bq = BiQuadFilterNode(ctx); bq.Frequency.Value = 1200.0; bq.Q.Value = 1.5
+        dp = GainNode(ctx); dp.Gain.Value = 0.6
+        df = GainNode(ctx); df.Gain.Value = 400.0
+        short.Connect(dp); dp.Connect(pn.Pan)
+        short.Connect(df); df.Connect(bq.Frequency)
+        carrier.Connect(pn); pn.Connect(ctx.Destination)
+        carrier.Connect(bq); bq.Connect(ctx.Destination)
+        carrier.Start(); short.Start(0.0021)
+        return hold + [carrier, short, pn, bq, dp, df]
+
+    for chunk in (0, 9, 2):
+        ref, got = pair(build, 2, frames, chunk=chunk)
+        assert G.rms(ref) > 1e-2
+        assert G.rms(ref - got) <= 2e-6 * G.rms(ref), (chunk, G.rms(ref - got))
