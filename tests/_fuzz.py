@@ -113,6 +113,8 @@ def build_random_graph(ctx, seed, frames, keep=None, handles=None):
                 handles.setdefault(type(n).__name__, []).append(n)
         # the remaining pure-Core nodes (drawn from rng2: the graphs of old seeds keep their shape and gain a tail)
         extra = float(rng2.random())
+        if seed >= 40000 and extra >= 0.30 and rng4.random() < 0.3:
+            extra = 0.25   # more splitter -> merger tails
         if extra < 0.12:
             n = StereoPannerNode(ctx)
             if rng2.random() < 0.5:
@@ -152,6 +154,10 @@ def build_random_graph(ctx, seed, frames, keep=None, handles=None):
             to = chain_of_voice[1 + int(rng3.integers(0, len(chain_of_voice) - 1))]
             if not isinstance(frm, (ChannelSplitterNode,)) and not isinstance(to, ChannelMergerNode):
                 frm.Connect(to)
+            elif seed >= 40000:   # splitter outputs / merger inputs by index
+                oi = int(rng3.integers(0, frm._output_count)) if isinstance(frm, ChannelSplitterNode) else 0
+                ii = int(rng3.integers(0, to._input_count)) if isinstance(to, ChannelMergerNode) else 0
+                frm.Connect(to, oi, ii)
         earlier_nodes.extend(chain_of_voice)
         voice_chains.append(chain_of_voice)
         target = buses[int(rng.integers(0, len(buses)))] if buses and rng.random() < 0.6 else ctx.Destination

@@ -19,7 +19,7 @@ REGRESSION_SEEDS = [215, 219, 357, 430, 459, 749, 1232, 1273, 1476, 2550, 2577, 
                     # exact zeros) is one of two connections of a biquad whose other source ended -- the delay's output flag
                     20256, 22316,
                     # a panner whose pan modulation falls silent inside a chunk (seeds >= 30000: chain signals into parameters of later chains)
-                    30941] + list(range(30000, 30012))
+                    30941] + list(range(30000, 30012)) + list(range(40000, 40010))   # (>= 40000: splitter outputs / merger inputs cross-connected by index)
 
 
 # coarse = 1: convolvers with more than 64 partitions are forced onto formulation D (coarse partitions) even though the pieces are
@@ -83,7 +83,7 @@ def _session_pair(seed, chunk=11, coarse=0):
 @pytest.mark.parametrize("coarse", [0, 1, 2, 3, 4])   # 2: D without carried tails; 3: D without the time-domain pre-mix; 4: tails for private IRs too
 # 2573: a ramp on a biquad's frequency -- the per-block coefficients are evaluated on the device, where cos / sin / pow have to be
 #       rounded once from double like the C library's cosf / sinf / powf behind MathF (7.9e-6 -> 2.7e-9)
-@pytest.mark.parametrize("seed", list(range(60)) + [2850, 2573, 20284] + list(range(20000, 20012)))
+@pytest.mark.parametrize("seed", list(range(60)) + [2850, 2573, 20284] + list(range(20000, 20012)) + list(range(30000, 30006)) + list(range(40000, 40006)))
 def test_random_edit_session_matches_oracle(seed, coarse):
     """The graph is edited between render pieces (parameter writes, automation, stop, new voices, dispose, rewiring,
     impulse-response swaps, audio-rate modulation, channel settings): same output and the same exceptions."""
