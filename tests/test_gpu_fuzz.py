@@ -95,3 +95,13 @@ def test_random_edit_session_matches_oracle(seed, coarse):
     err = G.rms(ref - got)
     scale = max(G.rms(ref), 1e-3)
     assert err <= 1e-5 and err <= 2e-5 * scale, (seed, err, scale)
+
+
+@pytest.mark.xfail(reason="OPEN at the end of round 3 (DESIGN.md section 8): edit session 42867 (generator >= 40000: convolvers of two depths cross-connected, "
+                          "impulse-response swaps and rewiring between the pieces) deviates by 3e-2 from frame 1411 on when formulation D is FORCED onto its "
+                          "9-block pieces (coarse_min_blocks = 1, a test-only setting); formulations B / C (the default for renders this short) are right",
+                   strict=False)
+def test_open_session_42867_with_formulation_d_forced():
+    ref, ref_log, got, got_log = _session_pair(42867, coarse=1)
+    assert ref_log == got_log
+    assert G.rms(ref - got) <= 1e-5

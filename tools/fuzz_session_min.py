@@ -24,7 +24,12 @@ nv = sum(1 for e in edges if e[0] == "AudioBufferSourceNode")
 for keep in [None, set()] + [{v} for v in range(12)]:
     try:
         o = OracleContext(48000); ref, rl = F.run_random_session(o, seed, keep=keep)
-        h = OfflineAudioContext(48000); got, gl = F.run_random_session(h, seed, keep=keep)
+        h = OfflineAudioContext(48000)
+        import os
+        for kv in os.environ.get("GA_OPTS", "").split(","):
+            if "=" in kv:
+                h.SetOption(kv.split("=")[0], float(kv.split("=")[1]))
+        got, gl = F.run_random_session(h, seed, keep=keep)
     except Exception as e:
         print(keep, "exception", type(e).__name__, e); continue
     d = np.abs(ref - got).max(axis=0); bf = np.nonzero(d > 2e-5)[0]
