@@ -847,6 +847,7 @@ struct Sim {
     if (!n_.outputs.empty()) {
       ns.outCh = n_.outputs[0].bufCh;
       ns.outSilent = n_.outputs[0].silent;
+      ns.outZero = !n_.outputs[0].silent && n_.outputs[0].zero;
     }
   }
 
@@ -855,7 +856,8 @@ struct Sim {
     for (const NodeSeg& ns : s.nodes) {
       h = hmix(h, (uint64_t)ns.id);
       h = hmix(h, ((uint64_t)ns.outCh << 8) | (ns.outSilent ? 1 : 0) | ((uint64_t)ns.srcPhase << 4) | (ns.bqActive ? 2 : 0) |
-                      ((uint64_t)ns.outMask << 16) | ((uint64_t)ns.panMode << 48) | ((uint64_t)(ns.panDyn ? 1 : 0) << 52));
+                      ((uint64_t)ns.outMask << 16) | ((uint64_t)ns.panMode << 48) | ((uint64_t)(ns.panDyn ? 1 : 0) << 52) |
+                      ((uint64_t)(ns.outZero ? 1 : 0) << 53));
       for (const InSeg& is : ns.ins) {
         h = hmix(h, ((uint64_t)is.bufCh << 1) | (is.silent ? 1 : 0));
         for (const TermS& t : is.terms) h = hmix(h, ((uint64_t)t.node << 16) | ((uint64_t)t.out << 8) | (uint64_t)t.ch);
@@ -1709,9 +1711,12 @@ void CoarseStage::resolveInputs() {
     bool allSame = true;
     for (int ch = 1; ch < nd.bInCh; ch++) allSame = allSame && (chIn[ch] == chIn[0]);
     if (nd.bShared && !allSame) {   // the channels start to differ: every channel inherits the (so far common) history
+      // (a plan entry like every other device action of the chunk: ordered with the chunk's launches, nothing is issued at plan time)
       if (const float* h0 = coarseHistory(nd, 0))
         for (int ch = 1; ch < nd.bInCh; ch++) {
-          GA_HIP(hipMemcpyAsync(nd.dHist[nd.dHistCur] + (size_t)ch * hl, h0, (size_t)hl * sizeof(float), hipMemcpyDeviceToDevice, c.stream));
+          float* dst = nd.dHist[nd.dHistCur] + (size_t)ch * hl;
+          hipStream_t st = c.stream;
+          ex.plan.add(LK_OTHER, [=](uint8_t*) { GA_HIP(hipMemcpyAsync(dst, h0, (size_t)hl * sizeof(float), hipMemcpyDeviceToDevice, st)); });
           if (ch < (int)nd.dHistExt.size()) nd.dHistExt[ch] = {nullptr, -1};
         }
       if (nd.dHistZero && coarseHistory(nd, 0)) nd.dHistZero = false;   // (the copies above are the channels' histories now)
@@ -2667,6 +2672,12 @@ void Context::chunkConvScratch(ChunkRun& r) {
   //      launch captures their address ----
   assignConvPaths(topo, n);
   planCoarseFusion(topo, segs);
+  for (int id : topo)
+    if (nodes[id]->type == GA_NODE_CONVOLVER) nodes[id]->dGroupSize = 0;
+  for (int id : topo) {
+    const NodeS& nd = *nodes[id];
+    if (nd.type == GA_NODE_CONVOLVER && nd.ir && nd.convPath == 4 && nd.dLeader >= 0) nodes[nd.dLeader]->dGroupSize++;
+  }
   aliasBusToLeader(r);
   bHistMax = 0;
   {
@@ -3326,6 +3337,21 @@ void Context::chunkPlanNodes(ChunkRun& r, int d) {
             // formulation D: the outputs of a fused group are summed as spectra; the sum is the LEADER's output, the other
             // members hand their consumer a null (= contributes nothing) view (Context::planCoarseFusion)
             if (nd.convPath == 4 && nd.dLeader >= 0 && nd.dLeader != ns.id) break;
+            // Nothing has reached this convolver since its delay line was created: the reference's partition sum is a sum of
+            // exact zeros (PartitionedConvolver.cs:154-223), and consumers that compare values -- StereoPannerNode's `pan !=
+            // _lastPan` (StereoPannerNode.cs:92-99), DelayNode's (int)(delayTime * sampleRate) -- see that.  The transform
+            // formulations (C, D) leave ~1e-9 of circular rounding in front of an onset inside the same window, so the blocks
+            // before the onset are served from the zero page instead of the output slab (fuzz session 42867).  The leader of a
+            // fused group carries the other members' sum and keeps its slab.
+#ifdef GA_EXPERIMENTS
+            static const bool noZeroPage = getenv("GA_NO_ZERO_PAGE") != nullptr;   // (to show that the regression tests catch the defect)
+#else
+            constexpr bool noZeroPage = false;
+#endif
+            if (!noZeroPage && ns.outZero && !(nd.convPath == 4 && nd.dGroupSize > 1)) {
+              for (int ch = 0; ch < ns.outCh; ch++) ov[ch] = zeros;
+              break;
+            }
             for (int ch = 0; ch < ns.outCh; ch++) ov[ch] = ex.nodeOut(ns.id, ch);
             break;
           }
@@ -3553,9 +3579,14 @@ void Context::planConvolversPrivate(ChunkRun& r, int d, ConvPlanCtx& k) {
     if (nd.bShared && !allSame) {
       // the channels start to differ: every channel inherits the (so far common) history of channel 0
       if (!nd.bHistZero && h > 0 && nd.bHistPlane < 0)   // (a plane-resident shared row is simply read by every channel)
-        for (int c = 1; c < nd.bInCh; c++) {
-          GA_HIP(hipMemcpyAsync(nd.bHistR + c * hstride, nd.bHistR, hstride * 4, hipMemcpyDeviceToDevice, stream));
-          GA_HIP(hipMemcpyAsync(nd.bHistI + c * hstride, nd.bHistI, hstride * 4, hipMemcpyDeviceToDevice, stream));
+        for (int c = 1; c < nd.bInCh; c++) {   // (plan entries: ordered with the chunk's launches)
+          float *dr = nd.bHistR + c * hstride, *di = nd.bHistI + c * hstride;
+          const float *sr = nd.bHistR, *sim = nd.bHistI;
+          hipStream_t st = stream;
+          ex.plan.add(LK_OTHER, [=](uint8_t*) {
+            GA_HIP(hipMemcpyAsync(dr, sr, hstride * 4, hipMemcpyDeviceToDevice, st));
+            GA_HIP(hipMemcpyAsync(di, sim, hstride * 4, hipMemcpyDeviceToDevice, st));
+          });
         }
       nd.bShared = false;
     }

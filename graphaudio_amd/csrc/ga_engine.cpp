@@ -588,6 +588,8 @@ void Context::releaseConvState(NodeS& n) {
   n.dHistCur = 0;
   n.dHistZero = true;
   n.dLeader = -1;
+  n.dGroupSize = 0;
+  n.everFed = false;   // (new PartitionedConvolver instances: an empty delay line, exact zeros out until something arrives)
   fusionKeyValid = false;
   n.bHistR = n.bHistI = n.bOverlap = nullptr;
   n.bHistPlane = -1;

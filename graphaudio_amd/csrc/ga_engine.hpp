@@ -290,6 +290,7 @@ struct NodeS {
   // per chunk: convolver outputs that one summing input consumes are summed as spectra (Context::planCoarseFusion);
   // the leader's output slabs carry the sum, the other members contribute no time-domain signal of their own
   int dLeader = -1;
+  int dGroupSize = 0;   // (on a leader) members of its fused group in this chunk, itself included
 };
 
 // A vector with inline room for N elements (heap only beyond): the per-node, per-segment records of the control-plane
@@ -421,6 +422,7 @@ struct NodeSeg {
   bool bqDynamic = false;   // biquad with automated parameters
   int outCh = 0;
   bool outSilent = true;
+  bool outZero = false;     // flagged non-silent, but exact zeros in the reference (OutputS::zero): consumers are handed the zero page
   int srcPhase = SRC_IDLE;
   int64_t srcPos = 0;
   int64_t srcBlk = 0;

@@ -529,3 +529,83 @@ def test_sixteen_column_jobs_at_every_partition_count(taps, mfma):
     kernels = " ".join(st["stage_kernel"])
     assert ("mfma16" in kernels) == (mfma == 1 and taps <= 32768), kernels
     check(ref, got)
+
+
+# ---- exact zeros in front of an onset (the round-3 open defect: edit session 42867) ----------------------------------------
+def _onset_scene(ctx, onset_block, taps=9000, frames=128 * 40, mono_mod=False, through_delay=False):
+    """A mono voice -> StereoPannerNode(pan 0) -> destination, the pan modulated (through a depth gain) by a true-stereo
+    convolver whose stereo source starts at `onset_block`.  Until then the reference's convolver puts out exact zeros, so
+    `pan != _lastPan` (StereoPannerNode.cs:92-99) never fires and the panner keeps the gains of its FIRST block (stereo law:
+    the first block's input is the up-mixed 2-channel buffer, AudioNodeInput.cs:140-168); any rounding noise in front of the
+    onset re-derives them with the mono law and the voice comes out ~1e7 times louder on the left."""
+    from graphaudio_amd import StereoPannerNode, DelayNode
+    ctx.Destination.SetChannelCount(2)
+    v = AudioBufferSourceNode(ctx)
+    v.Buffer = PlayableAudioBuffer.FromMonoArray(G.voice(3, frames + 256), SR)
+    pn = StereoPannerNode(ctx)
+    pn.Pan.Value = 0.0
+    v.Connect(pn).Connect(ctx.Destination)
+    v.Start()
+    m = AudioBufferSourceNode(ctx)
+    data = [G.voice(11, frames), G.voice(12, frames)]
+    m.Buffer = PlayableAudioBuffer.FromChannelArrays(data[:1] if mono_mod else data, SR)
+    cv = ConvolverNode(ctx)
+    cv.Buffer = PlayableAudioBuffer.FromChannelArrays([G.synth_ir(c, taps) for c in range(4)], SR)
+    depth = GainNode(ctx)
+    depth.Gain.Value = 0.48
+    m.Connect(cv).Connect(depth)
+    if through_delay:
+        d = DelayNode(ctx, 0.05)
+        d.DelayTime.Value = 0.001
+        depth.Connect(d)
+        d.Connect(pn.Pan)
+    else:
+        depth.Connect(pn.Pan)
+    m.Start(onset_block * 128 / SR + 1e-4)   # (block-granular start: the first block whose end lies behind this time)
+    return cv
+
+
+@pytest.mark.parametrize("mono_mod", [False, True])
+@pytest.mark.parametrize("pieces", [[128 * 10, 128 * 6, 128 * 24], [128 * 40], [128 * 3 + 77, 128 * 9, 128 * 5 + 51, 128 * 30]])
+def test_exact_zeros_in_front_of_an_onset_inside_the_chunk(pieces, mono_mod):
+    """Session 42867 as a deterministic case: the convolver's input is silent, then its two channels differ from the middle
+    of a chunk on (shared -> per-channel rows of formulation D in the same chunk)."""
+    frames = 128 * 40
+    for opts in ({"max_chunk_blocks": 11}, {}, {"coarse_min_blocks": 1 << 30}):   # D forced in short chunks / one chunk / formulation C
+        ref, got, st = pair(lambda c: (_onset_scene(c, 15, mono_mod=mono_mod), 2)[1], frames, pieces, **opts)
+        assert G.rms(ref - got) <= 1e-6, (opts, G.rms(ref - got), G.rms(ref))
+
+
+def test_exact_zeros_in_front_of_an_onset_after_an_impulse_response_swap():
+    """The same with the impulse response swapped before the onset: the new PartitionedConvolver instances start from an
+    empty delay line (ConvolverNode.cs:51-77), so the zeros stay exact -- and a swap AFTER the onset does too."""
+    frames = 128 * 40
+    for swap_at, onset in ((128 * 8, 15), (128 * 20, 5)):
+        outs = []
+        for ctx in (OracleContext(SR), hip(max_chunk_blocks=11)):
+            cv = _onset_scene(ctx, onset)
+            out = np.zeros((2, frames), np.float32)
+            ctx.Render(out, swap_at, 0)
+            cv.Buffer = PlayableAudioBuffer.FromChannelArrays([G.synth_ir(c, 12000, seed0=40) for c in range(4)], SR)
+            ctx.Render(out, frames - swap_at, swap_at)
+            outs.append(out)
+            ctx.Dispose()
+        assert G.rms(outs[0]) > 1e-3
+        assert G.rms(outs[0] - outs[1]) <= 1e-6, (swap_at, G.rms(outs[0] - outs[1]))
+
+
+def test_default_policy_onset_in_the_middle_of_a_long_chunk():
+    """The default policy (no option set): one render of 300 blocks takes formulation D, the onset sits in block 15."""
+    frames = 128 * 300
+
+    def scene(c):
+        _onset_scene(c, 15, frames=frames)
+        return 2
+    o = OracleContext(SR)
+    scene(o)
+    ref = G.render(o, 2, frames)
+    h = OfflineAudioContext(SR)
+    scene(h)
+    got = G.render(h, 2, frames)
+    assert h.GetStats()["stage_launches"][5] > 0
+    assert G.rms(ref - got) <= 1e-6, G.rms(ref - got)
