@@ -41,6 +41,7 @@ internal static unsafe partial class GraphAudioHip
         public long coarse_premixed_signals;
         public long deferred_handovers;
         public long biquad_split_cascades;
+        public long ref_order_rows;
     }
 
     [LibraryImport(Lib, EntryPoint = "ga_strerror")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]

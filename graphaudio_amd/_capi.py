@@ -85,8 +85,10 @@ class Stats(C.Structure):
         ("coarse_premixed_signals", C.c_int64),
         ("deferred_handovers", C.c_int64),
         ("biquad_split_cascades", C.c_int64),
+        ("ref_order_rows", C.c_int64),
     ]
-    STAGES = ("other", "mix", "rfft_fwd", "mac", "rfft_inv", "coarse_fwd", "coarse_mac", "coarse_inv", "coarse_hist", "coarse_section")
+    STAGES = ("other", "mix", "rfft_fwd", "mac", "rfft_inv", "coarse_fwd", "coarse_mac", "coarse_inv", "coarse_hist", "coarse_section",
+              "coarse_premix")   # index = GA_STAGE_* (tests/test_capi.py checks the length against GA_STAGE_COUNT)
 
     def as_dict(self):
         d = {}

@@ -2670,7 +2670,12 @@ void Context::chunkConvScratch(ChunkRun& r) {
 
   // ---- convolver scratch planes are shared by all groups: size them for the largest group BEFORE any recorded
   //      launch captures their address ----
+  refOrderSensitivity(topo);
   assignConvPaths(topo, n);
+  for (int id : topo) {
+    NodeS& nd = *nodes[id];
+    if (nd.type == GA_NODE_CONVOLVER) nd.refOrder = nd.refSens && nd.ir && (nd.convPath == 2 || nd.convPath == 3);
+  }
   planCoarseFusion(topo, segs);
   for (int id : topo)
     if (nodes[id]->type == GA_NODE_CONVOLVER) nodes[id]->dGroupSize = 0;
@@ -3507,7 +3512,7 @@ void Context::planConvolversShared(ChunkRun& r, int d, ConvPlanCtx& k) {
 }
 
 // formulations B / C: nodes with an impulse response of their own (per-node planes; block-axis FFT segments or the direct sum)
-void Context::planConvolversPrivate(ChunkRun& r, int d, ConvPlanCtx& k) {
+void Context::planConvolversPrivate(ChunkRun& r, int d, ConvPlanCtx& k, bool refOrder) {
   Context& c_ = *this; (void)c_;
   std::vector<int>& topo = r.topo;
   int& maxDepth = r.maxDepth; int& maxLevel = r.maxLevel; (void)maxDepth; (void)maxLevel;
@@ -3662,7 +3667,10 @@ void Context::planConvolversPrivate(ChunkRun& r, int d, ConvPlanCtx& k) {
           ovIn.push_back(nd.bOverlap + ((size_t)slot * 2 + nd.bOvCur) * kBlock);
           ovOut.push_back(nd.bOverlap + ((size_t)slot * 2 + (nd.bOvCur ^ 1)) * kBlock);
         }
-        if (nd.convPath == 3) {
+        if (refOrder) {
+          sets.push_back(st);
+          stats.ref_order_rows += st.ncol;
+        } else if (nd.convPath == 3) {
           SetTaps tp{nd.ir.get(), {}};
           for (int j = 0; j < st.ncol; j++) tp.slot[j] = cols[c0 + j];
           setsC[P].push_back(sc);
@@ -3696,12 +3704,13 @@ void Context::planConvolversPrivate(ChunkRun& r, int d, ConvPlanCtx& k) {
   Twiddles tw{w128, w256};
   const int nn = (int)n;
   const int maxn = std::max(hist, txb - hist - nn);
-  const bool f64 = fft64;
+  const bool f64 = fft64 || refOrder;   // (formulation R: the reference's FftFlat precision around its own partition sum)
   ex.plan.add(LK_FFT, [=](uint8_t* base) {
     launch_hist_copy_b(st, (const HistJobB*)(base + ro), nr, std::max(maxn, 1));
     launch_rfft_fwd_b(st, (const ConvRowIO*)(base + xo), nx, nn, hist, plb, tw, f64);
   });
-  if (ns_ > 0) ex.plan.add(LK_MAC, [=](uint8_t* base) { launch_spectral_mac_b(st, (const ConvSetB*)(base + so), ns_, nn, hist, plb); });
+  if (ns_ > 0 && refOrder) ex.plan.add(LK_MAC, [=](uint8_t* base) { launch_refmac(st, (const ConvSetB*)(base + so), ns_, nn, hist, plb); });
+  else if (ns_ > 0) ex.plan.add(LK_MAC, [=](uint8_t* base) { launch_spectral_mac_b(st, (const ConvSetB*)(base + so), ns_, nn, hist, plb); });
   for (auto& kv : setsC) {
     const int Pc = kv.first;
     static const char* r16env = expenv("GA_TCONV_RADIX16");   // A/B switches for measurements
@@ -3792,7 +3801,20 @@ void Context::chunkPlanConvolvers(ChunkRun& r, int d) {
     // ---- formulation D: coarse partitions, consumer sums fused in the frequency domain ----
     if (!dNodes.empty()) planCoarseStage(*this, ex, dNodes, n);
     // ---- formulations B / C: nodes with a private impulse response ----
-    if (!bNodes.empty()) planConvolversPrivate(r, d, k);
+    // (those that this chunk evaluates in the reference's own order -- formulation R -- in a pass of their own: double-precision
+    // transforms and launch_refmac instead of the matrix-core / block-axis-FFT partition sums)
+    if (!bNodes.empty()) {
+      std::vector<int> plain, ref;
+      for (int id : bNodes) (nodes[id]->refOrder ? ref : plain).push_back(id);
+      if (!plain.empty()) {
+        bNodes = plain;
+        planConvolversPrivate(r, d, k, false);
+      }
+      if (!ref.empty()) {
+        bNodes = ref;
+        planConvolversPrivate(r, d, k, true);
+      }
+    }
     auto& tsTemps = k.tsTemps;
     // true stereo: outL = conv0(L) + conv2(R) ; outR = conv1(L) + conv3(R)  (ConvolverNode.cs:127-144)
     for (auto& kv : tsTemps) {

@@ -663,6 +663,56 @@ ConvRowRef Context::addGroupRow(const std::shared_ptr<IrSpectra>& ir, int ch, in
 // Decide, for convolver nodes that do not have DSP state yet, which formulation serves them: nodes sharing an impulse
 // response with at least 7 others become rows of the shared-IR GEMM (A); nodes with a (nearly) private IR use the
 // per-node formulation (B), whose state is O(P) per input channel instead of O(P * 128 rows) per IR channel.
+// Which convolvers have to be evaluated in the reference's own order (formulation R, launch_refmac)?  Every device formulation of
+// the partition sum (A/B: matrix-core fma chains, C: FFT along the block axis, D: coarse partitions) associates the reference's
+// sequential float32 sum differently, so a convolver's output differs from the reference's in its last bits (~1e-7 relative).
+// That is far inside the 1e-5 contract -- unless something downstream amplifies or quantises it:
+//  * a parameter input (AudioParam.cs:97-101,123-135): DelayNode turns the value into a sample index ((int)(delayTime * sampleRate),
+//    DelayNode.cs:66,86), StereoPannerNode compares it with the previous value (StereoPannerNode.cs:92-99), BiQuadFilterNode
+//    thresholds it (BiQuadFilterNode.cs:126) -- a last-bit difference moves a whole sample / a coefficient set;
+//  * a biquad whose direct-form-II recursion has a large round-off noise gain (a resonant section at a low cut-off frequency): two
+//    float32 evaluations whose inputs differ in the last bit decorrelate and differ by ~sqrt(2) x that noise (biquadDeviation).
+// A convolver is sensitive when its output reaches such a sink through any chain of nodes (mixes included: they are bit-exact on
+// the device).  One reverse sweep over the processing order, per chunk.
+void Context::refOrderSensitivity(const std::vector<int>& topo) {
+  bool anyConv = false;
+  for (int id : topo) anyConv = anyConv || (nodes[id]->type == GA_NODE_CONVOLVER && nodes[id]->ir);
+  if (!anyConv) return;
+  if (convRefOrder != 1) {
+    for (int id : topo)
+      if (nodes[id]->type == GA_NODE_CONVOLVER) nodes[id]->refSens = convRefOrder == 2;
+    return;
+  }
+  std::vector<char>& sens = refSensScratch;
+  sens.assign(nodes.size(), 0);
+  for (auto it = topo.rbegin(); it != topo.rend(); ++it) {   // consumers before producers
+    NodeS& nd = *nodes[*it];
+    bool s = false;
+    if (nd.type == GA_NODE_BIQUAD) {
+      bool moving = false;
+      for (auto& p : nd.params) moving = moving || !p.events.empty() || !p.modulation.empty();
+      if (moving) {
+        s = true;   // (coefficients on a timeline or modulated: no single noise gain to look at)
+      } else {
+        const float nyq = sampleRate / 2.f;
+        float f = nd.params[0].value;
+        f = f < 1.f ? 1.f : (f > nyq ? nyq : f);
+        const float q = std::max(0.001f, nd.params[1].value);
+        float o[5];
+        biquadCoefficients(nd.filterType, (float)sampleRate, f, q, nd.params[2].value, o);
+        s = biquadDeviation(o, 1) > convRefMinDeviation;
+      }
+    }
+    for (const OutputS& out : nd.outputs)
+      for (const InRef& r : out.connectedInputs) {
+        if (r.node < 0 || r.node >= (int)sens.size() || !nodes[r.node] || !nodes[r.node]->reachable) continue;
+        if (r.input < 0 || sens[r.node]) s = true;
+      }
+    sens[*it] = s ? 1 : 0;
+    if (nd.type == GA_NODE_CONVOLVER) nd.refSens = s;
+  }
+}
+
 void Context::assignConvPaths(const std::vector<int>& topo, int64_t chunkBlocks) {
   std::map<IrSpectra*, int> users;
   std::map<IrSpectra*, bool> hasA;
@@ -717,8 +767,9 @@ void Context::assignConvPaths(const std::vector<int>& topo, int64_t chunkBlocks)
     // a short chunk would pay the transforms of the whole input history for a few blocks of output (the node keeps the
     // formulation it starts with: its state is formulation specific)
     const int coarseParts = (int)(((int64_t)ir->P * kBlock + kCoarseBlock - 1) / kCoarseBlock);
-    const bool pathD = useCoarse && useTimeFft && ir->P > 64 && coarseParts <= kCoarseMaxP && chunkBlocks >= coarseMinBlocks;
-    const bool pathA = !pathC && !pathD && (hasA[ir] || users[ir] >= 8);
+    // (a node that has to be evaluated in the reference's order takes the B / C state layout, which formulation R shares)
+    const bool pathD = !nd.refSens && useCoarse && useTimeFft && ir->P > 64 && coarseParts <= kCoarseMaxP && chunkBlocks >= coarseMinBlocks;
+    const bool pathA = !nd.refSens && !pathC && !pathD && (hasA[ir] || users[ir] >= 8);
     if (pathD) {
       nd.bInCh = nd.isTrueStereo ? 2 : channels;
       nd.bSlots = nd.isTrueStereo ? 4 : channels;
@@ -756,20 +807,15 @@ void Context::assignConvPaths(const std::vector<int>& topo, int64_t chunkBlocks)
 // ------------------------------------------------------------------------------------------------------
 // BiQuadFilterNode.UpdateCoefficients (BiQuadFilterNode.cs:149-258), float32, host libm
 // ------------------------------------------------------------------------------------------------------
-void Context::updateBiquadCoefficients(NodeS& n, float frequency, float q, float gain) {
-  // The reference recomputes the coefficients at sample 0 of every block (BiQuadFilterNode.cs:111-126: its "last" values are
-  // never updated) -- with unchanged parameters that is the same arithmetic on the same inputs: remember the result.
-  if (n.coefMemoValid && n.coefMemoType == n.filterType && n.coefMemoIn[0] == frequency && n.coefMemoIn[1] == q && n.coefMemoIn[2] == gain) {
-    n.b0 = n.coefMemoOut[0]; n.b1 = n.coefMemoOut[1]; n.b2 = n.coefMemoOut[2]; n.a1 = n.coefMemoOut[3]; n.a2 = n.coefMemoOut[4];
-    return;
-  }
+// the RBJ table itself (BiQuadFilterNode.cs:149-258), float32, host libm: o = {b0, b1, b2, a1, a2} / a0
+void biquadCoefficients(int filterType, float sampleRate, float frequency, float q, float gain, float o[5]) {
   const float PI = 3.14159274f;
   float w0 = 2.f * PI * frequency / sampleRate;
   float cosW0 = std::cos(w0);
   float sinW0 = std::sin(w0);
   float alpha = sinW0 / (2.f * q);
   float a0, A1, A2, B0, B1, B2;
-  switch (n.filterType) {
+  switch (filterType) {
     case GA_FILTER_LOWPASS:
       B0 = (1.f - cosW0) / 2.f; B1 = 1.f - cosW0; B2 = (1.f - cosW0) / 2.f;
       a0 = 1.f + alpha; A1 = -2.f * cosW0; A2 = 1.f - alpha;
@@ -824,11 +870,26 @@ void Context::updateBiquadCoefficients(NodeS& n, float frequency, float q, float
       B0 = 1.f; B1 = 0.f; B2 = 0.f; a0 = 1.f; A1 = 0.f; A2 = 0.f;
       break;
   }
-  n.b0 = B0 / a0;
-  n.b1 = B1 / a0;
-  n.b2 = B2 / a0;
-  n.a1 = A1 / a0;
-  n.a2 = A2 / a0;
+  o[0] = B0 / a0;
+  o[1] = B1 / a0;
+  o[2] = B2 / a0;
+  o[3] = A1 / a0;
+  o[4] = A2 / a0;
+}
+void Context::updateBiquadCoefficients(NodeS& n, float frequency, float q, float gain) {
+  // The reference recomputes the coefficients at sample 0 of every block (BiQuadFilterNode.cs:111-126: its "last" values are
+  // never updated) -- with unchanged parameters that is the same arithmetic on the same inputs: remember the result.
+  if (n.coefMemoValid && n.coefMemoType == n.filterType && n.coefMemoIn[0] == frequency && n.coefMemoIn[1] == q && n.coefMemoIn[2] == gain) {
+    n.b0 = n.coefMemoOut[0]; n.b1 = n.coefMemoOut[1]; n.b2 = n.coefMemoOut[2]; n.a1 = n.coefMemoOut[3]; n.a2 = n.coefMemoOut[4];
+    return;
+  }
+  float o[5];
+  biquadCoefficients(n.filterType, (float)sampleRate, frequency, q, gain, o);
+  n.b0 = o[0];
+  n.b1 = o[1];
+  n.b2 = o[2];
+  n.a1 = o[3];
+  n.a2 = o[4];
   n.coefMemoValid = true;
   n.coefMemoType = n.filterType;
   n.coefMemoIn[0] = frequency; n.coefMemoIn[1] = q; n.coefMemoIn[2] = gain;

@@ -291,6 +291,10 @@ struct NodeS {
   // the leader's output slabs carry the sum, the other members contribute no time-domain signal of their own
   int dLeader = -1;
   int dGroupSize = 0;   // (on a leader) members of its fused group in this chunk, itself included
+  // formulation R (the reference's own order and arithmetic, launch_refmac): refSens = the output reaches arithmetic that amplifies
+  // or quantises last-bit differences (Context::refOrderSensitivity, per chunk); refOrder = this chunk evaluates the node that way
+  // (nodes on the B / C state layout: spectra history + overlap, which R shares)
+  bool refSens = false, refOrder = false;
 };
 
 // A vector with inline room for N elements (heap only beyond): the per-node, per-segment records of the control-plane
@@ -487,6 +491,8 @@ struct ChunkRun;   // ga_chunk.cpp
 struct NodePlanCtx;   // ga_chunk.cpp
 struct ConvPlanCtx;   // ga_chunk.cpp
 
+void biquadCoefficients(int filterType, float sampleRate, float frequency, float q, float gain, float o[5]);   // BiQuadFilterNode.cs:149-258
+
 struct Context {
   int sampleRate;
   int device = 0;
@@ -627,6 +633,7 @@ struct Context {
 
   std::shared_ptr<IrSpectra> irSpectra(int bufId, bool normalize);
   void releaseConvState(NodeS& n);
+  void refOrderSensitivity(const std::vector<int>& topo);
   void assignConvPaths(const std::vector<int>& topo, int64_t chunkBlocks);
   // formulation D
   // Option `coarse_overlap` (default 0): run the forward transforms and the multiply-accumulate CONCURRENTLY -- the signals
@@ -654,6 +661,9 @@ struct Context {
   hipEvent_t dJoinEv = nullptr;
   bool coarseOverlap = false;
   bool coarseTail = true;    // option "coarse_tail": outputs carry their tails from chunk to chunk (0: input histories only)
+  int convRefOrder = 1;               // option "conv_reference_order": 0 = never, 1 = where refOrderSensitivity() asks for it, 2 = every convolver
+  double convRefMinDeviation = 2.5e-6;  // option "conv_ref_min_deviation": a downstream biquad counts as sensitive above this predicted deviation
+  std::vector<char> refSensScratch;
   bool coarseTailPrivate = false;  // option "coarse_tail_private": also groups whose members have impulse responses of their own (measured: the forward
                                    // stage saves P' - 1 windows per signal, the multiply-accumulate and inverse stages pay for the tail blocks -- 2.95 vs 2.97 ms at
                                    // 1024 voices per 10 s step, 0.50 vs 0.43 ms at 64 voices per 2.5 s call: off)
@@ -719,7 +729,7 @@ struct Context {
   void planBiquad(NodePlanCtx& k);
   void chunkPlanConvolvers(ChunkRun& r, int depth);
   void planConvolversShared(ChunkRun& r, int depth, ConvPlanCtx& k);    // formulation A groups
-  void planConvolversPrivate(ChunkRun& r, int depth, ConvPlanCtx& k);   // formulations B / C
+  void planConvolversPrivate(ChunkRun& r, int depth, ConvPlanCtx& k, bool refOrder);   // formulations B / C, and R on their state layout
   void chunkDelayCommit(ChunkRun& r);
   void chunkExecute(ChunkRun& r);
   void chunkCommit(ChunkRun& r);

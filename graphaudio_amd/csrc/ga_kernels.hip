@@ -756,6 +756,127 @@ void launch_spectral_mac_b(hipStream_t s, const ConvSetB* sets_dev, int nsets, i
   }
 }
 
+// =====================================================================================================
+//  Reference-order partition sum (formulation R): PartitionedConvolver.ProcessSpectralConvolution
+//  (PartitionedConvolver.cs:154-223) evaluated EXACTLY as the reference evaluates it -- for every (row, block t, bin k)
+//      acc = 0 ;  for p = 0 .. P-1:  acc.re += (X.re * H.re) - (X.im * H.im) ;  acc.im += (X.re * H.im) + (X.im * H.re)
+//  with X = X[t - p][k], H = H[p][k], every operation a separately rounded float32 operation (the reference's AVX
+//  Multiply / Subtract / Add and its scalar tail: no fused multiply-add anywhere) and the partitions in ascending order.
+//  All (t, k) chains are independent: only the order INSIDE a chain is serial.  Around it run the double-precision
+//  256-point transforms of the B layout (rfft_fwd_b_kernel<double> / irfft_ola_b_kernel<double>), so a convolver served by
+//  this route reproduces the reference's float32 output bit for bit (up to the ~1e-9 chance per value that two correct
+//  double-precision transforms round to different floats).  The planner takes it for convolvers whose output reaches
+//  arithmetic that amplifies or quantises last-bit differences (Context::refOrderSensitivity).
+//
+//  Workgroup = (set, bin, tile of 1024 blocks), 4 waves; lane l of wave w owns the four consecutive blocks
+//  t0 + 256 w + 4 l + {0..3}.  The window X[t0 - (Ps-1) .. t0 + 1023] of the bin and the taps H[p] sit in LDS as separate
+//  re / im float arrays: per 4 taps a lane reads ONE aligned 16-byte quad of each (consecutive lanes: consecutive quads, no
+//  bank conflict) and the taps by broadcast; the window slides through registers (two quads cover four taps x four blocks).  128 VALU operations per 4 LDS reads; taps beyond 1024 in further segments, accumulators carried.
+// =====================================================================================================
+constexpr int RM_TW = 1024;     // blocks per workgroup
+constexpr int RM_PSEG = 1024;   // taps per segment
+
+__device__ __forceinline__ void rm_cmac(float& ar, float& ai, float dr, float di, float hr, float hi) {
+  // (dr * ir) - (di * ii) ; (dr * ii) + (di * ir) ; acc += ...   PartitionedConvolver.cs:196-206,218-219
+  const float re = __fsub_rn(__fmul_rn(dr, hr), __fmul_rn(di, hi));
+  const float im = __fadd_rn(__fmul_rn(dr, hi), __fmul_rn(di, hr));
+  ar = __fadd_rn(ar, re);
+  ai = __fadd_rn(ai, im);
+}
+
+__global__ __launch_bounds__(256) void refmac_kernel(const ConvSetB* __restrict sets, int nblocks, int hist, ConvPlanesB pl) {
+  // w[i] <-> block  b0 + i ,  b0 = t0 - pa - (Ps4 - 1):  output block t0 + T + r needs, for tap pa + pp,  w[c + r - pp],  c = T + Ps4 - 1
+  __shared__ __attribute__((aligned(16))) float wr[RM_TW + RM_PSEG + 4];
+  __shared__ __attribute__((aligned(16))) float wi[RM_TW + RM_PSEG + 4];
+  __shared__ __attribute__((aligned(16))) float hrs[RM_PSEG];
+  __shared__ __attribute__((aligned(16))) float his[RM_PSEG];
+  const ConvSetB* __restrict Sp = &sets[blockIdx.z];
+  const int Sx = Sp->x, Sy0 = Sp->y0, ncol = Sp->ncol, P = Sp->P;
+  const int k = blockIdx.y;
+  const int t0 = blockIdx.x * RM_TW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int T = wave * 256 + 4 * lane;
+  const GA_GLOBAL float* xr = gptr(pl.xr + ((size_t)Sx * kBins + k) * pl.tx);
+  const GA_GLOBAL float* xi = gptr(pl.xi + ((size_t)Sx * kBins + k) * pl.tx);
+  const bool oneSeg = P <= RM_PSEG;
+  for (int j = 0; j < ncol; j++) {
+    const GA_GLOBAL float* hr = gptr(Sp->hr[j] + (size_t)k * P);
+    const GA_GLOBAL float* hi = gptr(Sp->hi[j] + (size_t)k * P);
+    float ar[4] = {0.f, 0.f, 0.f, 0.f}, ai[4] = {0.f, 0.f, 0.f, 0.f};   // Array.Clear(_accReal / _accImag), :157-158
+    for (int pa = 0; pa < P; pa += RM_PSEG) {
+      const int Ps = min(RM_PSEG, P - pa);
+      const int Ps4 = (Ps + 3) & ~3;   // (taps beyond Ps are zero: they add (+-)0 to the sums, which leaves every finite sum as it is)
+      __syncthreads();
+      for (int p = tid; p < Ps4; p += 256) {
+        hrs[p] = p < Ps ? hr[pa + p] : 0.f;
+        his[p] = p < Ps ? hi[pa + p] : 0.f;
+      }
+      if (!(oneSeg && j > 0)) {   // (one segment: the window is the same for every column)
+        const int b0 = t0 - pa - (Ps4 - 1);
+        const int wlen = RM_TW + Ps4 + 3;   // (+ 4: the unused tail of the newest quad)
+        for (int i = tid; i < wlen; i += 256) {
+          const int blk = b0 + i;   // plane index of block t is hist + t ; outside [-hist, nblocks): zero
+          float vr = 0.f, vi = 0.f;
+          if (blk >= -hist && blk < nblocks) {
+            vr = xr[hist + blk];
+            vi = xi[hist + blk];
+          }
+          wr[i] = vr;
+          wi[i] = vi;
+        }
+      }
+      __syncthreads();
+      if (t0 + T < nblocks) {
+        // quad Q_q = w[c - 4 q - 3 .. c - 4 q] (aligned: c == 3 mod 4).  Tap 4 q + s reads, for output r, w[c + r - 4 q - s]:
+        //   s = 0: (Q_q.w, Q_{q-1}.x, .y, .z)   s = 1: (Q_q.z, Q_q.w, Q_{q-1}.x, .y)   s = 2: (Q_q.y, .z, .w, Q_{q-1}.x)   s = 3: Q_q
+        int qi = T + Ps4;
+        float4 pr = *reinterpret_cast<const float4*>(&wr[qi]);   // Q_{-1}: the three blocks behind the lane's first one
+        float4 pi = *reinterpret_cast<const float4*>(&wi[qi]);
+        for (int q = 0; q < Ps4; q += 4) {
+          qi -= 4;
+          const float4 cr = *reinterpret_cast<const float4*>(&wr[qi]);
+          const float4 ci = *reinterpret_cast<const float4*>(&wi[qi]);
+          const float4 gr = *reinterpret_cast<const float4*>(&hrs[q]);   // (broadcast reads)
+          const float4 gi = *reinterpret_cast<const float4*>(&his[q]);
+          rm_cmac(ar[0], ai[0], cr.w, ci.w, gr.x, gi.x);
+          rm_cmac(ar[1], ai[1], pr.x, pi.x, gr.x, gi.x);
+          rm_cmac(ar[2], ai[2], pr.y, pi.y, gr.x, gi.x);
+          rm_cmac(ar[3], ai[3], pr.z, pi.z, gr.x, gi.x);
+          rm_cmac(ar[0], ai[0], cr.z, ci.z, gr.y, gi.y);
+          rm_cmac(ar[1], ai[1], cr.w, ci.w, gr.y, gi.y);
+          rm_cmac(ar[2], ai[2], pr.x, pi.x, gr.y, gi.y);
+          rm_cmac(ar[3], ai[3], pr.y, pi.y, gr.y, gi.y);
+          rm_cmac(ar[0], ai[0], cr.y, ci.y, gr.z, gi.z);
+          rm_cmac(ar[1], ai[1], cr.z, ci.z, gr.z, gi.z);
+          rm_cmac(ar[2], ai[2], cr.w, ci.w, gr.z, gi.z);
+          rm_cmac(ar[3], ai[3], pr.x, pi.x, gr.z, gi.z);
+          rm_cmac(ar[0], ai[0], cr.x, ci.x, gr.w, gi.w);
+          rm_cmac(ar[1], ai[1], cr.y, ci.y, gr.w, gi.w);
+          rm_cmac(ar[2], ai[2], cr.z, ci.z, gr.w, gi.w);
+          rm_cmac(ar[3], ai[3], cr.w, ci.w, gr.w, gi.w);
+          pr = cr;
+          pi = ci;
+        }
+      }
+    }
+    const int t = t0 + T;
+    if (t < nblocks) {   // (t is a multiple of 4 and so is the planes' pitch: the quad stays inside the row)
+      float* __restrict yr = pl.yr + ((size_t)(Sy0 + j) * kBins + k) * pl.ty;
+      float* __restrict yi = pl.yi + ((size_t)(Sy0 + j) * kBins + k) * pl.ty;
+      *reinterpret_cast<float4*>(yr + t) = make_float4(ar[0], ar[1], ar[2], ar[3]);
+      *reinterpret_cast<float4*>(yi + t) = make_float4(ai[0], ai[1], ai[2], ai[3]);
+    }
+  }
+}
+void launch_refmac(hipStream_t s, const ConvSetB* sets_dev, int nsets, int nblocks, int hist, ConvPlanesB pl) {
+  if (nsets <= 0 || nblocks <= 0) return;
+  const int ntt = (nblocks + RM_TW - 1) / RM_TW;
+  for (int z0 = 0; z0 < nsets; z0 += 32768) {   // gridDim.z limit
+    const int nz = std::min(32768, nsets - z0);
+    hipLaunchKernelGGL(refmac_kernel, dim3(ntt, kBins, nz), dim3(256), 0, s, sets_dev + z0, nblocks, hist, pl);
+  }
+}
+
 // inverse + overlap-add, B layout: workgroup = (y-row, run of 32 blocks).  All 33 inverse transforms of the run (the extra
 // one recovers the tail of the block before the run) are independent: 4 waves x 2 batches of 4, and the 33rd alone on one
 // wave.  Heads and tails land in LDS, then

@@ -92,6 +92,9 @@ struct HistJobB {          // history save / restore of one x-row: kBins runs of
 };
 void launch_rfft_fwd_b(hipStream_t s, const ConvRowIO* xrows_dev, int nx, int nblocks, int hist, ConvPlanesB pl, Twiddles tw, bool fp64);
 void launch_spectral_mac_b(hipStream_t s, const ConvSetB* sets_dev, int nsets, int nblocks, int hist, ConvPlanesB pl);
+// the same partition sum in the reference's own order and arithmetic (formulation R: every product and sum a separately rounded
+// float32 operation, partitions ascending -- PartitionedConvolver.cs:154-223); bit-exact with the reference, ~50x the time
+void launch_refmac(hipStream_t s, const ConvSetB* sets_dev, int nsets, int nblocks, int hist, ConvPlanesB pl);
 void launch_irfft_ola_b(hipStream_t s, const ConvRowIO* yrows_dev, int ny, int nblocks, ConvPlanesB pl,
                         const float* const* overlap_in_dev, float* const* overlap_out_dev, Twiddles tw, bool fp64);
 void launch_hist_copy_b(hipStream_t s, const HistJobB* jobs_dev, int njobs, int max_n);

@@ -117,6 +117,9 @@ typedef struct ga_stats {
   int64_t deferred_handovers;   /* asynchronous renders whose bus crossed PCIe inside the next chunk's pre-mix launch (option
                                    "host_defer") instead of at the end of their own last kernel */
   int64_t biquad_split_cascades; /* (cascade x channel, segment) pairs evaluated in pieces along time (option "biquad_time_split") */
+  int64_t ref_order_rows;       /* (convolver channel-instance, chunk) pairs whose partition sum was evaluated in the reference's own
+                                   order and float32 arithmetic between double-precision transforms (formulation R, option
+                                   "conv_reference_order"): PartitionedConvolver.cs:104-223 bit for bit */
 } ga_stats;
 enum {
   GA_STAGE_OTHER = 0,        /* sources, biquads, gains, parameter curves, ... */

@@ -19,7 +19,11 @@ REGRESSION_SEEDS = [215, 219, 357, 430, 459, 749, 1232, 1273, 1476, 2550, 2577, 
                     # exact zeros) is one of two connections of a biquad whose other source ended -- the delay's output flag
                     20256, 22316,
                     # a panner whose pan modulation falls silent inside a chunk (seeds >= 30000: chain signals into parameters of later chains)
-                    30941] + list(range(30000, 30012)) + list(range(40000, 40010))   # (>= 40000: splitter outputs / merger inputs cross-connected by index)
+                    30941,
+                    # round 4: documented above the 1e-5 contract in round 3 (2.6e-5: a peaking filter at 104 Hz, Q 2.1, behind a convolver;
+                    # 5.7e-5: a DelayNode's delay time modulated by a convolver's output) -- the planner now evaluates such convolvers in
+                    # the reference's own order (formulation R, tests/test_gpu_reforder.py); 23930 / 24413 / 24797 / 11679: the same class at 2e-6 .. 6e-6
+                    22879, 40542, 23930, 24413, 24797, 11679] + list(range(30000, 30012)) + list(range(40000, 40010))   # (>= 40000: splitter outputs / merger inputs cross-connected by index)
 
 
 # coarse = 1: convolvers with more than 64 partitions are forced onto formulation D (coarse partitions) even though the pieces are
@@ -83,7 +87,9 @@ def _session_pair(seed, chunk=11, coarse=0):
 @pytest.mark.parametrize("coarse", [0, 1, 2, 3, 4])   # 2: D without carried tails; 3: D without the time-domain pre-mix; 4: tails for private IRs too
 # 2573: a ramp on a biquad's frequency -- the per-block coefficients are evaluated on the device, where cos / sin / pow have to be
 #       rounded once from double like the C library's cosf / sinf / powf behind MathF (7.9e-6 -> 2.7e-9)
-@pytest.mark.parametrize("seed", list(range(60)) + [2850, 2573, 20284] + list(range(20000, 20012)) + list(range(30000, 30006)) + list(range(40000, 40006)))
+# 25085 (3.2e-5 in round 3: a biquad fed by a convolver and a source) and 5761 (a notch at 153 Hz, Q 2.5, behind a convolver: 9.4e-6):
+#       convolvers in front of resonant biquads take the reference-order route (formulation R) since round 4
+@pytest.mark.parametrize("seed", list(range(60)) + [2850, 2573, 20284, 25085, 5761] + list(range(20000, 20012)) + list(range(30000, 30006)) + list(range(40000, 40006)))
 def test_random_edit_session_matches_oracle(seed, coarse):
     """The graph is edited between render pieces (parameter writes, automation, stop, new voices, dispose, rewiring,
     impulse-response swaps, audio-rate modulation, channel settings): same output and the same exceptions."""
