@@ -124,6 +124,75 @@ def build_config5(ctx, sources, v0, taps, loop_frames, G, channels=16):
     return channels
 
 
+def build_config2(ctx, voices, loop_frames, G):
+    """BASELINE.json configs[1]: voices -> BiQuadFilterNode (lowpass, f = 200 * 2^(v/32) Hz capped at 20 kHz, Q 0.707) -> Gain(1/16) ->
+    mono mix (SURVEY.md 8d "Config 2"); the voices loop over one step like the headline's"""
+    from graphaudio_amd import AudioBufferSourceNode, BiQuadFilterNode, FilterType, GainNode, PlayableAudioBuffer
+    ctx.Destination.SetChannelCount(1)
+    for v in range(voices):
+        s = AudioBufferSourceNode(ctx)
+        s.Buffer = PlayableAudioBuffer.FromMonoArray(voice(G, v, loop_frames), SR)
+        s.Loop = True
+        bq = BiQuadFilterNode(ctx)
+        bq.Type = FilterType.Lowpass
+        bq.Frequency.Value = min(20000.0, 200.0 * 2.0 ** (v / 32.0))
+        bq.Q.Value = 0.707
+        g = GainNode(ctx)
+        g.Gain.Value = 1.0 / 16.0
+        bq.Inputs[0].SetChannelCount(1)
+        g.Inputs[0].SetChannelCount(1)
+        s.Connect(bq).Connect(g).Connect(ctx.Destination)
+        s.Start()
+    return 1
+
+
+def build_config4(ctx, voices, total_frames, G, distinct=64, src_sr=44100):
+    """BASELINE.json configs[3] whole on one GPU: voices at 44.1 kHz -> CubicResampler (rate 0.91875) -> 5-band biquad EQ -> gain
+    automation -> mix (SURVEY.md 8d "Config 4", tests/_graphs.py::config4_eq).  The voices play through (a looping resampled source
+    takes the general-replay path, not the one the configuration names), so the buffers cover every step of the run; to keep 4096 x
+    17 s of noise out of the host's memory the voices share `distinct` buffers (voice v plays buffer v mod distinct) -- every voice
+    still is a source node with its own resampler, equaliser and gain curve: the device work is that of 4096 distinct voices."""
+    from graphaudio_amd import AudioBufferSourceNode, BiQuadFilterNode, FilterType, GainNode, PlayableAudioBuffer
+    n_in = int(total_frames * src_sr / SR) + 2048
+    bufs = [PlayableAudioBuffer.FromMonoArray(G.voice(v, n_in), src_sr) for v in range(min(distinct, voices))]
+    bands = [(FilterType.Lowshelf, 100.0, 1.0, 6.0), (FilterType.Peaking, 400.0, 1.0, -6.0), (FilterType.Peaking, 1000.0, 1.0, 6.0),
+             (FilterType.Peaking, 4000.0, 1.0, -6.0), (FilterType.Highshelf, 10000.0, 1.0, 6.0)]
+    for v in range(voices):
+        s = AudioBufferSourceNode(ctx)
+        s.Buffer = bufs[v % len(bufs)]
+        node = s
+        for (ft, f, q, gdb) in bands:
+            bq = BiQuadFilterNode(ctx)
+            bq.Type = ft
+            bq.Frequency.Value = f
+            bq.Q.Value = q
+            bq.Gain.Value = gdb
+            node = node.Connect(bq)
+        g = GainNode(ctx)
+        g.Gain.SetValueAtTime(0.0, 0.0)
+        g.Gain.LinearRampToValueAtTime(1.0 / 64.0, 0.5)
+        g.Gain.SetTargetAtTime(0.0, 8.0, 0.3)
+        node.Connect(g).Connect(ctx.Destination)
+        s.Start()
+    return 2
+
+
+# the serial recurrences are latency bound, not bandwidth bound (SURVEY.md 8d): the bound that applies is the dependent-operation
+# chain of the reference's direct-form-II section,  w = (x - a1 * w1) - a2 * w2  (BiQuadFilterNode.cs:136-141): from w[n-1] to w[n]
+# one multiply and two subtractions that cannot overlap, at the measured latency of a dependent float32 operation
+DEP_OP_NS = 3.46   # profiles/r01_micro_dependent_valu_latency.txt: "dependent mul -> add", 8.25 cycles at 2.39 GHz
+DEP_OPS_PER_SAMPLE = 3
+
+
+def serial_bound(frames, kernel_ms, note):
+    bound_ms = frames * DEP_OPS_PER_SAMPLE * DEP_OP_NS * 1e-6
+    return {"bound": "dependent-operation latency of one cascade walked sample by sample (every cascade in parallel; the sections of a "
+                     "cascade pipelined across lanes): frames x 3 dependent float32 operations (mul, sub, sub of the direct-form-II "
+                     "recursion, BiQuadFilterNode.cs:136-141) x 3.46 ns (profiles/r01_micro_dependent_valu_latency.txt)",
+            "chain_ops_per_sample": DEP_OPS_PER_SAMPLE, "dependent_op_ns": DEP_OP_NS, "frames_per_step": frames,
+            "bound_ms_per_step": bound_ms, "kernel_ms_per_step": kernel_ms, "frac": bound_ms / kernel_ms if kernel_ms else None, "note": note}
+
+
 def _cpu_name():
     try:
         for line in open("/proc/cpuinfo"):
@@ -210,6 +279,7 @@ def cpu_baseline_and_parity(voices, taps, G, args, all_cores):
                         "rendered as one call and as 256 + the remaining blocks"}
     base = {
         "value": fps1, "unit": "frames/s", "cores": 1, "kind": "port",
+        "build": "oracle/Makefile: g++ -std=c++17 -O3 -mavx2 -ffp-contract=off -fno-fast-math (SURVEY.md 8d names -O2: -O3 is the faster CPU number)",
         "sample": f"all {voices} voices x {blocks - 1} blocks of the bench graph ({taps}-tap stereo IR, 1 s short form), "
                   f"{dt1:.1f} s on one thread, unscaled",
         "all_cores": all_cores,
@@ -332,6 +402,7 @@ def attach_pmc_traffic(roof, profile_json):
             nec = k.get("necessary_gb_per_launch (stage, planner)")
             if name.split("<")[0] in roof["kernel"] and nec and abs(nec * 1e9 / roof["necessary_bytes_per_launch"] - 1.0) < 0.02 and k.get("pmc_total_x2_gb"):
                 roof["traffic"] = k["pmc_total_x2_gb"] * 1e9
+                roof["traffic_measured_in_this_run"] = False   # (a committed measurement of the same command; counters need their own passes)
                 roof["traffic_source"] = (os.path.relpath(profile_json, ROOT) + ": rocprofv3 --pmc FETCH_SIZE (x 2: gfx950 correction) + WRITE_SIZE, "
                                           "separate passes of `" + str(prof.get("command", "bench.py")).strip() + "`, bytes per launch")
                 break
@@ -400,7 +471,31 @@ def precompute_truths(args, frames, voices_total):
     return out
 
 
-def run_variant(name, torch, G, frames, steps, warmup, build, channels, options, describe, truth=None):
+def oracle_short_form(build, channels, frames, options=None):
+    """the CPU oracle (one thread) and the device on the short form of a variant's graph: (frames/s of the oracle, rms error, bus rms)"""
+    from graphaudio_amd import OfflineAudioContext
+    from tests import _graphs as G
+    from tests._oracle import OracleContext
+    o = OracleContext(SR)
+    build(o)
+    ref = np.zeros((channels, frames), np.float32)
+    o.Render(ref, 128)
+    t0 = time.perf_counter()
+    o.Render(ref, frames - 128, 128)
+    dt = time.perf_counter() - t0
+    o.Dispose()
+    h = OfflineAudioContext(SR)
+    for k, v in (options or {}).items():
+        h.SetOption(k, v)
+    build(h)
+    got = np.zeros_like(ref)
+    h.Render(got, frames)
+    st = h.GetStats()
+    h.Dispose()
+    return (frames - 128) / dt, dt, G.rms(ref - got), G.rms(ref), st
+
+
+def run_variant(name, torch, G, frames, steps, warmup, build, channels, options, describe, truth=None, extra=None):
     """one more measurement on a context of its own: same step loop, same stage table, its own dominant kernel"""
     from graphaudio_amd import OfflineAudioContext
     from tests import _f64model as M
@@ -432,6 +527,8 @@ def run_variant(name, torch, G, frames, steps, warmup, build, channels, options,
         ref = truth()
         err, sig = M.rms(out - ref), M.rms(ref)
         rec["timed_step_rms_vs_f64"] = {"rms_abs": err, "rms_relative_to_bus": err / sig, "bus_rms": sig, "tolerance_rms_abs": 1e-5}
+    if extra is not None:
+        rec.update(extra(rec, st0, st1))
     ctx.Dispose()
     del host
     return rec
@@ -559,8 +656,14 @@ def main():
     check = not args.no_check and not args.no_profile
     xsum = np.zeros(frames, np.float64) if check and not args.private_ir else None
     build_graph(ctx, v1 - v0, v0, args.taps, frames, G, private=args.private_ir, xsum=xsum)
+    comm_info = None
     if use_reduce:
         init_sharded(ctx, rank, world)
+        # what RCCL itself says (ncclCommCount / ncclCommUserRank): a run whose ranks did not join ONE communicator of `world` ranks
+        # is not an N-GPU measurement, whatever WORLD_SIZE says
+        comm_info = ctx.CommInfo()
+        if comm_info["ranks"] != world or comm_info["rank"] != rank or (world > 1 and not comm_info["uses_rccl"]):
+            sys.exit(f"bench.py: rank {rank}: the communicator reports {comm_info}, expected {world} ranks")
 
     # the caller's output buffer is page-locked host memory (the D2H copy of the 3.8 MB bus is inside the timed region)
     host_pin = torch.zeros((2, frames), dtype=torch.float32).pin_memory()
@@ -639,6 +742,9 @@ def main():
                                       "note": "SURVEY.md 8(d) per-block streaming bytes of the reference's algorithm over the step time: "
                                               "the factor of traffic the executed formulation removes, not a roofline fraction"},
             "device_bytes_in_use": st1["device_bytes_in_use"],
+            # the communicator's own rank count (ga_comm_info -> ncclCommCount), checked against WORLD_SIZE on every rank above; null = no
+            # communicator in this run (one GPU).  No multi-GPU hardware was available to the builder: N > 1 is unmeasured until the driver runs it.
+            "comm": comm_info,
         }
         parity = {}
         if check and args.warmup + args.steps >= 2 and frames >= args.taps:
@@ -689,6 +795,43 @@ def main():
                 "BASELINE.json configs[4] whole on ONE GPU: 512 sources x 16-channel 32,768-tap private impulse responses -> 16-channel bus "
                 "(its 8-GPU form shards 64 sources per GPU)",
                 truth=(lambda: truths["config5_1gpu"]) if truths else None)
+            # ---- the latency-bound configurations (BASELINE.json configs[1], configs[3]) and the Kit scene, VERDICT r3 item 3
+            sf = int(2.5 * SR) // 128 * 128   # 2.5 s steps: these graphs play through (no looping), the buffers cover every step
+            ss, sw = 6, 2
+
+            def serial_extra(build_short, ch, short_frames, voices_n, what, bound_frames, options=None):
+                def extra(r, st0, st1):
+                    fps, dt, err, sig, _ = oracle_short_form(build_short, ch, short_frames, options)
+                    other = r["stages"].get("other", {}).get("ms_per_step", 0.0) + r["stages"].get("mix", {}).get("ms_per_step", 0.0)
+                    return {"parity_vs_oracle": {"rms_abs": err, "rms_relative_to_bus": err / max(sig, 1e-30), "bus_rms": sig, "tolerance_rms_abs": 1e-5,
+                                                 "sample": f"{voices_n} voices x {short_frames // 128} blocks (short form of this graph) vs the CPU oracle"},
+                            "cpu_baseline": {"value": fps, "unit": "frames/s", "cores": 1, "kind": "port",
+                                             "sample": f"{voices_n} voices x {short_frames // 128 - 1} blocks of this graph, {dt:.1f} s on one thread, unscaled"},
+                            "speedup_vs_cpu_1thread": r["frames_per_s"] / fps,
+                            "host_ms_vs_device_ms": {"host_issue_ms_per_step": r["host_issue_ms_per_step"], "device_ms_per_step": r["device_ms_per_step"]},
+                            "serial_bound": serial_bound(bound_frames, other, what)}
+                return extra
+            variants["config2_biquad"] = run_variant(
+                "config2_biquad", torch, G, frames, vs, vw, lambda c: build_config2(c, 256, frames, G), 1, {},
+                "BASELINE.json configs[1]: 256 mono voices -> BiQuadFilterNode (lowpass) -> Gain -> mono mix; latency bound, not bandwidth bound",
+                extra=serial_extra(lambda c: G.config2_biquad(c, voices=256, frames=SR + 256), 1, SR // 128 * 128, 256,
+                                   "the planner splits these well-conditioned low-passes along time (option biquad_time_split: pass A / scan / pass B "
+                                   "over G pieces, DESIGN.md section 4), which cuts the chain the bound is written for: frac > 1 says by how much",
+                                   frames))
+            variants["config4_eq_1gpu"] = run_variant(
+                "config4_eq_1gpu", torch, G, sf, ss, sw, lambda c: build_config4(c, 4096, sf * (ss + sw), G), 2, {},
+                "BASELINE.json configs[3] whole on ONE GPU: 4096 voices, 44.1 kHz -> CubicResampler -> 5-band biquad EQ -> gain automation -> mix "
+                "(its 8-GPU form shards 512 voices per GPU); 2.5 s steps of one continuing render; 64 distinct noise buffers shared by the voices",
+                extra=serial_extra(lambda c: G.config4_eq(c, voices=4096, frames=128 * 94), 2, 128 * 94, 4096,
+                                   "the planner refuses to split this equaliser (its 100 Hz low shelf carries ~1e-4 of round-off noise in the reference's "
+                                   "own arithmetic: any re-association leaves the 1e-5 contract, Context::biquadDeviation): one walk, five sections pipelined "
+                                   "across lanes (biquad_pipe_kernel<5>)", sf))
+            variants["kit_scene"] = run_variant(
+                "kit_scene", torch, G, sf, ss, sw, lambda c: G.kit_scene(c, voices=256, frames=sf * (ss + sw) + 256, taps=65536), 2, {},
+                "SURVEY.md 8(f) rank 4: 256 panned voices -> two buses (one fading) -> master -> ReverbEffect shape (dry / down-mix -> "
+                "65,536-tap convolver -> wet) -> destination; one post-mix convolver, launch bound; 2.5 s steps of one continuing render",
+                extra=serial_extra(lambda c: G.kit_scene(c, voices=256, frames=SR + 256, taps=65536), 2, SR // 128 * 128, 256,
+                                   "no serial recurrence in this graph: the entry only relates the elementwise stages' time to the same yardstick", sf))
             rec["variants"] = variants
         print(json.dumps(rec))
         sys.stdout.flush()

@@ -173,6 +173,8 @@ internal static unsafe partial class GraphAudioHip
     public static partial int ga_comm_init(IntPtr ctx, byte* id, int nRanks, int rank);   // collective
     [LibraryImport(Lib, EntryPoint = "ga_comm_destroy")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]
     public static partial int ga_comm_destroy(IntPtr ctx);
+    [LibraryImport(Lib, EntryPoint = "ga_comm_info")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]
+    public static partial int ga_comm_info(IntPtr ctx, out int nRanks, out int rank, out int usesRccl);   // what RCCL itself reports
     [LibraryImport(Lib, EntryPoint = "ga_shard_range")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]
     public static partial int ga_shard_range(long nVoices, int nRanks, int rank, out long first, out long count);
     [LibraryImport(Lib, EntryPoint = "ga_render_reduce")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]

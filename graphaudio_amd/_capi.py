@@ -162,6 +162,7 @@ SIGNATURES = {
     "comm_unique_id": (_i, [_vp]),
     "comm_init": (_i, [_vp, _vp, _i, _i]),
     "comm_destroy": (_i, [_vp]),
+    "comm_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "shard_range": (_i, [_i64, _i, _i, C.POINTER(_i64), C.POINTER(_i64)]),
     "render_reduce": (_i, [_vp, _pp, _i, _i64, _i64, _i]),
 }

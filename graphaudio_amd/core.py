@@ -676,6 +676,12 @@ class OfflineAudioContext(AudioContextBase):
     def CommDestroy(self):
         self._call("comm_destroy")
 
+    def CommInfo(self) -> dict:
+        """What the communicator itself reports (ncclCommCount / ncclCommUserRank), not what CommInit was told."""
+        n, r, u = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._call("comm_info", C.byref(n), C.byref(r), C.byref(u))
+        return {"ranks": n.value, "rank": r.value, "uses_rccl": bool(u.value)}
+
     def RenderReduce(self, output, frameCount: int, startIndex: int = 0, root: int = 0):
         """Render(output, frameCount, startIndex) of a voice-sharded graph: every rank renders its share, the destination
         buses are summed on the device (RCCL), `output` (per-channel float32 arrays) is written on `root` only."""

@@ -244,7 +244,9 @@ void Context::render(float* const* out, int channels, int64_t frameCount, int64_
       ~Target() { std::memset(c.busTarget, 0, sizeof(c.busTarget)); }
     } target{*this};
     // an asynchronous render into page-locked rows: the bus stays on the device and crosses PCIe under the next chunk's kernels
-    const bool defer = direct && !deviceOut && pipelined.callerAsync && hostDefer;
+    // (only on the context's OWN stream: a caller who supplied the stream (ga_context_set_stream) may wait on that stream or on an
+    // event of their own instead of calling ga_synchronize, and must then find the rows complete -- graphaudio_hip.h, "Pipelined rendering")
+    const bool defer = direct && !deviceOut && pipelined.callerAsync && hostDefer && ownStream;
     if (defer) {
       const size_t rowBytes = ((size_t)nblk * kBlock * sizeof(float) + 255) & ~(size_t)255;
       if (deferStageBytes < rowBytes * 32) {
@@ -931,6 +933,9 @@ int ga_comm_init(ga_context* ctx, const void* id, int n_ranks, int rank) {
 }
 int ga_comm_destroy(ga_context* ctx) {
   return guard(ctx, [&](Context& c) { c.commDestroy(); });
+}
+int ga_comm_info(ga_context* ctx, int* n_ranks, int* rank, int* uses_rccl) {
+  return guard(ctx, [&](Context& c) { c.commInfo(n_ranks, rank, uses_rccl); });
 }
 int ga_shard_range(int64_t n_voices, int n_ranks, int rank, int64_t* first, int64_t* count) {
   if (!first || !count) return GA_ERR_INVALID_ARGUMENT;

@@ -641,7 +641,10 @@ struct Sim {
         n_.outputs[0].zero = ns.ins[0].zero && !n_.everFed;   // zero input AND zero state
         ns.bqDynamic = !n_.params[0].events.empty() || !n_.params[1].events.empty() || !n_.params[2].events.empty() ||
                        !ns.pinSilent(0) || !ns.pinSilent(1) || !ns.pinSilent(2) ||   // a modulated parameter moves per sample
-                       n_.bqDynChunk;   // (went dynamic earlier in this chunk: the coefficient state lives on the device until the chunk ends)
+                       n_.bqDynChunk ||   // (went dynamic earlier in this chunk: the coefficient state lives on the device until the chunk ends)
+                       // the coefficient state is on the device and a signal is still connected to a parameter (silent right now):
+                       // the per-sample kernel serves constants too, and the state is not fetched back per chunk (Context::chunkTopology)
+                       (n_.coefOnDevice && (!n_.params[0].modulation.empty() || !n_.params[1].modulation.empty() || !n_.params[2].modulation.empty()));
         if (ns.bqDynamic && !ns.ins[0].silent) n_.bqDynChunk = true;
         if (!ns.ins[0].silent && ns.bqDynamic) {
           ns.bqActive = true;   // coefficients are refreshed per sample on the device
@@ -732,7 +735,8 @@ struct Sim {
         n_.outputs[0].silent = ns.ins[0].silent;
         n_.outputs[0].zero = ns.ins[0].zero;
         ns.panMode = ns.ins[0].bufCh == 1 ? 1 : 2;
-        if (!ns.ins[0].silent && (!n_.params[0].events.empty() || !ns.pinSilent(0) || n_.panDynChunk)) {
+        if (!ns.ins[0].silent && (!n_.params[0].events.empty() || !ns.pinSilent(0) || n_.panDynChunk ||
+                                  (n_.panOnDevice && !n_.params[0].modulation.empty()))) {   // (state on the device, a signal still connected: Context::chunkTopology)
           n_.panDynChunk = true;
           ns.panDyn = true;   // gains follow the a-rate curve on the device (stereo_panner_dynamic_kernel)
         } else if (!ns.ins[0].silent) {
@@ -2341,10 +2345,11 @@ void Context::chunkTopology(ChunkRun& r) {
     NodeS& nd = *nodes[id];
     if (nd.type == GA_NODE_STEREO_PANNER) nd.panDynChunk = false;
     if (nd.type == GA_NODE_BIQUAD) nd.bqDynChunk = false;
-    if (nd.type == GA_NODE_STEREO_PANNER && nd.panOnDevice && nd.params[0].events.empty()) {
+    // (while a signal is connected to the parameter the node stays on its per-sample kernel, which serves a silent modulation input
+    // as a constant too -- Sim::process -- so the state stays where it is: no stall of the pipeline per modulated node and chunk)
+    if (nd.type == GA_NODE_STEREO_PANNER && nd.panOnDevice && nd.params[0].events.empty() && nd.params[0].modulation.empty()) {
       PanState tmp;   // back to a constant pan: the gains the automated run left on the device are the node's state
-      GA_HIP(hipStreamSynchronize(stream));
-      if (asyncMode) GA_HIP(hipStreamSynchronize(stream));   // the state the previous chunk left
+      GA_HIP(hipStreamSynchronize(stream));   // the state the previous chunk left
       GA_HIP(hipMemcpy(&tmp, nd.panDev, sizeof(PanState), hipMemcpyDeviceToHost));
       nd.panLast = tmp.last_pan;
       nd.panGL = tmp.gain_l;
@@ -2353,11 +2358,10 @@ void Context::chunkTopology(ChunkRun& r) {
     }
     if (nd.type == GA_NODE_BIQUAD && nd.coefOnDevice && nd.bqDyn) {
       bool automated = false;
-      for (auto& p : nd.params) automated = automated || !p.events.empty();
+      for (auto& p : nd.params) automated = automated || !p.events.empty() || !p.modulation.empty();
       if (!automated) {  // back to constant parameters: fetch the coefficients the automated run left on the device
         BiquadDynState tmp;
         GA_HIP(hipStreamSynchronize(stream));
-        if (asyncMode) GA_HIP(hipStreamSynchronize(stream));
         GA_HIP(hipMemcpy(&tmp, nd.bqDyn, 24, hipMemcpyDeviceToHost));
         nd.b0 = tmp.b0; nd.b1 = tmp.b1; nd.b2 = tmp.b2; nd.a1 = tmp.a1; nd.a2 = tmp.a2;
         nd.coefDirty = tmp.dirty != 0;
@@ -3131,6 +3135,10 @@ void Context::planBiquad(NodePlanCtx& k) {
     dj.gval = nd.params[2].value;
     dj.channels = ns.outCh;
     dj.filter_type = nd.filterType;
+    if (nd.coefOnDevice && nd.coefDirty) {   // the Type setter ran while the coefficient state lives on the device: hand the flag over
+      dj.filter_type |= 0x100;
+      nd.coefDirty = false;
+    }
     dj.nyquist = sampleRate / 2.f;
     dj.sample_rate = (float)sampleRate;
     dj.state = nd.bqDyn;

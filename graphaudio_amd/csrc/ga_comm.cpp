@@ -36,6 +36,8 @@ struct Rccl {
   int (*Reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t) = nullptr;
   int (*CommAbort)(void*) = nullptr;                 // (optional: older libraries)
   int (*CommGetAsyncError)(void*, int*) = nullptr;   // (optional)
+  int (*CommCount)(void*, int*) = nullptr;           // (optional)
+  int (*CommUserRank)(void*, int*) = nullptr;        // (optional)
   const char* (*GetErrorString)(int) = nullptr;
   std::string error;
 };
@@ -58,6 +60,8 @@ Rccl& rccl() {
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
     r.CommAbort = (decltype(r.CommAbort))dlsym(r.lib, "ncclCommAbort");
     r.CommGetAsyncError = (decltype(r.CommGetAsyncError))dlsym(r.lib, "ncclCommGetAsyncError");
+    r.CommCount = (decltype(r.CommCount))dlsym(r.lib, "ncclCommCount");
+    r.CommUserRank = (decltype(r.CommUserRank))dlsym(r.lib, "ncclCommUserRank");
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.Reduce || !r.GetErrorString) r.error = "RCCL library lacks an expected symbol";
   });
   return r;
@@ -95,6 +99,20 @@ void Context::commInit(const void* id, int nRanks, int rank) {
   }
   commRanks = nRanks;
   commRank = rank;
+}
+
+// ncclCommCount / ncclCommUserRank of the live communicator (include/graphaudio_hip.h, ga_comm_info)
+void Context::commInfo(int* nRanks, int* rank, int* usesRccl) {
+  if (!nRanks || !rank || !usesRccl) fail(GA_ERR_INVALID_ARGUMENT, "null pointer");
+  *nRanks = 1;
+  *rank = 0;
+  *usesRccl = 0;
+  if (!comm) return;
+  Rccl& r = rccl();
+  if (!r.CommCount || !r.CommUserRank) fail(GA_ERR_UNSUPPORTED, "the RCCL library lacks ncclCommCount / ncclCommUserRank");
+  check(r, r.CommCount(comm, nRanks), "ncclCommCount");
+  check(r, r.CommUserRank(comm, rank), "ncclCommUserRank");
+  *usesRccl = 1;
 }
 
 // A rank that cannot take part in a collective its peers have already enqueued (its render failed) must not leave them waiting:
@@ -198,7 +216,7 @@ void Context::renderReduce(float* const* out, int channels, int64_t frames, int6
     if (isRoot) {
       // page-locked rows of an asynchronous caller: the sum crosses PCIe inside the next step's pre-mix launch (Context::pendingHandOver)
       float* devAlias[32];
-      bool locked = callerAsync && hostDefer && (frames % 4) == 0;
+      bool locked = callerAsync && hostDefer && ownStream && (frames % 4) == 0;   // (never on a caller-supplied stream, see Context::render)
       for (int ch = 0; ch < channels && locked; ch++) {
         hipPointerAttribute_t at{};
         if (hipPointerGetAttributes(&at, out[ch] + start) != hipSuccess || at.type != hipMemoryTypeHost || !at.devicePointer ||

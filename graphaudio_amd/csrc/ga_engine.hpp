@@ -751,6 +751,7 @@ struct Context {
   double commTimeoutS = 120.0;   // option "comm_timeout_s"
   void commInit(const void* id, int nRanks, int rank);
   void commDestroy();
+  void commInfo(int* nRanks, int* rank, int* usesRccl);
   void commAbort();
   void commWait();               // wait for the stream; a dead peer becomes an error code, not a hang
   void renderReduce(float* const* out, int channels, int64_t frames, int64_t start, int root);

@@ -2186,9 +2186,10 @@ __global__ __launch_bounds__(64) void biquad_dynamic_kernel(const BiquadDynJob* 
   const BiquadDynJob* __restrict job = &jobs[j];
   GA_GLOBAL BiquadDynState* st = gptr(job->state);
   float b0 = st->b0, b1 = st->b1, b2 = st->b2, a1 = st->a1, a2 = st->a2;
-  bool dirty = st->dirty != 0;
+  // (bit 8 of filter_type: the Type setter ran on the host while the state lived here -- _coefficientsDirty, BiQuadFilterNode.cs:24-36)
+  bool dirty = st->dirty != 0 || (job->filter_type & 0x100) != 0;
   const int C = job->channels;
-  const int type = job->filter_type;
+  const int type = job->filter_type & 0xFF;
   const float nyq = job->nyquist, sr = job->sample_rate;
   for (int64_t b = 0; b < job->nblocks; b++) {
     const int64_t f0 = (job->b0 + b) * kBlock;

@@ -253,13 +253,20 @@ GA_EXPORT int GA_FN(process_blocks)(ga_context* ctx, float* const* out_planar, i
 GA_EXPORT int GA_FN(process_blocks_interleaved)(ga_context* ctx, float* interleaved, int channels, int64_t block_count,
                                                 int out_on_device);
 
-/* Run the render on this HIP stream (a hipStream_t passed as void*) instead of the context's own stream. */
+/* Run the render on this HIP stream (a hipStream_t passed as void*) instead of the context's own stream.  On a caller-supplied
+   stream every render call enqueues ALL of its work, the copy into the caller's rows included, before it returns: the caller may
+   order later work behind it on the same stream, or wait on the stream / an event of their own, and finds the rows complete. */
 GA_EXPORT int GA_FN(context_set_stream)(ga_context* ctx, void* hip_stream);
 /* Pipelined rendering (no counterpart in the reference, whose Render is synchronous, OfflineAudioContext.cs:30-102): with
    ga_set_option(ctx, "async", 1) ga_render / ga_render_device return as soon as the work of the call is enqueued on the
    context's stream, so the host-side graph simulation of the next call overlaps the device execution of this one (the host
-   runs at most one chunk ahead).  Output arrays (page-locked host memory or device memory) are complete after
-   ga_synchronize, or after any later work on the same stream.  The default is synchronous, as in the reference. */
+   runs at most one chunk ahead).  When are the output arrays (page-locked host memory or device memory) complete?
+     * on a caller-supplied stream (ga_context_set_stream): after any later work on that stream, a wait on it, or ga_synchronize;
+     * on the context's own stream: after ga_synchronize ONLY.  With option "host_defer" (default 1) the bus of a render into
+       page-locked rows stays in device staging rows when the call returns and crosses PCIe inside the NEXT render call's first
+       long launch (or from ga_synchronize) -- the rows of call k are complete once call k + 1's stream work has finished, or
+       after ga_synchronize, not before.  Device-memory outputs (ga_render_device) are written by the call's own work.
+   The default is synchronous, as in the reference. */
 GA_EXPORT int GA_FN(synchronize)(ga_context* ctx);
 
 
@@ -278,6 +285,11 @@ GA_EXPORT int GA_FN(synchronize)(ga_context* ctx);
 GA_EXPORT int GA_FN(comm_unique_id)(void* id_out);   /* GA_COMM_ID_BYTES bytes; rank 0 calls it, every rank gets a copy */
 GA_EXPORT int GA_FN(comm_init)(ga_context* ctx, const void* id, int n_ranks, int rank);   /* collective over the ranks */
 GA_EXPORT int GA_FN(comm_destroy)(ga_context* ctx);
+/* What the communicator itself says about this context: the number of ranks RCCL sees (ncclCommCount) and this context's rank in it
+   (ncclCommUserRank) -- not what ga_comm_init was told.  A host (or a scaling benchmark) compares them with its own world size, so a
+   run in which the ranks did not join ONE communicator cannot pass as an N-GPU measurement.  Without a communicator (ga_comm_init was
+   never called, or n_ranks == 1: no RCCL involved) both come back as 1 / 0 and *uses_rccl = 0. */
+GA_EXPORT int GA_FN(comm_info)(ga_context* ctx, int* n_ranks, int* rank, int* uses_rccl);
 /* voices [first, first + count) of n_voices for `rank` of n_ranks (contiguous, sizes differ by at most one) */
 GA_EXPORT int GA_FN(shard_range)(int64_t n_voices, int n_ranks, int rank, int64_t* first, int64_t* count);
 /* Render(output, frameCount, startIndex) of the sharded graph: collective; out_planar (host arrays, page-locked for

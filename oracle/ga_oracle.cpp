@@ -2115,6 +2115,13 @@ int gao_comm_init(ga_context* ctx, const void*, int n_ranks, int rank) {
   return (n_ranks == 1 && rank == 0) ? GA_OK : GA_ERR_UNSUPPORTED;
 }
 int gao_comm_destroy(ga_context* ctx) { return ctx ? GA_OK : GA_ERR_INVALID_ARGUMENT; }
+int gao_comm_info(ga_context* ctx, int* n_ranks, int* rank, int* uses_rccl) {
+  if (!ctx || !n_ranks || !rank || !uses_rccl) return GA_ERR_INVALID_ARGUMENT;
+  *n_ranks = 1;
+  *rank = 0;
+  *uses_rccl = 0;
+  return GA_OK;
+}
 int gao_shard_range(int64_t n_voices, int n_ranks, int rank, int64_t* first, int64_t* count) {
   if (!first || !count) return GA_ERR_INVALID_ARGUMENT;
   if (n_voices < 0 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return GA_ERR_OUT_OF_RANGE;

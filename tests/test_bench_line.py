@@ -54,3 +54,19 @@ def test_committed_pmc_traffic_is_attached_only_to_the_matching_kernel_and_bytes
     assert other["traffic"] is None
     assert b.attach_pmc_traffic(dict(roof), str(tmp_path / "missing.json"))["traffic"] is None
     assert b.attach_pmc_traffic(None, str(prof)) is None
+
+
+def test_attached_traffic_says_that_it_was_not_measured_in_this_run(tmp_path):
+    b = _bench()
+    prof = tmp_path / "p.json"
+    prof.write_text(json.dumps({"command": "python3 bench.py", "kernels": {
+        "coarse_premix_kernel": {"necessary_gb_per_launch (stage, planner)": 1.975296, "pmc_total_x2_gb": 1.9745}}}))
+    got = b.attach_pmc_traffic({"kernel": "coarse_premix_kernel", "necessary_bytes_per_launch": 1.975296e9, "traffic": None}, str(prof))
+    assert got["traffic_measured_in_this_run"] is False
+
+
+def test_serial_bound_of_the_latency_bound_configurations():
+    b = _bench()
+    r = b.serial_bound(480000, 2.0, "x")
+    assert abs(r["bound_ms_per_step"] - 480000 * 3 * 3.46e-6) < 1e-9 and abs(r["frac"] - r["bound_ms_per_step"] / 2.0) < 1e-12
+    assert r["chain_ops_per_sample"] == 3 and "r01_micro_dependent_valu_latency" in r["bound"]

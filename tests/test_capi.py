@@ -78,3 +78,15 @@ def test_ga_stats_layout_is_the_same_in_c_python_and_csharp(tmp_path):
             m = re.search(r"\[(\d+)\]", name)
             size += width * (int(m.group(1)) if m else 1)
     assert size == c_size
+
+
+def test_stage_name_table_covers_every_stage_of_the_header():
+    """Stats.STAGES is zipped with stage_ms / stage_bytes / stage_kernel by consumers -- a missing name drops a stage
+    (GA_STAGE_COARSE_PREMIX, the headline's dominant kernel, was missing)."""
+    hdr = open(os.path.join(ROOT, "include", "graphaudio_hip.h")).read()
+    count = int(re.search(r"GA_STAGE_COUNT\s*=\s*(\d+)", hdr).group(1))
+    assert len(_capi.Stats.STAGES) == count
+    names = re.findall(r"GA_STAGE_(\w+)\s*=\s*(\d+)", hdr)
+    for name, idx in names:
+        if name != "COUNT":
+            assert _capi.Stats.STAGES[int(idx)] == name.lower().replace("rfft_fwd", "rfft_fwd"), (name, idx)

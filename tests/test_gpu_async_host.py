@@ -97,3 +97,40 @@ def test_render_spanning_several_chunks_and_a_biquad_graph():
         got, _ = _steps(build, frames, 2, async_=True, pinned=True, coarse_min_blocks=1, max_chunk_blocks=64)
         for k in range(2):
             assert np.array_equal(ref[k], got[k]), k
+
+
+def test_caller_supplied_stream_rows_are_complete_after_a_stream_wait():
+    """on a stream the caller supplied (ga_context_set_stream) a host may wait on that stream -- or order its own work
+    behind the render on it -- instead of calling ga_synchronize.  The deferred hand-over (the bus of call k crossing PCIe inside
+    call k + 1) must therefore not apply there: every call enqueues its own copy."""
+    frames, steps = 128 * 300, 3
+    build = lambda c: G.config3_convolver(c, voices=12, taps=30000, frames=frames * steps)
+    ref, _ = _steps(build, frames, steps, async_=False, pinned=False, coarse_min_blocks=1)
+    ctx = OfflineAudioContext(SR)
+    ctx.SetOption("coarse_min_blocks", 1)
+    ch = build(ctx)
+    stream = torch.cuda.Stream()
+    ctx.SetStream(stream.cuda_stream)
+    ctx.SetOption("async", 1)
+    rows = [torch.zeros((ch, frames), dtype=torch.float32).pin_memory() for _ in range(steps)]
+    for k in range(steps):
+        ctx.Render(rows[k].numpy(), frames)
+        stream.synchronize()   # the caller's own wait -- NOT ga_synchronize
+        assert np.array_equal(ref[k], rows[k].numpy()), k
+    assert ctx.GetStats()["deferred_handovers"] == 0
+    # work ordered behind the render on the same stream sees the rows too (a device-side copy of the pinned rows)
+    ctx2 = OfflineAudioContext(SR)
+    ctx2.SetOption("coarse_min_blocks", 1)
+    build(ctx2)
+    ctx2.SetStream(stream.cuda_stream)
+    ctx2.SetOption("async", 1)
+    row = torch.zeros((ch, frames), dtype=torch.float32).pin_memory()
+    ctx2.Render(row.numpy(), frames)
+    with torch.cuda.stream(stream):
+        dev = row.to("cuda", non_blocking=True)
+    stream.synchronize()
+    assert np.array_equal(ref[0], dev.cpu().numpy())
+    ctx.Synchronize()
+    ctx2.Synchronize()
+    ctx.Dispose()
+    ctx2.Dispose()

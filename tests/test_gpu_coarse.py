@@ -279,9 +279,15 @@ def _chain(ctx, frames):
 
 def test_convolvers_in_series():
     frames = 128 * 300
-    ref, got, st = pair(lambda c: _chain(c, frames), frames, [128 * 100, 128 * 200])
+    # (conv_reference_order = 0: this test is about formulation D at two convolver depths; by default the planner evaluates the FIRST
+    # convolver in the reference's own order, because the biquad behind it amplifies last-bit differences -- second half of the test)
+    ref, got, st = pair(lambda c: _chain(c, frames), frames, [128 * 100, 128 * 200], conv_reference_order=0)
     assert used_coarse(st)
     check(ref, got, rel=2e-5)   # the high-pass recursion amplifies the 4e-7 of the first convolver
+    ref, got2, st2 = pair(lambda c: _chain(c, frames), frames, [128 * 100, 128 * 200])
+    assert st2["ref_order_rows"] > 0 and st2["stage_launches"][5] > 0   # first convolver: formulation R, second: D
+    check(ref, got2)
+    assert G.rms(ref - got2) < G.rms(ref - got)
 
 
 def _scheduled(ctx, frames):
@@ -571,8 +577,13 @@ def test_exact_zeros_in_front_of_an_onset_inside_the_chunk(pieces, mono_mod):
     """Session 42867 as a deterministic case: the convolver's input is silent, then its two channels differ from the middle
     of a chunk on (shared -> per-channel rows of formulation D in the same chunk)."""
     frames = 128 * 40
-    for opts in ({"max_chunk_blocks": 11}, {}, {"coarse_min_blocks": 1 << 30}):   # D forced in short chunks / one chunk / formulation C
+    # conv_reference_order = 0: since round 4 the planner evaluates a convolver that feeds a PARAMETER in the reference's own order
+    # (formulation R, exact anyway); this test is about the transform formulations' zeros, so the route is switched off.
+    # D forced in short chunks / D in one chunk / formulation C / and the default (R)
+    for opts in ({"max_chunk_blocks": 11, "conv_reference_order": 0}, {"conv_reference_order": 0},
+                 {"coarse_min_blocks": 1 << 30, "conv_reference_order": 0}, {}):
         ref, got, st = pair(lambda c: (_onset_scene(c, 15, mono_mod=mono_mod), 2)[1], frames, pieces, **opts)
+        assert (st["ref_order_rows"] > 0) == (not opts)
         assert G.rms(ref - got) <= 1e-6, (opts, G.rms(ref - got), G.rms(ref))
 
 
@@ -582,7 +593,7 @@ def test_exact_zeros_in_front_of_an_onset_after_an_impulse_response_swap():
     frames = 128 * 40
     for swap_at, onset in ((128 * 8, 15), (128 * 20, 5)):
         outs = []
-        for ctx in (OracleContext(SR), hip(max_chunk_blocks=11)):
+        for ctx in (OracleContext(SR), hip(max_chunk_blocks=11, conv_reference_order=0)):
             cv = _onset_scene(ctx, onset)
             out = np.zeros((2, frames), np.float32)
             ctx.Render(out, swap_at, 0)
@@ -604,8 +615,11 @@ def test_default_policy_onset_in_the_middle_of_a_long_chunk():
     o = OracleContext(SR)
     scene(o)
     ref = G.render(o, 2, frames)
-    h = OfflineAudioContext(SR)
-    scene(h)
-    got = G.render(h, 2, frames)
-    assert h.GetStats()["stage_launches"][5] > 0
-    assert G.rms(ref - got) <= 1e-6, G.rms(ref - got)
+    for ref_order in (0, 1):   # formulation D (the route of round 3, where the defect lived) / the planner's choice now: R
+        h = OfflineAudioContext(SR)
+        h.SetOption("conv_reference_order", ref_order)
+        scene(h)
+        got = G.render(h, 2, frames)
+        st = h.GetStats()
+        assert (st["stage_launches"][5] > 0) == (ref_order == 0) and (st["ref_order_rows"] > 0) == (ref_order == 1)
+        assert G.rms(ref - got) <= 1e-6, (ref_order, G.rms(ref - got))

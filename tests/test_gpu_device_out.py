@@ -112,7 +112,9 @@ def _reduce_matches_render(n_ranks_id):
     frames = 128 * 32
     ref = G.render(ref_ctx, ch, frames)
     ctx, _ = _ctx()
+    assert ctx.CommInfo() == {"ranks": 1, "rank": 0, "uses_rccl": False}   # (before and after ga_comm_init at one rank: no RCCL involved)
     ctx.CommInit(n_ranks_id, 1, 0)
+    assert ctx.CommInfo() == {"ranks": 1, "rank": 0, "uses_rccl": False}
     got = np.zeros((ch, frames), np.float32)
     ctx.RenderReduce(got, 128 * 20 + 5, 0)               # uneven pieces: the leftover-frame cache behind the reduce
     ctx.RenderReduce(got, 128 * 12 - 5, 128 * 20 + 5)

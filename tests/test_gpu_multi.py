@@ -38,6 +38,8 @@ def _rank(rank, world, uid, frames, voices, results, errors, steps=3, async_=Tru
             s.Connect(cv).Connect(ctx.Destination)
             s.Start()
         ctx.CommInit(uid, world, rank)
+        info = ctx.CommInfo()   # ncclCommCount / ncclCommUserRank: what the SCALE record's `comm` field is read from
+        assert info == {"ranks": world, "rank": rank, "uses_rccl": True}, info
         if async_:
             ctx.SetOption("async", 1)
         outs = []
