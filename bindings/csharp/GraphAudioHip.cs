@@ -42,6 +42,7 @@ internal static unsafe partial class GraphAudioHip
         public long deferred_handovers;
         public long biquad_split_cascades;
         public long ref_order_rows;
+        public long sim_replays;
     }
 
     [LibraryImport(Lib, EntryPoint = "ga_strerror")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]

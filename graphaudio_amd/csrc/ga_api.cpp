@@ -34,7 +34,7 @@ struct ga_context {
 
 namespace {
 template <class F>
-int guard(ga_context* h, F&& f) {
+int guardRO(ga_context* h, F&& f) {   // renders and queries: calls that do not change what a later render computes
   if (!h) return GA_ERR_INVALID_ARGUMENT;
   try {
     f(h->c);
@@ -52,6 +52,11 @@ int guard(ga_context* h, F&& f) {
     h->c.lastError = "unknown error";
     return GA_ERR_INVALID_OPERATION;
   }
+}
+template <class F>
+int guard(ga_context* h, F&& f) {   // everything else: the next chunk simulates its first block from scratch (Context::apiEpoch)
+  if (h) h->c.apiEpoch++;
+  return guardRO(h, std::forward<F>(f));
 }
 NodeS* typed(Context& c, int id, int type) {
   NodeS* n = c.node(id);
@@ -371,6 +376,7 @@ int ga_set_option(ga_context* ctx, const char* key, double value) {
     else if (k == "coarse_carry") c.coarseCarry = value != 0;
     else if (k == "coarse_tail") c.coarseTail = value != 0;
     else if (k == "coarse_tail_private") c.coarseTailPrivate = value != 0;
+    else if (k == "sim_replay") c.simReplay = value != 0;
     else if (k == "conv_reference_order") c.convRefOrder = (int)std::min(2.0, std::max(0.0, value));
     else if (k == "conv_ref_min_deviation") c.convRefMinDeviation = std::max(0.0, value);
     else if (k == "coarse_premix") c.coarsePremix = value != 0;
@@ -394,7 +400,7 @@ int ga_set_option(ga_context* ctx, const char* key, double value) {
   });
 }
 int ga_get_stats(ga_context* ctx, ga_stats* out) {
-  return guard(ctx, [&](Context& c) {
+  return guardRO(ctx, [&](Context& c) {
     if (!out) fail(GA_ERR_INVALID_ARGUMENT, "null pointer");
     c.harvestProfile(true);
     c.stats.device_bytes_in_use = c.devBytes;
@@ -406,7 +412,7 @@ int ga_get_stats(ga_context* ctx, ga_stats* out) {
   });
 }
 int ga_synchronize(ga_context* ctx) {
-  return guard(ctx, [&](Context& c) { c.synchronize(); });
+  return guardRO(ctx, [&](Context& c) { c.synchronize(); });
 }
 int ga_context_set_stream(ga_context* ctx, void* hip_stream) {
   return guard(ctx, [&](Context& c) {
@@ -593,7 +599,7 @@ int ga_node_disconnect_param(ga_context* ctx, int src, int dst_node, int dst_par
 }
 int ga_node_has_ended(ga_context* ctx, int node) {
   int r = 0;
-  int rc = guard(ctx, [&](Context& c) {
+  int rc = guardRO(ctx, [&](Context& c) {
     NodeS* n = c.node(node);
     r = n->endedRaised ? 1 : 0;
   });
@@ -602,7 +608,7 @@ int ga_node_has_ended(ga_context* ctx, int node) {
 
 int ga_poll_ended(ga_context* ctx, int* out_ids, int capacity) {
   int n = 0;
-  int rc = guard(ctx, [&](Context& c) {
+  int rc = guardRO(ctx, [&](Context& c) {
     if (!out_ids || capacity < 0) fail(GA_ERR_INVALID_ARGUMENT, "bad buffer");
     while (n < capacity && !c.endedQueue.empty()) {
       out_ids[n++] = c.endedQueue.front();
@@ -659,7 +665,7 @@ int ga_param_set_value(ga_context* ctx, int node, int param, float value) {
   });
 }
 int ga_param_get_value(ga_context* ctx, int node, int param, float* out) {
-  return guard(ctx, [&](Context& c) {
+  return guardRO(ctx, [&](Context& c) {
     if (!out) fail(GA_ERR_INVALID_ARGUMENT, "null pointer");
     *out = c.param(node, param)->value;
   });
@@ -860,20 +866,20 @@ int ga_convolver_set_buffer(ga_context* ctx, int node, int buffer_id) {
 }
 
 int ga_render(ga_context* ctx, float* const* out_planar, int out_channels, int64_t frame_count, int64_t start_index) {
-  return guard(ctx, [&](Context& c) { c.render(out_planar, out_channels, frame_count, start_index, false); });
+  return guardRO(ctx, [&](Context& c) { c.render(out_planar, out_channels, frame_count, start_index, false); });
 }
 int ga_process_blocks(ga_context* ctx, float* const* out_planar, int out_channels, int64_t block_count, int out_on_device) {
-  return guard(ctx, [&](Context& c) {
+  return guardRO(ctx, [&](Context& c) {
     if (out_channels > 0 && !out_planar) fail(GA_ERR_INVALID_ARGUMENT, "outputBuffers");
     static float* const none[1] = {nullptr};
     c.processBlocks(out_planar ? out_planar : none, nullptr, out_channels, block_count, out_on_device != 0);
   });
 }
 int ga_process_blocks_interleaved(ga_context* ctx, float* interleaved, int channels, int64_t block_count, int out_on_device) {
-  return guard(ctx, [&](Context& c) { c.processBlocks(nullptr, interleaved, channels, block_count, out_on_device != 0); });
+  return guardRO(ctx, [&](Context& c) { c.processBlocks(nullptr, interleaved, channels, block_count, out_on_device != 0); });
 }
 int ga_render_device(ga_context* ctx, float* const* out_planar_dev, int out_channels, int64_t frame_count, int64_t start_index) {
-  return guard(ctx, [&](Context& c) { c.render(out_planar_dev, out_channels, frame_count, start_index, true); });
+  return guardRO(ctx, [&](Context& c) { c.render(out_planar_dev, out_channels, frame_count, start_index, true); });
 }
 
 // ---- AudioStreamNodeBase (GraphAudio.IO/AudioStreamSourceNodeBase.cs) ----
@@ -908,12 +914,12 @@ int ga_stream_dequeue_processed(ga_context* ctx, int node, int* buffer_id_out) {
 }
 int ga_stream_queued_count(ga_context* ctx, int node) {
   int v = 0;
-  int rc = guard(ctx, [&](Context& c) { v = (int)typed(c, node, GA_NODE_STREAM_SOURCE)->stQueued.size(); });
+  int rc = guardRO(ctx, [&](Context& c) { v = (int)typed(c, node, GA_NODE_STREAM_SOURCE)->stQueued.size(); });
   return rc < 0 ? rc : v;
 }
 int ga_stream_processed_count(ga_context* ctx, int node) {
   int v = 0;
-  int rc = guard(ctx, [&](Context& c) { v = (int)typed(c, node, GA_NODE_STREAM_SOURCE)->stProcessed.size(); });
+  int rc = guardRO(ctx, [&](Context& c) { v = (int)typed(c, node, GA_NODE_STREAM_SOURCE)->stProcessed.size(); });
   return rc < 0 ? rc : v;
 }
 
@@ -935,7 +941,7 @@ int ga_comm_destroy(ga_context* ctx) {
   return guard(ctx, [&](Context& c) { c.commDestroy(); });
 }
 int ga_comm_info(ga_context* ctx, int* n_ranks, int* rank, int* uses_rccl) {
-  return guard(ctx, [&](Context& c) { c.commInfo(n_ranks, rank, uses_rccl); });
+  return guardRO(ctx, [&](Context& c) { c.commInfo(n_ranks, rank, uses_rccl); });
 }
 int ga_shard_range(int64_t n_voices, int n_ranks, int rank, int64_t* first, int64_t* count) {
   if (!first || !count) return GA_ERR_INVALID_ARGUMENT;
@@ -946,7 +952,7 @@ int ga_shard_range(int64_t n_voices, int n_ranks, int rank, int64_t* first, int6
   return GA_OK;
 }
 int ga_render_reduce(ga_context* ctx, float* const* out_planar, int out_channels, int64_t frame_count, int64_t start_index, int root) {
-  return guard(ctx, [&](Context& c) { c.renderReduce(out_planar, out_channels, frame_count, start_index, root); });
+  return guardRO(ctx, [&](Context& c) { c.renderReduce(out_planar, out_channels, frame_count, start_index, root); });
 }
 
 }  // extern "C"

@@ -597,6 +597,7 @@ struct Sim {
     n_.lastProcessedBlock = blockNumber;
     NodeSeg ns;
     ns.id = id;
+    ns.type = n_.type;
     ns.ins.resize(n_.inputs.size());
     // params first: ComputeValues pulls the modulation input (1 channel, explicit) before the node's inputs (:167-175)
     bool anyMod = false;
@@ -641,11 +642,11 @@ struct Sim {
         n_.outputs[0].zero = ns.ins[0].zero && !n_.everFed;   // zero input AND zero state
         ns.bqDynamic = !n_.params[0].events.empty() || !n_.params[1].events.empty() || !n_.params[2].events.empty() ||
                        !ns.pinSilent(0) || !ns.pinSilent(1) || !ns.pinSilent(2) ||   // a modulated parameter moves per sample
-                       n_.bqDynChunk ||   // (went dynamic earlier in this chunk: the coefficient state lives on the device until the chunk ends)
+                       n_.bqDynSeq == c.chunkSeq ||   // (went dynamic earlier in this chunk: the coefficient state lives on the device until the chunk ends)
                        // the coefficient state is on the device and a signal is still connected to a parameter (silent right now):
                        // the per-sample kernel serves constants too, and the state is not fetched back per chunk (Context::chunkTopology)
                        (n_.coefOnDevice && (!n_.params[0].modulation.empty() || !n_.params[1].modulation.empty() || !n_.params[2].modulation.empty()));
-        if (ns.bqDynamic && !ns.ins[0].silent) n_.bqDynChunk = true;
+        if (ns.bqDynamic && !ns.ins[0].silent) n_.bqDynSeq = c.chunkSeq;
         if (!ns.ins[0].silent && ns.bqDynamic) {
           ns.bqActive = true;   // coefficients are refreshed per sample on the device
         } else if (!ns.ins[0].silent) {
@@ -735,9 +736,9 @@ struct Sim {
         n_.outputs[0].silent = ns.ins[0].silent;
         n_.outputs[0].zero = ns.ins[0].zero;
         ns.panMode = ns.ins[0].bufCh == 1 ? 1 : 2;
-        if (!ns.ins[0].silent && (!n_.params[0].events.empty() || !ns.pinSilent(0) || n_.panDynChunk ||
+        if (!ns.ins[0].silent && (!n_.params[0].events.empty() || !ns.pinSilent(0) || n_.panDynSeq == c.chunkSeq ||
                                   (n_.panOnDevice && !n_.params[0].modulation.empty()))) {   // (state on the device, a signal still connected: Context::chunkTopology)
-          n_.panDynChunk = true;
+          n_.panDynSeq = c.chunkSeq;
           ns.panDyn = true;   // gains follow the a-rate curve on the device (stereo_panner_dynamic_kernel)
         } else if (!ns.ins[0].silent) {
           float pan = std::min(std::max(n_.params[0].value, -1.0f), 1.0f);
@@ -2269,6 +2270,7 @@ struct ChunkRun {
   int maxDepth = 0, maxLevel = 0;
   std::vector<double> bt;              // accumulated block clock
   std::vector<int> srcIds;
+  std::vector<int> srcIndex;           // node id -> position in srcIds / srcPlans, -1 = not a source of this chunk
   std::vector<SrcPlanOut> srcPlans;
   std::vector<int> streamIds;          // AudioStreamSourceNodes of the chunk
   std::vector<Segment> segs;
@@ -2337,14 +2339,35 @@ void Context::chunkTopology(ChunkRun& r) {
   topoCache = topo;
   topoVersion = graphVersion;
   }
-  maxDepth = 0;
-  maxLevel = 0;
-  for (int id : topo) {
-    maxDepth = std::max(maxDepth, nodes[id]->depth);
-    maxLevel = std::max(maxLevel, nodes[id]->level);
-    NodeS& nd = *nodes[id];
-    if (nd.type == GA_NODE_STEREO_PANNER) nd.panDynChunk = false;
-    if (nd.type == GA_NODE_BIQUAD) nd.bqDynChunk = false;
+  if (topoStatsVersion != graphVersion || topoStatsSize != topo.size()) {   // (cached with the order: a sweep over 28,672 node records is 0.5 ms)
+    topoMaxDepth = topoMaxLevel = 0;
+    topoHasTimeNodes = topoHasConvolvers = topoHasOscillators = false;
+    for (int id : topo) {
+      const NodeS& nd = *nodes[id];
+      topoMaxDepth = std::max(topoMaxDepth, nd.depth);
+      topoMaxLevel = std::max(topoMaxLevel, nd.level);
+      if (nd.type == GA_NODE_DELAY || nd.type == GA_NODE_STREAM_SOURCE) topoHasTimeNodes = true;
+      if (nd.type == GA_NODE_CONVOLVER) topoHasConvolvers = true;   // (with or without an impulse response: Buffer setters run in drain())
+      if (nd.type == GA_NODE_OSCILLATOR) topoHasOscillators = true;
+    }
+    topoStatsVersion = graphVersion;
+    topoStatsSize = topo.size();
+  }
+  maxDepth = topoMaxDepth;
+  maxLevel = topoMaxLevel;
+  // automated runs that ended hand their state back to the host: only nodes whose state went to the device are looked at
+  // (Context::deviceStateNodes; "this chunk ran the per-sample kernel" is a stamp, NodeS::bqDynSeq / panDynSeq, not a flag to reset)
+  for (size_t i = 0; i < deviceStateNodes.size();) {
+    const int id = deviceStateNodes[i];
+    NodeS* np = id < (int)nodes.size() ? nodes[id].get() : nullptr;
+    if (!np || np->disposed || (!np->panOnDevice && !np->coefOnDevice)) {
+      deviceStateNodes[i] = deviceStateNodes.back();
+      deviceStateNodes.pop_back();
+      continue;
+    }
+    i++;
+    NodeS& nd = *np;
+    if (!nd.reachable) continue;
     // (while a signal is connected to the parameter the node stays on its per-sample kernel, which serves a silent modulation input
     // as a constant too -- Sim::process -- so the state stays where it is: no stall of the pipeline per modulated node and chunk)
     if (nd.type == GA_NODE_STEREO_PANNER && nd.panOnDevice && nd.params[0].events.empty() && nd.params[0].modulation.empty()) {
@@ -2355,6 +2378,7 @@ void Context::chunkTopology(ChunkRun& r) {
       nd.panGL = tmp.gain_l;
       nd.panGR = tmp.gain_r;
       nd.panOnDevice = false;
+      apiEpoch++;   // (host-tracked state changed: the next first block is traversed)
     }
     if (nd.type == GA_NODE_BIQUAD && nd.coefOnDevice && nd.bqDyn) {
       bool automated = false;
@@ -2366,6 +2390,7 @@ void Context::chunkTopology(ChunkRun& r) {
         nd.b0 = tmp.b0; nd.b1 = tmp.b1; nd.b2 = tmp.b2; nd.a1 = tmp.a1; nd.a2 = tmp.a2;
         nd.coefDirty = tmp.dirty != 0;
         nd.coefOnDevice = false;
+        apiEpoch++;
       }
     }
   }
@@ -2396,6 +2421,8 @@ void Context::chunkSimulate(ChunkRun& r) {
     NodeS& nd = *nodes[id];
     const bool scheduled = nd.type == GA_NODE_CONSTANT_SOURCE || nd.type == GA_NODE_OSCILLATOR;
     if (nd.type != GA_NODE_BUFFER_SOURCE && !scheduled) continue;
+    if (r.srcIndex.empty()) r.srcIndex.assign(nodes.size(), -1);
+    r.srcIndex[id] = (int)srcIds.size();
     srcIds.push_back(id);
     srcPlans.push_back(scheduled ? planScheduled(*this, nd, n, bt) : planSource(*this, nd, n, bt));
     for (const SrcSpan& sp : nd.spans)
@@ -2451,22 +2478,70 @@ void Context::chunkSimulate(ChunkRun& r) {
       sim.cur = &sg;
       sim.brel = b;
       sim.blockNumber = currentBlock + b + 1;
-      inRender = true;
-      try {
-        sim.evalNode(0);
-      } catch (...) {
-        inRender = false;
-        topoVersion = 0;   // nodes may be left marked as processing: rebuild (and reset) everything next time
-        throw;
-      }
-      inRender = false;
-      for (int64_t x : extraBreaks)   // e.g. the block in which delayed audio reaches a DelayNode's output
-        if (x > b && x < n) {
-          auto it = std::lower_bound(breaks.begin(), breaks.end(), x);
-          if (it == breaks.end() || *it != x) breaks.insert(it, x);
+      // the first block of a steady chunk: nothing can have moved since the previous chunk's last segment (see Context::lastSegNodes)
+      // -- its records are taken over, the traversal is skipped
+      bool replayed = false;
+      if (b == 0 && simReplay && lastSegStable && !lastSegNodes.empty() && lastSegEpoch == apiEpoch && lastSegGraphVersion == graphVersion &&
+          !topoHasTimeNodes && lastSegNodes.size() == topo.size() && g == goneAt.end()) {
+        bool same = true;
+        for (const NodeSeg& ns : lastSegNodes) {   // every source still in the phase (and on the buffer) the records say
+          if (ns.type != GA_NODE_BUFFER_SOURCE && ns.type != GA_NODE_CONSTANT_SOURCE && ns.type != GA_NODE_OSCILLATOR) continue;
+          const NodeS& sn = *nodes[ns.id];
+          const SrcSpan& sp = spanAt(sn, 0);
+          if (sp.phase != ns.srcPhase || (ns.type == GA_NODE_BUFFER_SOURCE && ns.srcBuf != sn.bufId)) {
+            same = false;
+            break;
+          }
         }
-      extraBreaks.clear();
-      sg.hash = sim.hashSeg(sg);
+        if (same) {
+          if (!sg.nodes.empty() || sg.nodes.capacity()) segNodePool.push_back(std::move(sg.nodes));
+          sg.nodes = std::move(lastSegNodes);
+          lastSegNodes.clear();
+          for (NodeSeg& ns : sg.nodes) {
+            switch (ns.type) {
+              case GA_NODE_BUFFER_SOURCE:
+                if (ns.srcPhase == SRC_PLAY) {
+                  const SrcSpan& sp = spanAt(*nodes[ns.id], 0);
+                  ns.srcPos = sp.pos + (0 - sp.b0) * kBlock;
+                  ns.srcBlk = sp.blkIdx + (0 - sp.b0);
+                }
+                break;
+              case GA_NODE_BIQUAD:   // (per-chunk flags the traversal would have set again: Sim::process)
+                if (ns.bqDynamic && !ns.ins[0].silent) nodes[ns.id]->bqDynSeq = chunkSeq;
+                break;
+              case GA_NODE_STEREO_PANNER:
+                if (ns.panDyn) nodes[ns.id]->panDynSeq = chunkSeq;
+                break;
+              case GA_NODE_DESTINATION:
+                destOutCh = ns.outCh;
+                break;
+              default: break;
+            }
+          }
+          sg.hash = lastSegHash;
+          replayed = true;
+          stats.sim_replays++;
+        }
+      }
+      if (!replayed) {
+        inRender = true;
+        try {
+          sim.evalNode(0);
+        } catch (...) {
+          inRender = false;
+          topoVersion = 0;   // nodes may be left marked as processing: rebuild (and reset) everything next time
+          throw;
+        }
+        inRender = false;
+        for (int64_t x : extraBreaks)   // e.g. the block in which delayed audio reaches a DelayNode's output
+          if (x > b && x < n) {
+            auto it = std::lower_bound(breaks.begin(), breaks.end(), x);
+            if (it == breaks.end() || *it != x) breaks.insert(it, x);
+          }
+        extraBreaks.clear();
+        sg.hash = sim.hashSeg(sg);
+      }
+      lastSegStable = sg.hash == prevHash;   // (of the segment that turns out to be the chunk's last: a fixpoint of the traversal)
       int64_t nb;
       if (sg.hash != prevHash) {
         nb = b + 1;
@@ -2580,39 +2655,59 @@ void Context::chunkParamCurves(ChunkRun& r) {
   Exec& ex = *r.ex;
   // ---- AudioParam curves (AudioParam.cs:93-166) for automated gain params: one launch for the whole chunk ----
   {
+    // Which parameters of the reachable nodes carry a timeline?  The list stands while no API call, no drained command and no graph
+    // edit happened (apiEpoch / graphVersion): a sweep over the parameter vectors of 28,672 nodes per chunk was 1.5 - 2 ms.
+    if (curveListEpoch != apiEpoch || curveListGraphVersion != graphVersion || curveListTopoSize != topo.size()) {
+      for (auto& e : curveList)   // (curves handed out for the previous list)
+        if (e.first < (int)nodes.size() && nodes[e.first] && e.second < (int)nodes[e.first]->params.size()) nodes[e.first]->params[e.second].curve = nullptr;
+      curveList.clear();
+      for (int id : topo) {
+        NodeS& nd = *nodes[id];
+        for (auto& p : nd.params) p.curve = nullptr;
+        if (nd.type != GA_NODE_GAIN && nd.type != GA_NODE_BIQUAD && nd.type != GA_NODE_CONSTANT_SOURCE && nd.type != GA_NODE_OSCILLATOR &&
+            nd.type != GA_NODE_DELAY && nd.type != GA_NODE_STEREO_PANNER)
+          continue;
+        for (int pi = 0; pi < (int)nd.params.size(); pi++)
+          if (!nd.params[pi].events.empty()) curveList.push_back({id, pi});
+      }
+      curveListEpoch = apiEpoch;
+      curveListGraphVersion = graphVersion;
+      curveListTopoSize = topo.size();
+    }
     std::vector<ParamJob> pjobs;
     std::vector<ParamEvent> events;
-    std::unordered_map<std::string, float*> curveOf;
-    for (int id : topo) {
-      NodeS& nd = *nodes[id];
-      for (auto& p : nd.params) p.curve = nullptr;
-      if (nd.type != GA_NODE_GAIN && nd.type != GA_NODE_BIQUAD && nd.type != GA_NODE_CONSTANT_SOURCE && nd.type != GA_NODE_OSCILLATOR &&
-          nd.type != GA_NODE_DELAY && nd.type != GA_NODE_STEREO_PANNER)
-        continue;
-      for (ParamS& p : nd.params) {
-        if (p.events.empty()) continue;
-        // identical timelines (same events, value and rate -- e.g. the same fade on every voice) share one curve
-        std::string key((const char*)p.events.data(), p.events.size() * sizeof(ParamEvent));
-        key.append((const char*)&p.value, sizeof(float));
-        key.push_back(p.arate ? 1 : 0);
-        auto seen = curveOf.find(key);
-        if (seen != curveOf.end()) {
-          p.curve = seen->second;
-          continue;
-        }
-        p.curve = getSlab(*this);
-        curveOf.emplace(std::move(key), p.curve);
-        ParamJob pj;
-        pj.out = p.curve;
-        pj.ev0 = (int)events.size();
-        pj.nev = (int)p.events.size();
-        pj.value = p.value;
-        pj.arate = p.arate ? 1 : 0;
-        pj.b0 = 0;
-        pj.nblocks = n;
-        events.insert(events.end(), p.events.begin(), p.events.end());
-        pjobs.push_back(pj);
-      }
+    // identical timelines (same events, value and rate -- e.g. the same fade on every voice) share one curve: hash of the bytes,
+    // verified against the job that owns the curve
+    std::unordered_multimap<uint64_t, int> jobOf;
+    auto sameTimeline = [&](const ParamJob& pj, const ParamS& p) {
+      return pj.nev == (int)p.events.size() && pj.value == p.value && pj.arate == (p.arate ? 1 : 0) &&
+             std::memcmp(&events[pj.ev0], p.events.data(), p.events.size() * sizeof(ParamEvent)) == 0;
+    };
+    for (auto& e : curveList) {
+      ParamS& p = nodes[e.first]->params[e.second];
+      p.curve = nullptr;
+      uint64_t h = 1469598103934665603ull;
+      const uint64_t* w = (const uint64_t*)p.events.data();
+      for (size_t i = 0; i < p.events.size() * sizeof(ParamEvent) / 8; i++) h = (h ^ w[i]) * 1099511628211ull;
+      uint32_t vb;
+      std::memcpy(&vb, &p.value, 4);
+      h = (h ^ vb ^ (p.arate ? 0x100000000ull : 0)) * 1099511628211ull;
+      auto range = jobOf.equal_range(h);
+      for (auto it = range.first; it != range.second && !p.curve; ++it)
+        if (sameTimeline(pjobs[it->second], p)) p.curve = pjobs[it->second].out;
+      if (p.curve) continue;
+      p.curve = getSlab(*this);
+      ParamJob pj;
+      pj.out = p.curve;
+      pj.ev0 = (int)events.size();
+      pj.nev = (int)p.events.size();
+      pj.value = p.value;
+      pj.arate = p.arate ? 1 : 0;
+      pj.b0 = 0;
+      pj.nblocks = n;
+      events.insert(events.end(), p.events.begin(), p.events.end());
+      jobOf.emplace(h, (int)pjobs.size());
+      pjobs.push_back(pj);
     }
     if (!pjobs.empty()) {
       size_t jo = ex.plan.putv(pjobs), eo = ex.plan.putv(events), bo = ex.plan.putv(bt);
@@ -2674,22 +2769,24 @@ void Context::chunkConvScratch(ChunkRun& r) {
 
   // ---- convolver scratch planes are shared by all groups: size them for the largest group BEFORE any recorded
   //      launch captures their address ----
-  refOrderSensitivity(topo);
-  assignConvPaths(topo, n);
-  for (int id : topo) {
-    NodeS& nd = *nodes[id];
-    if (nd.type == GA_NODE_CONVOLVER) nd.refOrder = nd.refSens && nd.ir && (nd.convPath == 2 || nd.convPath == 3);
+  if (topoHasConvolvers) {   // (a graph without convolvers -- tens of thousands of nodes of config 4 -- skips these sweeps)
+    refOrderSensitivity(topo);
+    assignConvPaths(topo, n);
+    for (int id : topo) {
+      NodeS& nd = *nodes[id];
+      if (nd.type == GA_NODE_CONVOLVER) nd.refOrder = nd.refSens && nd.ir && (nd.convPath == 2 || nd.convPath == 3);
+    }
+    planCoarseFusion(topo, segs);
+    for (int id : topo)
+      if (nodes[id]->type == GA_NODE_CONVOLVER) nodes[id]->dGroupSize = 0;
+    for (int id : topo) {
+      const NodeS& nd = *nodes[id];
+      if (nd.type == GA_NODE_CONVOLVER && nd.ir && nd.convPath == 4 && nd.dLeader >= 0) nodes[nd.dLeader]->dGroupSize++;
+    }
+    aliasBusToLeader(r);
   }
-  planCoarseFusion(topo, segs);
-  for (int id : topo)
-    if (nodes[id]->type == GA_NODE_CONVOLVER) nodes[id]->dGroupSize = 0;
-  for (int id : topo) {
-    const NodeS& nd = *nodes[id];
-    if (nd.type == GA_NODE_CONVOLVER && nd.ir && nd.convPath == 4 && nd.dLeader >= 0) nodes[nd.dLeader]->dGroupSize++;
-  }
-  aliasBusToLeader(r);
   bHistMax = 0;
-  {
+  if (topoHasConvolvers) {
     size_t xMax = 0, yMax = 0;
     size_t bx = 0, by = 0;
     for (int id : topo) {
@@ -2769,6 +2866,7 @@ void Context::chunkConvScratch(ChunkRun& r) {
     }
   }
 
+  if (topoHasOscillators)
   for (int id : topo) {  // OscillatorNode._phase lives on the device (one double, zero at Start)
     NodeS& nd = *nodes[id];
     if (nd.type != GA_NODE_OSCILLATOR || nd.oscPhase) continue;
@@ -2925,6 +3023,7 @@ void Context::planStereoPanner(NodePlanCtx& k) {
     dj.value = nd.params[0].value;
     dj.pad_ = 0;
     dj.init = nd.panOnDevice ? 0 : 1;   // the host-tracked state is handed over once
+    if (!nd.panOnDevice) deviceStateNodes.push_back(ns.id);
     nd.panOnDevice = true;
     dj.stereo = ns.panMode == 2 ? 1 : 0;
     dj.f0 = f0;
@@ -3007,13 +3106,15 @@ void Context::planBufferSource(NodePlanCtx& k) {
     int64_t avail = g.durationEndFrame - nd.rsStartPos;
     // a partial block (input ran out) is its own one-block segment with a custom trajectory entry
     int traj0 = rs.devOffset + (int)ns.srcBlk;
-    for (size_t k = 0; k < srcIds.size(); k++)
-      if (srcIds[k] == ns.id && srcPlans[k].partialBlock == sg.b0) {
-        ResampleBlock rb = rs.blocks[ns.srcBlk];
-        rb.produced = srcPlans[k].partialProduced;
-        traj0 = (int)ex.traj.size();
-        ex.traj.push_back(rb);
-      }
+    // (this source's plan by its index: a scan of the chunk's sources per source was 4096 x 4096 comparisons per chunk of config 4 --
+    // 60 % of the planning time at 28,672 nodes)
+    const int sk = ns.id < (int)k.r.srcIndex.size() ? k.r.srcIndex[ns.id] : -1;
+    if (sk >= 0 && srcIds[sk] == ns.id && srcPlans[sk].partialBlock == sg.b0) {
+      ResampleBlock rb = rs.blocks[ns.srcBlk];
+      rb.produced = srcPlans[sk].partialProduced;
+      traj0 = (int)ex.traj.size();
+      ex.traj.push_back(rb);
+    }
     {  // host-side bound of the device reads of this job: a wrong plan must be an error, not a GPU fault
       const bool partial = ex.traj[traj0].produced != kBlock;
       if (nd.rsStartPos < 0 || avail < 0 || nd.rsStartPos + avail > pb.length ||
@@ -3151,6 +3252,7 @@ void Context::planBiquad(NodePlanCtx& k) {
       GA_HIP(hipMemcpyAsync(nd.bqDyn, &init, 24, hipMemcpyHostToDevice, stream));
       GA_HIP(hipStreamSynchronize(stream));
       nd.coefOnDevice = true;
+      deviceStateNodes.push_back(ns.id);
     }
     ex.bqDynJobs.push_back(dj);
     return;
@@ -4080,6 +4182,17 @@ void Context::runChunkImpl(int64_t nblocks, float* const* /*unused*/) {
   // the big per-node tables go back to the pools
   for (auto& ov : r.ex->outViews)
     if (!ov.empty() && viewsPool.size() < 8) viewsPool.push_back(std::move(ov));
+  if (!r.segs.empty() && simReplay) {   // the last segment's records stay: the next chunk may take them over (Context::lastSegNodes)
+    if (lastSegNodes.capacity() && segNodePool.size() < 8) {
+      lastSegNodes.clear();
+      segNodePool.push_back(std::move(lastSegNodes));
+    }
+    lastSegNodes = std::move(r.segs.back().nodes);
+    lastSegHash = r.segs.back().hash;
+    lastSegEpoch = apiEpoch;
+    lastSegGraphVersion = graphVersion;
+    r.segs.pop_back();
+  }
   for (Segment& sg : r.segs) {
     sg.nodes.clear();
     if (segNodePool.size() < 8) segNodePool.push_back(std::move(sg.nodes));

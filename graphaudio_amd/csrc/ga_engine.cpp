@@ -302,6 +302,7 @@ void Context::drain() {  // exceptions thrown by queued commands are swallowed (
   while (!pending.empty()) {
     auto cmd = std::move(pending.front());
     pending.pop_front();
+    apiEpoch++;   // (whatever the command does, the next chunk simulates from scratch)
     try {
       cmd();
     } catch (const Err&) {

@@ -120,6 +120,8 @@ typedef struct ga_stats {
   int64_t ref_order_rows;       /* (convolver channel-instance, chunk) pairs whose partition sum was evaluated in the reference's own
                                    order and float32 arithmetic between double-precision transforms (formulation R, option
                                    "conv_reference_order"): PartitionedConvolver.cs:104-223 bit for bit */
+  int64_t sim_replays;          /* chunks whose first block was not traversed again: the control-plane records of the previous chunk's
+                                   last segment were taken over (steady renders, option "sim_replay") */
 } ga_stats;
 enum {
   GA_STAGE_OTHER = 0,        /* sources, biquads, gains, parameter curves, ... */
