@@ -74,6 +74,7 @@ static void resetSlabs(Context& c, int64_t frames) {
     c.slabBlocks.clear();
     c.slabAll.clear();
     c.slabFrames = need;
+    c.slabGen++;
   }
   c.slabFree = c.slabAll;
 }
@@ -576,11 +577,12 @@ struct Sim {
       Conn cn = in.connected[k];
       if (k + 2 < in.connected.size()) __builtin_prefetch(c.nodes[in.connected[k + 2].node].get());   // (tens of thousands of nodes: the walk is bound by cache misses)
       evalNode(cn.node);
-      OutputS& o = c.nodes[cn.node]->outputs[cn.out];
-      if (o.bufCh != 0 && !o.silent) {
-        is.terms.push_back(TermS{cn.node, cn.out, o.bufCh});
+      const NodeS& pn = *c.nodes[cn.node];
+      const OutputS& o = pn.outputs[cn.out];
+      if (o.bufCh != 0 && !o.silent) {   // (a producer that is still being processed shows the state of its PREVIOUS block: a stale term)
+        is.terms.push_back(TermS{cn.node, cn.out, o.bufCh, pn.isProcessing});
         mixed = true;
-        allZero = allZero && o.zero;
+        allZero = allZero && o.zero && !pn.isProcessing;
       }
     }
     in.silent = !mixed;
@@ -592,7 +594,7 @@ struct Sim {
   void evalNode(int id) {  // AudioNode.ProcessInternal, Nodes/AudioNode.cs:152-183
     NodeS& n_ = *c.nodes[id];
     if (n_.lastProcessedBlock == blockNumber) return;
-    if (n_.isProcessing) fail(GA_ERR_CYCLE, "Audio graph cycle detected at node " + std::to_string(id));
+    if (n_.isProcessing) fail(GA_ERR_CYCLE, "Audio graph cycle detected at node " + std::to_string(id));   // (unreachable, as in the reference)
     n_.isProcessing = true;
     n_.lastProcessedBlock = blockNumber;
     NodeSeg ns;
@@ -610,9 +612,10 @@ struct Sim {
       is.silent = true;
       for (auto& m : mod) {
         evalNode(m.first);
-        OutputS& o = c.nodes[m.first]->outputs[m.second];
+        const NodeS& pn = *c.nodes[m.first];
+        const OutputS& o = pn.outputs[m.second];
         if (o.bufCh != 0 && !o.silent) {
-          is.terms.push_back(TermS{m.first, m.second, o.bufCh});
+          is.terms.push_back(TermS{m.first, m.second, o.bufCh, pn.isProcessing});
           is.silent = false;
         }
       }
@@ -865,10 +868,10 @@ struct Sim {
                       ((uint64_t)(ns.outZero ? 1 : 0) << 53));
       for (const InSeg& is : ns.ins) {
         h = hmix(h, ((uint64_t)is.bufCh << 1) | (is.silent ? 1 : 0));
-        for (const TermS& t : is.terms) h = hmix(h, ((uint64_t)t.node << 16) | ((uint64_t)t.out << 8) | (uint64_t)t.ch);
+        for (const TermS& t : is.terms) h = hmix(h, ((uint64_t)t.node << 16) | ((uint64_t)t.out << 8) | (uint64_t)t.ch | ((uint64_t)t.stale << 60));
       }
       for (const InSeg& is : ns.pins)
-        for (const TermS& t : is.terms) h = hmix(h, 0x5151ull ^ (((uint64_t)t.node << 16) | ((uint64_t)t.out << 8) | (uint64_t)t.ch));
+        for (const TermS& t : is.terms) h = hmix(h, 0x5151ull ^ (((uint64_t)t.node << 16) | ((uint64_t)t.out << 8) | (uint64_t)t.ch | ((uint64_t)t.stale << 60)));
     }
     return h;
   }
@@ -996,8 +999,15 @@ struct Exec {
     struct Tm { const float* p; float g; };
     SmallVec<SmallVec<Tm, 2>, 4> lists((size_t)dstCh);
     for (const TermS& t : is.terms) {
-      const auto& uvAll = outViews[si][t.node];
-      const float g = scaleOf(si, t.node);   // (a folded constant GainNode: its views are its INPUT's, to be multiplied here)
+      Views staleViews;
+      if (t.stale) {   // feedback edge: the block the producer put out last (kept by Context::chunkStaleCommit; the chunk is one block)
+        const NodeS& pn = *c.nodes[t.node];
+        const int rows = pn.type == GA_NODE_CHANNEL_SPLITTER ? (int)pn.outputs.size() : t.ch;
+        staleViews.assign((size_t)rows, nullptr);
+        for (int r = 0; r < rows; r++) staleViews[r] = (pn.staleBuf && r < pn.staleRows) ? pn.staleBuf + (size_t)r * kBlock : c.zeros;
+      }
+      const auto& uvAll = t.stale ? staleViews : outViews[si][t.node];
+      const float g = t.stale ? 1.f : scaleOf(si, t.node);   // (a folded constant GainNode: its views are its INPUT's, to be multiplied here)
       // a ChannelSplitterNode keeps one mono view per OUTPUT; every other node has one output with t.ch channels
       Views uvOne;
       if (c.nodes[t.node]->type == GA_NODE_CHANNEL_SPLITTER) uvOne.assign(1, t.out < (int)uvAll.size() ? uvAll[t.out] : nullptr);
@@ -2303,10 +2313,21 @@ void Context::chunkTopology(ChunkRun& r) {
     np->depth = 0;
   }
   {
+    // The traversal order is the reference's (parameters first, then the inputs, connections in order: Nodes/AudioNode.cs:167-175).
+    // A node met again while it is still being processed closes a feedback cycle.  The reference does not refuse that: its memo
+    // check (Nodes/AudioNode.cs:153-156) returns before the "cycle detected" test can fire, and the consumer mixes the producer's
+    // PREVIOUS block.  Such an edge carries no ordering constraint -- the producer is processed later in the block, as there.
     std::vector<int> color(nodes.size(), 0);
-    std::function<void(int)> dfs = [&](int id) {
-      if (color[id] == 2) return;
-      if (color[id] == 1) fail(GA_ERR_CYCLE, "Audio graph cycle detected at node " + std::to_string(id));
+    for (int id : staleProducers)
+      if (id < (int)nodes.size() && nodes[id]) nodes[id]->staleProducer = false;
+    staleProducers.clear();
+    std::function<bool(int)> dfs = [&](int id) {   // false: `id` is being processed (the edge that led here is a feedback edge)
+      if (color[id] == 2) return true;
+      if (color[id] == 1) {
+        if (!nodes[id]->staleProducer) staleProducers.push_back(id);
+        nodes[id]->staleProducer = true;
+        return false;
+      }
       color[id] = 1;
       NodeS& nd = *nodes[id];
       nd.reachable = true;
@@ -2316,7 +2337,7 @@ void Context::chunkTopology(ChunkRun& r) {
           if (nd.type == GA_NODE_BUFFER_SOURCE)   // a modulated playbackRate makes the resampler's consumption depend on audio data
             fail(GA_ERR_UNSUPPORTED, "audio-rate modulation of AudioBufferSourceNode.playbackRate is not on the device path");
           for (auto& m : p.modulation) {
-            dfs(m.first);
+            if (!dfs(m.first)) continue;
             NodeS& up = *nodes[m.first];
             lvl = std::max(lvl, up.level + 1);
             dep = std::max(dep, up.depth + ((up.type == GA_NODE_CONVOLVER && up.ir) ? 1 : 0));
@@ -2324,7 +2345,7 @@ void Context::chunkTopology(ChunkRun& r) {
         }
       for (auto& in : nd.inputs)
         for (const Conn& cn : in.connected) {
-          dfs(cn.node);
+          if (!dfs(cn.node)) continue;
           NodeS& up = *nodes[cn.node];
           lvl = std::max(lvl, up.level + 1);
           dep = std::max(dep, up.depth + ((up.type == GA_NODE_CONVOLVER && up.ir) ? 1 : 0));
@@ -2333,12 +2354,17 @@ void Context::chunkTopology(ChunkRun& r) {
       nd.depth = dep;
       color[id] = 2;
       topo.push_back(id);
+      return true;
     };
     dfs(0);
   }
   topoCache = topo;
   topoVersion = graphVersion;
+  topoHasCycles = !staleProducers.empty();
   }
+  // Feedback: the loop closes through the block a producer put out LAST, so nothing can be batched along time -- the chunk is one
+  // block, the reference's own granularity (a 10 s render = 3,750 chunks: launch bound, ~0.1 - 0.3 ms each)
+  if (topoHasCycles) r.n = 1;
   if (topoStatsVersion != graphVersion || topoStatsSize != topo.size()) {   // (cached with the order: a sweep over 28,672 node records is 0.5 ms)
     topoMaxDepth = topoMaxLevel = 0;
     topoHasTimeNodes = topoHasConvolvers = topoHasOscillators = false;
@@ -3938,6 +3964,86 @@ void Context::chunkPlanConvolvers(ChunkRun& r, int d) {
     }
 }
 
+// feedback cycles, first chunk after an edit closed a loop: the reference's consumer finds the block the producer put out BEFORE the
+// edit in the producer's output buffer.  That block is the tail of the producer's slab of the previous chunk, which nothing has
+// overwritten yet when this chunk's first launch runs -- copied from there (only from memory the context knows to be alive: slabs
+// and other producers' kept blocks; a zero-copy view of a sample buffer, which may have been released since, is not chased).
+void Context::chunkStaleSeed(ChunkRun& r) {
+  if (staleProducers.empty()) return;
+  Exec& ex = *r.ex;
+  std::vector<StaleJob> jobs;
+  auto alive = [&](const float* p) {
+    if (!p) return false;
+    const size_t blockBytes = (size_t)slabFrames * sizeof(float) * std::max<size_t>(8, std::min<size_t>(1024, ((size_t)1 << 30) / std::max<size_t>((size_t)slabFrames * sizeof(float), 1)));
+    for (void* b : slabBlocks)
+      if ((const char*)p >= (const char*)b && (const char*)p + kBlock * sizeof(float) <= (const char*)b + blockBytes) return true;
+    for (int id : staleProducers) {
+      const NodeS& o = *nodes[id];
+      if (o.staleBuf && p >= o.staleBuf && p + kBlock <= o.staleBuf + (size_t)o.staleRows * kBlock) return true;
+    }
+    return false;
+  };
+  for (int id : staleProducers) {
+    NodeS& nd = *nodes[id];
+    if (nd.staleBuf) continue;   // (a producer that already keeps its blocks)
+    const int rows = nd.type == GA_NODE_CHANNEL_SPLITTER ? std::max<int>(1, (int)nd.outputs.size()) : 32;
+    nd.staleRows = rows;
+    nd.staleBuf = (float*)dalloc((size_t)rows * kBlock * sizeof(float));
+    nd.staleNext = (float*)dalloc((size_t)rows * kBlock * sizeof(float));
+    GA_HIP(hipMemsetAsync(nd.staleBuf, 0, (size_t)rows * kBlock * sizeof(float), stream));
+    GA_HIP(hipMemsetAsync(nd.staleNext, 0, (size_t)rows * kBlock * sizeof(float), stream));
+    if (lastViewSlabGen != slabGen || lastViewFrames < kBlock || id >= (int)lastViews.size()) continue;
+    const Views& ov = lastViews[id];
+    const float g = id < (int)lastViewScale.size() ? lastViewScale[id] : 1.f;
+    for (int rw = 0; rw < rows && rw < (int)ov.size(); rw++) {
+      const float* src = ov[rw] ? ov[rw] + (lastViewFrames - kBlock) : nullptr;
+      if (alive(src)) jobs.push_back(StaleJob{nd.staleBuf + (size_t)rw * kBlock, src, g, 0});
+    }
+  }
+  if (jobs.empty()) return;
+  const size_t off = ex.plan.putv(jobs);
+  const int nj = (int)jobs.size();
+  hipStream_t st = stream;
+  ex.plan.add(LK_OTHER, [=](uint8_t* base) { launch_stale_copy(st, (const StaleJob*)(base + off), nj); });
+}
+
+// pass 8b: feedback cycles -- what every stale producer put out in this (one-block) chunk is what the consumers that pull it while
+// it is being processed will mix in the next block (TermS::stale).  Written to the OTHER copy: a pass-through node may hand on a
+// view of another producer's current copy, and the jobs of one launch are not ordered.
+void Context::chunkStaleCommit(ChunkRun& r) {
+  if (staleProducers.empty()) return;
+  Exec& ex = *r.ex;
+  std::vector<StaleJob> jobs;
+  const int si = (int)r.segs.size() - 1;
+  for (int id : staleProducers) {
+    NodeS& nd = *nodes[id];
+    const int rows = nd.type == GA_NODE_CHANNEL_SPLITTER ? std::max<int>(1, (int)nd.outputs.size()) : 32;
+    if (!nd.staleBuf || nd.staleRows < rows) {
+      if (nd.staleBuf) {
+        GA_HIP(hipStreamSynchronize(stream));
+        dfree(nd.staleBuf, (size_t)nd.staleRows * kBlock * sizeof(float));
+        dfree(nd.staleNext, (size_t)nd.staleRows * kBlock * sizeof(float));
+      }
+      nd.staleRows = rows;
+      nd.staleBuf = (float*)dalloc((size_t)rows * kBlock * sizeof(float));
+      nd.staleNext = (float*)dalloc((size_t)rows * kBlock * sizeof(float));
+      GA_HIP(hipMemsetAsync(nd.staleBuf, 0, (size_t)rows * kBlock * sizeof(float), stream));
+      GA_HIP(hipMemsetAsync(nd.staleNext, 0, (size_t)rows * kBlock * sizeof(float), stream));
+    }
+    const Views* ov = (si >= 0 && id < (int)ex.outViews[si].size()) ? &ex.outViews[si][id] : nullptr;
+    const float g = si >= 0 ? ex.scaleOf(si, id) : 1.f;
+    for (int rw = 0; rw < nd.staleRows; rw++) {
+      const float* src = (ov && rw < (int)ov->size()) ? (*ov)[rw] : nullptr;
+      jobs.push_back(StaleJob{nd.staleNext + (size_t)rw * kBlock, src, g, 0});
+    }
+    std::swap(nd.staleBuf, nd.staleNext);
+  }
+  const size_t off = ex.plan.putv(jobs);
+  const int nj = (int)jobs.size();
+  hipStream_t st = stream;
+  ex.plan.add(LK_OTHER, [=](uint8_t* base) { launch_stale_copy(st, (const StaleJob*)(base + off), nj); });
+}
+
 // pass 8: delay-line histories of the next chunk
 void Context::chunkDelayCommit(ChunkRun& r) {
   Context& c_ = *this; (void)c_;
@@ -4162,6 +4268,7 @@ void Context::runChunkImpl(int64_t nblocks, float* const* /*unused*/) {
   r.ex = std::make_unique<Exec>(*this, r.n, r.segs);
   r.ex->outViews.resize(r.segs.size());
   r.ex->plan.host.resize(16);  // reserved header
+  chunkStaleSeed(r);
   chunkParamCurves(r);
   const double tmPar = nowMs();
   chunkConvScratch(r);
@@ -4176,10 +4283,21 @@ void Context::runChunkImpl(int64_t nblocks, float* const* /*unused*/) {
     tmConv += nowMs() - b;
   }
   chunkDelayCommit(r);
+  chunkStaleCommit(r);
   chunkExecute(r);
   const double tmEx = nowMs();
   chunkCommit(r);
-  // the big per-node tables go back to the pools
+  // the last segment's output views stay for one chunk (Context::chunkStaleSeed); the other per-node tables go back to the pools
+  if (!r.ex->outViews.empty() && !r.segs.empty()) {
+    if (!lastViews.empty() && viewsPool.size() < 8) viewsPool.push_back(std::move(lastViews));
+    lastViews = std::move(r.ex->outViews.back());
+    r.ex->outViews.pop_back();
+    const size_t sl = r.segs.size() - 1;
+    if (sl < r.ex->outScale.size() && !r.ex->outScale[sl].empty()) lastViewScale = r.ex->outScale[sl];
+    else lastViewScale.clear();
+    lastViewFrames = r.n * kBlock;
+    lastViewSlabGen = slabGen;
+  }
   for (auto& ov : r.ex->outViews)
     if (!ov.empty() && viewsPool.size() < 8) viewsPool.push_back(std::move(ov));
   if (!r.segs.empty() && simReplay) {   // the last segment's records stay: the next chunk may take them over (Context::lastSegNodes)

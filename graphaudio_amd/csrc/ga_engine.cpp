@@ -538,6 +538,13 @@ void Context::doDispose(int id) {
     n.delayHistRings = n.delayLineRings = 0;
     n.delayCap = 0;
   }
+  if (n.staleBuf) {   // (feedback cycles: the kept output block goes with the node)
+    if (stream) (void)hipStreamSynchronize(stream);
+    dfree(n.staleBuf, (size_t)n.staleRows * kBlock * sizeof(float));
+    dfree(n.staleNext, (size_t)n.staleRows * kBlock * sizeof(float));
+    n.staleBuf = n.staleNext = nullptr;
+    n.staleRows = 0;
+  }
   if (n.type == GA_NODE_BUFFER_SOURCE) n.bufId = -1;  // AudioBufferSourceNode.cs:412
   if (n.type == GA_NODE_STREAM_SOURCE && n.stState != GA_STREAM_STOPPED) {   // AudioStreamSourceNodeBase.cs:315-327
     n.stState = GA_STREAM_STOPPED;

@@ -296,6 +296,12 @@ struct NodeS {
   // or quantises last-bit differences (Context::refOrderSensitivity, per chunk); refOrder = this chunk evaluates the node that way
   // (nodes on the B / C state layout: spectra history + overlap, which R shares)
   bool refSens = false, refOrder = false;
+  // feedback cycles: a node that some consumer pulls while it is being processed keeps a copy of the block it put out last
+  // (shape of its output views: one row of 128 frames per channel, per output for a ChannelSplitterNode)
+  bool staleProducer = false;
+  float* staleBuf = nullptr;   // the copy consumers read in this chunk: [staleRows][128]
+  float* staleNext = nullptr;  // ... and the one this chunk's output is written to (the two swap when the chunk is planned)
+  int staleRows = 0;
 };
 
 // A vector with inline room for N elements (heap only beyond): the per-node, per-segment records of the control-plane
@@ -410,6 +416,10 @@ using Views = SmallVec<const float*, 4>;   // per-channel views (device pointers
 // one evaluated control state of a node within a segment
 struct TermS {
   int node, out, ch;
+  // The producer was still being processed when this input pulled it (a feedback cycle): ProcessInternal's memo check returns at
+  // once (Nodes/AudioNode.cs:153-156), so the consumer mixes the buffer the producer's output STILL holds -- its previous block
+  // (an implicit one-block delay on the edge that closes the loop).  The device keeps that block per producer (NodeS::staleBuf).
+  bool stale = false;
 };
 struct InSeg {
   int bufCh = 0;
@@ -733,6 +743,8 @@ struct Context {
   void planConvolversShared(ChunkRun& r, int depth, ConvPlanCtx& k);    // formulation A groups
   void planConvolversPrivate(ChunkRun& r, int depth, ConvPlanCtx& k, bool refOrder);   // formulations B / C, and R on their state layout
   void chunkDelayCommit(ChunkRun& r);
+  void chunkStaleSeed(ChunkRun& r);
+  void chunkStaleCommit(ChunkRun& r);   // feedback cycles: the block every stale producer put out becomes what its consumers read next
   void chunkExecute(ChunkRun& r);
   void chunkCommit(ChunkRun& r);
   void ensureBiquadState(NodeS& bn);
@@ -801,6 +813,14 @@ struct Context {
   uint64_t apiEpoch = 0;       // bumped by every API call that can change what a render computes (ga_api.cpp guard) and by drained commands
   bool simReplay = true;       // option "sim_replay"
   bool topoHasTimeNodes = false, topoHasConvolvers = false, topoHasOscillators = false;
+  bool topoHasCycles = false;   // (chunkTopology) some node is pulled while it is being processed: chunks of ONE block (the reference's own granularity)
+  std::vector<int> staleProducers;
+  // the output views of the previous chunk's last segment (and the gains folded into them): when an edit closes a cycle, the block
+  // the new stale producer put out LAST is still in those slabs (Context::chunkStaleSeed)
+  std::vector<Views> lastViews;
+  std::vector<float> lastViewScale;
+  int64_t lastViewFrames = 0;
+  uint64_t slabGen = 0, lastViewSlabGen = ~0ull;   // (slabGen: bumped when the slab pool is reallocated -- old views dangle)
   uint64_t topoStatsVersion = ~0ull;
   size_t topoStatsSize = 0;
   std::vector<std::pair<int, int>> curveList;   // (node, parameter) pairs with a timeline among the reachable nodes (chunkParamCurves)

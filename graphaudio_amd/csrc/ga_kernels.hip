@@ -1055,6 +1055,16 @@ void launch_irfft_ola_b(hipStream_t s, const ConvRowIO* yrows_dev, int ny, int n
   }
 }
 
+__global__ __launch_bounds__(128) void stale_copy_kernel(const StaleJob* __restrict jobs) {
+  const StaleJob j = jobs[blockIdx.x];
+  const int i = threadIdx.x;
+  gptr(j.dst)[i] = j.src ? ldg1(j.src + i) * j.scale : 0.f;
+}
+void launch_stale_copy(hipStream_t s, const StaleJob* jobs_dev, int njobs) {
+  if (njobs <= 0) return;
+  hipLaunchKernelGGL(stale_copy_kernel, dim3(njobs), dim3(128), 0, s, jobs_dev);
+}
+
 // one wavefront per (job, bin): 4 bins per workgroup (a workgroup per bin moved 2 KB and was launch-rate bound)
 __global__ __launch_bounds__(256) void hist_copy_b_kernel(const HistJobB* __restrict jobs) {
   const HistJobB j = jobs[blockIdx.y];

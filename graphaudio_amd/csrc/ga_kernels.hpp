@@ -98,6 +98,15 @@ void launch_refmac(hipStream_t s, const ConvSetB* sets_dev, int nsets, int nbloc
 void launch_irfft_ola_b(hipStream_t s, const ConvRowIO* yrows_dev, int ny, int nblocks, ConvPlanesB pl,
                         const float* const* overlap_in_dev, float* const* overlap_out_dev, Twiddles tw, bool fp64);
 void launch_hist_copy_b(hipStream_t s, const HistJobB* jobs_dev, int njobs, int max_n);
+// feedback cycles: dst[0..128) = src[0..128) * scale (src == nullptr: zeros) -- the block a producer put out, kept for the consumers
+// that pull it while it is being processed in the NEXT block (Nodes/AudioNode.cs:153-156)
+struct StaleJob {
+  float* dst;
+  const float* src;
+  float scale;
+  int pad_;
+};
+void launch_stale_copy(hipStream_t s, const StaleJob* jobs_dev, int njobs);
 
 // ---- convolver pipeline, formulation C: the partition sum as an FFT convolution ALONG THE BLOCK AXIS -----------------
 // For one (row, bin) the reference's  acc[t] = sum_{p<P} X[t-p] H[p]  (PartitionedConvolver.cs:154-223) is a length-P

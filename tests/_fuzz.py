@@ -158,6 +158,28 @@ def build_random_graph(ctx, seed, frames, keep=None, handles=None):
                 oi = int(rng3.integers(0, frm._output_count)) if isinstance(frm, ChannelSplitterNode) else 0
                 ii = int(rng3.integers(0, to._input_count)) if isinstance(to, ChannelMergerNode) else 0
                 frm.Connect(to, oi, ii)
+        # seeds >= 50000 (round 4): FEEDBACK -- a later node of the chain feeds an earlier one through a gain below 1.  The reference
+        # renders such loops with an implicit one-block delay on the edge that closes them (Nodes/AudioNode.cs:153-156), the device
+        # path one block per chunk since round 4.  (Drawn from a generator of their own: older seeds keep their graphs.)
+        if seed >= 50000:
+            rng5 = np.random.default_rng(seed * 31 + v)
+            inner = [n for n in chain_of_voice[1:] if not isinstance(n, (ChannelSplitterNode, ChannelMergerNode))]
+            if len(inner) >= 2 and rng5.random() < 0.6:
+                i0 = int(rng5.integers(0, len(inner) - 1))
+                i1 = int(rng5.integers(i0 + 1, len(inner)))
+                fb = GainNode(ctx)
+                fb.Gain.Value = float(rng5.uniform(0.05, 0.35))
+                inner[i1].Connect(fb)
+                if rng5.random() < 0.25 and isinstance(inner[i0], GainNode):
+                    fb.Connect(inner[i0].Gain)      # the loop closes through a parameter
+                else:
+                    fb.Connect(inner[i0])
+                # (not handed to the session's edit list: a feedback gain edited up to 1.2 makes the loop blow up)
+            elif len(inner) == 1 and isinstance(inner[0], (GainNode, DelayNode, BiQuadFilterNode)) and rng5.random() < 0.4:
+                fb = GainNode(ctx)              # node -> gain -> node
+                fb.Gain.Value = float(rng5.uniform(0.05, 0.35))
+                inner[0].Connect(fb)
+                fb.Connect(inner[0])
         earlier_nodes.extend(chain_of_voice)
         voice_chains.append(chain_of_voice)
         target = buses[int(rng.integers(0, len(buses)))] if buses and rng.random() < 0.6 else ctx.Destination

@@ -32,7 +32,8 @@ REGRESSION_SEEDS = [215, 219, 357, 430, 459, 749, 1232, 1273, 1476, 2550, 2577, 
 # 4: D with carried tails also for groups of private impulse responses (option coarse_tail_private, off by default)
 @pytest.mark.parametrize("coarse", [0, 1, 2, 3, 4])
 # seeds >= 20000: graphs with GainNodes at exactly 1 (buses and chain gains: their input views are handed on, no kernel)
-@pytest.mark.parametrize("seed", list(range(120)) + REGRESSION_SEEDS + list(range(20000, 20024)))
+# seeds >= 50000 (round 4): feedback loops inside the voice chains (rendered one block per chunk, the stale block of the loop's producer kept)
+@pytest.mark.parametrize("seed", list(range(120)) + REGRESSION_SEEDS + list(range(20000, 20024)) + list(range(50000, 50016)))
 def test_random_graph_matches_oracle(seed, coarse):
     frames = 128 * 36
     o = OracleContext(48000)
@@ -89,7 +90,7 @@ def _session_pair(seed, chunk=11, coarse=0):
 #       rounded once from double like the C library's cosf / sinf / powf behind MathF (7.9e-6 -> 2.7e-9)
 # 25085 (3.2e-5 in round 3: a biquad fed by a convolver and a source) and 5761 (a notch at 153 Hz, Q 2.5, behind a convolver: 9.4e-6):
 #       convolvers in front of resonant biquads take the reference-order route (formulation R) since round 4
-@pytest.mark.parametrize("seed", list(range(60)) + [2850, 2573, 20284, 25085, 5761] + list(range(20000, 20012)) + list(range(30000, 30006)) + list(range(40000, 40006)))
+@pytest.mark.parametrize("seed", list(range(60)) + [2850, 2573, 20284, 25085, 5761] + list(range(20000, 20012)) + list(range(30000, 30006)) + list(range(40000, 40006)) + list(range(50000, 50010)))
 def test_random_edit_session_matches_oracle(seed, coarse):
     """The graph is edited between render pieces (parameter writes, automation, stop, new voices, dispose, rewiring,
     impulse-response swaps, audio-rate modulation, channel settings): same output and the same exceptions."""
@@ -100,7 +101,9 @@ def test_random_edit_session_matches_oracle(seed, coarse):
     assert ref_log == got_log
     err = G.rms(ref - got)
     scale = max(G.rms(ref), 1e-3)
-    assert err <= 1e-5 and err <= 2e-5 * scale, (seed, err, scale)
+    # (seeds >= 50000 have feedback loops; an edit can push a loop's gain above 1 and the signal grows without bound -- the absolute
+    # bound is then taken at the signal's level)
+    assert err <= 1e-5 * max(1.0, scale if seed >= 50000 else 1.0) and err <= 2e-5 * scale, (seed, err, scale)
 
 
 def test_session_42867_with_formulation_d_forced():

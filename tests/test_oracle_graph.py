@@ -271,8 +271,8 @@ def test_start_twice_errors_after_first_block_and_cycle_detection():
         s.Start()
     # A cycle is NOT an error in the reference: ProcessInternal's memo check (Nodes/AudioNode.cs:154) runs before the
     # _isProcessing check (:157-160), so re-entering a node returns immediately and the loop closes with the node's
-    # previous-block buffer -- an implicit one-block feedback delay.  The oracle restates that; the device path
-    # refuses such graphs (GA_ERR_CYCLE) because feedback cannot be time-batched.
+    # previous-block buffer -- an implicit one-block feedback delay.  The oracle restates that; so does the device path since
+    # round 4 (one block per chunk, tests/test_gpu_cycles.py).
     g1, g2 = GainNode(ctx), GainNode(ctx)
     g1.Gain.Value = 0.5
     g1.Connect(g2)
