@@ -902,11 +902,26 @@ struct Exec {
     if (outScale[si].empty()) outScale[si].assign(c.nodes.size(), 1.f);
     outScale[si][node] = g;
   }
-  void pushTerm(const float* p, float g) {
+  // ... and a GainNode whose gain follows a TIMELINE (no audio-rate modulation) and has one consumer hands on its input views with
+  // the curve: the consumer's mix multiplies the term by curve[f] first -- GainNode.Process's `out = in * gain[i]` (GainNode.cs:
+  // 52-57), the same product, without writing and re-reading the voice (config 4: 4096 gain curves in front of the destination)
+  std::vector<const float*> termCurves;          // parallel to `terms` (missing entries = null)
+  bool anyTermCurve = false;
+  std::vector<std::vector<const float*>> outCurve;   // [segment][node]
+  const float* curveOf(int si, int node) const { return (si < (int)outCurve.size() && !outCurve[si].empty()) ? outCurve[si][node] : nullptr; }
+  void setCurve(int si, int node, const float* cv) {
+    if ((int)outCurve.size() <= si) outCurve.resize(si + 1);
+    if (outCurve[si].empty()) outCurve[si].assign(c.nodes.size(), nullptr);
+    outCurve[si][node] = cv;
+  }
+  void pushTerm(const float* p, float g, const float* cv = nullptr) {
     termGains.resize(terms.size(), 1.f);
+    termCurves.resize(terms.size(), nullptr);
     terms.push_back(p);
     termGains.push_back(g);
+    termCurves.push_back(cv);
     if (g != 1.f) anyTermGain = true;
+    if (cv) anyTermGain = anyTermCurve = true;
   }
   std::vector<MixJob> mixJobs;
   std::vector<DownmixJob> dmJobs;
@@ -996,7 +1011,7 @@ struct Exec {
     const Segment& sg = segs[si];
     const int dstCh = is.bufCh;
     const int64_t f0 = sg.b0 * kBlock, nf = (sg.b1 - sg.b0) * kBlock;
-    struct Tm { const float* p; float g; };
+    struct Tm { const float* p; float g; const float* c; };
     SmallVec<SmallVec<Tm, 2>, 4> lists((size_t)dstCh);
     for (const TermS& t : is.terms) {
       Views staleViews;
@@ -1008,6 +1023,7 @@ struct Exec {
       }
       const auto& uvAll = t.stale ? staleViews : outViews[si][t.node];
       const float g = t.stale ? 1.f : scaleOf(si, t.node);   // (a folded constant GainNode: its views are its INPUT's, to be multiplied here)
+      const float* gc = t.stale ? nullptr : curveOf(si, t.node);   // (... or by its gain curve)
       // a ChannelSplitterNode keeps one mono view per OUTPUT; every other node has one output with t.ch channels
       Views uvOne;
       if (c.nodes[t.node]->type == GA_NODE_CHANNEL_SPLITTER) uvOne.assign(1, t.out < (int)uvAll.size() ? uvAll[t.out] : nullptr);
@@ -1015,10 +1031,10 @@ struct Exec {
       const int srcCh = t.ch;
       if (srcCh == dstCh) {
         for (int ch = 0; ch < dstCh; ch++)
-          if (uv[ch]) lists[ch].push_back(Tm{uv[ch], g});
+          if (uv[ch]) lists[ch].push_back(Tm{uv[ch], g, gc});
       } else if (srcCh == 1 && dstCh > 1) {
         if (uv[0])
-          for (int ch = 0; ch < dstCh; ch++) lists[ch].push_back(Tm{uv[0], g});
+          for (int ch = 0; ch < dstCh; ch++) lists[ch].push_back(Tm{uv[0], g, gc});
       } else if (srcCh > 1 && dstCh == 1) {
         // (sum over channels) * 1/sqrt(N), AudioNodeInput.cs:214-228
         bool anyCh = false;
@@ -1033,11 +1049,11 @@ struct Exec {
         dj.n = nf;
         for (int ch = 0; ch < srcCh; ch++) pushTerm(uv[ch] ? uv[ch] : c.zeros, g);
         dmJobs.push_back(dj);
-        lists[0].push_back(Tm{dj.out, 1.f});
+        lists[0].push_back(Tm{dj.out, 1.f, nullptr});
       } else {
         int m = std::min(srcCh, dstCh);
         for (int ch = 0; ch < m; ch++)
-          if (uv[ch]) lists[ch].push_back(Tm{uv[ch], g});
+          if (uv[ch]) lists[ch].push_back(Tm{uv[ch], g, gc});
       }
     }
     Views views((size_t)dstCh, nullptr);
@@ -1045,14 +1061,14 @@ struct Exec {
       auto& l = lists[ch];
       if (!force) {
         if (l.empty()) continue;
-        if (l.size() == 1 && l[0].g == 1.f) {
+        if (l.size() == 1 && l[0].g == 1.f && !l[0].c) {
           views[ch] = l[0].p;
           continue;
         }
       }
       float* out = forcedSlabs ? forcedSlabs[ch] : inMixed(nodeId, i + 64, ch);
       if (!out) continue;
-      if (l.size() == 1 && l[0].p == out && l[0].g == 1.f) {   // the only term was produced in place (Context::aliasBusToLeader)
+      if (l.size() == 1 && l[0].p == out && l[0].g == 1.f && !l[0].c) {   // the only term was produced in place (Context::aliasBusToLeader)
         views[ch] = out;
         continue;
       }
@@ -1063,8 +1079,9 @@ struct Exec {
       mj.f0 = f0;
       mj.n = nf;
       for (const Tm& tm : l) {
-        pushTerm(tm.p, tm.g);
+        pushTerm(tm.p, tm.g, tm.c);
         noteAlign(tm.p, f0);
+        if (tm.c) noteAlign(tm.c, f0);
       }
       noteAlign(out, f0);
       mixJobs.push_back(mj);
@@ -1100,8 +1117,11 @@ struct Exec {
     // order: down-mix -> mix -> sources -> gain -> biquad (everything in one level is independent)
     size_t termsOff = plan.putv(terms);
     termGains.resize(terms.size(), 1.f);
+    termCurves.resize(terms.size(), nullptr);
     const bool scaled = anyTermGain;
     const size_t gainsOff = scaled ? plan.putv(termGains) : 0;
+    const bool curved = anyTermCurve;
+    const size_t curvesOff = curved ? plan.putv(termCurves) : 0;
     if (!dmJobs.empty()) {
       size_t off = plan.putv(dmJobs);
       int nj = (int)dmJobs.size();
@@ -1122,7 +1142,8 @@ struct Exec {
       double mixBytes = 0;
       for (auto& j : mixJobs) mixBytes += 4.0 * (double)(j.nterms + 1) * (double)j.n;
       plan.add(LK_MIX, [=](uint8_t* base) {
-        launch_mix(st, (const MixJob*)(base + off), nj, (const float* const*)(base + termsOff), mx, v4, scaled ? (const float*)(base + gainsOff) : nullptr);
+        launch_mix(st, (const MixJob*)(base + off), nj, (const float* const*)(base + termsOff), mx, v4, scaled ? (const float*)(base + gainsOff) : nullptr,
+                   curved ? (const float* const*)(base + curvesOff) : nullptr);
       }, mixBytes);
     }
     if (!pmodJobs.empty()) {   // after the mixes (the modulation inputs), before the nodes that read the parameter
@@ -1280,7 +1301,8 @@ struct Exec {
     bqDynJobs.clear();
     terms.clear();
     termGains.clear();
-    anyTermGain = false;
+    termCurves.clear();
+    anyTermGain = anyTermCurve = false;
     mixJobs.clear();
     dmJobs.clear();
     gainJobs.clear();
@@ -3215,9 +3237,21 @@ void Context::planGain(NodePlanCtx& k) {
   // any other constant gain with ONE consumer connection: the consumer's mix multiplies (Exec::scaleOf) -- no pass of its own
   const bool fold = constant && !unity && gainFold && nd.outputs.size() == 1 && nd.outputs[0].connectedInputs.size() == 1;
   if (fold) ex.setScale((int)si, ns.id, nd.params[0].value);
+  // a gain on a timeline (no modulation) with one consumer INPUT that mixes it channel by channel: the curve goes with the views
+  // (Exec::curveOf).  Not in front of a down-mix (its kernel takes constants only), not for a node some consumer reads one block late.
+  bool foldCurve = false;
+  if (!gmod && nd.params[0].curve && gainFold && !nd.staleProducer && nd.outputs.size() == 1 && nd.outputs[0].connectedInputs.size() == 1) {
+    const InRef& to = nd.outputs[0].connectedInputs[0];
+    const NodeSeg* cs = to.input >= 0 ? k.segNode.find(to.node) : nullptr;   // (a consumer of this stage: same convolver depth)
+    if (cs && to.input >= 0 && to.input < (int)cs->ins.size()) {
+      const int dstCh = cs->ins[to.input].bufCh;
+      foldCurve = !(ns.outCh > 1 && dstCh == 1);
+    }
+  }
+  if (foldCurve) ex.setCurve((int)si, ns.id, nd.params[0].curve);
   for (int ch = 0; ch < ns.outCh; ch++) {
     if (!iv[ch]) continue;
-    if (unity || fold) {
+    if (unity || fold || foldCurve) {
       ov[ch] = iv[ch];
       continue;
     }

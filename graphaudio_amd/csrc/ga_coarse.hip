@@ -72,6 +72,14 @@ __device__ __forceinline__ f2 cmulc(f2 a, f2 b) { return cmulp(a, b); }
 
 // acc + a b  (two packed fmas)
 __device__ __forceinline__ f2 cfmap(f2 a, f2 b, f2 acc) {
+#if defined(GA_EXPERIMENTS) && defined(GA_MAC_SCALAR_FMA)   // (measurement: four v_fma_f32 instead of two v_pk_fma_f32 -- same values)
+  float re, im, re2, im2;
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(re) : "v"(a.x), "v"(b.x), "v"(acc.x));
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(im) : "v"(a.x), "v"(b.y), "v"(acc.y));
+  asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(re2) : "v"(a.y), "v"(b.y), "v"(re));
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(im2) : "v"(a.y), "v"(b.x), "v"(im));
+  return f2{re2, im2};
+#endif
   f2 t, r;
   asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(t) : "v"(a), "v"(b), "v"(acc));
   asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));

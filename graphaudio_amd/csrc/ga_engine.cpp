@@ -695,7 +695,10 @@ void Context::refOrderSensitivity(const std::vector<int>& topo) {
   sens.assign(nodes.size(), 0);
   for (auto it = topo.rbegin(); it != topo.rend(); ++it) {   // consumers before producers
     NodeS& nd = *nodes[*it];
-    bool s = false;
+    // * a feedback loop: what a convolver adds to a signal that comes back to it is multiplied by the loop again and again -- last-bit
+    //   differences compound (fuzz session 50178: 2.7e-5 with the loop's convolver on formulation B, exactly 0 in the reference's order).
+    //   Everything that feeds a node some consumer reads one block late (a stale producer: the loop's entry) counts.
+    bool s = nd.staleProducer;
     if (nd.type == GA_NODE_BIQUAD) {
       bool moving = false;
       for (auto& p : nd.params) moving = moving || !p.events.empty() || !p.modulation.empty();

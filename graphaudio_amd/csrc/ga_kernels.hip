@@ -1576,20 +1576,25 @@ void launch_pair_sum(hipStream_t s, float* out, const float* a, const float* b, 
 //  starting from the cleared buffer (0 + t0 + t1 + ...), one thread per 1 or 4 frames.
 // =====================================================================================================
 template <int VEC, bool SCALED>
-__global__ __launch_bounds__(256) void mix_kernel(const MixJob* __restrict jobs, const float* const* __restrict terms, const float* __restrict gains) {
+__global__ __launch_bounds__(256) void mix_kernel(const MixJob* __restrict jobs, const float* const* __restrict terms, const float* __restrict gains,
+                                                  const float* const* __restrict curves) {
   const MixJob job = jobs[blockIdx.y];
   const int64_t nv = (job.n + VEC - 1) / VEC;
   const float* const* __restrict tp = terms + job.term0;
   const float* __restrict gp = SCALED ? gains + job.term0 : nullptr;   // SCALED: term j contributes fl(x * gain[j]) -- a folded constant GainNode
+  // ... or fl(x * curve_j[f]) where the folded GainNode's gain follows a timeline (curves[j] != null): GainNode.cs:52-57
+  const float* const* __restrict cp = (SCALED && curves) ? curves + job.term0 : nullptr;
   if (SCALED && job.nterms == 1) {   // a gain on its own: out = in * g, as gain_kernel writes it (no 0 + in front)
     const float g = gp[0];
+    const float* __restrict cv = cp ? cp[0] : nullptr;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
       const int64_t f = job.f0 + i * VEC;
       if (VEC == 4) {
         const v4f v = ldg4(tp[0] + f);
-        stg4(job.out + f, v4f{v.x * g, v.y * g, v.z * g, v.w * g});
+        const v4f gv = cv ? ldg4(cv + f) : v4f{g, g, g, g};
+        stg4(job.out + f, v4f{v.x * gv.x, v.y * gv.y, v.z * gv.z, v.w * gv.w});
       } else {
-        gptr(job.out)[f] = ldg1(tp[0] + f) * g;
+        gptr(job.out)[f] = ldg1(tp[0] + f) * (cv ? ldg1(cv + f) : g);
       }
     }
     return;
@@ -1606,10 +1611,17 @@ __global__ __launch_bounds__(256) void mix_kernel(const MixJob* __restrict jobs,
         v4f v3 = ldg4(tp[j + 3] + f);
         if (SCALED) {   // (products rounded on their own: -ffp-contract=off, no fma with the add below)
           const float g0 = gp[j], g1 = gp[j + 1], g2 = gp[j + 2], g3 = gp[j + 3];
-          v0 = v4f{v0.x * g0, v0.y * g0, v0.z * g0, v0.w * g0};
-          v1 = v4f{v1.x * g1, v1.y * g1, v1.z * g1, v1.w * g1};
-          v2 = v4f{v2.x * g2, v2.y * g2, v2.z * g2, v2.w * g2};
-          v3 = v4f{v3.x * g3, v3.y * g3, v3.z * g3, v3.w * g3};
+          v4f m0 = v4f{g0, g0, g0, g0}, m1 = v4f{g1, g1, g1, g1}, m2 = v4f{g2, g2, g2, g2}, m3 = v4f{g3, g3, g3, g3};
+          if (cp) {
+            if (cp[j]) m0 = ldg4(cp[j] + f);
+            if (cp[j + 1]) m1 = ldg4(cp[j + 1] + f);
+            if (cp[j + 2]) m2 = ldg4(cp[j + 2] + f);
+            if (cp[j + 3]) m3 = ldg4(cp[j + 3] + f);
+          }
+          v0 = v4f{v0.x * m0.x, v0.y * m0.y, v0.z * m0.z, v0.w * m0.w};
+          v1 = v4f{v1.x * m1.x, v1.y * m1.y, v1.z * m1.z, v1.w * m1.w};
+          v2 = v4f{v2.x * m2.x, v2.y * m2.y, v2.z * m2.z, v2.w * m2.w};
+          v3 = v4f{v3.x * m3.x, v3.y * m3.y, v3.z * m3.z, v3.w * m3.w};
         }
         acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
         acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
@@ -1620,7 +1632,8 @@ __global__ __launch_bounds__(256) void mix_kernel(const MixJob* __restrict jobs,
         v4f v = ldg4(tp[j] + f);
         if (SCALED) {
           const float g = gp[j];
-          v = v4f{v.x * g, v.y * g, v.z * g, v.w * g};
+          const v4f m = (cp && cp[j]) ? ldg4(cp[j] + f) : v4f{g, g, g, g};
+          v = v4f{v.x * m.x, v.y * m.y, v.z * m.z, v.w * m.w};
         }
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
       }
@@ -1629,26 +1642,27 @@ __global__ __launch_bounds__(256) void mix_kernel(const MixJob* __restrict jobs,
       float acc = 0.f;
       for (int j = 0; j < job.nterms; j++) {
         float v = ldg1(tp[j] + f);
-        if (SCALED) v = v * gp[j];
+        if (SCALED) v = v * ((cp && cp[j]) ? ldg1(cp[j] + f) : gp[j]);
         acc += v;
       }
       gptr(job.out)[f] = acc;
     }
   }
 }
-void launch_mix(hipStream_t s, const MixJob* jobs_dev, int njobs, const float* const* terms_dev, int64_t max_n, bool vec4, const float* gains_dev) {
+void launch_mix(hipStream_t s, const MixJob* jobs_dev, int njobs, const float* const* terms_dev, int64_t max_n, bool vec4, const float* gains_dev,
+                const float* const* curves_dev) {
   if (njobs <= 0 || max_n <= 0) return;
   int64_t nv = vec4 ? (max_n + 3) / 4 : max_n;
   int gx = (int)std::min<int64_t>((nv + 255) / 256, 2048);
   if (gains_dev) {
     if (vec4)
-      GA_LAUNCH_JOBS((mix_kernel<4, true>), gx, 256, jobs_dev, njobs, terms_dev, gains_dev);
+      GA_LAUNCH_JOBS((mix_kernel<4, true>), gx, 256, jobs_dev, njobs, terms_dev, gains_dev, curves_dev);
     else
-      GA_LAUNCH_JOBS((mix_kernel<1, true>), gx, 256, jobs_dev, njobs, terms_dev, gains_dev);
+      GA_LAUNCH_JOBS((mix_kernel<1, true>), gx, 256, jobs_dev, njobs, terms_dev, gains_dev, curves_dev);
   } else if (vec4) {
-    GA_LAUNCH_JOBS((mix_kernel<4, false>), gx, 256, jobs_dev, njobs, terms_dev, gains_dev);
+    GA_LAUNCH_JOBS((mix_kernel<4, false>), gx, 256, jobs_dev, njobs, terms_dev, gains_dev, curves_dev);
   } else {
-    GA_LAUNCH_JOBS((mix_kernel<1, false>), gx, 256, jobs_dev, njobs, terms_dev, gains_dev);
+    GA_LAUNCH_JOBS((mix_kernel<1, false>), gx, 256, jobs_dev, njobs, terms_dev, gains_dev, curves_dev);
   }
 }
 

@@ -245,7 +245,8 @@ struct MixJob {
   int64_t n;      // frames
 };
 // gains_dev (may be null): one factor per entry of the term table -- term j contributes fl(term[j][f] * gain[j]) (a folded constant GainNode)
-void launch_mix(hipStream_t s, const MixJob* jobs_dev, int njobs, const float* const* terms_dev, int64_t max_n, bool vec4, const float* gains_dev = nullptr);
+void launch_mix(hipStream_t s, const MixJob* jobs_dev, int njobs, const float* const* terms_dev, int64_t max_n, bool vec4, const float* gains_dev = nullptr,
+                const float* const* curves_dev = nullptr);   // curves: per term, null or a chunk-frame indexed gain curve (a folded automated GainNode)
 
 // down-mix N -> 1: out[f] = (sum_ch in[ch][f]) * scale   (AudioNodeInput.cs:214-228); 'ins' index the term table
 struct DownmixJob {
