@@ -937,6 +937,7 @@ struct Exec {
   std::vector<BiquadDynJob> bqDynJobs;
   std::vector<LoopJob> loopJobs;
   std::vector<ResampleJob> rsJobs;
+  std::vector<ResampleFastJob> rsFastJobs;   // (full blocks of a trajectory whose per-sample table is on the device: one lane per output)
   std::vector<GsrJob> gsrJobs;
   std::vector<StreamJob> streamJobs;
   std::vector<ConstJob> constJobs;
@@ -1174,6 +1175,14 @@ struct Exec {
         launch_resample(st, (const ResampleJob*)(base + r.off), r.nj, (const ResampleBlock*)(base + trajOffFinal), r.mx);
       });
     }
+    if (!rsFastJobs.empty()) {
+      size_t off = plan.putv(rsFastJobs);
+      int nj = (int)rsFastJobs.size();
+      int64_t mx = 0;
+      for (auto& j : rsFastJobs) mx = std::max(mx, j.nblocks);
+      hipStream_t st = c.stream;
+      plan.add(LK_OTHER, [=](uint8_t* base) { launch_resample_fast(st, (const ResampleFastJob*)(base + off), nj, mx); });
+    }
     if (!gsrJobs.empty()) {
       size_t off = plan.putv(gsrJobs);
       int nj = (int)gsrJobs.size();
@@ -1310,6 +1319,7 @@ struct Exec {
     bqSecs.clear();
     loopJobs.clear();
     rsJobs.clear();
+    rsFastJobs.clear();
     gsrJobs.clear();
     streamJobs.clear();
     constJobs.clear();
@@ -3097,6 +3107,34 @@ void Context::planStereoPanner(NodePlanCtx& k) {
   ov[1] = pj.out_r;
 }
 
+// The per-sample table of a resampler trajectory on the device, up to (excluding) block `upto`: what extend() left in `pending` is
+// appended (through the chunk's tables: a plan entry in front of the launches that read it), the buffer doubles when it is full.
+bool Context::ensureResampleSamples(Exec& ex, Resampler& rs, int64_t upto) {
+  const int64_t have = rs.devBlocks + (int64_t)rs.pending.size() / kBlock;
+  if (upto > have) return false;                       // (blocks the trajectory was extended to before the table existed)
+  if (upto <= rs.devBlocks || rs.pending.empty()) return upto <= rs.devBlocks;
+  const int64_t need = have;
+  if (need > rs.devCapBlocks) {
+    const int64_t cap = std::max<int64_t>(4096, std::max(need, 2 * rs.devCapBlocks));
+    ResampleSample* nw = (ResampleSample*)dalloc((size_t)cap * kBlock * sizeof(ResampleSample));
+    if (rs.devSamples) {
+      GA_HIP(hipStreamSynchronize(stream));   // (rare: the table doubles)
+      GA_HIP(hipMemcpy(nw, rs.devSamples, (size_t)rs.devBlocks * kBlock * sizeof(ResampleSample), hipMemcpyDeviceToDevice));
+      dfree(rs.devSamples, (size_t)rs.devCapBlocks * kBlock * sizeof(ResampleSample));
+    }
+    rs.devSamples = nw;
+    rs.devCapBlocks = cap;
+  }
+  const size_t bytes = rs.pending.size() * sizeof(ResampleSample);
+  const size_t off = ex.plan.put(rs.pending.data(), bytes);
+  ResampleSample* dst = rs.devSamples + (size_t)rs.devBlocks * kBlock;
+  hipStream_t st = stream;
+  ex.plan.add(LK_OTHER, [=](uint8_t* base) { GA_HIP(hipMemcpyAsync(dst, base + off, bytes, hipMemcpyDeviceToDevice, st)); });
+  rs.devBlocks = need;
+  rs.pending.clear();
+  return true;
+}
+
 // AudioBufferSourceNode.Process (AudioBufferSourceNode.cs:150-260): zero-copy windows, loop walks, resampler jobs, general replay
 void Context::planBufferSource(NodePlanCtx& k) {
   Exec& ex = k.ex; const size_t si = k.si; const Segment& sg = k.sg; const NodeSeg& ns = k.ns; NodeS& nd = k.nd; Views& ov = k.ov;
@@ -3168,6 +3206,23 @@ void Context::planBufferSource(NodePlanCtx& k) {
       if (nd.rsStartPos < 0 || avail < 0 || nd.rsStartPos + avail > pb.length ||
           (!partial && rs.blocks[ns.srcBlk + nb].consumed > avail))
         fail(GA_ERR_DEVICE, "internal: resampler job reads beyond the source buffer");
+    }
+    // Full blocks of the shared trajectory: one lane per OUTPUT sample from the trajectory's per-sample table (resample_fast_kernel).
+    // The table lives on the device and only grows; what extend() produced since the last upload rides in this chunk's tables.
+    if (resampleFast && traj0 == rs.devOffset + (int)ns.srcBlk && rs.samplesOk && (int64_t)ns.srcBlk + nb <= (int64_t)rs.blocks.size() - 1 &&
+        ensureResampleSamples(ex, rs, ns.srcBlk + nb)) {
+      for (int ch = 0; ch < pb.channels; ch++) {
+        ResampleFastJob fj;
+        fj.buf = pb.dev + (size_t)ch * pb.stride;
+        fj.out = ex.nodeOut(ns.id, ch);
+        fj.samples = rs.devSamples + (size_t)ns.srcBlk * kBlock;
+        fj.start_pos = nd.rsStartPos;
+        fj.b0 = sg.b0;
+        fj.nblocks = nb;
+        ex.rsFastJobs.push_back(fj);
+        ov[ch] = fj.out;
+      }
+      return;
     }
     for (int ch = 0; ch < pb.channels; ch++) {
       ResampleJob rj;

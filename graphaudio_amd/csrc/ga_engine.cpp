@@ -264,6 +264,13 @@ Context::~Context() {
   if (coarseY.p) (void)hipFree(coarseY.p);
   if (coarseM.p) (void)hipFree(coarseM.p);
   if (deferStage) (void)hipFree(deferStage);
+  for (auto& kv : resamplers)
+    if (kv.second->devSamples) (void)hipFree(kv.second->devSamples);
+  for (auto& np : nodes)
+    if (np && np->staleBuf) {
+      (void)hipFree(np->staleBuf);
+      (void)hipFree(np->staleNext);
+    }
   for (float* p : bqSplitBlocks) (void)hipFree(p);
   if (ilvDev) (void)hipFree(ilvDev);
   if (tables.p) (void)hipFree(tables.p);
@@ -1178,6 +1185,12 @@ void Resampler::extend(int64_t nblocks) {
       int consume = (int)Pos;
       in += consume;
       Pos -= consume;
+      if (in > 0xFFFFFFF0ll || pending.size() > ((size_t)1 << 24)) {   // (32-bit index exhausted, or nobody takes the samples: 128 MB of them)
+        samplesOk = false;
+        pending.clear();
+        pending.shrink_to_fit();
+      }
+      if (samplesOk) pending.push_back(ResampleSample{(uint32_t)in, (float)Pos});   // `t = (float)Pos`, CubicResampler.cs:50
       Pos += rate;
     }
     consumedEnd = in;

@@ -496,10 +496,17 @@ struct Resampler {  // host replay of CubicResampler's position recurrence (Cubi
   double posEnd = 0.0;
   int readyEnd = 0;
   int devOffset = -1;                 // offset in the per-chunk device trajectory table
+  // per OUTPUT SAMPLE (resample_fast_kernel): where the window ends and the interpolation fraction.  Produced by extend() next to the
+  // block states, moved to a device table that only grows (1 KB per block and rate, shared by every voice of the rate)
+  std::vector<ResampleSample> pending;   // samples of blocks [devBlocks, devBlocks + pending.size() / 128): not on the device yet
+  ResampleSample* devSamples = nullptr;
+  int64_t devBlocks = 0, devCapBlocks = 0;
+  bool samplesOk = true;                 // false once a consumption count no longer fits the table's 32-bit index
   void extend(int64_t nblocks);
 };
 
 struct ChunkRun;   // ga_chunk.cpp
+struct Exec;       // ga_chunk.cpp
 struct NodePlanCtx;   // ga_chunk.cpp
 struct ConvPlanCtx;   // ga_chunk.cpp
 
@@ -646,6 +653,8 @@ struct Context {
   std::shared_ptr<IrSpectra> irSpectra(int bufId, bool normalize);
   void releaseConvState(NodeS& n);
   void refOrderSensitivity(const std::vector<int>& topo);
+  bool ensureResampleSamples(Exec& ex, Resampler& rs, int64_t upto);
+  bool resampleFast = true;   // option "resample_fast": one lane per output sample from the trajectory's per-sample table
   void assignConvPaths(const std::vector<int>& topo, int64_t chunkBlocks);
   // formulation D
   // Option `coarse_overlap` (default 0): run the forward transforms and the multiply-accumulate CONCURRENTLY -- the signals

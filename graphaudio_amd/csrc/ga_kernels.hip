@@ -2344,6 +2344,26 @@ __global__ __launch_bounds__(64) void resample_kernel(const ResampleJob* __restr
     out[(int64_t)r * kBlock + 64 + lane] = tile[r][64 + lane];
   }
 }
+__global__ __launch_bounds__(256) void resample_fast_kernel(const ResampleFastJob* __restrict jobs) {
+  const ResampleFastJob job = jobs[blockIdx.y];
+  const int64_t total = job.nblocks * kBlock;
+  const GA_GLOBAL float* __restrict in = gptr(job.buf) + job.start_pos;
+  const GA_GLOBAL v2f* __restrict sm = (const GA_GLOBAL v2f*)job.samples;   // (ip as the bits of .x, t = .y: one 8-byte load)
+  GA_GLOBAL float* __restrict out = gptr(job.out) + job.b0 * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const v2f e = sm[i];
+    const GA_GLOBAL float* __restrict w = in + (int64_t)__float_as_uint(e.x) - 4;
+    const float S0 = w[0], S1 = w[1], S2 = w[2], S3 = w[3];
+    const float t = e.y;
+    // CubicResampler.cs:52-57, the reference's expression tree
+    out[i] = S1 + t * (0.5f * (S2 - S0) + t * ((S0 - 2.5f * S1 + 2.f * S2 - 0.5f * S3) + t * (0.5f * (S3 - S0) + 1.5f * (S1 - S2))));
+  }
+}
+void launch_resample_fast(hipStream_t s, const ResampleFastJob* jobs_dev, int njobs, int64_t max_blocks) {
+  if (njobs <= 0 || max_blocks <= 0) return;
+  const int gx = (int)std::min<int64_t>((max_blocks * kBlock + 255) / 256, 512);
+  GA_LAUNCH_JOBS(resample_fast_kernel, gx, 256, jobs_dev, njobs);
+}
 void launch_resample(hipStream_t s, const ResampleJob* jobs_dev, int njobs, const ResampleBlock* traj_dev, int64_t max_blocks) {
   if (njobs <= 0 || max_blocks <= 0) return;
   int gx = (int)((max_blocks + 63) / 64);

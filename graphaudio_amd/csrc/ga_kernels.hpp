@@ -433,6 +433,24 @@ struct ResampleJob {
   int64_t nblocks;
 };
 void launch_resample(hipStream_t s, const ResampleJob* jobs_dev, int njobs, const ResampleBlock* traj_dev, int64_t max_blocks);
+// The same arithmetic with ONE LANE PER OUTPUT SAMPLE.  The only serial part of CubicResampler.Process is the position recurrence
+// (Pos += rate in double, consume = (int)Pos: CubicResampler.cs:40-60); the host replays it once per distinct rate anyway (Resampler)
+// and leaves, per output sample, where the window ends and the interpolation fraction -- every voice of that rate reads the same
+// table.  A lane then gathers its four taps and evaluates the reference's float32 polynomial: bit-exact, coalesced, bound by HBM
+// instead of by 128 dependent steps per lane (config 4 at 4096 voices: 4.3 -> ~1 ms per 2.5 s).
+struct ResampleSample {
+  uint32_t ip;   // input samples consumed when this output is produced (relative to the job's start position): taps ip-4 .. ip-1
+  float t;       // (float)Pos
+};
+struct ResampleFastJob {
+  const float* buf;                // channel data
+  float* out;                      // chunk-frame indexed
+  const ResampleSample* samples;   // the trajectory's samples from the job's first block on (128 per block)
+  int64_t start_pos;
+  int64_t b0;
+  int64_t nblocks;
+};
+void launch_resample_fast(hipStream_t s, const ResampleFastJob* jobs_dev, int njobs, int64_t max_blocks);
 
 // General source replay: the host replays AudioBufferSourceNode.Process block by block (AudioBufferSourceNode.cs:165-358:
 // k-rate playbackRate per block, loop wrap, the copy path when the effective rate is exactly 1, the resampler's window
