@@ -735,7 +735,7 @@ def main():
             "host_issue_ms_per_step": t_enq / args.steps * 1e3,
             "device_ms_per_step": dev_ms,
             "profiled_chunks": nprof,
-            "roofline": attach_pmc_traffic(roofline_of(stages), os.path.join(ROOT, "profiles", "r03_cfg3_pmc_hbm_traffic.json")),
+            "roofline": attach_pmc_traffic(roofline_of(stages), os.path.join(ROOT, "profiles", "r04_cfg3_pmc_hbm_traffic.json")),
             "stages": stages,
             "whole_step": whole,
             "streaming_formulation": {"bytes_per_step": stream_bytes, "tb_per_s_if_streamed": stream_bytes / (dt / args.steps) / 1e12,
@@ -803,6 +803,9 @@ def main():
                 def extra(r, st0, st1):
                     fps, dt, err, sig, _ = oracle_short_form(build_short, ch, short_frames, options)
                     other = r["stages"].get("other", {}).get("ms_per_step", 0.0) + r["stages"].get("mix", {}).get("ms_per_step", 0.0)
+                    if r.get("roofline"):
+                        r["roofline"]["note"] = ("the HBM-bound stage of this graph; its dominant stage by time is 'other' (serial recurrences / launch-bound "
+                                                 "elementwise kernels), which no bandwidth roof prices: see serial_bound")
                     return {"parity_vs_oracle": {"rms_abs": err, "rms_relative_to_bus": err / max(sig, 1e-30), "bus_rms": sig, "tolerance_rms_abs": 1e-5,
                                                  "sample": f"{voices_n} voices x {short_frames // 128} blocks (short form of this graph) vs the CPU oracle"},
                             "cpu_baseline": {"value": fps, "unit": "frames/s", "cores": 1, "kind": "port",

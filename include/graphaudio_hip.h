@@ -43,7 +43,9 @@ extern "C" {
 #define GA_ERR_OUT_OF_RANGE (-2)      /* ArgumentOutOfRangeException (AudioBuffer.cs:18, AudioNodeInput.cs:43) */
 #define GA_ERR_INVALID_OPERATION (-3) /* InvalidOperationException   (ConvolverNode.cs:45-49, AudioBufferSourceNode.cs:83-90) */
 #define GA_ERR_DISPOSED (-4)          /* ObjectDisposedException     (AudioContextBase.cs:54,268) */
-#define GA_ERR_CYCLE (-5)             /* InvalidOperationException "Audio graph cycle detected" (Nodes/AudioNode.cs:157-160) */
+#define GA_ERR_CYCLE (-5)             /* InvalidOperationException "Audio graph cycle detected" (Nodes/AudioNode.cs:157-160): unreachable in the
+                                         reference (its memo check returns first) and no longer returned here -- loops render with the
+                                         reference's one-block stale buffer */
 #define GA_ERR_UNSUPPORTED (-6)       /* graph uses a feature outside the accelerated path: host must fall back to the CPU context */
 #define GA_ERR_DEVICE (-7)            /* HIP runtime error */
 #define GA_ERR_OUT_OF_MEMORY (-8)
