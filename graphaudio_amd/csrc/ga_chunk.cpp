@@ -1016,11 +1016,53 @@ struct Exec {
     SmallVec<SmallVec<Tm, 2>, 4> lists((size_t)dstCh);
     for (const TermS& t : is.terms) {
       Views staleViews;
-      if (t.stale) {   // feedback edge: the block the producer put out last (kept by Context::chunkStaleCommit; the chunk is one block)
+      if (t.stale) {   // feedback edge: the block the producer put out last (kept by Context::chunkStaleCommit)
         const NodeS& pn = *c.nodes[t.node];
         const int rows = pn.type == GA_NODE_CHANNEL_SPLITTER ? (int)pn.outputs.size() : t.ch;
         staleViews.assign((size_t)rows, nullptr);
-        for (int r = 0; r < rows; r++) staleViews[r] = (pn.staleBuf && r < pn.staleRows) ? pn.staleBuf + (size_t)r * kBlock : c.zeros;
+        if (frames <= kBlock) {   // a chunk of one block: the kept block itself
+          for (int r = 0; r < rows; r++) staleViews[r] = (pn.staleBuf && r < pn.staleRows) ? pn.staleBuf + (size_t)r * kBlock : c.zeros;
+        } else {
+          // A chunk of several blocks (every loop cut at a DelayNode, Context::chunkTopology): block b of this input reads block
+          // b - 1 of the producer -- the kept block for the chunk's first block, the producer's own output of THIS chunk, one block
+          // late, for the others (the producer is planned before this consumer: the stale edge is an ordinary forward edge of the
+          // cut graph).  Materialised per row by two copy jobs (the down-mix launch of this level runs before its mix launch).
+          const float gB = scaleOf(si, t.node);
+          for (int r = 0; r < rows; r++) {
+            float* T = getSlab(c);
+            const float* srcA = nullptr;
+            float gA = 1.f;
+            if (sg.b0 == 0) {
+              srcA = (pn.staleBuf && r < pn.staleRows) ? pn.staleBuf + (size_t)r * kBlock : nullptr;   // (indexed from frame 0)
+            } else if (si > 0 && t.node < (int)outViews[si - 1].size() && r < (int)outViews[si - 1][t.node].size() && outViews[si - 1][t.node][r]) {
+              srcA = outViews[si - 1][t.node][r] - kBlock;
+              gA = scaleOf(si - 1, t.node);
+            }
+            DownmixJob a;
+            a.out = T;
+            a.term0 = (int)terms.size();
+            a.nch = 1;
+            a.scale = 1.0f;
+            a.f0 = f0;
+            a.n = std::min<int64_t>(nf, kBlock);
+            pushTerm(srcA ? srcA : c.zeros, gA);
+            dmJobs.push_back(a);
+            if (nf > kBlock) {
+              const auto& cv = outViews[si][t.node];
+              const float* srcB = (r < (int)cv.size() && cv[r]) ? cv[r] - kBlock : nullptr;
+              DownmixJob b;
+              b.out = T;
+              b.term0 = (int)terms.size();
+              b.nch = 1;
+              b.scale = 1.0f;
+              b.f0 = f0 + kBlock;
+              b.n = nf - kBlock;
+              pushTerm(srcB ? srcB : c.zeros, srcB ? gB : 1.f);
+              dmJobs.push_back(b);
+            }
+            staleViews[r] = T;
+          }
+        }
       }
       const auto& uvAll = t.stale ? staleViews : outViews[si][t.node];
       const float g = t.stale ? 1.f : scaleOf(si, t.node);   // (a folded constant GainNode: its views are its INPUT's, to be multiplied here)
@@ -2335,7 +2377,9 @@ void Context::chunkTopology(ChunkRun& r) {
   int& bHistMax = r.bHistMax; (void)bHistMax;
   // ---- reachability, level, convolver depth on the graph as it stands after the queued commands ----
   // (cached while no connection, disposal or impulse response changed since the last chunk)
-  if (topoVersion == graphVersion && !topoCache.empty()) {
+  // (a graph with feedback is walked again every chunk: whether its loops can be cut at their DelayNodes depends on the delay
+  // times, which are parameters, not graph structure)
+  if (topoVersion == graphVersion && !topoCache.empty() && !topoHasCycles) {
     topo = topoCache;
   } else {
   for (auto& np : nodes) {
@@ -2343,24 +2387,48 @@ void Context::chunkTopology(ChunkRun& r) {
     np->isProcessing = false;
     np->level = 0;
     np->depth = 0;
+    np->delaySplit = false;
   }
+  cycleBlocks = 1;
+  std::vector<int> color(nodes.size(), 0);
+  std::vector<char> candidate;   // DelayNodes on a loop whose delay is a constant of at least two blocks
+  bool unbreakable = false;
   {
     // The traversal order is the reference's (parameters first, then the inputs, connections in order: Nodes/AudioNode.cs:167-175).
     // A node met again while it is still being processed closes a feedback cycle.  The reference does not refuse that: its memo
     // check (Nodes/AudioNode.cs:153-156) returns before the "cycle detected" test can fire, and the consumer mixes the producer's
     // PREVIOUS block.  Such an edge carries no ordering constraint -- the producer is processed later in the block, as there.
-    std::vector<int> color(nodes.size(), 0);
     for (int id : staleProducers)
       if (id < (int)nodes.size() && nodes[id]) nodes[id]->staleProducer = false;
     staleProducers.clear();
+    std::vector<int> stack;
+    auto splittable = [&](const NodeS& d) {
+      if (d.type != GA_NODE_DELAY || !d.params[0].events.empty() || !d.params[0].modulation.empty()) return 0;
+      int dl = (int)(d.params[0].value * (float)sampleRate);   // DelayNode.cs:66 (float * int -> float, truncated)
+      dl = std::min(std::max(dl, 0), d.maxDelaySamples);
+      return dl / kBlock;   // whole blocks of delay
+    };
     std::function<bool(int)> dfs = [&](int id) {   // false: `id` is being processed (the edge that led here is a feedback edge)
       if (color[id] == 2) return true;
       if (color[id] == 1) {
         if (!nodes[id]->staleProducer) staleProducers.push_back(id);
         nodes[id]->staleProducer = true;
+        // the loop this edge closes: the nodes on the stack from `id` up.  It can be cut where a DelayNode delays by >= 2 blocks.
+        if (candidate.empty()) candidate.assign(nodes.size(), 0);
+        bool any = false;
+        for (size_t q = stack.size(); q-- > 0;) {
+          const int m = stack[q];
+          if (splittable(*nodes[m]) >= 2) {
+            candidate[m] = 1;
+            any = true;
+          }
+          if (m == id) break;
+        }
+        if (!any) unbreakable = true;
         return false;
       }
       color[id] = 1;
+      stack.push_back(id);
       NodeS& nd = *nodes[id];
       nd.reachable = true;
       int lvl = 0, dep = 0;
@@ -2385,18 +2453,73 @@ void Context::chunkTopology(ChunkRun& r) {
       nd.level = lvl;
       nd.depth = dep;
       color[id] = 2;
+      stack.pop_back();
       topo.push_back(id);
       return true;
     };
     dfs(0);
+    // ---- loops that can be cut at a DelayNode (option "cycle_delay_split") ----
+    // A DelayNode whose delay is a constant of d >= 128 K samples reads, for any K consecutive blocks, only samples its ring held
+    // BEFORE those blocks: its output for the whole K-block chunk can be produced first (a gather from the history: the READER, a node
+    // without inputs), and its input appended afterwards (the WRITER).  With every loop cut that way the chunk's graph is acyclic; the
+    // reference's stale edge becomes an ordinary edge that reads its producer ONE BLOCK LATE (Exec::resolveInSeg).  Chunks of K blocks
+    // instead of one: a 0.25 s echo renders 93 blocks per chunk.
+    if (!staleProducers.empty() && !unbreakable && cycleDelaySplit) {
+      int K = 1 << 30;
+      for (size_t m = 0; m < candidate.size(); m++)
+        if (candidate[m]) K = std::min(K, splittable(*nodes[m]));
+      // second walk, edges OUT of a cut DelayNode carry no ordering: is anything still cyclic?
+      std::vector<int> color2(nodes.size(), 0), order, deferred;
+      std::vector<int> lvl2(nodes.size(), 0), dep2(nodes.size(), 0);
+      bool cyclic = false;
+      std::function<void(int)> dfs2 = [&](int id) {
+        if (color2[id] == 2 || cyclic) return;
+        if (color2[id] == 1) {
+          cyclic = true;
+          return;
+        }
+        color2[id] = 1;
+        NodeS& nd = *nodes[id];
+        int lvl = 0, dep = 0;
+        auto edge = [&](int up) {
+          if (candidate[up]) {   // the reader: a source (planned in front of everything); its writer is walked as a root of its own
+            if (color2[up] == 0) deferred.push_back(up);
+            return;
+          }
+          dfs2(up);
+          lvl = std::max(lvl, lvl2[up] + 1);
+          dep = std::max(dep, dep2[up] + ((nodes[up]->type == GA_NODE_CONVOLVER && nodes[up]->ir) ? 1 : 0));
+        };
+        for (auto& p : nd.params)
+          for (auto& m : p.modulation) edge(m.first);
+        for (auto& in : nd.inputs)
+          for (const Conn& cn : in.connected) edge(cn.node);
+        lvl2[id] = lvl;
+        dep2[id] = dep;
+        color2[id] = 2;
+        order.push_back(id);
+      };
+      dfs2(0);
+      for (size_t q = 0; q < deferred.size() && !cyclic; q++) dfs2(deferred[q]);
+      if (!cyclic && K >= 2 && order.size() == topo.size()) {
+        topo = order;
+        for (int id : topo) {
+          nodes[id]->level = lvl2[id];
+          nodes[id]->depth = dep2[id];
+          nodes[id]->delaySplit = candidate[id] != 0;
+        }
+        cycleBlocks = K;
+      }
+    }
   }
   topoCache = topo;
   topoVersion = graphVersion;
   topoHasCycles = !staleProducers.empty();
   }
-  // Feedback: the loop closes through the block a producer put out LAST, so nothing can be batched along time -- the chunk is one
-  // block, the reference's own granularity (a 10 s render = 3,750 chunks: launch bound, ~0.1 - 0.3 ms each)
-  if (topoHasCycles) r.n = 1;
+  // Feedback: the loop closes through the block a producer put out LAST.  Unless every loop can be cut at a DelayNode (above: chunks
+  // of `cycleBlocks` blocks) nothing can be batched along time -- the chunk is one block, the reference's own granularity (a 10 s
+  // render = 3,750 chunks: launch bound, ~0.1 - 0.3 ms each)
+  if (topoHasCycles) r.n = std::min<int64_t>(r.n, cycleBlocks);
   if (topoStatsVersion != graphVersion || topoStatsSize != topo.size()) {   // (cached with the order: a sweep over 28,672 node records is 0.5 ms)
     topoMaxDepth = topoMaxLevel = 0;
     topoHasTimeNodes = topoHasConvolvers = topoHasOscillators = false;
@@ -2670,6 +2793,7 @@ void Context::chunkResources(ChunkRun& r) {
       nd.delayLine = (float*)dalloc((maxD + (size_t)nd.delayCap) * rings * sizeof(float));
     }
     nd.delayW.assign(rings, 0);
+    nd.delayR.assign(rings, 0);
   }
 
   // ---- device resources for this chunk ----
@@ -2963,6 +3087,7 @@ struct NodePlanCtx {
   ChunkRun& r; Exec& ex; size_t si; const Segment& sg; int64_t f0, nf, nb;
   const NodeSeg& ns; NodeS& nd; Views& ov;
   const DenseSeg& segNode; const DenseInt& absorbedBy; int levelBqHeads;
+  int delayPhase = 0;   // DelayNode: 0 = the whole node, 1 = reader only, 2 = writer only (a loop cut at this node)
 };
 
 // ConstantSourceNode.Process (ConstantSourceNode.cs:76-141)
@@ -3014,6 +3139,7 @@ void Context::planDelay(NodePlanCtx& k) {
   if (!nd.delayLoaded) {   // history of the previous chunks in front of every ring's line
     nd.delayLoaded = true;
     std::fill(nd.delayW.begin(), nd.delayW.end(), 0);
+    std::fill(nd.delayR.begin(), nd.delayR.end(), 0);
     float* line = nd.delayLine;
     float* hist = nd.delayHist;
     const int rings = nd.delayHistRings;
@@ -3028,8 +3154,14 @@ void Context::planDelay(NodePlanCtx& k) {
   // a second job that copies a mixed slab into the ring would sit in the same launch as the mix that produces the slab -- no
   // order between them (until round 3 a DelayNode with two connections, or behind a folded GainNode, read a half-written slab).
   SmallVec<float*, 4> ring((size_t)std::max(ch, 1), nullptr);
-  for (int cch = 0; cch < ch; cch++) ring[cch] = nd.delayLine + (size_t)cch * pitch + maxD + nd.delayW[cch] - f0;   // ring[c][f] = input sample of frame f
-  if (!ns.ins[0].silent) {
+  // A DelayNode at which a feedback loop is cut (NodeS::delaySplit, Context::chunkTopology) is planned twice per segment: the READER
+  // in front of everything (its gather only touches what the ring held before the chunk), the WRITER at the node's level -- possibly
+  // a convolver depth later, i.e. after the readers of ALL segments: the reader counts the ring positions on its own (delayR).
+  const bool reader = k.delayPhase != 2, writer = k.delayPhase != 1;
+  for (int cch = 0; cch < ch; cch++)   // ring[c][f] = input sample of frame f
+    ring[cch] = nd.delayLine + (size_t)cch * pitch + maxD + (k.delayPhase == 1 ? nd.delayR[cch] : nd.delayW[cch]) - f0;
+  if (!writer) {
+  } else if (!ns.ins[0].silent) {
     ex.resolveInput((int)si, ns, 0, true, ring.data());
   } else {
     for (int cch = 0; cch < ch; cch++) {   // zeros
@@ -3042,6 +3174,10 @@ void Context::planDelay(NodePlanCtx& k) {
       ex.noteAlign(ring[cch], f0);
       ex.mixJobs.push_back(mj);
     }
+  }
+  if (!reader) {
+    for (int cch = 0; cch < ch; cch++) nd.delayW[cch] += nf;
+    return;
   }
   const float* delayCurve = ex.paramView((int)si, ns, 0);
   for (int cch = 0; cch < ch; cch++) {
@@ -3057,7 +3193,8 @@ void Context::planDelay(NodePlanCtx& k) {
     dj.f0 = f0;
     dj.n = nf;
     ex.delayJobs.push_back(dj);
-    nd.delayW[cch] += nf;
+    if (writer) nd.delayW[cch] += nf;
+    else nd.delayR[cch] += nf;
     if (ns.delayAudible) ov[cch] = dj.out;   // a buffer still flagged silent is skipped by every consumer
   }
 }
@@ -3514,6 +3651,18 @@ void Context::chunkPlanNodes(ChunkRun& r, int d) {
         fuseLen[b_.id] = la_ + 1;
       }
       int curLevel = -1, levelBqHeads = 0;
+      if (d == 0 && topoHasCycles && cycleBlocks > 1) {   // the readers of the DelayNodes at which this chunk's loops are cut: sources
+        for (const NodeSeg& ns : sg.nodes) {
+          NodeS& nd = *nodes[ns.id];
+          if (nd.type != GA_NODE_DELAY || !nd.delaySplit) continue;
+          auto& ov = ex.outViews[si][ns.id];
+          ov.assign(std::max(ns.outCh, 1), nullptr);
+          NodePlanCtx k{r, ex, si, sg, f0, nf, nb, ns, nd, ov, segNode, absorbedBy, 0};
+          k.delayPhase = 1;
+          planDelay(k);
+        }
+        ex.flushLevel();
+      }
       for (size_t ti = 0; ti < todo.size(); ti++) {
         const NodeSeg* nsp = todo[ti];
         if (ti + 4 < todo.size()) {   // (the sweep is bound by cache misses on the node records)
@@ -3534,8 +3683,10 @@ void Context::chunkPlanNodes(ChunkRun& r, int d) {
           }
         }
         auto& ov = ex.outViews[si][ns.id];
-        ov.assign(nd.type == GA_NODE_CHANNEL_SPLITTER ? (int)nd.outputs.size() : std::max(ns.outCh, 1), nullptr);
+        const bool cutDelay = nd.type == GA_NODE_DELAY && nd.delaySplit && topoHasCycles && cycleBlocks > 1;   // (its reader set the views)
+        if (!cutDelay) ov.assign(nd.type == GA_NODE_CHANNEL_SPLITTER ? (int)nd.outputs.size() : std::max(ns.outCh, 1), nullptr);
         NodePlanCtx k{r, ex, si, sg, f0, nf, nb, ns, nd, ov, segNode, absorbedBy, levelBqHeads};
+        if (cutDelay) k.delayPhase = 2;
         switch (nd.type) {
           case GA_NODE_CHANNEL_SPLITTER: {   // zero-copy: output o IS channel o of the mixed input
             if (!ns.outMask) break;
@@ -4122,7 +4273,7 @@ void Context::chunkStaleCommit(ChunkRun& r) {
     const Views* ov = (si >= 0 && id < (int)ex.outViews[si].size()) ? &ex.outViews[si][id] : nullptr;
     const float g = si >= 0 ? ex.scaleOf(si, id) : 1.f;
     for (int rw = 0; rw < nd.staleRows; rw++) {
-      const float* src = (ov && rw < (int)ov->size()) ? (*ov)[rw] : nullptr;
+      const float* src = (ov && rw < (int)ov->size() && (*ov)[rw]) ? (*ov)[rw] + (r.n - 1) * kBlock : nullptr;   // (the chunk's LAST block)
       jobs.push_back(StaleJob{nd.staleNext + (size_t)rw * kBlock, src, g, 0});
     }
     std::swap(nd.staleBuf, nd.staleNext);

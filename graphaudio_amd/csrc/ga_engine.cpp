@@ -693,9 +693,11 @@ void Context::refOrderSensitivity(const std::vector<int>& topo) {
   bool anyConv = false;
   for (int id : topo) anyConv = anyConv || (nodes[id]->type == GA_NODE_CONVOLVER && nodes[id]->ir);
   if (!anyConv) return;
-  if (convRefOrder != 1) {
+  if (convRefOrder != 1 || topoHasCycles) {
+    // (a graph with a feedback loop: every convolver -- with loops cut at DelayNodes the processing order no longer says which
+    // convolvers feed the loop, and such graphs run in short chunks where the reference order costs little)
     for (int id : topo)
-      if (nodes[id]->type == GA_NODE_CONVOLVER) nodes[id]->refSens = convRefOrder == 2;
+      if (nodes[id]->type == GA_NODE_CONVOLVER) nodes[id]->refSens = convRefOrder == 2 || (convRefOrder == 1 && topoHasCycles);
     return;
   }
   std::vector<char>& sens = refSensScratch;

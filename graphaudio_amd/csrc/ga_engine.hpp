@@ -204,6 +204,7 @@ struct NodeS {
   float* delayLine = nullptr;      // device scratch [rings][maxDelaySamples + delayCap]: history followed by the chunk's input
   int64_t delayCap = 0;
   int delayLineRings = 0;
+  std::vector<int64_t> delayR;     // the same count as seen by the READER of a DelayNode at which a loop is cut (planned a convolver depth earlier)
   std::vector<int64_t> delayW;     // per ring: frames appended in the current chunk (a ring only advances while it is processed)
   bool delayLoaded = false;        // per chunk: history copied in front of the line
   // control-plane model of what the rings hold, each ring on its OWN time line (a ring beyond the input's channel count is not
@@ -299,6 +300,7 @@ struct NodeS {
   // feedback cycles: a node that some consumer pulls while it is being processed keeps a copy of the block it put out last
   // (shape of its output views: one row of 128 frames per channel, per output for a ChannelSplitterNode)
   bool staleProducer = false;
+  bool delaySplit = false;     // (per chunk) a DelayNode at which a feedback loop is cut: reader in front of everything, writer at its level
   float* staleBuf = nullptr;   // the copy consumers read in this chunk: [staleRows][128]
   float* staleNext = nullptr;  // ... and the one this chunk's output is written to (the two swap when the chunk is planned)
   int staleRows = 0;
@@ -824,6 +826,8 @@ struct Context {
   bool topoHasTimeNodes = false, topoHasConvolvers = false, topoHasOscillators = false;
   bool topoHasCycles = false;   // (chunkTopology) some node is pulled while it is being processed: chunks of ONE block (the reference's own granularity)
   std::vector<int> staleProducers;
+  int cycleBlocks = 1;          // blocks per chunk of a graph with feedback (1 unless every loop is cut at a DelayNode)
+  bool cycleDelaySplit = true;  // option "cycle_delay_split"
   // the output views of the previous chunk's last segment (and the gains folded into them): when an edit closes a cycle, the block
   // the new stale producer put out LAST is still in those slabs (Context::chunkStaleSeed)
   std::vector<Views> lastViews;

@@ -171,3 +171,128 @@ def test_master_echo_behind_sixteen_voices():
         d.Connect(ctx.Destination)
     ref, got = both(build, frames)
     assert G.rms(ref) > 1e-3 and np.array_equal(ref, got)
+
+
+# ---- loops cut at their DelayNodes: chunks of floor(delay / 128) blocks instead of one (Context::chunkTopology) ----------------
+def _echo(ctx, delay_s, frames, fb=0.55, burst=128 * 30, through=None):
+    s = src(ctx, 21, burst)
+    d = DelayNode(ctx, 1.0)
+    d.DelayTime.Value = delay_s
+    g = GainNode(ctx)
+    g.Gain.Value = fb
+    s.Connect(d)
+    node = d
+    if through == "biquad":
+        bq = BiQuadFilterNode(ctx)
+        bq.Type = FilterType.Lowpass
+        bq.Frequency.Value = 5000.0
+        node = d.Connect(bq)
+    node.Connect(g).Connect(d)
+    d.Connect(ctx.Destination)
+    return d, g
+
+
+@pytest.mark.parametrize("delay_s,blocks_per_chunk", [(0.001, 1), (0.0123, 4), (0.25, 93), (0.9, 337)])
+def test_echo_renders_in_chunks_of_the_delay(delay_s, blocks_per_chunk):
+    frames = 128 * 700
+    stats = {}
+
+    def build(ctx):
+        _echo(ctx, delay_s, frames)
+        stats["ctx"] = ctx
+    outs = []
+    for dev, ctx in enumerate((OracleContext(SR), OfflineAudioContext(SR))):
+        build(ctx)
+        out = np.zeros((2, frames), np.float32)
+        ctx.Render(out, 128 * 300 + 17, 0)
+        ctx.Render(out, frames - (128 * 300 + 17), 128 * 300 + 17)
+        if dev:
+            st = ctx.GetStats()
+        outs.append(out)
+        ctx.Dispose()
+    assert G.rms(outs[0]) > 1e-4   # (the tail of the shortest echo decays into denormals -- which have to match too)
+    assert np.array_equal(outs[0], outs[1])
+    expect = 700 / blocks_per_chunk
+    assert expect - 1 <= st["chunks"] <= expect + 6, (st["chunks"], expect)
+
+
+def test_echo_through_a_biquad_and_a_delay_time_change_between_calls():
+    frames = 128 * 400
+
+    def build(ctx):
+        return _echo(ctx, 0.05, frames, through="biquad")
+
+    def edit(ctx, h, k):
+        d, g = h
+        if k == 1:
+            d.DelayTime.Value = 0.02      # the chunk length follows the delay (18 -> 7 blocks)
+        if k == 2:
+            d.DelayTime.Value = 0.0005    # too short to cut the loop: one block per chunk
+        if k == 3:
+            g.Gain.Value = 0.3
+            d.DelayTime.Value = 0.1
+    ref, got = both(build, frames, pieces=[128 * 90 + 3, 128 * 60, 128 * 20 - 3, 128 * 100], edit=edit)
+    assert G.rms(ref) > 1e-4 and np.array_equal(ref, got)
+
+
+def test_two_loops_with_different_delays_and_one_that_cannot_be_cut():
+    frames = 128 * 300
+
+    def build(kind):
+        def b(ctx):
+            s = src(ctx, 30, 128 * 40, stereo=True)
+            bus = GainNode(ctx)
+            bus.Gain.Value = 0.7
+            s.Connect(bus)
+            for i, dt in enumerate((0.03, 0.071)):
+                d = DelayNode(ctx, 0.5)
+                d.DelayTime.Value = dt
+                fb = GainNode(ctx)
+                fb.Gain.Value = 0.4 + 0.1 * i
+                bus.Connect(d)
+                d.Connect(fb).Connect(d)
+                d.Connect(ctx.Destination)
+            if kind == "uncut":            # a third loop without a DelayNode: the whole graph falls back to one block per chunk
+                a, c = GainNode(ctx), GainNode(ctx)
+                a.Gain.Value = 0.5
+                c.Gain.Value = 0.5
+                bus.Connect(a).Connect(c).Connect(a)
+                c.Connect(ctx.Destination)
+            bus.Connect(ctx.Destination)
+        return b
+    for kind in ("cut", "uncut"):
+        ref, got = both(build(kind), frames)
+        assert G.rms(ref) > 1e-4 and np.array_equal(ref, got), kind
+
+
+def test_master_echo_behind_voices_with_convolvers_runs_in_long_chunks():
+    """The shape feedback is used for: many voices (convolvers included), ONE echo on the master bus."""
+    frames = 128 * 400
+    st = {}
+
+    def build(ctx):
+        bus = GainNode(ctx)
+        bus.Gain.Value = 0.5
+        ir = PlayableAudioBuffer.FromChannelArrays([G.synth_ir(c, 3000) for c in range(2)], SR)
+        for v in range(12):
+            s = src(ctx, 40 + v, frames)
+            cv = ConvolverNode(ctx)
+            cv.Buffer = ir
+            s.Connect(cv).Connect(bus)
+        d = DelayNode(ctx, 1.0)
+        d.DelayTime.Value = 0.2
+        fb = GainNode(ctx)
+        fb.Gain.Value = 0.5
+        bus.Connect(d)
+        d.Connect(fb).Connect(d)
+        bus.Connect(ctx.Destination)
+        d.Connect(ctx.Destination)
+    outs = []
+    for dev, ctx in enumerate((OracleContext(SR), OfflineAudioContext(SR))):
+        build(ctx)
+        outs.append(G.render(ctx, 2, frames))
+        if dev:
+            st = ctx.GetStats()
+        ctx.Dispose()
+    assert st["chunks"] <= 400 / 75 + 2   # 0.2 s = 9600 samples = 75 blocks per chunk
+    assert G.rms(outs[0] - outs[1]) <= 1e-9 and st["ref_order_rows"] > 0   # (the convolvers in front of the loop: formulation R)
