@@ -2390,6 +2390,7 @@ void Context::chunkTopology(ChunkRun& r) {
     np->delaySplit = false;
   }
   cycleBlocks = 1;
+  loopGainBound = 0.0;
   std::vector<int> color(nodes.size(), 0);
   std::vector<char> candidate;   // DelayNodes on a loop whose delay is a constant of at least two blocks
   bool unbreakable = false;
@@ -2416,14 +2417,31 @@ void Context::chunkTopology(ChunkRun& r) {
         // the loop this edge closes: the nodes on the stack from `id` up.  It can be cut where a DelayNode delays by >= 2 blocks.
         if (candidate.empty()) candidate.assign(nodes.size(), 0);
         bool any = false;
+        double bound = 1.0;   // an upper estimate of the loop's gain: what a last-bit difference that enters it is multiplied by per turn
         for (size_t q = stack.size(); q-- > 0;) {
           const int m = stack[q];
-          if (splittable(*nodes[m]) >= 2) {
+          const NodeS& mn = *nodes[m];
+          if (splittable(mn) >= 2) {
             candidate[m] = 1;
             any = true;
           }
+          bool moving = false;
+          for (auto& p : mn.params) moving = moving || !p.events.empty() || !p.modulation.empty();
+          switch (mn.type) {
+            case GA_NODE_GAIN: bound *= moving ? 1e9 : std::fabs((double)mn.params[0].value); break;
+            case GA_NODE_BIQUAD:
+              if (moving) bound *= 1e9;
+              else if (mn.filterType == GA_FILTER_PEAKING || mn.filterType == GA_FILTER_LOWSHELF || mn.filterType == GA_FILTER_HIGHSHELF)
+                bound *= std::max(1.0, std::pow(10.0, (double)mn.params[2].value / 20.0));
+              else bound *= std::max(1.0, (double)mn.params[1].value);   // (the resonance peak of a low / high / band pass is ~Q)
+              break;
+            case GA_NODE_CONVOLVER: bound *= mn.normalize ? 2.0 : 1e9; break;   // (normalised responses: broadband gain well below 1, peaks unknown)
+            case GA_NODE_STEREO_PANNER: bound *= 2.0; break;                    // (oL = inL + inR * gainL)
+            default: break;
+          }
           if (m == id) break;
         }
+        loopGainBound = std::max(loopGainBound, bound);
         if (!any) unbreakable = true;
         return false;
       }
@@ -2458,6 +2476,7 @@ void Context::chunkTopology(ChunkRun& r) {
       return true;
     };
     dfs(0);
+    topoRefOrder = staleProducers.empty() ? std::vector<int>() : topo;   // (the reference's processing order: Context::refOrderSensitivity)
     // ---- loops that can be cut at a DelayNode (option "cycle_delay_split") ----
     // A DelayNode whose delay is a constant of d >= 128 K samples reads, for any K consecutive blocks, only samples its ring held
     // BEFORE those blocks: its output for the whole K-block chunk can be produced first (a gather from the history: the READER, a node

@@ -693,21 +693,24 @@ void Context::refOrderSensitivity(const std::vector<int>& topo) {
   bool anyConv = false;
   for (int id : topo) anyConv = anyConv || (nodes[id]->type == GA_NODE_CONVOLVER && nodes[id]->ir);
   if (!anyConv) return;
-  if (convRefOrder != 1 || topoHasCycles) {
-    // (a graph with a feedback loop: every convolver -- with loops cut at DelayNodes the processing order no longer says which
-    // convolvers feed the loop, and such graphs run in short chunks where the reference order costs little)
+  if (convRefOrder != 1) {
     for (int id : topo)
-      if (nodes[id]->type == GA_NODE_CONVOLVER) nodes[id]->refSens = convRefOrder == 2 || (convRefOrder == 1 && topoHasCycles);
+      if (nodes[id]->type == GA_NODE_CONVOLVER) nodes[id]->refSens = convRefOrder == 2;
     return;
   }
+  // (a graph with feedback: the sweep follows the reference's processing order -- the planning order may have cut loops at DelayNodes)
+  const std::vector<int>& order = (topoHasCycles && topoRefOrder.size() == topo.size()) ? topoRefOrder : topo;
+  // A loop multiplies what enters it by 1 / (1 - gain): only where the estimated loop gain (Context::chunkTopology: constant gains,
+  // filter boosts) comes near 1 does a last-bit difference grow -- a master echo at 0.5 doubles it and is left alone.
+  const bool wildLoops = topoHasCycles && loopGainBound >= 0.7;
   std::vector<char>& sens = refSensScratch;
   sens.assign(nodes.size(), 0);
-  for (auto it = topo.rbegin(); it != topo.rend(); ++it) {   // consumers before producers
+  for (auto it = order.rbegin(); it != order.rend(); ++it) {   // consumers before producers
     NodeS& nd = *nodes[*it];
-    // * a feedback loop: what a convolver adds to a signal that comes back to it is multiplied by the loop again and again -- last-bit
-    //   differences compound (fuzz session 50178: 2.7e-5 with the loop's convolver on formulation B, exactly 0 in the reference's order).
-    //   Everything that feeds a node some consumer reads one block late (a stale producer: the loop's entry) counts.
-    bool s = nd.staleProducer;
+    // * a feedback loop whose gain may come near 1: what enters it is multiplied by 1 / (1 - gain) (fuzz session 50178: 2.7e-5 with the
+    //   loop's convolver on formulation B, exactly 0 in the reference's order).  Everything that feeds a node some consumer reads one
+    //   block late (a stale producer: the loop's entry) counts -- unless the loops are tame (wildLoops above).
+    bool s = nd.staleProducer && wildLoops;
     if (nd.type == GA_NODE_BIQUAD) {
       bool moving = false;
       for (auto& p : nd.params) moving = moving || !p.events.empty() || !p.modulation.empty();
@@ -788,7 +791,14 @@ void Context::assignConvPaths(const std::vector<int>& topo, int64_t chunkBlocks)
     // formulation it starts with: its state is formulation specific)
     const int coarseParts = (int)(((int64_t)ir->P * kBlock + kCoarseBlock - 1) / kCoarseBlock);
     // (a node that has to be evaluated in the reference's order takes the B / C state layout, which formulation R shares)
-    const bool pathD = !nd.refSens && useCoarse && useTimeFft && ir->P > 64 && coarseParts <= kCoarseMaxP && chunkBlocks >= coarseMinBlocks;
+    // ... unless the node is one of many that share the impulse response and feed one consumer each: such a group is summed in the
+    // time domain in front of ONE set of transforms and carries its tail from chunk to chunk (ga_chunk.cpp, classifyGroups), which
+    // costs little at any chunk length -- the headline graph behind a master echo renders in chunks of the echo's delay (1024 voices,
+    // 0.25 s echo: 69 ms per 10 s on formulation C, 22 ms on D).  coarse_min_blocks >= 2^29 still means "never".
+    const bool manyShare = users[ir] >= 8 && nd.outputs.size() == 1 && nd.outputs[0].connectedInputs.size() == 1 && coarsePremix &&
+                           coarseMinBlocks < ((int64_t)1 << 29);
+    const bool pathD = !nd.refSens && useCoarse && useTimeFft && ir->P > 64 && coarseParts <= kCoarseMaxP &&
+                       (chunkBlocks >= coarseMinBlocks || manyShare);
     const bool pathA = !nd.refSens && !pathC && !pathD && (hasA[ir] || users[ir] >= 8);
     if (pathD) {
       nd.bInCh = nd.isTrueStereo ? 2 : channels;

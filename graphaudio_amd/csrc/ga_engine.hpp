@@ -826,6 +826,8 @@ struct Context {
   bool topoHasTimeNodes = false, topoHasConvolvers = false, topoHasOscillators = false;
   bool topoHasCycles = false;   // (chunkTopology) some node is pulled while it is being processed: chunks of ONE block (the reference's own granularity)
   std::vector<int> staleProducers;
+  double loopGainBound = 0.0;   // (chunkTopology) the largest estimated gain of a feedback loop: differences that enter it grow by 1 / (1 - gain)
+  std::vector<int> topoRefOrder;   // the reference-order walk of a graph with feedback (the planning order may cut loops at DelayNodes)
   int cycleBlocks = 1;          // blocks per chunk of a graph with feedback (1 unless every loop is cut at a DelayNode)
   bool cycleDelaySplit = true;  // option "cycle_delay_split"
   // the output views of the previous chunk's last segment (and the gains folded into them): when an edit closes a cycle, the block
