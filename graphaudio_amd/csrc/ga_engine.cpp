@@ -1,5 +1,5 @@
 // ga_engine.cpp -- graph state, command queue, device resources.  See ga_engine.hpp for the design overview and
-// ga_chunk.cpp for the control-plane simulation + chunk executor.
+// ga_chunk.cpp (+ ga_sources / ga_plan_nodes / ga_plan_conv) for the control-plane simulation + chunk executor.
 #include "ga_engine.hpp"
 
 #include <algorithm>
@@ -792,7 +792,7 @@ void Context::assignConvPaths(const std::vector<int>& topo, int64_t chunkBlocks)
     const int coarseParts = (int)(((int64_t)ir->P * kBlock + kCoarseBlock - 1) / kCoarseBlock);
     // (a node that has to be evaluated in the reference's order takes the B / C state layout, which formulation R shares)
     // ... unless the node is one of many that share the impulse response and feed one consumer each: such a group is summed in the
-    // time domain in front of ONE set of transforms and carries its tail from chunk to chunk (ga_chunk.cpp, classifyGroups), which
+    // time domain in front of ONE set of transforms and carries its tail from chunk to chunk (ga_plan_conv.cpp, classifyGroups), which
     // costs little at any chunk length -- the headline graph behind a master echo renders in chunks of the echo's delay (1024 voices,
     // 0.25 s echo: 69 ms per 10 s on formulation C, 22 ms on D).  coarse_min_blocks >= 2^29 still means "never".
     const bool manyShare = users[ir] >= 8 && nd.outputs.size() == 1 && nd.outputs[0].connectedInputs.size() == 1 && coarsePremix &&

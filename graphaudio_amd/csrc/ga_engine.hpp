@@ -260,7 +260,7 @@ struct NodeS {
   bool dHistZero = true;
   bool everFed = false;   // (control plane) a non-silent, not-known-zero block has reached this node's input: its state / tail may be non-zero
   // ... and the LEADER of a fused group (or a convolver on its own) carries, per output channel, what the input so far adds to
-  // the samples behind the last chunk's end (ga_chunk.cpp, planCoarseStage): valid for the next chunk only, and only while the
+  // the samples behind the last chunk's end (ga_plan_conv.cpp, planCoarseStage): valid for the next chunk only, and only while the
   // group's signature is the same; the input histories above stay the authoritative state
   float* dTail[2] = {nullptr, nullptr};   // [dTailCh][dTailLen]
   int64_t dTailLen = 0;
@@ -507,10 +507,10 @@ struct Resampler {  // host replay of CubicResampler's position recurrence (Cubi
   void extend(int64_t nblocks);
 };
 
-struct ChunkRun;   // ga_chunk.cpp
-struct Exec;       // ga_chunk.cpp
-struct NodePlanCtx;   // ga_chunk.cpp
-struct ConvPlanCtx;   // ga_chunk.cpp
+struct ChunkRun;   // ga_chunk_internal.hpp
+struct Exec;       // ga_chunk_internal.hpp
+struct NodePlanCtx;   // ga_chunk_internal.hpp
+struct ConvPlanCtx;   // ga_chunk_internal.hpp
 
 void biquadCoefficients(int filterType, float sampleRate, float frequency, float q, float gain, float o[5]);   // BiQuadFilterNode.cs:149-258
 
@@ -735,7 +735,7 @@ struct Context {
   void render(float* const* out, int channels, int64_t frames, int64_t start, bool deviceOut);
   void runChunk(int64_t nblocks, float* const* bus);
   void runChunkImpl(int64_t nblocks, float* const* bus);
-  // the passes of one chunk (ga_chunk.cpp; ChunkRun holds what they share)
+  // the passes of one chunk (ga_chunk.cpp, ga_plan_nodes.cpp, ga_plan_conv.cpp; ChunkRun holds what they share)
   void chunkTopology(ChunkRun& r);
   void chunkSimulate(ChunkRun& r);
   void chunkResources(ChunkRun& r);

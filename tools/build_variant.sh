@@ -7,7 +7,10 @@ cd "$(dirname "$0")/../graphaudio_amd/csrc"
 mkdir -p ../../tools/variants /tmp/variant_$name
 F="-DGA_EXPERIMENTS --offload-arch=gfx950 -O3 -g1 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -Wall -Wno-unused-function"
 /opt/rocm/bin/hipcc $F "$@" -c ga_coarse.hip -o /tmp/variant_$name/ga_coarse.o &
-/opt/rocm/bin/hipcc $F "$@" -x hip -c ga_chunk.cpp -o /tmp/variant_$name/ga_chunk.o &   # (the planner shares the job-size constants)
+for f in ga_chunk ga_sources ga_plan_nodes ga_plan_conv; do   # (the planner shares the job-size constants and the experiment switches)
+  /opt/rocm/bin/hipcc $F "$@" -x hip -c $f.cpp -o /tmp/variant_$name/$f.o &
+done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/variants/$name.so ga_kernels.o /tmp/variant_$name/ga_coarse.o ga_engine.o /tmp/variant_$name/ga_chunk.o ga_comm.o ga_api.o -ldl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/variants/$name.so ga_kernels.o /tmp/variant_$name/ga_coarse.o ga_engine.o /tmp/variant_$name/ga_chunk.o \
+  /tmp/variant_$name/ga_sources.o /tmp/variant_$name/ga_plan_nodes.o /tmp/variant_$name/ga_plan_conv.o ga_comm.o ga_api.o -ldl
 echo built tools/variants/$name.so
