@@ -255,12 +255,13 @@ void Context::chunkTopology(ChunkRun& r) {
   if (topoHasCycles) r.n = std::min<int64_t>(r.n, cycleBlocks);
   if (topoStatsVersion != graphVersion || topoStatsSize != topo.size()) {   // (cached with the order: a sweep over 28,672 node records is 0.5 ms)
     topoMaxDepth = topoMaxLevel = 0;
-    topoHasTimeNodes = topoHasConvolvers = topoHasOscillators = false;
+    topoHasTimeNodes = topoHasConvolvers = topoHasOscillators = topoHasStreams = false;
     for (int id : topo) {
       const NodeS& nd = *nodes[id];
       topoMaxDepth = std::max(topoMaxDepth, nd.depth);
       topoMaxLevel = std::max(topoMaxLevel, nd.level);
       if (nd.type == GA_NODE_DELAY || nd.type == GA_NODE_STREAM_SOURCE) topoHasTimeNodes = true;
+      if (nd.type == GA_NODE_STREAM_SOURCE) topoHasStreams = true;
       if (nd.type == GA_NODE_CONVOLVER) topoHasConvolvers = true;   // (with or without an impulse response: Buffer setters run in drain())
       if (nd.type == GA_NODE_OSCILLATOR) topoHasOscillators = true;
     }
@@ -396,9 +397,19 @@ void Context::chunkSimulate(ChunkRun& r) {
       // -- its records are taken over, the traversal is skipped
       bool replayed = false;
       if (b == 0 && simReplay && lastSegStable && !lastSegNodes.empty() && lastSegEpoch == apiEpoch && lastSegGraphVersion == graphVersion &&
-          !topoHasTimeNodes && lastSegNodes.size() == topo.size() && g == goneAt.end()) {
+          !topoHasStreams && lastSegNodes.size() == topo.size() && g == goneAt.end()) {
         bool same = true;
         for (const NodeSeg& ns : lastSegNodes) {   // every source still in the phase (and on the buffer) the records say
+          if (ns.type == GA_NODE_DELAY) {
+            // a DelayNode's control state is its output flag, which is sticky once raised (DelayNode.cs:96-97): a node that is audible
+            // with a constant delay time behaves like any other node; until then its ring model has to be walked block by block
+            const NodeS& dn = *nodes[ns.id];
+            if (!ns.delayAudible || !dn.delayAudible || !dn.params[0].events.empty() || !dn.params[0].modulation.empty()) {
+              same = false;
+              break;
+            }
+            continue;
+          }
           if (ns.type != GA_NODE_BUFFER_SOURCE && ns.type != GA_NODE_CONSTANT_SOURCE && ns.type != GA_NODE_OSCILLATOR) continue;
           const NodeS& sn = *nodes[ns.id];
           const SrcSpan& sp = spanAt(sn, 0);

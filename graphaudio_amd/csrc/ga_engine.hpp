@@ -823,7 +823,7 @@ struct Context {
   bool lastSegStable = false;
   uint64_t apiEpoch = 0;       // bumped by every API call that can change what a render computes (ga_api.cpp guard) and by drained commands
   bool simReplay = true;       // option "sim_replay"
-  bool topoHasTimeNodes = false, topoHasConvolvers = false, topoHasOscillators = false;
+  bool topoHasTimeNodes = false, topoHasConvolvers = false, topoHasOscillators = false, topoHasStreams = false;
   bool topoHasCycles = false;   // (chunkTopology) some node is pulled while it is being processed: chunks of ONE block (the reference's own granularity)
   std::vector<int> staleProducers;
   double loopGainBound = 0.0;   // (chunkTopology) the largest estimated gain of a feedback loop: differences that enter it grow by 1 / (1 - gain)

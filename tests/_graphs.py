@@ -159,6 +159,61 @@ def kit_scene(ctx, voices=64, frames=48000, sr=48000, taps=32768):
     return 2
 
 
+def kit_bus_hierarchy(ctx, voices=24, frames=48000, sr=48000, taps=(9000, 20000, 3000)):
+    """SURVEY.md 8(f) rank 4, the other Kit shape: a HIERARCHY of buses, each with its own EffectChain.
+    `AudioBus` = one GainNode whose EffectChain leads to the parent's input (AudioBus.cs:76-91); `EffectChain.Rebuild`
+    (EffectChain.cs:127-149) wires source -> effect[0].Input ... effect[n-1].Output -> destination; the only Kit effect is
+    `ReverbEffect` (ReverbEffect.cs:63-81: inputSplit -> dry -> outputMerge ; inputSplit -> downmixer (explicit mono) -> convolver ->
+    wet -> outputMerge).  Here: master (one reverb) <- sfx (two reverbs in series) <- {sfx/weapons (none), sfx/steps (one reverb,
+    fading)} ; master <- music (none).  Voices: source -> StereoPanner -> a leaf bus."""
+    from graphaudio_amd import ChannelCountMode, StereoPannerNode
+
+    def reverb(ir_seed, ntaps, wet_level):
+        split, merge, dry, wet, down = (GainNode(ctx) for _ in range(5))
+        dry.Gain.Value = 1.0 - 0.5 * wet_level
+        wet.Gain.Value = wet_level
+        down.Inputs[0].SetChannelCount(1)
+        down.Inputs[0].SetChannelCountMode(ChannelCountMode.Explicit)
+        conv = ConvolverNode(ctx)
+        conv.Buffer = PlayableAudioBuffer.FromChannelArrays([synth_ir(c, ntaps, seed0=ir_seed) for c in range(2)], sr)
+        split.Connect(dry)
+        dry.Connect(merge)
+        split.Connect(down)
+        down.Connect(conv)
+        conv.Connect(wet)
+        wet.Connect(merge)
+        return split, merge
+
+    def bus(parent_input, effects, gain=1.0):
+        g = GainNode(ctx)
+        g.Gain.Value = gain
+        node = g
+        for (inp, out) in effects:
+            node.Connect(inp)
+            node = out
+        node.Connect(parent_input)
+        return g
+
+    master = bus(ctx.Destination, [reverb(7, taps[0], 0.3)], 0.8)
+    sfx = bus(master, [reverb(40, taps[1], 0.25), reverb(60, taps[2], 0.4)], 0.9)
+    music = bus(master, [])
+    weapons = bus(sfx, [])
+    steps = bus(sfx, [reverb(80, taps[2], 0.5)], 1.0)
+    steps.Gain.SetValueAtTime(1.0, 0.0)                      # AudioBus.Fade
+    steps.Gain.LinearRampToValueAtTime(0.2, frames / sr * 0.7)
+    leaves = [weapons, steps, music]
+    for v in range(voices):
+        s = AudioBufferSourceNode(ctx)
+        s.Buffer = PlayableAudioBuffer.FromMonoArray(voice(v, frames, 0.25 / 4), sr)
+        p = StereoPannerNode(ctx)
+        p.Inputs[0].SetChannelCount(1)
+        p.Pan.Value = -1.0 + 2.0 * v / max(voices - 1, 1)
+        s.Connect(p)
+        p.Connect(leaves[v % 3])
+        s.Start(0.0 if v % 5 else 0.02)
+    return 2
+
+
 def render(ctx, channels, frames):
     out = np.zeros((channels, frames), dtype=np.float32)
     ctx.Render(out, frames)

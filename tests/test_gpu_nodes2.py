@@ -315,6 +315,29 @@ def test_kit_scene_buses_panners_and_post_mix_reverb():
     assert err <= 1e-5 and err <= 2e-6 * G.rms(ref), (err, G.rms(ref))
 
 
+@pytest.mark.parametrize("opts", [{}, {"max_chunk_blocks": 50}, {"coarse_min_blocks": 1, "max_chunk_blocks": 90}])
+def test_kit_bus_hierarchy_with_effect_chains_per_bus(opts):
+    """The other Kit shape (missing 7): AudioBus hierarchy (AudioBus.cs:76-91) with an EffectChain per bus
+    (EffectChain.cs:127-149) -- reverbs in series on one bus, a reverb on a fading leaf bus, one on the master: five post-mix
+    convolvers at four convolver depths, on the default route (one long chunk: formulation D), in chunks and with D forced."""
+    frames = 128 * 300
+    o = OracleContext(SR)
+    ch = G.kit_bus_hierarchy(o, voices=24, frames=frames)
+    ref = G.render(o, ch, frames)
+    o.Dispose()
+    h = OfflineAudioContext(SR)
+    for k, v in opts.items():
+        h.SetOption(k, v)
+    G.kit_bus_hierarchy(h, voices=24, frames=frames)
+    got = G.render(h, ch, frames)
+    st = h.GetStats()
+    h.Dispose()
+    assert G.rms(ref) > 1e-3
+    err = G.rms(ref - got)
+    assert err <= 1e-5 and err <= 4e-6 * G.rms(ref), (opts, err, G.rms(ref))
+    assert st["ref_order_rows"] == 0   # (gains and mixes behind the convolvers: nothing that amplifies the last bit)
+
+
 def test_audio_rate_modulation_of_oscillator_panner_delay_biquad_and_offset():
     """AudioParam._input (AudioParam.cs:97-101,123-135,148-160): a ConstantSourceNode / an LFO buffer drives the parameters of
     the new nodes and of a biquad; values are clamp(intrinsic + modulation) while the modulator is non-silent."""

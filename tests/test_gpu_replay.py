@@ -109,17 +109,30 @@ def test_anything_that_can_move_control_state_switches_the_shortcut_off():
     assert np.array_equal(ref, a)
 
 
-def test_time_dependent_nodes_are_never_replayed():
-    frames, piece = 128 * 60, 128 * 10
+def test_delay_nodes_are_replayed_only_once_their_output_flag_is_up():
+    """A DelayNode's control state is its sticky output flag (DelayNode.cs:96-97): until delayed audio has arrived its ring model is
+    walked block by block; afterwards (constant delay time) it is a node like any other.  A delay time on a timeline never is."""
+    frames, piece = 128 * 80, 128 * 10
 
-    def build(ctx):
-        s = AudioBufferSourceNode(ctx)
-        s.Buffer = PlayableAudioBuffer.FromMonoArray(G.voice(1, frames + 256), SR)
-        d = DelayNode(ctx, 0.05)
-        d.DelayTime.Value = 0.02
-        s.Connect(d).Connect(ctx.Destination)
-        s.Start()
-        return 2
-    a, sa = _render(build, frames, piece, 1)
-    b, sb = _render(build, frames, piece, 0)
-    assert sa["sim_replays"] == 0 and np.array_equal(a, b)
+    def build(automated):
+        def b(ctx):
+            s = AudioBufferSourceNode(ctx)
+            s.Buffer = PlayableAudioBuffer.FromMonoArray(G.voice(1, frames + 256), SR)
+            d = DelayNode(ctx, 0.5)
+            d.DelayTime.Value = 0.03       # 1440 samples: audible from block 11 on
+            if automated:
+                d.DelayTime.LinearRampToValueAtTime(0.01, frames / SR)
+            s.Connect(d).Connect(ctx.Destination)
+            s.Start()
+            return 2
+        return b
+    a, sa = _render(build(False), frames, piece, 1)
+    b, sb = _render(build(False), frames, piece, 0)
+    assert np.array_equal(a, b) and G.rms(a) > 1e-3
+    assert 0 < sa["sim_replays"] < sa["chunks"] - 1, (sa["sim_replays"], sa["chunks"])   # (not the chunks in which the delayed audio arrives)
+    c, sc = _render(build(True), frames, piece, 1)
+    d, sd = _render(build(True), frames, piece, 0)
+    assert sc["sim_replays"] == 0 and np.array_equal(c, d)
+    o = OracleContext(SR)
+    build(True)(o)
+    assert np.array_equal(G.render(o, 2, frames), c)
