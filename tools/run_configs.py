@@ -4,8 +4,11 @@ bench.py measures configs[2]; these are parity-test cases, timed here to find pe
 import os, sys, time, json
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from graphaudio_amd import OfflineAudioContext
+from graphaudio_amd import OfflineAudioContext, _capi
 from tests import _graphs as G
+
+if os.environ.get("GA_TOOL_LIBRARY"):   # a tools/build_variant.sh build (this tool only; the product reads no such variable)
+    _capi.use_library(os.environ["GA_TOOL_LIBRARY"])
 
 SR = 48000
 which = sys.argv[1] if len(sys.argv) > 1 else "2"
