@@ -1915,17 +1915,43 @@ static void launch_biquad_jpw(hipStream_t s, const BiquadJob* jobs_dev, int njob
   }
 }
 // ---- cascades of NSEC >= 2 sections: the sections of one cascade sit on NEIGHBOURING LANES -----------------------------------
-// Lane q of a group runs section q on sample k - q at step k and hands its output to lane q + 1 with one DPP row shift: a
-// software pipeline across lanes.  Per sample the wave issues ONE section's arithmetic (~10 instructions) instead of NSEC
-// sections back to back on a single lane; every section still sees exactly the reference's sample-by-sample float
-// arithmetic (BiQuadFilterNode.cs:137-141), so the result stays bit-exact.  16 / NSEC cascades per 16-lane row.
+// Lane q of a group runs section q on sample k - SK q at step k and takes its input from lane q - 1 with one DPP row shift: a
+// software pipeline across lanes.  Per step the wave issues ONE section's arithmetic instead of NSEC sections back to back on
+// a single lane; every section still sees exactly the reference's sample-by-sample float arithmetic
+// (BiQuadFilterNode.cs:137-138: w = (x - a1 w1) - a2 w2 ; y = (b0 w + b1 w1) + b2 w2), so the result stays bit-exact.
+// 16 / NSEC cascades per 16-lane row.
+//
+// A wave that is alone on its SIMD pays ~5 cycles per instruction, whatever the instruction (vector, scalar, s_nop, LDS; measured with
+// tools/micro/bq_pipe_probe.hip: 221 instructions per 16 steps = 1131 cycles), and ~4 more when it needs the result of the
+// instruction right before it: the walk costs its instruction COUNT.  Its steady state is therefore ONE inline-assembly
+// statement with fixed registers (ga_biquad_pipe_asm.inc, written by tools/gen_biquad_pipe_asm.py, where the schedule is
+// described): 8 vector instructions per step --
+//   the four products of w[k-1] as two packed multiplies ({a1, b1} w and {a2, b2} w: P1, R1 of this step, P2, R2 of the next);
+//   the recursion  t = x - P1 ; w = t - P2 ;
+//   the output half (m = b0 w ; s = m + R1 ; y = s + R2) one and two steps behind, in the gaps of the recursion;
+//   the hand-over from the lane to the left and the select of the cascade's input for section 0 as one v_cndmask_b32_dpp
+// -- plus one instruction per step for the LDS traffic and the loop; no instruction follows its producer.  SK = 4 steps between
+// neighbouring sections keep the hand-over off the dependency chain.  The pipeline is filled once per JOB and drained once
+// (masked batches, plain C++), not per tile: step k hands out sample k - D, D = SK (NSEC - 1), the tile is stored D samples late.
+#ifdef GA_BQ_PROBE   // tools/micro/bq_pipe_probe.hip: where a wave's cycles go (s_memtime around the phases of every tile)
+__device__ unsigned long long ga_bq_probe[8];
+#define GA_BQ_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define GA_BQ_ACC(i, v) probe_acc[i] += (v)
+#else
+#define GA_BQ_T(v)
+#define GA_BQ_ACC(i, v)
+#endif
 template <int NSEC>
 __global__ __launch_bounds__(64) void biquad_pipe_kernel(const BiquadJob* __restrict jobs, int njobs, const BiquadSection* __restrict secs,
                                                          int jpw) {
   constexpr int GPR = 16 / NSEC;        // cascades (groups of NSEC lanes) per row
-  constexpr int MAXJ = 4 * GPR;
-  constexpr int PT = 256, TM = PT / 64;   // samples per tile: amortises the tile load / store / barriers and the pipeline fill
-  __shared__ float tile[MAXJ][PT + 1];
+  constexpr int MAXJ = 4 * GPR < 16 ? 4 * GPR : 16;   // (16: the tile's rows live in registers twice, prefetched and outgoing)
+  constexpr int PT = 256, TM = PT / 64;   // steps per tile
+  constexpr int SK = 4;                   // steps between a section and the next
+  constexpr int D = SK * (NSEC - 1);      // step k hands out sample k - D
+  constexpr int LD = PT + 4;              // 16-byte aligned rows: a batch of 16 steps reads / writes its samples as four b128
+  __shared__ __attribute__((aligned(16))) float tile[MAXJ][LD];
+  __shared__ __attribute__((aligned(16))) float dump[64][16];   // where the lanes that are not a last section "write their outputs"
   const int lane = threadIdx.x;
   const int row = lane >> 4, lr = lane & 15;
   const int grp = lr / NSEC, q = lr % NSEC;
@@ -1937,115 +1963,195 @@ __global__ __launch_bounds__(64) void biquad_pipe_kernel(const BiquadJob* __rest
   if (have) me = jobs[myj];
   const float* inb = have ? me.in + me.f0 : nullptr;
   float* outb = have ? me.out + me.f0 : nullptr;
-  float b0 = 0.f, b1 = 0.f, b2 = 0.f, a1 = 0.f, a2 = 0.f, w1 = 0.f, w2 = 0.f;
+  float b0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;   // w3: the w before w2 (for the assembly walk to pick up mid-stream; not state)
+  v2f ab1 = {0.f, 0.f}, ab2 = {0.f, 0.f};   // {a1, b1}, {a2, b2}
   float* st = nullptr;
   if (have) {
     const BiquadSection sc = secs[me.sec0 + q];
-    b0 = sc.b0; b1 = sc.b1; b2 = sc.b2; a1 = sc.a1; a2 = sc.a2;
+    b0 = sc.b0;
+    ab1 = v2f{sc.a1, sc.b1};
+    ab2 = v2f{sc.a2, sc.b2};
     st = me.state ? me.state + 2 * q : sc.state;
     w1 = ldg1(st);
     w2 = ldg1(st + 1);
   }
-  const int64_t n = have ? me.n : 0;
-  int64_t nmax = n;
+  const int n = have ? (int)me.n : 0;
+  int nmax = n, nmin = have ? n : 0x7fffffff;
 #pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) nmax = max(nmax, (int64_t)__shfl_xor((long long)nmax, m, 64));
+  for (int m = 32; m >= 1; m >>= 1) {
+    nmax = max(nmax, __shfl_xor(nmax, m, 64));
+    nmin = min(nmin, __shfl_xor(nmin, m, 64));
+  }
+  nmax = __builtin_amdgcn_readfirstlane(nmax);
+  nmin = __builtin_amdgcn_readfirstlane(nmin);
   const int jcount = min(jpw, njobs - j0);
   auto lane_of = [](int r) { return (r / GPR) * 16 + (r % GPR) * NSEC; };   // lane of section 0 of slot r
 
-  float pre[MAXJ][TM];   // prefetched tile: pre[r][u] = frame (base + 64 u + lane) of cascade slot r
-  auto fetch = [&](int64_t base) {
+  // A tile row in flight (prefetched / outgoing) is four registers per lane, in one of two layouts:
+  //   whole tiles   lane l holds frames 4 l .. 4 l + 3 of the row: ONE 16-byte global access and one b128 LDS access per row
+  //   ragged tiles  register u holds frame 64 u + l, every access bounds-checked (a job's first and last tiles)
+  v4f pre[MAXJ];
+  bool pre_whole = false;
+  auto fetch = [&](int base) {
+    pre_whole = base + PT <= nmin;
+    if (pre_whole) {
+#pragma unroll
+      for (int r = 0; r < MAXJ; r++)
+        if (r < jcount) pre[r] = ldg4(bcast_ptr(inb, lane_of(r)) + base + 4 * lane);
+      return;
+    }
 #pragma unroll
     for (int r = 0; r < MAXJ; r++) {
-#pragma unroll
-      for (int u = 0; u < TM; u++) pre[r][u] = 0.f;
+      pre[r] = v4f{0.f, 0.f, 0.f, 0.f};
       if (r < jcount) {
         const float* p = bcast_ptr(inb, lane_of(r));
-        int64_t nr = __builtin_amdgcn_readlane((int)n, lane_of(r));
+        const int nr = __builtin_amdgcn_readlane(n, lane_of(r));
 #pragma unroll
         for (int u = 0; u < TM; u++) {
-          int64_t fi = base + 64 * u + lane;
+          const int fi = base + 64 * u + lane;
           if (fi < nr) pre[r][u] = ldg1(p + fi);
         }
       }
     }
   };
-  fetch(0);
-  for (int64_t base = 0; base < nmax; base += PT) {
+  const int srow = have ? slot : 0;
+  const bool q0 = q == 0;
+  const bool qlast = have && q == NSEC - 1;
+  const int jofs = SK * q;
+  float yh[SK];   // this lane's outputs of the last SK steps, yh[0] the latest
 #pragma unroll
-    for (int r = 0; r < MAXJ; r++)
-      if (r < jcount) {
+  for (int i = 0; i < SK; i++) yh[i] = 0.f;
+  auto dpp_left = [](float v) {   // lane l takes lane l - 1's value (row_shr:1); a row's lane 0 is always a section 0
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, false));
+  };
+  // nb batches of 16 steps in which every section of every cascade of the wave has a sample (tile positions p0 ...)
+  const unsigned long long q0mask = __builtin_amdgcn_ballot_w64(q0);
+  auto steady_run = [&](int p0, int nb) {
+    typedef __attribute__((address_space(3))) float* lds_ptr;   // (a 32-bit LDS offset: what ds_read / ds_write address)
+    const unsigned ain = (unsigned)(size_t)(lds_ptr)&tile[srow][p0];
+    const unsigned aout = qlast ? ain : (unsigned)(size_t)(lds_ptr)&dump[lane][0];
+    const unsigned ainc = qlast ? 64u : 0u;
+    asm volatile(
+#include "ga_biquad_pipe_asm.inc"
+        : [w1] "+v"(w1), [w2] "+v"(w2), [w3] "+v"(w3), [y0] "+v"(yh[0]), [y1] "+v"(yh[1]), [y2] "+v"(yh[2]), [y3] "+v"(yh[3]), [nb] "+s"(nb)
+        : [ab1] "v"(ab1), [ab2] "v"(ab2), [b0] "v"(b0), [ain] "v"(ain), [aout] "v"(aout), [ainc] "v"(ainc), [q0] "s"(q0mask)
+        :
+#include "ga_biquad_pipe_asm_clobbers.inc"
+    );
+  };
+  // 16 steps of the fill / the drain of the pipeline, or past the end of a shorter cascade: lanes without a sample hold still
+  auto masked = [&](int k0, int p0) {
+#pragma unroll 4
+    for (int i = 0; i < 16; i++) {
+      const int j = k0 + i - jofs;
+      const bool active = have && j >= 0 && j < n;
+      const float up = dpp_left(yh[SK - 1]);
+      const float x = q0 ? tile[srow][p0 + i] : up;
+      const float w = x - ab1.x * w1 - ab2.x * w2;           // BiQuadFilterNode.cs:137
+      const float yy = b0 * w + ab1.y * w1 + ab2.y * w2;     // :138
+      w3 = active ? w2 : w3;
+      w2 = active ? w1 : w2;
+      w1 = active ? w : w1;
 #pragma unroll
-        for (int u = 0; u < TM; u++) tile[r][64 * u + lane] = pre[r][u];
-      }
-    __syncthreads();
-    if (base + PT < nmax) fetch(base + PT);   // next tile's loads fly during the recurrence below
-    const int cnt = (int)max<int64_t>(0, min<int64_t>(PT, n - base));
-    float y = 0.f;
-    const int srow = have ? slot : 0;
-    // one batch of 16 pipeline steps.  PRED = false is the steady state of a full tile: every section has a sample at every
-    // step, so there is nothing to mask; the last section's outputs are collected and written once per batch.
-    auto batch = [&](int k0, auto pred_tag) {
-      constexpr bool PRED = decltype(pred_tag)::value;
-      float xv[16], ov[16];
-#pragma unroll
-      for (int i = 0; i < 16; i++) xv[i] = (k0 + i < PT) ? tile[srow][k0 + i] : 0.f;
-#pragma unroll
-      for (int i = 0; i < 16; i++) {
-        const int k = k0 + i;
-        // the previous lane's output of the previous step (row_shr:1); section 0 takes the input sample
-        const float up = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(y), 0x111, 0xF, 0xF, false));
-        const float x = q == 0 ? xv[i] : up;
-        const float w = x - a1 * w1 - a2 * w2;            // BiQuadFilterNode.cs:137
-        const float yy = b0 * w + b1 * w1 + b2 * w2;      // :138
-        if constexpr (PRED) {
-          const bool active = k - q >= 0 && k - q < cnt;
-          w2 = active ? w1 : w2;
-          w1 = active ? w : w1;
-          y = active ? yy : y;
-        } else {
-          w2 = w1;
-          w1 = w;
-          y = yy;
-        }
-        ov[i] = yy;
-      }
-      if (have && q == NSEC - 1) {   // output of step k is sample k - (NSEC - 1)
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-          const int jx = k0 + i - (NSEC - 1);
-          if (jx >= 0 && jx < (PRED ? cnt : PT)) tile[srow][jx] = ov[i];
-        }
-      }
-    };
-    constexpr int NBATCH = (PT + NSEC - 1 + 15) / 16;
-    int cntmin = have ? cnt : PT;   // a full tile for every cascade of the wave?
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) cntmin = min(cntmin, __shfl_xor(cntmin, m, 64));
-    if (cntmin == PT) {
-      batch(0, std::true_type{});                                   // pipeline fill
-#pragma unroll 1
-      for (int bq = 1; bq < NBATCH - 1; bq++) batch(16 * bq, std::false_type{});
-      batch(16 * (NBATCH - 1), std::true_type{});                   // pipeline drain
-    } else {
-#pragma unroll 1
-      for (int bq = 0; bq < NBATCH; bq++) batch(16 * bq, std::true_type{});
+      for (int h = SK - 1; h > 0; h--) yh[h] = yh[h - 1];
+      yh[0] = yy;
+      if (qlast && active) tile[srow][p0 + i] = yy;
     }
-    __syncthreads();
+  };
+  const int nsteps = nmax + D;
+  // (the coefficient and state loads complete HERE: left pending, their first use inside the loop would wait for vmcnt(0), that is
+  // for the next tile's prefetch as well, once per tile -- the whole memory latency on the recurrence's clock)
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+  // Order of the memory operations of a tile: the samples of tile i + 1 are requested before tile i is walked and waited for
+  // after it; the results of tile i leave AFTER that wait -- issued before it, every tile would wait for its stores to be
+  // acknowledged (vmcnt counts loads and stores in one queue), a few microseconds on the recurrence's clock.
+  v4f outv[MAXJ];
+  bool out_whole = false;
+  auto store_tile = [&](int base) {   // position p of the tile holds sample base + p - D
+    if (out_whole) {
+#pragma unroll
+      for (int r = 0; r < MAXJ; r++)
+        if (r < jcount) stg4((float*)bcast_ptr(outb, lane_of(r)) + (base - D) + 4 * lane, outv[r]);
+      return;
+    }
 #pragma unroll
     for (int r = 0; r < MAXJ; r++) {
       if (r < jcount) {
         float* o = (float*)bcast_ptr(outb, lane_of(r));
-        int64_t nr = __builtin_amdgcn_readlane((int)n, lane_of(r));
+        const int nr = __builtin_amdgcn_readlane(n, lane_of(r));
 #pragma unroll
         for (int u = 0; u < TM; u++) {
-          int64_t fi = base + 64 * u + lane;
-          if (fi < nr) stg1(o + fi, tile[r][64 * u + lane]);
+          const int fi = base + 64 * u + lane - D;
+          if (fi >= 0 && fi < nr) stg1(o + fi, outv[r][u]);
         }
       }
     }
+  };
+#ifdef GA_BQ_PROBE
+  unsigned long long probe_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  GA_BQ_T(tk0);
+  fetch(0);
+  for (int base = 0; base < nsteps; base += PT) {
+    GA_BQ_T(ta);
+    // (one explicit wait for the prefetch on every path: the compiler cannot see that a row without a cascade was never requested
+    // and would otherwise wait for "its" load -- that is for the stores below -- when fetch() next overwrites the registers)
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    if (pre_whole) {
+#pragma unroll
+      for (int r = 0; r < MAXJ; r++)
+        if (r < jcount) *(v4f*)&tile[r][4 * lane] = pre[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < MAXJ; r++)
+        if (r < jcount) {
+#pragma unroll
+          for (int u = 0; u < TM; u++) tile[r][64 * u + lane] = pre[r][u];
+        }
+    }
+    if (base > 0) store_tile(base - PT);
     __syncthreads();
+    if (base + PT < nmax) fetch(base + PT);   // next tile's loads fly during the recurrence below
+    GA_BQ_T(tb);
+    // the tile's batches: [0, ps) masked (fill) | [ps, pe) steady, one assembly run | [pe, end) masked (drain, shorter cascades)
+    const int pend = min(PT, (nsteps - base + 15) & ~15);
+    const int ps = min(pend, max(0, (D - base + 15) & ~15));
+    const int pe = max(ps, min(pend, (nmin - base) & ~15));
+#pragma unroll 1
+    for (int p0 = 0; p0 < ps; p0 += 16) { masked(base + p0, p0); GA_BQ_ACC(5, 1); }
+    if (pe > ps) { steady_run(ps, (pe - ps) >> 4); GA_BQ_ACC(4, (pe - ps) >> 4); }
+#pragma unroll 1
+    for (int p0 = pe; p0 < pend; p0 += 16) { masked(base + p0, p0); GA_BQ_ACC(5, 1); }
+    GA_BQ_T(tc);
+    __syncthreads();
+    out_whole = base >= D && base + PT - D <= nmin;
+    if (out_whole) {
+#pragma unroll
+      for (int r = 0; r < MAXJ; r++)
+        if (r < jcount) outv[r] = *(const v4f*)&tile[r][4 * lane];
+    } else {
+#pragma unroll
+      for (int r = 0; r < MAXJ; r++)
+        if (r < jcount) {
+#pragma unroll
+          for (int u = 0; u < TM; u++) outv[r][u] = tile[r][64 * u + lane];
+        }
+    }
+    __syncthreads();
+    GA_BQ_T(td);
+    GA_BQ_ACC(0, tb - ta);
+    GA_BQ_ACC(1, tc - tb);
+    GA_BQ_ACC(2, td - tc);
   }
+  store_tile((nsteps - 1) / PT * PT);
+#ifdef GA_BQ_PROBE
+  {
+    GA_BQ_T(tk1);
+    probe_acc[3] = tk1 - tk0;
+    if (lane == 0)
+      for (int i = 0; i < 6; i++) atomicAdd(&ga_bq_probe[i], probe_acc[i]);
+  }
+#endif
   if (have) {
     stg1(st, w1);
     stg1(st + 1, w2);
@@ -2053,9 +2159,11 @@ __global__ __launch_bounds__(64) void biquad_pipe_kernel(const BiquadJob* __rest
 }
 template <int NSEC>
 static void launch_biquad_pipe(hipStream_t s, const BiquadJob* jobs_dev, int njobs, const BiquadSection* secs_dev) {
-  constexpr int MAXJ = 4 * (16 / NSEC);
-  // latency-bound: one wave per SIMD is the most the chip can use; more cascades than that share waves
-  int jpw = std::min(MAXJ, std::max(1, (njobs + 1023) / 1024));
+  constexpr int MAXJ = 4 * (16 / NSEC) < 16 ? 4 * (16 / NSEC) : 16;
+  // The walk is bound by one wave's instruction issue, not by lanes, and a cascade more in a wave costs ~200 cycles of staging per
+  // tile of 256 steps (12,200): up to 512 waves (one per two SIMDs) one cascade each, then fuller waves -- measured on MI355X
+  // (tools/micro/bq_pipe_probe.hip, 4096 cascades of 5 sections x 120,000 frames): 512 waves of 8: 3.1-3.2 ms, 342 of 12: 3.1-3.3.
+  int jpw = std::min(MAXJ, std::max(1, (njobs + 511) / 512));
   if (const char* e = expenv("GA_BQ_JPW")) jpw = std::min(MAXJ, std::max(1, atoi(e)));
   hipLaunchKernelGGL(biquad_pipe_kernel<NSEC>, dim3((njobs + jpw - 1) / jpw), dim3(64), 0, s, jobs_dev, njobs, secs_dev, jpw);
 }
