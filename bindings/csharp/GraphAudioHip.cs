@@ -43,6 +43,7 @@ internal static unsafe partial class GraphAudioHip
         public long biquad_split_cascades;
         public long ref_order_rows;
         public long sim_replays;
+        public long twin_rows;
     }
 
     [LibraryImport(Lib, EntryPoint = "ga_strerror")] [UnmanagedCallConv(CallConvs = new[] { typeof(CallConvCdecl) })]

@@ -87,6 +87,7 @@ class Stats(C.Structure):
         ("biquad_split_cascades", C.c_int64),
         ("ref_order_rows", C.c_int64),
         ("sim_replays", C.c_int64),
+        ("twin_rows", C.c_int64),
     ]
     STAGES = ("other", "mix", "rfft_fwd", "mac", "rfft_inv", "coarse_fwd", "coarse_mac", "coarse_inv", "coarse_hist", "coarse_section",
               "coarse_premix")   # index = GA_STAGE_* (tests/test_capi.py checks the length against GA_STAGE_COUNT)

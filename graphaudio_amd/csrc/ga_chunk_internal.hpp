@@ -663,8 +663,38 @@ struct Exec {
       }
     }
     Views views((size_t)dstCh, nullptr);
+    // Twin channels: a channel whose term list (views, gains, curves, in this order) equals channel 0's gets the same sums -- mono
+    // material in a stereo input.  It shares channel 0's view; where the caller wants its own row (forcedSlabs: the destination
+    // bus, a delay ring) channel 0's job writes its sums to both rows (MixJob::out2).
+    int twinOf0 = 0;   // channels 1 .. twinOf0 equal channel 0
+    if (c.twinChannels && dstCh > 1 && !lists[0].empty()) {
+      for (int ch = 1; ch < dstCh; ch++) {
+        const auto &a = lists[0], &b = lists[ch];
+        bool eq = a.size() == b.size();
+        for (size_t j = 0; eq && j < a.size(); j++) eq = a[j].p == b[j].p && a[j].g == b[j].g && a[j].c == b[j].c;
+        if (!eq) break;
+        twinOf0 = ch;
+      }
+      if (twinOf0 > 1 && forcedSlabs) twinOf0 = 1;   // (one extra row per job)
+    }
+    int job0 = -1;     // channel 0's MixJob, if it got one
     for (int ch = 0; ch < dstCh; ch++) {
       auto& l = lists[ch];
+      if (ch > 0 && ch <= twinOf0) {
+        if (!forcedSlabs) {
+          views[ch] = views[0];
+          c.stats.twin_rows++;
+          continue;
+        }
+        float* row = forcedSlabs[ch];
+        if (row && job0 >= 0 && row != mixJobs[job0].out) {
+          mixJobs[job0].out2 = row;
+          noteAlign(row, f0);
+          views[ch] = row;
+          c.stats.twin_rows++;
+          continue;
+        }
+      }
       if (!force) {
         if (l.empty()) continue;
         if (l.size() == 1 && l[0].g == 1.f && !l[0].c) {
@@ -690,6 +720,7 @@ struct Exec {
         if (tm.c) noteAlign(tm.c, f0);
       }
       noteAlign(out, f0);
+      if (ch == 0) job0 = (int)mixJobs.size();
       mixJobs.push_back(mj);
       views[ch] = out;
     }
@@ -737,6 +768,33 @@ struct Exec {
       plan.add(LK_OTHER, [=](uint8_t* base) {
         launch_downmix(st, (const DownmixJob*)(base + off), nj, (const float* const*)(base + termsOff), mx, scaled ? (const float*)(base + gainsOff) : nullptr);
       });
+    }
+    // buses of many terms go to the wide kernel while there are few of them (ga_kernels.hip, mix_wide_kernel)
+    std::vector<MixJob> wideJobs;
+    {
+      size_t nw = 0;
+      for (auto& j : mixJobs) nw += j.nterms >= kMixWideMinTerms;
+      if (nw > 0 && nw <= 64) {
+        std::vector<MixJob> rest;
+        rest.reserve(mixJobs.size() - nw);
+        for (auto& j : mixJobs) (j.nterms >= kMixWideMinTerms ? wideJobs : rest).push_back(j);
+        mixJobs.swap(rest);
+      }
+    }
+    if (!wideJobs.empty()) {
+      size_t off = plan.putv(wideJobs);
+      int nj = (int)wideJobs.size();
+      int64_t mx = 0;
+      double mixBytes = 0;
+      for (auto& j : wideJobs) {
+        mx = std::max(mx, j.n);
+        mixBytes += 4.0 * (double)(j.nterms + 1) * (double)j.n;
+      }
+      hipStream_t st = c.stream;
+      plan.add(LK_MIX, [=](uint8_t* base) {
+        launch_mix_wide(st, (const MixJob*)(base + off), nj, (const float* const*)(base + termsOff), mx, scaled ? (const float*)(base + gainsOff) : nullptr,
+                        curved ? (const float* const*)(base + curvesOff) : nullptr);
+      }, mixBytes);
     }
     if (!mixJobs.empty()) {
       size_t off = plan.putv(mixJobs);

@@ -226,6 +226,8 @@ struct NodeS {
   float coefMemoIn[3] = {0, 0, 0}, coefMemoOut[5] = {0, 0, 0, 0, 0};
   BiquadDynState* bqDyn = nullptr;  // device: coefficients + dirty flag + {W1, W2} per channel
   float* bqState = nullptr;         // = bqDyn->w
+  int bqTwinN = 32;                 // channels 0 .. bqTwinN-1 hold the SAME filter state (all zero at first; kept equal while the channels are
+                                    // fed the same signal -- mono material in a stereo node -- and evaluated once: planBiquad, BiquadJob::twins)
   bool coefOnDevice = false;        // the device copy of the coefficients is newer than b0..a2 above (automated run)
   // ConvolverNode (ConvolverNode.cs:12-16,87,95)
   int irBuf = -1;
@@ -823,6 +825,7 @@ struct Context {
   bool lastSegStable = false;
   uint64_t apiEpoch = 0;       // bumped by every API call that can change what a render computes (ga_api.cpp guard) and by drained commands
   bool simReplay = true;       // option "sim_replay"
+  bool twinChannels = true;    // option "twin_channels": channels that carry the same signal from the same state are evaluated once
   bool topoHasTimeNodes = false, topoHasConvolvers = false, topoHasOscillators = false, topoHasStreams = false;
   bool topoHasCycles = false;   // (chunkTopology) some node is pulled while it is being processed: chunks of ONE block (the reference's own granularity)
   std::vector<int> staleProducers;

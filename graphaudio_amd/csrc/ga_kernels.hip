@@ -1592,9 +1592,13 @@ __global__ __launch_bounds__(256) void mix_kernel(const MixJob* __restrict jobs,
       if (VEC == 4) {
         const v4f v = ldg4(tp[0] + f);
         const v4f gv = cv ? ldg4(cv + f) : v4f{g, g, g, g};
-        stg4(job.out + f, v4f{v.x * gv.x, v.y * gv.y, v.z * gv.z, v.w * gv.w});
+        const v4f r = v4f{v.x * gv.x, v.y * gv.y, v.z * gv.z, v.w * gv.w};
+        stg4(job.out + f, r);
+        if (job.out2) stg4(job.out2 + f, r);
       } else {
-        gptr(job.out)[f] = ldg1(tp[0] + f) * (cv ? ldg1(cv + f) : g);
+        const float r = ldg1(tp[0] + f) * (cv ? ldg1(cv + f) : g);
+        gptr(job.out)[f] = r;
+        if (job.out2) gptr(job.out2)[f] = r;
       }
     }
     return;
@@ -1638,6 +1642,7 @@ __global__ __launch_bounds__(256) void mix_kernel(const MixJob* __restrict jobs,
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
       }
       stg4(job.out + f, v4f{acc.x, acc.y, acc.z, acc.w});
+      if (job.out2) stg4(job.out2 + f, v4f{acc.x, acc.y, acc.z, acc.w});
     } else {
       float acc = 0.f;
       for (int j = 0; j < job.nterms; j++) {
@@ -1646,6 +1651,7 @@ __global__ __launch_bounds__(256) void mix_kernel(const MixJob* __restrict jobs,
         acc += v;
       }
       gptr(job.out)[f] = acc;
+      if (job.out2) gptr(job.out2)[f] = acc;
     }
   }
 }
@@ -1664,6 +1670,83 @@ void launch_mix(hipStream_t s, const MixJob* jobs_dev, int njobs, const float* c
   } else {
     GA_LAUNCH_JOBS((mix_kernel<1, false>), gx, 256, jobs_dev, njobs, terms_dev, gains_dev, curves_dev);
   }
+}
+
+// ---- a bus of MANY terms (hundreds to thousands of voices into one input): few jobs, each a long strictly ordered sum ----------
+// With one job per channel the launch above is a few hundred waves whose every step waits for a scalar load (the term's pointer,
+// gain, curve) and then for a vector load: at 4 terms per step a 4096-term bus is 1024 such round trips per wave (measured: 0.95 ms
+// for 2 x 4096 terms x 120,000 frames, 0.26 of the HBM rate).  Here a wave takes 64 frames, one per lane, reads the descriptors of
+// 64 terms with ONE coalesced load each (pointer / gain / curve: lane l holds term t0 + l, handed out with v_readlane) and keeps
+// the loads of 32 terms in flight; the additions stay in term order (AudioNodeInput.cs:118-132).
+template <bool SCALED>
+__global__ __launch_bounds__(64) void mix_wide_kernel(const MixJob* __restrict jobs, const float* const* __restrict terms, const float* __restrict gains,
+                                                     const float* const* __restrict curves) {
+  const MixJob job = jobs[blockIdx.y];
+  const int lane = threadIdx.x;
+  const float* const* __restrict tp = terms + job.term0;
+  const float* __restrict gp = SCALED ? gains + job.term0 : nullptr;
+  const float* const* __restrict cp = (SCALED && curves) ? curves + job.term0 : nullptr;
+  constexpr int NB = 32;
+  for (int64_t i0 = (int64_t)blockIdx.x * 64; i0 < job.n; i0 += (int64_t)gridDim.x * 64) {
+    const int64_t i = i0 + lane;
+    const bool live = i < job.n;
+    const int64_t f = job.f0 + (live ? i : 0);
+    float acc = 0.f;
+    for (int t0 = 0; t0 < job.nterms; t0 += 64) {
+      const int cnt = min(64, job.nterms - t0);
+      const bool mine = lane < cnt;
+      const float* myp = mine ? tp[t0 + lane] : nullptr;
+      const float myg = (SCALED && mine) ? gp[t0 + lane] : 1.f;
+      const float* myc = (cp && mine) ? cp[t0 + lane] : nullptr;
+      auto ptr_of = [](const float* p, int l) {
+        const unsigned long long v = (unsigned long long)p;
+        const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, l), hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), l);
+        return (const float*)(((unsigned long long)hi << 32) | lo);
+      };
+#pragma unroll
+      for (int u0 = 0; u0 < 64; u0 += NB) {
+        if (u0 >= cnt) break;
+        if (u0 + NB <= cnt) {
+          float v[NB], m[NB];
+#pragma unroll
+          for (int u = 0; u < NB; u++) v[u] = ldg1(ptr_of(myp, u0 + u) + f);
+          if (SCALED) {
+#pragma unroll
+            for (int u = 0; u < NB; u++) {
+              m[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myg), u0 + u));
+              if (cp) {
+                const float* c = ptr_of(myc, u0 + u);
+                if (c) m[u] = ldg1(c + f);
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < NB; u++) v[u] = v[u] * m[u];   // (rounded on its own: -ffp-contract=off)
+          }
+#pragma unroll
+          for (int u = 0; u < NB; u++) acc += v[u];
+        } else {
+          for (int u = u0; u < cnt; u++) {   // the last, partial batch of the bus
+            float v = ldg1(tp[t0 + u] + f);
+            if (SCALED) v = v * ((cp && cp[t0 + u]) ? ldg1(cp[t0 + u] + f) : gp[t0 + u]);
+            acc += v;
+          }
+        }
+      }
+    }
+    if (live) {
+      gptr(job.out)[f] = acc;
+      if (job.out2) gptr(job.out2)[f] = acc;
+    }
+  }
+}
+void launch_mix_wide(hipStream_t s, const MixJob* jobs_dev, int njobs, const float* const* terms_dev, int64_t max_n, const float* gains_dev,
+                     const float* const* curves_dev) {
+  if (njobs <= 0 || max_n <= 0) return;
+  const int gx = (int)std::min<int64_t>((max_n + 63) / 64, 8192);
+  if (gains_dev)
+    GA_LAUNCH_JOBS((mix_wide_kernel<true>), gx, 64, jobs_dev, njobs, terms_dev, gains_dev, curves_dev);
+  else
+    GA_LAUNCH_JOBS((mix_wide_kernel<false>), gx, 64, jobs_dev, njobs, terms_dev, gains_dev, curves_dev);
 }
 
 template <bool SCALED>
@@ -1894,10 +1977,11 @@ __global__ __launch_bounds__(64) void biquad_kernel(const BiquadJob* __restrict 
   }
   if (have) {
 #pragma unroll
-    for (int q = 0; q < NSEC; q++) {
-      stg1(st[q], w1[q]);
-      stg1(st[q] + 1, w2[q]);
-    }
+    for (int q = 0; q < NSEC; q++)
+      for (int t = 0; t < me.twins; t++) {   // (twin channels: BiquadJob::twins)
+        stg1(st[q] + 2 * t, w1[q]);
+        stg1(st[q] + 2 * t + 1, w2[q]);
+      }
   }
 }
 template <int JPW>
@@ -1935,6 +2019,15 @@ static void launch_biquad_jpw(hipStream_t s, const BiquadJob* jobs_dev, int njob
 // (masked batches, plain C++), not per tile: step k hands out sample k - D, D = SK (NSEC - 1), the tile is stored D samples late.
 #ifdef GA_BQ_PROBE   // tools/micro/bq_pipe_probe.hip: where a wave's cycles go (s_memtime around the phases of every tile)
 __device__ unsigned long long ga_bq_probe[8];
+}   // namespace ga
+// (a library built with -DGA_BQ_PROBE hands the sums out and clears them: tools/bq_probe_product.py)
+extern "C" __attribute__((visibility("default"))) void ga_bq_probe_read(unsigned long long* out) {
+  unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(ga::ga_bq_probe), sizeof zero);
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(ga::ga_bq_probe), zero, sizeof zero);
+}
+namespace ga {
 #define GA_BQ_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
 #define GA_BQ_ACC(i, v) probe_acc[i] += (v)
 #else
@@ -2148,13 +2241,17 @@ __global__ __launch_bounds__(64) void biquad_pipe_kernel(const BiquadJob* __rest
   {
     GA_BQ_T(tk1);
     probe_acc[3] = tk1 - tk0;
+    probe_acc[6] = 1;   // waves
+    probe_acc[7] = (unsigned long long)jcount;
     if (lane == 0)
-      for (int i = 0; i < 6; i++) atomicAdd(&ga_bq_probe[i], probe_acc[i]);
+      for (int i = 0; i < 8; i++) atomicAdd(&ga_bq_probe[i], probe_acc[i]);
   }
 #endif
   if (have) {
-    stg1(st, w1);
-    stg1(st + 1, w2);
+    for (int t = 0; t < me.twins; t++) {   // (twin channels: BiquadJob::twins)
+      stg1(st + 2 * t, w1);
+      stg1(st + 2 * t + 1, w2);
+    }
   }
 }
 template <int NSEC>
@@ -2187,9 +2284,12 @@ __global__ __launch_bounds__(256) void biquad_split_expand_kernel(const BiquadSc
   b.f0 = C.f0 + (int64_t)l * K;
   b.n = min(K, C.n - (int64_t)l * K);
   b.state = l + 1 < G ? C.scratch + (size_t)l * C.nsec * 2 : nullptr;   // the last piece runs on the cascade's own state
+  b.twins = l + 1 < G ? 1 : C.twins;
+  b.pad_ = 0;
   passB[(size_t)j * G + l] = b;
   if (l + 1 < G) {
     b.out = nullptr;
+    b.twins = 1;
     passA[(size_t)j * (G - 1) + l] = b;
   }
 }

@@ -243,10 +243,17 @@ struct MixJob {
   int nterms;
   int64_t f0;     // first chunk frame
   int64_t n;      // frames
+  float* out2 = nullptr;   // a second row that receives the same sums (a channel whose term list equals this one's: mono material in a
+                           // stereo input, AudioNodeInput.cs:182-244 adds the same values to both channels in the same order)
 };
 // gains_dev (may be null): one factor per entry of the term table -- term j contributes fl(term[j][f] * gain[j]) (a folded constant GainNode)
 void launch_mix(hipStream_t s, const MixJob* jobs_dev, int njobs, const float* const* terms_dev, int64_t max_n, bool vec4, const float* gains_dev = nullptr,
                 const float* const* curves_dev = nullptr);   // curves: per term, null or a chunk-frame indexed gain curve (a folded automated GainNode)
+
+// the same sums for jobs of many terms (a bus of hundreds of voices; any alignment): one frame per lane, 32 terms' loads in flight
+void launch_mix_wide(hipStream_t s, const MixJob* jobs_dev, int njobs, const float* const* terms_dev, int64_t max_n, const float* gains_dev = nullptr,
+                     const float* const* curves_dev = nullptr);
+constexpr int kMixWideMinTerms = 256;   // (the planner hands jobs of at least this many terms to launch_mix_wide while they are few)
 
 // down-mix N -> 1: out[f] = (sum_ch in[ch][f]) * scale   (AudioNodeInput.cs:214-228); 'ins' index the term table
 struct DownmixJob {
@@ -289,6 +296,8 @@ struct BiquadJob {
   int64_t f0;
   int64_t n;
   float* state;   // nullptr: every section's own `state` ; else {W1, W2} of section q at state + 2 q (a piece of a split cascade)
+  int twins = 1;  // the job stands for this many channels of its node(s) that carry the SAME signal from the same state (mono
+  int pad_ = 0;   // material in a stereo node): the end state is written to the state slots of all of them (state + 2 t, t < twins)
 };
 void launch_biquad(hipStream_t s, const BiquadJob* jobs_dev, int njobs, const BiquadSection* secs_dev, int nsec);
 
@@ -308,6 +317,8 @@ struct BiquadScanJob {   // one cascade (node chain x channel) cut into G pieces
   float* scratch;     // [G - 1][nsec][2]: in: z_l of pass A ; out: s_l, where pass B's piece l starts
   int sec0, nsec;     // the cascade's own sections (their `state` is the persistent state: in s_0, out s_{G-1})
   int64_t f0, n;
+  int twins = 1;      // as BiquadJob::twins (handed to the last piece)
+  int pad_ = 0;
 };
 // the pieces of `ncasc` cascades as BiquadJobs, written on the device (the host tables stay one record per cascade):
 // pass A: ncasc x (G - 1) state-only jobs ; pass B: ncasc x G jobs

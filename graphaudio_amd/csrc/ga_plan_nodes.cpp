@@ -486,6 +486,7 @@ void Context::planBiquad(NodePlanCtx& k) {
   if (ns.bqDynamic) {  // automated parameters: per-sample coefficient refresh on the device
     auto iv = ex.resolveInput((int)si, ns, 0, false, nullptr);
     ensureBiquadState(nd);
+    nd.bqTwinN = 1;   // (every channel is walked on its own from here on)
     BiquadDynJob dj{};
     for (int ch = 0; ch < ns.outCh && ch < 32; ch++) {
       dj.in[ch] = iv[ch];
@@ -558,7 +559,24 @@ void Context::planBiquad(NodePlanCtx& k) {
   }
   if (G > 1 && (G != ex.bqG || K != ex.bqK)) G = 1;   // (one cut per level: the pieces of a level are expanded by one launch)
   const std::vector<float>* AK = G > 1 ? &biquadTransition(coefs, (int)chain.size(), K).M : nullptr;
+  // Twin channels: a mono signal in a stereo node arrives as the SAME view on every channel (AudioNodeInput.cs:182-244 copies the
+  // mono mix to all of them), and while every channel's state has been the same so far (NodeS::bqTwinN) the reference computes
+  // the same numbers once per channel (BiQuadFilterNode.cs:117-146).  One job then stands for all of them: every channel's output
+  // view is the one row, the end state goes to every channel's slot.
+  int twins = 1;
+  if (twinChannels && ns.outCh > 1) {
+    bool same = true;
+    for (int ch = 1; ch < ns.outCh; ch++) same = same && iv[ch] == iv[0];
+    for (const NodeSeg* cn : chain) same = same && nodes[cn->id]->bqTwinN >= ns.outCh;
+    if (same) twins = ns.outCh;
+  }
+  for (const NodeSeg* cn : chain) nodes[cn->id]->bqTwinN = twins;   // (channels beyond outCh are not advanced: no longer the same)
+  if (twins > 1) stats.twin_rows += twins - 1;
   for (int ch = 0; ch < ns.outCh; ch++) {
+    if (twins > 1 && ch > 0) {
+      ov[ch] = ov[0];
+      continue;
+    }
     BiquadJob bj;
     bj.in = iv[ch] ? iv[ch] : zeros;
     bj.out = ex.nodeOut(ns.id, ch);
@@ -567,6 +585,7 @@ void Context::planBiquad(NodePlanCtx& k) {
     bj.f0 = f0;
     bj.n = nf;
     bj.state = nullptr;
+    bj.twins = twins;
     for (const NodeSeg* cn : chain) {
       BiquadSection sc;
       sc.b0 = cn->b0; sc.b1 = cn->b1; sc.b2 = cn->b2; sc.a1 = cn->a1; sc.a2 = cn->a2;
@@ -582,7 +601,7 @@ void Context::planBiquad(NodePlanCtx& k) {
     stats.biquad_split_cascades++;
     float* scratch = bqSplitAlloc((size_t)(G - 1) * bj.nsec * 2);
     ex.bqMats[bj.nsec].push_back(AK);
-    ex.bqScans[bj.nsec].push_back(BiquadScanJob{bj.in, bj.out, 0, scratch, bj.sec0, bj.nsec, f0, nf});
+    ex.bqScans[bj.nsec].push_back(BiquadScanJob{bj.in, bj.out, 0, scratch, bj.sec0, bj.nsec, f0, nf, twins, 0});
   }
 }
 

@@ -124,6 +124,8 @@ typedef struct ga_stats {
                                    "conv_reference_order"): PartitionedConvolver.cs:104-223 bit for bit */
   int64_t sim_replays;          /* chunks whose first block was not traversed again: the control-plane records of the previous chunk's
                                    last segment were taken over (steady renders, option "sim_replay") */
+  int64_t twin_rows;            /* channel rows that were not computed a second time: a mono signal in a stereo node or input is the
+                                   same numbers on every channel (AudioNodeInput.cs:182-244), evaluated once (option "twin_channels") */
 } ga_stats;
 enum {
   GA_STAGE_OTHER = 0,        /* sources, biquads, gains, parameter curves, ... */

@@ -41,13 +41,13 @@ def run(ctx, builder, frames, pieces):
     return out
 
 
-def three_way(builder, frames, pieces, expect_premix=True, rel=2e-6):
+def three_way(builder, frames, pieces, expect_premix=True, rel=2e-6, **opts):
     o = OracleContext(SR)
     ref = run(o, builder, frames, [frames])
     o.Dispose()
     outs = []
     for premix in (1, 0):
-        h = hip(coarse_premix=premix)
+        h = hip(coarse_premix=premix, **opts)
         outs.append(run(h, builder, frames, pieces))
         st = h.GetStats()
         h.Dispose()
@@ -209,8 +209,11 @@ def test_group_behind_gains_and_into_a_bus():
 
 
 def test_members_behind_unity_and_other_gains_are_summed_as_spectra():
-    """one member's gain is exactly 1 (its convolver reads the source's buffer view, the others read slabs): the group is not uniform,
-    so it is not pre-mixed -- every member is transformed and the spectra are summed; same result"""
+    """One member's gain is exactly 1: both channels of its convolver's input are the source's buffer view -- ONE signal to transform
+    -- while the others' inputs are products.  With every channel's product written on its own (twin_channels = 0) those members
+    have two signals each: the group is not uniform and is not pre-mixed, every member is transformed and the spectra are summed.
+    By default a product that is the same on both channels is written once (tests/test_gpu_twin.py): every member has one signal,
+    the group is pre-mixed.  Same result either way."""
     frames = 128 * 300
 
     def build(ctx):
@@ -227,4 +230,5 @@ def test_members_behind_unity_and_other_gains_are_summed_as_spectra():
             s.Start()
         return 2
 
-    three_way(build, frames, [128 * 100, 128 * 200], expect_premix=False)
+    three_way(build, frames, [128 * 100, 128 * 200], expect_premix=False, twin_channels=0)
+    three_way(build, frames, [128 * 100, 128 * 200], expect_premix=True)

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 TAG=$1; shift
 rm -rf /tmp/prof_$TAG
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o st -- python3 tools/run_configs.py "$@" > gpurun_out/${TAG}_run.log 2> gpurun_out/${TAG}.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o st -- python3 tools/run_configs.py "$@" > gpurun_out/${TAG}_run.log 2> gpurun_out/${TAG}.err
 cp $(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1) gpurun_out/${TAG}_kernel_stats.csv
 tail -4 gpurun_out/${TAG}_run.log
 python3 - gpurun_out/${TAG}_kernel_stats.csv <<'PY'
