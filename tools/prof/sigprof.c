@@ -33,7 +33,12 @@ __attribute__((constructor)) static void start(void) {
   sigaction(SIGPROF, &sa, NULL);
   void* warm[4];
   backtrace(warm, 4);   // (loads libgcc outside the handler)
+  if (getenv("GA_SIGPROF_DEFER")) return;   // the script calls sigprof_start() once the graph is built
   struct itimerval it = {{0, 500}, {0, 500}};
+  setitimer(ITIMER_PROF, &it, NULL);
+}
+void sigprof_start(void) {
+  struct itimerval it = {{0, 200}, {0, 200}};
   setitimer(ITIMER_PROF, &it, NULL);
 }
 
@@ -43,6 +48,7 @@ void sigprof_dump(void) {
   setitimer(ITIMER_PROF, &it, NULL);
   if (nsamples == 0) return;
   const char* out = getenv("GA_SIGPROF_OUT");
+  const char* lib = getenv("GA_SIGPROF_LIB") ? getenv("GA_SIGPROF_LIB") : "libgraphaudio_hip";   // (file name of the library whose frames count)
   FILE* f = fopen(out ? out : "sigprof.txt", "w");
   if (!f) return;
   int n = nsamples < MAXS ? nsamples : MAXS;
@@ -51,7 +57,7 @@ void sigprof_dump(void) {
     int any = 0;
     for (int d = 2; d < depth[i]; d++) {   // (0, 1: the handler and the signal trampoline)
       Dl_info di;
-      if (!dladdr(samples[i][d], &di) || !di.dli_fname || !strstr(di.dli_fname, "libgraphaudio_hip")) continue;
+      if (!dladdr(samples[i][d], &di) || !di.dli_fname || !strstr(di.dli_fname, lib)) continue;
       fprintf(f, "%s%lx", any ? " " : "", (unsigned long)((char*)samples[i][d] - (char*)di.dli_fbase));
       any = 1;
     }
