@@ -189,6 +189,9 @@ def serial_bound(frames, kernel_ms, note):
     return {"bound": "dependent-operation latency of one cascade walked sample by sample (every cascade in parallel; the sections of a "
                      "cascade pipelined across lanes): frames x 3 dependent float32 operations (mul, sub, sub of the direct-form-II "
                      "recursion, BiQuadFilterNode.cs:136-141) x 3.46 ns (profiles/r01_micro_dependent_valu_latency.txt)",
+            "what_the_walk_costs": "measured (profiles/r04_biquad_pipe_probe.txt): a wave that has a SIMD to itself pays ~5.1 cycles per instruction, "
+                                   "whatever the instruction; biquad_pipe_kernel's steady state is 8 vector instructions per step + 1.2 for LDS and the loop "
+                                   "(47 cycles; the 3-operation chain is 25)",
             "chain_ops_per_sample": DEP_OPS_PER_SAMPLE, "dependent_op_ns": DEP_OP_NS, "frames_per_step": frames,
             "bound_ms_per_step": bound_ms, "kernel_ms_per_step": kernel_ms, "frac": bound_ms / kernel_ms if kernel_ms else None, "note": note}
 

@@ -788,6 +788,8 @@ void Context::runChunkImpl(int64_t nblocks, float* const* /*unused*/) {
     const size_t sl = r.segs.size() - 1;
     if (sl < r.ex->outScale.size() && !r.ex->outScale[sl].empty()) lastViewScale = r.ex->outScale[sl];
     else lastViewScale.clear();
+    if (sl < r.ex->outCurve.size() && !r.ex->outCurve[sl].empty()) lastViewCurve = r.ex->outCurve[sl];
+    else lastViewCurve.clear();
     lastViewFrames = r.n * kBlock;
     lastViewSlabGen = slabGen;
   }

@@ -306,6 +306,8 @@ struct NodeS {
   float* staleBuf = nullptr;   // the copy consumers read in this chunk: [staleRows][128]
   float* staleNext = nullptr;  // ... and the one this chunk's output is written to (the two swap when the chunk is planned)
   int staleRows = 0;
+  uint64_t staleSeq = 0;       // Context::chunkSeq of the chunk that last wrote staleBuf (chunkStaleCommit): a node that stops being pulled
+                               // from inside its own evaluation and later is again must not find the block it kept back then
 };
 
 // A vector with inline room for N elements (heap only beyond): the per-node, per-segment records of the control-plane
@@ -837,6 +839,7 @@ struct Context {
   // the new stale producer put out LAST is still in those slabs (Context::chunkStaleSeed)
   std::vector<Views> lastViews;
   std::vector<float> lastViewScale;
+  std::vector<const float*> lastViewCurve;   // (a GainNode folded into its consumer with a gain CURVE: its output is view x curve)
   int64_t lastViewFrames = 0;
   uint64_t slabGen = 0, lastViewSlabGen = ~0ull;   // (slabGen: bumped when the slab pool is reallocated -- old views dangle)
   uint64_t topoStatsVersion = ~0ull;

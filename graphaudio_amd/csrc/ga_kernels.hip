@@ -776,12 +776,22 @@ void launch_spectral_mac_b(hipStream_t s, const ConvSetB* sets_dev, int nsets, i
 constexpr int RM_TW = 1024;     // blocks per workgroup
 constexpr int RM_PSEG = 1024;   // taps per segment
 
+// Each operation is spelled out as one scalar VALU instruction: left to itself the compiler pairs the products and sums of
+// neighbouring chains into v_pk_mul_f32 / v_pk_add_f32 and pays for the pairs with moves -- 58 v_mov per 68 packed operations in
+// this loop, while a packed f32 instruction costs the same SIMD cycles as the two scalar ones it replaces on gfx950
+// (profiles/r01_micro_pk_f32_issue_rate.txt).
+#define GA_RM_OP(op, r, a, b) asm(op " %0, %1, %2" : "=v"(r) : "v"(a), "v"(b))
 __device__ __forceinline__ void rm_cmac(float& ar, float& ai, float dr, float di, float hr, float hi) {
   // (dr * ir) - (di * ii) ; (dr * ii) + (di * ir) ; acc += ...   PartitionedConvolver.cs:196-206,218-219
-  const float re = __fsub_rn(__fmul_rn(dr, hr), __fmul_rn(di, hi));
-  const float im = __fadd_rn(__fmul_rn(dr, hi), __fmul_rn(di, hr));
-  ar = __fadd_rn(ar, re);
-  ai = __fadd_rn(ai, im);
+  float p0, p1, p2, p3, re, im;
+  GA_RM_OP("v_mul_f32", p0, dr, hr);
+  GA_RM_OP("v_mul_f32", p1, di, hi);
+  GA_RM_OP("v_mul_f32", p2, dr, hi);
+  GA_RM_OP("v_mul_f32", p3, di, hr);
+  GA_RM_OP("v_sub_f32", re, p0, p1);
+  GA_RM_OP("v_add_f32", im, p2, p3);
+  GA_RM_OP("v_add_f32", ar, ar, re);
+  GA_RM_OP("v_add_f32", ai, ai, im);
 }
 
 __global__ __launch_bounds__(256) void refmac_kernel(const ConvSetB* __restrict sets, int nblocks, int hist, ConvPlanesB pl) {
@@ -1058,7 +1068,7 @@ void launch_irfft_ola_b(hipStream_t s, const ConvRowIO* yrows_dev, int ny, int n
 __global__ __launch_bounds__(128) void stale_copy_kernel(const StaleJob* __restrict jobs) {
   const StaleJob j = jobs[blockIdx.x];
   const int i = threadIdx.x;
-  gptr(j.dst)[i] = j.src ? ldg1(j.src + i) * j.scale : 0.f;
+  gptr(j.dst)[i] = j.src ? ldg1(j.src + i) * (j.curve ? ldg1(j.curve + i) : j.scale) : 0.f;
 }
 void launch_stale_copy(hipStream_t s, const StaleJob* jobs_dev, int njobs) {
   if (njobs <= 0) return;

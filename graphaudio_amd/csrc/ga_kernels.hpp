@@ -102,9 +102,10 @@ void launch_hist_copy_b(hipStream_t s, const HistJobB* jobs_dev, int njobs, int 
 // that pull it while it is being processed in the NEXT block (Nodes/AudioNode.cs:153-156)
 struct StaleJob {
   float* dst;
-  const float* src;
+  const float* src;     // nullptr: zeros
   float scale;
   int pad_;
+  const float* curve = nullptr;   // non-null: dst = src x curve (a GainNode that was folded into its consumer with its gain curve)
 };
 void launch_stale_copy(hipStream_t s, const StaleJob* jobs_dev, int njobs);
 

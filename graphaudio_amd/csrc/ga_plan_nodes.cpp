@@ -802,19 +802,25 @@ void Context::chunkStaleSeed(ChunkRun& r) {
   };
   for (int id : staleProducers) {
     NodeS& nd = *nodes[id];
-    if (nd.staleBuf) continue;   // (a producer that already keeps its blocks)
+    // a producer that kept its last block in the chunk before this one goes on; one that is new to the role -- or BACK in it after chunks
+    // in which nothing pulled it from inside its own evaluation (an edit moved the point where the traversal enters the loop away and
+    // back: fuzz session 61173) -- takes the block it put out last from the previous chunk's output views
+    if (nd.staleBuf && nd.staleSeq + 1 == chunkSeq) continue;
     const int rows = nd.type == GA_NODE_CHANNEL_SPLITTER ? std::max<int>(1, (int)nd.outputs.size()) : 32;
-    nd.staleRows = rows;
-    nd.staleBuf = (float*)dalloc((size_t)rows * kBlock * sizeof(float));
-    nd.staleNext = (float*)dalloc((size_t)rows * kBlock * sizeof(float));
-    GA_HIP(hipMemsetAsync(nd.staleBuf, 0, (size_t)rows * kBlock * sizeof(float), stream));
-    GA_HIP(hipMemsetAsync(nd.staleNext, 0, (size_t)rows * kBlock * sizeof(float), stream));
-    if (lastViewSlabGen != slabGen || lastViewFrames < kBlock || id >= (int)lastViews.size()) continue;
-    const Views& ov = lastViews[id];
-    const float g = id < (int)lastViewScale.size() ? lastViewScale[id] : 1.f;
-    for (int rw = 0; rw < rows && rw < (int)ov.size(); rw++) {
-      const float* src = ov[rw] ? ov[rw] + (lastViewFrames - kBlock) : nullptr;
-      if (alive(src)) jobs.push_back(StaleJob{nd.staleBuf + (size_t)rw * kBlock, src, g, 0});
+    if (!nd.staleBuf) {
+      nd.staleRows = rows;
+      nd.staleBuf = (float*)dalloc((size_t)rows * kBlock * sizeof(float));
+      nd.staleNext = (float*)dalloc((size_t)rows * kBlock * sizeof(float));
+      GA_HIP(hipMemsetAsync(nd.staleNext, 0, (size_t)rows * kBlock * sizeof(float), stream));
+    }
+    const bool haveViews = lastViewSlabGen == slabGen && lastViewFrames >= kBlock && id < (int)lastViews.size();
+    const float g = (haveViews && id < (int)lastViewScale.size()) ? lastViewScale[id] : 1.f;
+    const float* cv = (haveViews && id < (int)lastViewCurve.size() && lastViewCurve[id]) ? lastViewCurve[id] + (lastViewFrames - kBlock) : nullptr;
+    for (int rw = 0; rw < nd.staleRows; rw++) {
+      const float* src = (haveViews && rw < (int)lastViews[id].size() && lastViews[id][rw]) ? lastViews[id][rw] + (lastViewFrames - kBlock) : nullptr;
+      StaleJob sj{nd.staleBuf + (size_t)rw * kBlock, alive(src) ? src : nullptr, g, 0};
+      sj.curve = (sj.src && cv && alive(cv)) ? cv : nullptr;
+      jobs.push_back(sj);   // (rows without a view: zeros)
     }
   }
   if (jobs.empty()) return;
@@ -854,6 +860,7 @@ void Context::chunkStaleCommit(ChunkRun& r) {
       jobs.push_back(StaleJob{nd.staleNext + (size_t)rw * kBlock, src, g, 0});
     }
     std::swap(nd.staleBuf, nd.staleNext);
+    nd.staleSeq = chunkSeq;
   }
   const size_t off = ex.plan.putv(jobs);
   const int nj = (int)jobs.size();

@@ -31,6 +31,19 @@
 #include <string>
 #include <vector>
 
+// The reference's MathF.Cos / Sin / Pow are the C runtime's single-precision functions: std::cos(float) etc. here.  A diagnostic
+// build (-DGAO_DOUBLE_TRIG, tools/fuzz_libm_class.py -- never the oracle the tests use) evaluates them in double and rounds once,
+// which is what the device does: a deviation between device and oracle that vanishes against that build is the last bit of libm.
+#ifdef GAO_DOUBLE_TRIG
+static inline float gaoCos(float x) { return (float)std::cos((double)x); }
+static inline float gaoSin(float x) { return (float)std::sin((double)x); }
+static inline float gaoPow(float a, float b) { return (float)std::pow((double)a, (double)b); }
+#else
+static inline float gaoCos(float x) { return std::cos(x); }
+static inline float gaoSin(float x) { return std::sin(x); }
+static inline float gaoPow(float a, float b) { return std::pow(a, b); }
+#endif
+
 namespace {
 
 constexpr int kBlock = 128;  // AudioBuffer.FramesPerBlock, AudioBuffer.cs:10
@@ -808,6 +821,30 @@ AudioBuffer* Context::processBlock() {
     throw;
   }
   inRender = false;
+#ifdef GAO_DEBUG_DUMP   // diagnostic build only (tools/fuzz_node_dump.py): every node's output buffers of the blocks GAO_DUMP_FROM..GAO_DUMP_TO
+  if (const char* f0 = getenv("GAO_DUMP_FROM")) {
+    const int from = atoi(f0), to = getenv("GAO_DUMP_TO") ? atoi(getenv("GAO_DUMP_TO")) : from;
+    if (nextBlock - 1 >= from && nextBlock - 1 <= to) {
+      FILE* f = fopen(getenv("GAO_DUMP_FILE") ? getenv("GAO_DUMP_FILE") : "gao_dump.txt", "a");
+      if (f) {
+        for (auto& n : nodes) {
+          if (!n) continue;
+          for (auto& o : n->outputs) {
+            if (!o->buffer) continue;
+            fprintf(f, "block %d node %d type %d processed %d out %d ch %d silent %d\n", nextBlock - 1, n->id, n->type, n->lastProcessedBlock == nextBlock,
+                    o->index, o->buffer->channelCount, (int)o->buffer->silent);
+            for (int ch = 0; ch < o->buffer->channelCount; ch++) {
+              const float* p = o->buffer->span(ch);
+              for (int i = 0; i < kBlock; i++) fprintf(f, "%.9g ", p[i]);
+              fprintf(f, "\n");
+            }
+          }
+        }
+        fclose(f);
+      }
+    }
+  }
+#endif
   double increment = (double)kBlock / sampleRate;
   currentTime = blockTime + increment;  // accumulated, not block * 128 / sr (:78-79)
   return destination()->outputBuffer.get();
@@ -908,8 +945,8 @@ struct BiquadNode : Node {
   void updateCoefficients(float frequency, float q, float gain) {  // :149-258
     const float PI = 3.14159274f;  // MathF.PI
     float w0 = 2.f * PI * frequency / ctx->sampleRate;
-    float cosW0 = std::cos(w0);
-    float sinW0 = std::sin(w0);
+    float cosW0 = gaoCos(w0);
+    float sinW0 = gaoSin(w0);
     float alpha = sinW0 / (2.f * q);
     float a0, A1, A2, B0, B1, B2;
     switch (filterType) {
@@ -934,13 +971,13 @@ struct BiquadNode : Node {
         a0 = 1.f + alpha; A1 = -2.f * cosW0; A2 = 1.f - alpha;
         break;
       case GA_FILTER_PEAKING: {
-        float A = std::pow(10.f, gain / 40.f);
+        float A = gaoPow(10.f, gain / 40.f);
         B0 = 1.f + alpha * A; B1 = -2.f * cosW0; B2 = 1.f - alpha * A;
         a0 = 1.f + alpha / A; A1 = -2.f * cosW0; A2 = 1.f - alpha / A;
         break;
       }
       case GA_FILTER_LOWSHELF: {
-        float A = std::pow(10.f, gain / 40.f);
+        float A = gaoPow(10.f, gain / 40.f);
         float sqrtA = std::sqrt(A);
         float beta = sqrtA / q;  // non-standard RBJ variant, kept as in the reference (:221)
         B0 = A * ((A + 1.f) - (A - 1.f) * cosW0 + beta * sinW0);
@@ -952,7 +989,7 @@ struct BiquadNode : Node {
         break;
       }
       case GA_FILTER_HIGHSHELF: {
-        float A = std::pow(10.f, gain / 40.f);
+        float A = gaoPow(10.f, gain / 40.f);
         float sqrtA = std::sqrt(A);
         float beta = sqrtA / q;
         B0 = A * ((A + 1.f) + (A - 1.f) * cosW0 + beta * sinW0);
@@ -1603,8 +1640,8 @@ struct StereoPannerNode : Node {
         float pan = std::min(std::max(pv[i], -1.0f), 1.0f);
         if (pan != lp) {
           float xx = (pan + 1.0f) * 0.5f;
-          gainL = std::cos(xx * PIf / 2.0f);
-          gainR = std::sin(xx * PIf / 2.0f);
+          gainL = gaoCos(xx * PIf / 2.0f);
+          gainR = gaoSin(xx * PIf / 2.0f);
           lp = pan;
         }
         float sm = x[i];
@@ -1619,8 +1656,8 @@ struct StereoPannerNode : Node {
         float pan = std::min(std::max(pv[i], -1.0f), 1.0f);
         if (pan != lp) {
           float xx = pan <= 0.0f ? pan + 1.0f : pan;
-          gainL = std::cos(xx * PIf / 2.0f);
-          gainR = std::sin(xx * PIf / 2.0f);
+          gainL = gaoCos(xx * PIf / 2.0f);
+          gainR = gaoSin(xx * PIf / 2.0f);
           lp = pan;
         }
         float inL = xl[i], inR = xr[i];

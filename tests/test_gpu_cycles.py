@@ -148,6 +148,40 @@ def test_an_edit_closes_a_loop_and_opens_it_again():
     assert G.rms(ref) > 1e-3 and np.array_equal(ref, got)
 
 
+def test_the_point_where_the_traversal_enters_a_loop_moves_away_and_back():
+    """Which node of a loop hands out its previous block follows from where the traversal enters the loop.  Here the loop a -> b -> a is
+    entered through a (a -> destination); while a tap of b hangs on a bus that the destination pulls FIRST it is entered through b; then
+    the tap goes and a is the stale producer again -- with the block it put out in the call before, not the one it kept when it last had
+    the role (fuzz sessions 61173 and 60001 of the round-4 sweep: one and two blocks at 3e-2)."""
+    frames = 128 * 60
+
+    def build(ctx):
+        bus = GainNode(ctx)
+        bus.Connect(ctx.Destination)          # the destination's FIRST connection
+        s = src(ctx, 11, frames)
+        a, b, tap = GainNode(ctx), GainNode(ctx), GainNode(ctx)
+        a.Gain.Value = 0.9
+        b.Gain.Value = 0.6
+        tap.Gain.Value = 0.5
+        s.Connect(a).Connect(b).Connect(a)    # a -> b -> a
+        a.Connect(ctx.Destination)
+        b.Connect(tap)
+        return bus, tap
+
+    def edit(ctx, h, k):
+        bus, tap = h
+        if k == 2:
+            tap.Connect(bus)       # the loop is entered through b from here on
+        if k == 4:
+            tap.Disconnect()       # ... and through a again
+        if k == 6:
+            tap.Connect(bus)
+        if k == 7:
+            tap.Disconnect()
+    ref, got = both(build, frames, pieces=[128 * 5, 128 * 4 + 30, 128 * 6, 128 * 3 - 30, 128 * 7, 128 * 2 + 1, 128 * 3, 128 * 20], edit=edit)
+    assert G.rms(ref) > 1e-3 and np.array_equal(ref, got)
+
+
 def test_master_echo_behind_sixteen_voices():
     frames = 128 * 200
 

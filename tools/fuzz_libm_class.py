@@ -1,0 +1,29 @@
+"""tools/fuzz_libm_class.py SEED...: is a session's deviation from the oracle the last bit of cosf / sinf / powf?
+
+The reference's MathF.Cos / Sin / Pow are the C runtime's single-precision functions (the oracle: glibc's); the device evaluates the
+coefficients of AUTOMATED biquads and the gains of panners in double and rounds once (ga_kernels.hip, biquad_update_coefficients) --
+the same float except where the true value lies within ~1e-9 of a rounding boundary.  A graph that quantises such a value (a delay
+time in whole samples, `pan != lastPan`) turns that last bit into a block that sounds different.  This tool renders the session
+three times: oracle, device, and a DIAGNOSTIC oracle built with -DGAO_DOUBLE_TRIG (the device's evaluation of those three functions,
+everything else the reference's): a deviation that vanishes against the third is that class and nothing else.
+    g++ -std=c++17 -O3 -mavx2 -ffp-contract=off -fno-fast-math -fPIC -DGAO_DOUBLE_TRIG -shared -o tools/variants/libga_oracle_dtrig.so oracle/ga_oracle.cpp
+"""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, ".")
+from graphaudio_amd import OfflineAudioContext
+from graphaudio_amd._capi import CApi
+from tests import _graphs as G
+import tests._fuzz as F
+from tests._oracle import OracleContext
+dtrig = CApi(C.CDLL(os.path.join("tools", "variants", "libga_oracle_dtrig.so")), "gao_")
+for seed in [int(a) for a in sys.argv[1:]]:
+    ref, _ = F.run_random_session(OracleContext(48000), seed)
+    ref2, _ = F.run_random_session(OfflineAudioContext(48000, _api=dtrig), seed)
+    h = OfflineAudioContext(48000)
+    h.SetOption("max_chunk_blocks", 11)
+    h.SetOption("coarse_min_blocks", 1)
+    got, _ = F.run_random_session(h, seed)
+    scale = max(G.rms(ref), 1e-3)
+    print(f"session {seed}: device vs oracle {G.rms(ref - got):.3e}   device vs oracle with the device's cos/sin/pow {G.rms(ref2 - got):.3e}   "
+          f"oracle vs that oracle {G.rms(ref - ref2):.3e}   (signal {scale:.3f})", flush=True)
