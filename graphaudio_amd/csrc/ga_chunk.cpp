@@ -96,7 +96,9 @@ void Context::chunkTopology(ChunkRun& r) {
   if (topoVersion == graphVersion && !topoCache.empty() && !topoHasCycles) {
     topo = topoCache;
   } else {
+  staleLeavers.clear();
   for (auto& np : nodes) {
+    np->prevReachable = np->reachable;
     np->reachable = false;
     np->isProcessing = false;
     np->level = 0;
@@ -248,6 +250,8 @@ void Context::chunkTopology(ChunkRun& r) {
   topoCache = topo;
   topoVersion = graphVersion;
   topoHasCycles = !staleProducers.empty();
+  for (auto& np : nodes)
+    if (np->prevReachable && !np->reachable && !np->disposed) staleLeavers.push_back(np->id);
   }
   // Feedback: the loop closes through the block a producer put out LAST.  Unless every loop can be cut at a DelayNode (above: chunks
   // of `cycleBlocks` blocks) nothing can be batched along time -- the chunk is one block, the reference's own granularity (a 10 s

@@ -157,6 +157,7 @@ struct NodeS {
   int64_t lastProcessedBlock = -1;
   bool isProcessing = false;
   bool reachable = false;
+  bool prevReachable = false;   // reachable in the topology the PREVIOUS chunk ran on (= it was evaluated there; chunkTopology)
   int level = 0, depth = 0;
 
   // AudioBufferSourceNode (AudioBufferSourceNode.cs:15-30)
@@ -831,6 +832,8 @@ struct Context {
   bool topoHasTimeNodes = false, topoHasConvolvers = false, topoHasOscillators = false, topoHasStreams = false;
   bool topoHasCycles = false;   // (chunkTopology) some node is pulled while it is being processed: chunks of ONE block (the reference's own granularity)
   std::vector<int> staleProducers;
+  std::vector<int> staleLeavers;   // nodes that were evaluated in the previous chunk and are not in this one (an edit took them out of
+                                   // the graph): their output buffers keep the last block, which a later loop through them would read
   double loopGainBound = 0.0;   // (chunkTopology) the largest estimated gain of a feedback loop: differences that enter it grow by 1 / (1 - gain)
   std::vector<int> topoRefOrder;   // the reference-order walk of a graph with feedback (the planning order may cut loops at DelayNodes)
   int cycleBlocks = 1;          // blocks per chunk of a graph with feedback (1 unless every loop is cut at a DelayNode)

@@ -786,7 +786,7 @@ void Context::chunkPlanNodes(ChunkRun& r, int d) {
 // overwritten yet when this chunk's first launch runs -- copied from there (only from memory the context knows to be alive: slabs
 // and other producers' kept blocks; a zero-copy view of a sample buffer, which may have been released since, is not chased).
 void Context::chunkStaleSeed(ChunkRun& r) {
-  if (staleProducers.empty()) return;
+  if (staleProducers.empty() && staleLeavers.empty()) return;
   Exec& ex = *r.ex;
   std::vector<StaleJob> jobs;
   auto alive = [&](const float* p) {
@@ -794,18 +794,19 @@ void Context::chunkStaleSeed(ChunkRun& r) {
     const size_t blockBytes = (size_t)slabFrames * sizeof(float) * std::max<size_t>(8, std::min<size_t>(1024, ((size_t)1 << 30) / std::max<size_t>((size_t)slabFrames * sizeof(float), 1)));
     for (void* b : slabBlocks)
       if ((const char*)p >= (const char*)b && (const char*)p + kBlock * sizeof(float) <= (const char*)b + blockBytes) return true;
-    for (int id : staleProducers) {
-      const NodeS& o = *nodes[id];
+    for (const auto& np : nodes) {
+      const NodeS& o = *np;
       if (o.staleBuf && p >= o.staleBuf && p + kBlock <= o.staleBuf + (size_t)o.staleRows * kBlock) return true;
+      // (the OTHER copy: what a pass-through node behind a stale edge showed in the previous chunk -- the producer's kept block of that
+      // chunk -- sits there since the swap at that chunk's end, untouched until this chunk's commit runs; fuzz session 70427)
+      if (o.staleNext && p >= o.staleNext && p + kBlock <= o.staleNext + (size_t)o.staleRows * kBlock) return true;
     }
     return false;
   };
-  for (int id : staleProducers) {
-    NodeS& nd = *nodes[id];
-    // a producer that kept its last block in the chunk before this one goes on; one that is new to the role -- or BACK in it after chunks
-    // in which nothing pulled it from inside its own evaluation (an edit moved the point where the traversal enters the loop away and
-    // back: fuzz session 61173) -- takes the block it put out last from the previous chunk's output views
-    if (nd.staleBuf && nd.staleSeq + 1 == chunkSeq) continue;
+  const bool haveLast = lastViewSlabGen == slabGen && lastViewFrames >= kBlock;
+  // the block node `id` put out LAST (the previous chunk's last block, through the gain / gain curve a folded GainNode stood for) -> its staleBuf
+  auto keepLastBlock = [&](NodeS& nd) {
+    const int id = nd.id;
     const int rows = nd.type == GA_NODE_CHANNEL_SPLITTER ? std::max<int>(1, (int)nd.outputs.size()) : 32;
     if (!nd.staleBuf) {
       nd.staleRows = rows;
@@ -813,7 +814,7 @@ void Context::chunkStaleSeed(ChunkRun& r) {
       nd.staleNext = (float*)dalloc((size_t)rows * kBlock * sizeof(float));
       GA_HIP(hipMemsetAsync(nd.staleNext, 0, (size_t)rows * kBlock * sizeof(float), stream));
     }
-    const bool haveViews = lastViewSlabGen == slabGen && lastViewFrames >= kBlock && id < (int)lastViews.size();
+    const bool haveViews = haveLast && id < (int)lastViews.size();
     const float g = (haveViews && id < (int)lastViewScale.size()) ? lastViewScale[id] : 1.f;
     const float* cv = (haveViews && id < (int)lastViewCurve.size() && lastViewCurve[id]) ? lastViewCurve[id] + (lastViewFrames - kBlock) : nullptr;
     for (int rw = 0; rw < nd.staleRows; rw++) {
@@ -821,8 +822,34 @@ void Context::chunkStaleSeed(ChunkRun& r) {
       StaleJob sj{nd.staleBuf + (size_t)rw * kBlock, alive(src) ? src : nullptr, g, 0};
       sj.curve = (sj.src && cv && alive(cv)) ? cv : nullptr;
       jobs.push_back(sj);   // (rows without a view: zeros)
+#ifdef GA_EXPERIMENTS
+      if (expenv("GA_DEBUG_STALE") && rw < 2)
+        fprintf(stderr, "[stale] chunk %llu node %d type %d row %d: views %d (of %zu nodes) view %p alive %d scale %g curve %p\n", (unsigned long long)chunkSeq, id,
+                nd.type, rw, haveViews ? (int)lastViews[id].size() : -1, lastViews.size(), (const void*)src, (int)alive(src), g, (const void*)sj.curve);
+#endif
     }
+  };
+  // A node's output buffer holds the block it put out last for as long as the node lives (AudioNode.cs:153-160 hands THAT out when the
+  // node is pulled from inside its own evaluation).  Three ways a node comes to be a stale producer in this chunk:
+  //   it was one in the chunk before                      its kept block is current (chunkStaleCommit)
+  //   it was evaluated in the chunk before, in no loop
+  //     or in a loop that was entered somewhere else      its last block is in the previous chunk's views (fuzz sessions 60001, 61173)
+  //   it was out of the graph (unplugged) for a while     the block it had when it LEFT: kept at that moment (staleLeavers, below)
+  for (int id : staleProducers) {
+    NodeS& nd = *nodes[id];
+    if (nd.staleBuf && nd.staleSeq + 1 == chunkSeq) continue;
+    if (nd.prevReachable || !nd.staleBuf) keepLastBlock(nd);
   }
+  // nodes an edit has just taken out of the graph: what their output buffers hold stays there until they are evaluated again
+  for (int id : staleLeavers) {
+    NodeS& nd = *nodes[id];
+    if (nd.staleBuf && nd.staleSeq + 1 == chunkSeq) continue;   // (a stale producer of the previous chunk: kept already)
+    if (!haveLast || id >= (int)lastViews.size()) continue;
+    bool any = false;
+    for (const float* v : lastViews[id]) any = any || v != nullptr;
+    if (any || nd.staleBuf) keepLastBlock(nd);   // (silent and never kept: nothing to remember -- a later seed reads zeros)
+  }
+  staleLeavers.clear();
   if (jobs.empty()) return;
   const size_t off = ex.plan.putv(jobs);
   const int nj = (int)jobs.size();

@@ -17,13 +17,31 @@ from tests import _graphs as G
 import tests._fuzz as F
 from tests._oracle import OracleContext
 dtrig = CApi(C.CDLL(os.path.join("tools", "variants", "libga_oracle_dtrig.so")), "gao_")
-for seed in [int(a) for a in sys.argv[1:]]:
-    ref, _ = F.run_random_session(OracleContext(48000), seed)
-    ref2, _ = F.run_random_session(OfflineAudioContext(48000, _api=dtrig), seed)
+def run(ctx, seed, graph):
+    if not graph:
+        return F.run_random_session(ctx, seed)[0]
+    frames = 128 * 36
+    ch = F.build_random_graph(ctx, seed, frames)
+    out = np.zeros((ch, frames), np.float32)
+    pos = 0
+    rng = np.random.default_rng(1000 + seed)
+    while pos < frames:   # (the pieces of tests/test_gpu_fuzz.py::test_random_graph_matches_oracle)
+        n = int(min(frames - pos, rng.integers(1, 128 * 9)))
+        ctx.Render(out, n, pos)
+        pos += n
+    return out
+
+
+for a in sys.argv[1:]:   # SEED: an edit session ; gSEED: a graph of test_random_graph_matches_oracle
+    graph = a.startswith("g")
+    seed = int(a[1:] if graph else a)
+    ref = run(OracleContext(48000), seed, graph)
+    ref2 = run(OfflineAudioContext(48000, _api=dtrig), seed, graph)
     h = OfflineAudioContext(48000)
     h.SetOption("max_chunk_blocks", 11)
     h.SetOption("coarse_min_blocks", 1)
-    got, _ = F.run_random_session(h, seed)
+    got = run(h, seed, graph)
     scale = max(G.rms(ref), 1e-3)
-    print(f"session {seed}: device vs oracle {G.rms(ref - got):.3e}   device vs oracle with the device's cos/sin/pow {G.rms(ref2 - got):.3e}   "
-          f"oracle vs that oracle {G.rms(ref - ref2):.3e}   (signal {scale:.3f})", flush=True)
+    d = np.abs(ref - got).max(axis=0).reshape(-1, 128).max(axis=1)
+    print(f"{'graph' if graph else 'session'} {seed}: device vs oracle {G.rms(ref - got):.3e}   device vs oracle with the device's cos/sin/pow {G.rms(ref2 - got):.3e}   "
+          f"oracle vs that oracle {G.rms(ref - ref2):.3e}   (signal {scale:.3f}; blocks off by > 1e-4: {np.nonzero(d > 1e-4)[0][:8].tolist()})", flush=True)

@@ -37,3 +37,5 @@ for b in range(ref.shape[1] // 128):
     if m > 1e-5:
         print("   block %2d max diff %.3e per channel" % (b, m), [float("%.3g" % x) for x in d[:, b * 128:(b + 1) * 128].max(axis=1)])
 print("pieces", F.last_pieces)
+np.save(f"gpurun_out/got_{seed}.npy", got)   # (for tools/fuzz_node_dump.py SEED KEEP BLOCK gpurun_out/got_SEED.npy)
+print("keep", ",".join(str(v) for v in sorted(keep)))

@@ -17,7 +17,8 @@ base = {"max_chunk_blocks": 11, "coarse_min_blocks": 1 if coarse else 1 << 30}
 for name, extra in (("as the test runs it", {}), ("twin_channels 0", {"twin_channels": 0}), ("sim_replay 0", {"sim_replay": 0}),
                     ("gain_fold / pass 0", {"gain_fold": 0, "gain_pass_through": 0}), ("biquad_time_split 0", {"biquad_time_split": 0}),
                     ("resample_fast 0", {"resample_fast": 0}), ("cycle_delay_split 0", {"cycle_delay_split": 0}),
-                    ("every convolver in reference order", {"conv_ref_min_deviation": 0.0}), ("one block per chunk", {"max_chunk_blocks": 1})):
+                    ("every sensitive sink counts", {"conv_ref_min_deviation": 0.0}), ("EVERY convolver in reference order", {"conv_reference_order": 2}),
+                    ("no convolver in reference order", {"conv_reference_order": 0}), ("one block per chunk", {"max_chunk_blocks": 1})):
     h = OfflineAudioContext(48000)
     for k, v in {**base, **extra}.items():
         h.SetOption(k, v)
