@@ -145,7 +145,10 @@ struct Sim {
       if (o.bufCh != 0 && !o.silent) {   // (a producer that is still being processed shows the state of its PREVIOUS block: a stale term)
         is.terms.push_back(TermS{cn.node, cn.out, o.bufCh, pn.isProcessing});
         mixed = true;
-        allZero = allZero && o.zero && !pn.isProcessing;
+        // (a stale term shows the producer's PREVIOUS block, and so does `o.zero` while the producer is being processed: a loop of
+        // convolvers that nothing has reached yet carries exact zeros round and round -- fuzz session 64064: a DelayNode behind
+        // such a loop must not be taken to hold audio)
+        allZero = allZero && o.zero;
       }
     }
     in.silent = !mixed;

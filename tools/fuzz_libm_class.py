@@ -43,5 +43,8 @@ for a in sys.argv[1:]:   # SEED: an edit session ; gSEED: a graph of test_random
     got = run(h, seed, graph)
     scale = max(G.rms(ref), 1e-3)
     d = np.abs(ref - got).max(axis=0).reshape(-1, 128).max(axis=1)
+    for b in np.nonzero(d > 1e-4)[0][:6]:   # a block that is exact silence on one side only: a silence FLAG differs (DelayNode)
+        rb, gb = ref[:, b * 128:(b + 1) * 128], got[:, b * 128:(b + 1) * 128]
+        print(f"      block {b}: oracle rms {G.rms(rb):.4g} ({int((rb != 0).sum())} non-zero samples)  device rms {G.rms(gb):.4g} ({int((gb != 0).sum())} non-zero)")
     print(f"{'graph' if graph else 'session'} {seed}: device vs oracle {G.rms(ref - got):.3e}   device vs oracle with the device's cos/sin/pow {G.rms(ref2 - got):.3e}   "
           f"oracle vs that oracle {G.rms(ref - ref2):.3e}   (signal {scale:.3f}; blocks off by > 1e-4: {np.nonzero(d > 1e-4)[0][:8].tolist()})", flush=True)

@@ -9,12 +9,25 @@ sys.path.insert(0, ".")
 from graphaudio_amd import OfflineAudioContext
 from graphaudio_amd._capi import CApi
 import tests._fuzz as F
-seed = int(sys.argv[1]); keep = {int(x) for x in sys.argv[2].split(",")}; block = int(sys.argv[3]); got = np.load(sys.argv[4])
+graph = sys.argv[1].startswith("g")   # gSEED: a graph of test_random_graph_matches_oracle
+seed = int(sys.argv[1][1:] if graph else sys.argv[1]); keep = {int(x) for x in sys.argv[2].split(",")}; block = int(sys.argv[3]); got = np.load(sys.argv[4])
 dump = "/tmp/gao_dump.txt"
 if os.path.exists(dump): os.remove(dump)
 os.environ["GAO_DUMP_FROM"] = str(block - 1); os.environ["GAO_DUMP_TO"] = str(block); os.environ["GAO_DUMP_FILE"] = dump
 api = CApi(C.CDLL(os.path.join("tools", "variants", "libga_oracle_dump.so")), "gao_")
-ref, _ = F.run_random_session(OfflineAudioContext(48000, _api=api), seed, keep=keep)
+if graph:
+    frames = 128 * 36
+    octx = OfflineAudioContext(48000, _api=api)
+    ch = F.build_random_graph(octx, seed, frames, keep=keep)
+    ref = np.zeros((ch, frames), np.float32)
+    pos = 0
+    rng = np.random.default_rng(1000 + seed)
+    while pos < frames:
+        n = int(min(frames - pos, rng.integers(1, 128 * 9)))
+        octx.Render(ref, n, pos)
+        pos += n
+else:
+    ref, _ = F.run_random_session(OfflineAudioContext(48000, _api=api), seed, keep=keep)
 err = (got - ref)[:, block * 128:(block + 1) * 128]
 print("error per channel (max abs)", np.abs(err).max(axis=1))
 rows = {}

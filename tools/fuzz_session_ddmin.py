@@ -6,16 +6,32 @@ from graphaudio_amd import OfflineAudioContext
 from tests import _graphs as G
 import tests._fuzz as F
 from tests._oracle import OracleContext
-seed = int(sys.argv[1])
+graph = sys.argv[1].startswith("g")   # gSEED: a graph of test_random_graph_matches_oracle instead of an edit session
+seed = int(sys.argv[1][1:] if graph else sys.argv[1])
+
+
+def run(ctx, keep):
+    if not graph:
+        return F.run_random_session(ctx, seed, keep=keep)[0]
+    frames = 128 * 36
+    ch = F.build_random_graph(ctx, seed, frames, keep=keep)
+    out = np.zeros((ch, frames), np.float32)
+    pos = 0
+    rng = np.random.default_rng(1000 + seed)
+    while pos < frames:
+        n = int(min(frames - pos, rng.integers(1, 128 * 9)))
+        ctx.Render(out, n, pos)
+        pos += n
+    return out
 
 
 def err_of(keep):
     try:
-        ref, _ = F.run_random_session(OracleContext(48000), seed, keep=keep)
+        ref = run(OracleContext(48000), keep)
         h = OfflineAudioContext(48000)
         h.SetOption("max_chunk_blocks", 11)
         h.SetOption("coarse_min_blocks", 1)
-        got, _ = F.run_random_session(h, seed, keep=keep)
+        got = run(h, keep)
     except Exception as e:   # noqa: BLE001
         return None, None, None
     return G.rms(ref - got), ref, got
@@ -36,6 +52,6 @@ for b in range(ref.shape[1] // 128):
     m = d[:, b * 128:(b + 1) * 128].max()
     if m > 1e-5:
         print("   block %2d max diff %.3e per channel" % (b, m), [float("%.3g" % x) for x in d[:, b * 128:(b + 1) * 128].max(axis=1)])
-print("pieces", F.last_pieces)
+print("pieces", getattr(F, "last_pieces", None))
 np.save(f"gpurun_out/got_{seed}.npy", got)   # (for tools/fuzz_node_dump.py SEED KEEP BLOCK gpurun_out/got_SEED.npy)
 print("keep", ",".join(str(v) for v in sorted(keep)))
