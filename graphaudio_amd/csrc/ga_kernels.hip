@@ -2274,8 +2274,95 @@ static void launch_biquad_pipe(hipStream_t s, const BiquadJob* jobs_dev, int njo
   if (const char* e = expenv("GA_BQ_JPW")) jpw = std::min(MAXJ, std::max(1, atoi(e)));
   hipLaunchKernelGGL(biquad_pipe_kernel<NSEC>, dim3((njobs + jpw - 1) / jpw), dim3(64), 0, s, jobs_dev, njobs, secs_dev, jpw);
 }
-void launch_biquad_lanes(hipStream_t s, const BiquadJob* jobs_dev, int njobs, const BiquadSection* secs_dev, int nsec) {
+// ---- ONE section per job, one job per lane, nothing staged --------------------------------------------------------------------
+// The pieces of cascades that are split along time (BiquadScanJob: tens of thousands of short walks) and any other single
+// section.  The lane-per-cascade kernel above stages [jobs][frames] tiles through LDS so that every global access is a coalesced
+// row -- ~80 instructions per row and tile of 64 frames, 85 per step of a 64-lane wave, and a wave pays ~5 cycles per instruction
+// (config 2: 0.41 ms per pass over 0.49 GB).  Here a lane reads ITS piece 16 bytes at a time (four consecutive loads of a lane
+// cover one 64-byte line, which the vector cache keeps), walks the four samples in registers -- the two packed products of w[n-1]
+// ({a1, b1} w, {a2, b2} w) serve the recursion and the output half alike, 7 instructions per sample, 3 when only the state is
+// wanted -- and writes 16 bytes.  The arithmetic is BiQuadFilterNode.cs:137-138 operation by operation (as biquad_pipe_kernel).
+template <bool STATE_ONLY>
+__global__ __launch_bounds__(64) void biquad1_kernel(const BiquadJob* __restrict jobs, int njobs, const BiquadSection* __restrict secs) {
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  if (j >= njobs) return;
+  const BiquadJob me = jobs[j];
+  const BiquadSection sc = secs[me.sec0];
+  float* st = me.state ? me.state : sc.state;
+  const float b0 = sc.b0;
+  const v2f ab1 = {sc.a1, sc.b1}, ab2 = {sc.a2, sc.b2};
+  float w1 = ldg1(st), w2 = ldg1(st + 1);
+  const float* __restrict in = me.in + me.f0;
+  float* __restrict out = (!STATE_ONLY && me.out) ? me.out + me.f0 : nullptr;
+  const int n = (int)me.n;
+  v2f Bp = {ab2.x * w2, ab2.y * w2};   // {a2, b2} w[n-2]
+  auto step = [&](float x) {
+    const v2f A = {ab1.x * w1, ab1.y * w1};   // {a1, b1} w[n-1]
+    const float t = x - A.x;
+    const float w = t - Bp.x;                 // w = (x - a1 w1) - a2 w2
+    float y = 0.f;
+    if (!STATE_ONLY) {
+      const float m = b0 * w;
+      const float sum = m + A.y;
+      y = sum + Bp.y;                         // y = (b0 w + b1 w1) + b2 w2
+    }
+    Bp = v2f{ab2.x * w1, ab2.y * w1};
+    w2 = w1;
+    w1 = w;
+    return y;
+  };
+  // 32 frames = 128 bytes = one cache line of the lane's stream per round: the eight loads of a round go out back to back (the line is
+  // used up while it is resident -- with 16 bytes per round the 64 lines of every wave of a CU evict each other between two uses and each
+  // is fetched from L2 several times), the next round's are in flight during this round's 32 steps
+  int i = 0;
+  if (n >= 32) {
+    v4f cur[8], nxt[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) cur[u] = ldg4(in + 4 * u);
+    for (; i + 32 <= n; i += 32) {
+      const bool more = i + 64 <= n;
+#pragma unroll
+      for (int u = 0; u < 8; u++) nxt[u] = more ? ldg4(in + i + 32 + 4 * u) : cur[u];
+      v4f y[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        y[u].x = step(cur[u].x);
+        y[u].y = step(cur[u].y);
+        y[u].z = step(cur[u].z);
+        y[u].w = step(cur[u].w);
+      }
+      if (!STATE_ONLY && out) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) stg4(out + i + 4 * u, y[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) cur[u] = nxt[u];
+    }
+  }
+  for (; i + 4 <= n; i += 4) {
+    const v4f c = ldg4(in + i);
+    const float y0 = step(c.x), y1 = step(c.y), y2 = step(c.z), y3 = step(c.w);
+    if (!STATE_ONLY && out) stg4(out + i, v4f{y0, y1, y2, y3});
+  }
+  for (; i < n; i++) {
+    const float y = step(ldg1(in + i));
+    if (!STATE_ONLY && out) stg1(out + i, y);
+  }
+  for (int t = 0; t < me.twins; t++) {   // (twin channels: BiquadJob::twins)
+    stg1(st + 2 * t, w1);
+    stg1(st + 2 * t + 1, w2);
+  }
+}
+void launch_biquad_lanes(hipStream_t s, const BiquadJob* jobs_dev, int njobs, const BiquadSection* secs_dev, int nsec, bool state_only) {
   if (njobs <= 0) return;
+  static const bool staged1 = expenv("GA_BQ_STAGED1") != nullptr;   // (measurement: the staged kernel for single sections too)
+  if (nsec == 1 && !staged1) {
+    if (state_only)
+      hipLaunchKernelGGL(biquad1_kernel<true>, dim3((njobs + 63) / 64), dim3(64), 0, s, jobs_dev, njobs, secs_dev);
+    else
+      hipLaunchKernelGGL(biquad1_kernel<false>, dim3((njobs + 63) / 64), dim3(64), 0, s, jobs_dev, njobs, secs_dev);
+    return;
+  }
   if (njobs <= 16 * 1024) launch_biquad_jpw<32>(s, jobs_dev, njobs, secs_dev, nsec);   // (more, emptier waves while the chip has room)
   else launch_biquad_jpw<64>(s, jobs_dev, njobs, secs_dev, nsec);
 }
@@ -2339,9 +2426,74 @@ __global__ __launch_bounds__(64) void biquad_scan_kernel(const BiquadScanJob* __
     stg1(st + 1, (float)cur[2 * q + 1]);
   }
 }
-void launch_biquad_scan(hipStream_t s, const BiquadScanJob* jobs_dev, int njobs, int G, const BiquadSection* secs_dev, const uint8_t* tables) {
+// The same scan with the cascade length known at compile time: state, matrix and the pieces' z_l live in registers (with a run-time
+// length they are indexed arrays in scratch memory, and every step waits for its own loads: 0.19 ms for config 2's 255 steps), and
+// z_{l+1} is requested before s_l is written over z_l.  Same operations in the same order: the same bits.
+template <int NS>
+__global__ __launch_bounds__(64) void biquad_scan_fixed_kernel(const BiquadScanJob* __restrict jobs, int njobs, int G, const BiquadSection* __restrict secs,
+                                                              const uint8_t* __restrict tables) {
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  if (j >= njobs) return;
+  const BiquadScanJob J = jobs[j];
+  constexpr int D = 2 * NS;
+  const float* Mg = (const float*)(tables + J.m_off);
+  float M[D * D];
+#pragma unroll
+  for (int e = 0; e < D * D; e++) M[e] = ldg1(Mg + e);
+  double cur[D];
+#pragma unroll
+  for (int q = 0; q < NS; q++) {
+    const float* st = secs[J.sec0 + q].state;
+    cur[2 * q] = ldg1(st);
+    cur[2 * q + 1] = ldg1(st + 1);
+  }
+  float zn[D];
+  if (G > 1) {
+#pragma unroll
+    for (int r = 0; r < D; r++) zn[r] = ldg1(J.scratch + r);
+  }
+  for (int l = 0; l + 1 < G; l++) {
+    float* sc = J.scratch + (size_t)l * D;
+    float z[D];
+#pragma unroll
+    for (int r = 0; r < D; r++) z[r] = zn[r];
+    if (l + 2 < G) {
+#pragma unroll
+      for (int r = 0; r < D; r++) zn[r] = ldg1(sc + D + r);
+    }
+    double nxt[D];
+#pragma unroll
+    for (int r = 0; r < D; r++) {
+      double a = (double)z[r];   // z_l
+#pragma unroll
+      for (int c = 0; c < D; c++) a += (double)M[r * D + c] * cur[c];
+      nxt[r] = a;
+    }
+#pragma unroll
+    for (int r = 0; r < D; r++) {
+      stg1(sc + r, (float)cur[r]);       // s_l: where pass B's piece l starts
+      cur[r] = (double)(float)nxt[r];    // (the state is float in the filter)
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NS; q++) {
+    float* st = secs[J.sec0 + q].state;
+    stg1(st, (float)cur[2 * q]);
+    stg1(st + 1, (float)cur[2 * q + 1]);
+  }
+}
+// (the launch's jobs all have `nsec` sections: Exec::bqScans is kept by cascade length)
+void launch_biquad_scan(hipStream_t s, const BiquadScanJob* jobs_dev, int njobs, int G, const BiquadSection* secs_dev, const uint8_t* tables, int nsec) {
   if (njobs <= 0) return;
-  hipLaunchKernelGGL(biquad_scan_kernel, dim3((njobs + 63) / 64), dim3(64), 0, s, jobs_dev, njobs, G, secs_dev, tables);
+  const dim3 g((njobs + 63) / 64), b(64);
+  switch (nsec) {
+    case 1: hipLaunchKernelGGL(biquad_scan_fixed_kernel<1>, g, b, 0, s, jobs_dev, njobs, G, secs_dev, tables); return;
+    case 2: hipLaunchKernelGGL(biquad_scan_fixed_kernel<2>, g, b, 0, s, jobs_dev, njobs, G, secs_dev, tables); return;
+    case 3: hipLaunchKernelGGL(biquad_scan_fixed_kernel<3>, g, b, 0, s, jobs_dev, njobs, G, secs_dev, tables); return;
+    case 4: hipLaunchKernelGGL(biquad_scan_fixed_kernel<4>, g, b, 0, s, jobs_dev, njobs, G, secs_dev, tables); return;
+    default: break;
+  }
+  hipLaunchKernelGGL(biquad_scan_kernel, g, b, 0, s, jobs_dev, njobs, G, secs_dev, tables);
 }
 void launch_biquad(hipStream_t s, const BiquadJob* jobs_dev, int njobs, const BiquadSection* secs_dev, int nsec) {
   if (njobs <= 0) return;

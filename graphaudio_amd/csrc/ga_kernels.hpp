@@ -325,8 +325,9 @@ struct BiquadScanJob {   // one cascade (node chain x channel) cut into G pieces
 // pass A: ncasc x (G - 1) state-only jobs ; pass B: ncasc x G jobs
 void launch_biquad_split_expand(hipStream_t s, const BiquadScanJob* casc_dev, int ncasc, int G, int64_t K, BiquadJob* passA, BiquadJob* passB);
 // lane-per-cascade kernel for any number of jobs (a job with out == nullptr only advances its state)
-void launch_biquad_lanes(hipStream_t s, const BiquadJob* jobs_dev, int njobs, const BiquadSection* secs_dev, int nsec);
-void launch_biquad_scan(hipStream_t s, const BiquadScanJob* casc_dev, int ncasc, int G, const BiquadSection* secs_dev, const uint8_t* tables);
+// (state_only: every job of the launch has out == nullptr -- pass A of a split: the output half is not evaluated)
+void launch_biquad_lanes(hipStream_t s, const BiquadJob* jobs_dev, int njobs, const BiquadSection* secs_dev, int nsec, bool state_only = false);
+void launch_biquad_scan(hipStream_t s, const BiquadScanJob* casc_dev, int ncasc, int G, const BiquadSection* secs_dev, const uint8_t* tables, int nsec = 0);   // nsec: the cascade length of every job (0 = mixed)
 
 // BiQuadFilterNode with automated parameters (BiQuadFilterNode.cs:87-147): one lane per NODE walks block by block and
 // channel by channel exactly like the reference, refreshing the coefficients whenever the per-sample frequency / Q move

@@ -551,7 +551,7 @@ void Context::planBiquad(NodePlanCtx& k) {
     }
     if (biquadTimeSplit == 1 && biquadDeviation(coefs, (int)chain.size()) > biquadSplitMaxDeviation) G = 1;
   }
-  int64_t K = G > 1 ? ((nf + G - 1) / G + 3) / 4 * 4 : nf;
+  int64_t K = G > 1 ? ((nf + G - 1) / G + 31) / 32 * 32 : nf;   // (whole cache lines per piece: biquad1_kernel reads 128 bytes per round)
   if (G > 1) G = (int)((nf + K - 1) / K);
   if (G > 1 && ex.bqG == 0) {
     ex.bqG = G;
