@@ -2731,7 +2731,11 @@ __global__ __launch_bounds__(256) void resample_fast_kernel(const ResampleFastJo
 }
 void launch_resample_fast(hipStream_t s, const ResampleFastJob* jobs_dev, int njobs, int64_t max_blocks) {
   if (njobs <= 0 || max_blocks <= 0) return;
-  const int gx = (int)std::min<int64_t>((max_blocks * kBlock + 255) / 256, 512);
+  // (8 rounds per workgroup when there are thousands of jobs: 4096 voices x 469 one-round workgroups were bound by the dispatch rate)
+  int rounds = 1;
+  if (const char* e = expenv("GA_RS_ROUNDS")) rounds = std::max(1, atoi(e));
+  else if ((int64_t)njobs * ((max_blocks * kBlock + 255) / 256) > 200000) rounds = 8;
+  const int gx = (int)std::min<int64_t>((max_blocks * kBlock + 256 * rounds - 1) / (256 * rounds), 512);
   GA_LAUNCH_JOBS(resample_fast_kernel, gx, 256, jobs_dev, njobs);
 }
 void launch_resample(hipStream_t s, const ResampleJob* jobs_dev, int njobs, const ResampleBlock* traj_dev, int64_t max_blocks) {
