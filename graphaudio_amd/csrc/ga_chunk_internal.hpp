@@ -166,6 +166,9 @@ struct Sim {
     NodeSeg ns;
     ns.id = id;
     ns.type = n_.type;
+    ns.level = (int16_t)std::min(n_.level, 32767);
+    ns.depth = (int16_t)std::min(n_.depth, 32767);
+    ns.fan1 = !n_.outputs.empty() && n_.outputs[0].connectedInputs.size() == 1;
     ns.ins.resize(n_.inputs.size());
     // params first: ComputeValues pulls the modulation input (1 channel, explicit) before the node's inputs (:167-175)
     bool anyMod = false;

@@ -437,6 +437,11 @@ struct InSeg {
 struct NodeSeg {
   int id = 0;
   int type = 0;   // (the node's type, so that a replayed record is dispatched without touching the node: Context::chunkSimulate)
+  // ... and what the planner's sorting / cascade-fusion sweeps ask of every node, so that only the planning pass itself touches the
+  // 1.2 KB node records (config 4: 28,672 of them, three sweeps of cache misses per chunk): set when the record is made, valid
+  // while the graph stands (a replayed record belongs to the same graph version)
+  int16_t level = 0, depth = 0;
+  bool fan1 = false;   // output 0 feeds exactly one input
   SmallVec<InSeg, 1> ins;
   // AudioParam modulation inputs (AudioParam.cs:97-101), one per param -- sized only when some parameter of the node HAS a
   // modulation input (rare); otherwise empty, which reads as "every pin silent" (pinSilent)

@@ -636,9 +636,8 @@ void Context::chunkPlanNodes(ChunkRun& r, int d) {
         std::vector<std::pair<int, const NodeSeg*>> mine;
         std::vector<int> count(maxLevel + 2, 0);
         for (const NodeSeg& ns : sg.nodes) {
-          const NodeS& nd = *nodes[ns.id];
-          if (nd.depth != d) continue;
-          const int lv = std::min(std::max(nd.level, 0), maxLevel);
+          if (ns.depth != d) continue;
+          const int lv = std::min(std::max((int)ns.level, 0), maxLevel);
           mine.push_back({lv, &ns});
           count[lv + 1]++;
         }
@@ -666,16 +665,15 @@ void Context::chunkPlanNodes(ChunkRun& r, int d) {
       DenseInt absorbedBy{fuseStamp, fuseAbs, stamp, -1}, chainLen{fuseStamp, fuseLen, stamp, 0};
       for (const NodeSeg* nsp : todo) {
         const NodeSeg& b_ = *nsp;
-        if (nodes[b_.id]->type != GA_NODE_BIQUAD || !b_.bqActive || b_.bqDynamic) continue;
+        if (b_.type != GA_NODE_BIQUAD || !b_.bqActive || b_.bqDynamic) continue;
         fuseLen[b_.id] = 1;
         if (b_.ins[0].terms.size() != 1) continue;
         const TermS& t = b_.ins[0].terms[0];
         const NodeSeg* ia = segNode.find(t.node);
         if (!ia) continue;
         const NodeSeg& a_ = *ia;
-        NodeS& an = *nodes[a_.id];
-        if (an.type != GA_NODE_BIQUAD || !a_.bqActive || a_.bqDynamic || t.ch != b_.ins[0].bufCh || a_.outCh != b_.outCh) continue;
-        if (an.outputs[0].connectedInputs.size() != 1) continue;
+        if (a_.type != GA_NODE_BIQUAD || !a_.bqActive || a_.bqDynamic || t.ch != b_.ins[0].bufCh || a_.outCh != b_.outCh) continue;
+        if (!a_.fan1) continue;
         int la_ = chainLen.get(a_.id) ? chainLen.get(a_.id) : 1;
         if (la_ >= kMaxBiquadSections) continue;
         fuseAbs[a_.id] = b_.id;
@@ -704,13 +702,13 @@ void Context::chunkPlanNodes(ChunkRun& r, int d) {
         }
         const NodeSeg& ns = *nsp;
         NodeS& nd = *nodes[ns.id];
-        if (nd.level != curLevel) {
+        if (ns.level != curLevel) {
           ex.flushLevel();
-          curLevel = nd.level;
+          curLevel = ns.level;
           levelBqHeads = 0;   // constant-coefficient cascade outputs of this level (all levels' biquad launches are separate)
-          for (size_t tj = ti; tj < todo.size() && nodes[todo[tj]->id]->level == curLevel; tj++) {
+          for (size_t tj = ti; tj < todo.size() && todo[tj]->level == curLevel; tj++) {
             const NodeSeg& o = *todo[tj];
-            if (nodes[o.id]->type == GA_NODE_BIQUAD && o.bqActive && !o.bqDynamic && absorbedBy.get(o.id) < 0) levelBqHeads += std::max(o.outCh, 1);
+            if (o.type == GA_NODE_BIQUAD && o.bqActive && !o.bqDynamic && absorbedBy.get(o.id) < 0) levelBqHeads += std::max(o.outCh, 1);
           }
         }
         auto& ov = ex.outViews[si][ns.id];
