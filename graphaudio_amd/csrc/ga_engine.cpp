@@ -272,6 +272,7 @@ Context::~Context() {
   for (auto& e : arenaEv)
     if (e) (void)hipEventDestroy(e);
   if (deferStage) (void)hipFree(deferStage);
+  for (auto& r : retired) (void)hipFree(r.first);
   for (auto& kv : resamplers)
     if (kv.second->devSamples) (void)hipFree(kv.second->devSamples);
   for (auto& np : nodes)
@@ -430,6 +431,11 @@ void Context::synchronize() {
   commWait();   // (= hipStreamSynchronize without a communicator)
   waitHostCopies();
   harvestProfile(true);
+  freeRetired();
+}
+void Context::freeRetired() {
+  for (auto& r : retired) dfree(r.first, r.second);
+  retired.clear();
 }
 void Context::waitHostCopies() {
   if (!copyStream) return;

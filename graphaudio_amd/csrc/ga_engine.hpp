@@ -819,6 +819,10 @@ struct Context {
   // nothing else runs.  Without a next chunk: plain copies on the stream, from ga_synchronize or whatever touches the stream next.
   struct HandOver { const float* src; float* dst_dev; float* dst_host; int64_t n; };
   std::vector<HandOver> pendingHandOver;
+  // device memory that has been replaced while launches that read it may still be in flight (a per-rate sample table that doubled):
+  // freed at the next point where the stream is known to be idle (synchronize, destruction) -- hipFree would wait for the device
+  std::vector<std::pair<void*, size_t>> retired;
+  void freeRetired();
   bool premixStreamPlanned = false;   // the chunk being planned put its pre-mix on stream2 (CoarseStage::enqueue -> chunkExecute)
   float* deferStage = nullptr;
   size_t deferStageBytes = 0;

@@ -267,9 +267,14 @@ bool Context::ensureResampleSamples(Exec& ex, Resampler& rs, int64_t upto) {
     const int64_t cap = std::max<int64_t>(4096, std::max(need, 2 * rs.devCapBlocks));
     ResampleSample* nw = (ResampleSample*)dalloc((size_t)cap * kBlock * sizeof(ResampleSample));
     if (rs.devSamples) {
-      GA_HIP(hipStreamSynchronize(stream));   // (rare: the table doubles)
-      GA_HIP(hipMemcpy(nw, rs.devSamples, (size_t)rs.devBlocks * kBlock * sizeof(ResampleSample), hipMemcpyDeviceToDevice));
-      dfree(rs.devSamples, (size_t)rs.devCapBlocks * kBlock * sizeof(ResampleSample));
+      // The table doubles.  No wait: the copy is a plan entry in front of the launches that read the new table, and the old one is freed
+      // when the stream is next known to be idle -- jobs planned earlier in this chunk (and the chunk in flight) still read it.
+      // (A synchronisation here stalled a pipelined render for a whole chunk at every doubling: config 4, steps 3 and 7 of the bench.)
+      ResampleSample* old = rs.devSamples;
+      const size_t cb = (size_t)rs.devBlocks * kBlock * sizeof(ResampleSample);
+      hipStream_t stc = stream;
+      ex.plan.add(LK_OTHER, [=](uint8_t*) { GA_HIP(hipMemcpyAsync(nw, old, cb, hipMemcpyDeviceToDevice, stc)); });
+      retired.push_back({old, (size_t)rs.devCapBlocks * kBlock * sizeof(ResampleSample)});
     }
     rs.devSamples = nw;
     rs.devCapBlocks = cap;

@@ -167,3 +167,32 @@ def test_premix_on_its_own_stream_equals_the_single_stream_render(same_rows):
         else:
             assert np.array_equal(ref, out)
             assert np.array_equal(np.concatenate(blocking[:4], axis=1), out) or G.rms(np.concatenate(blocking[:4], axis=1) - out) < 1e-6
+
+
+def test_the_resampler_table_doubles_without_stopping_the_pipeline():
+    """The per-rate table of sample positions (resample_fast_kernel) holds 4096 blocks at first and doubles when a voice plays past it:
+    the copy into the larger table is a plan entry, the old table is freed later (Context::retired) -- no wait, same samples."""
+    from graphaudio_amd import AudioBufferSourceNode, GainNode, PlayableAudioBuffer
+    from tests._oracle import OracleContext
+    frames, steps = 128 * 700, 7   # 4,900 blocks
+    total = frames * steps
+
+    def build(ctx):
+        ctx.Destination.SetChannelCount(2)
+        for v in range(3):
+            s = AudioBufferSourceNode(ctx)
+            s.Buffer = PlayableAudioBuffer.FromMonoArray(G.voice(40 + v, int(total * 44100 / SR) + 4096), 44100)
+            g = GainNode(ctx)
+            g.Gain.Value = 0.3
+            s.Connect(g).Connect(ctx.Destination)
+            s.Start(0.0 if v else 0.01)
+        return 2
+
+    got, _ = _steps(build, frames, steps, async_=True, pinned=True)
+    blocking, _ = _steps(build, frames, steps, async_=False, pinned=False)
+    o = OracleContext(SR)
+    build(o)
+    ref = G.render(o, 2, total)
+    for k in range(steps):
+        assert np.array_equal(got[k], blocking[k]), k
+        assert np.array_equal(got[k], ref[:, k * frames:(k + 1) * frames]), k
