@@ -828,7 +828,7 @@ def main():
                                    "over G pieces, DESIGN.md section 4), which cuts the chain the bound is written for: frac > 1 says by how much",
                                    frames))
             variants["config4_eq_1gpu"] = run_variant(
-                "config4_eq_1gpu", torch, G, sf, ss, sw, lambda c: build_config4(c, 4096, sf * (ss + sw), G), 2, {},
+                "config4_eq_1gpu", torch, G, sf, 14, sw, lambda c: build_config4(c, 4096, sf * (14 + sw), G), 2, {},   # (14 steps: with 6 the one chunk that drains the pipeline at the end was a seventh of the time)
                 "BASELINE.json configs[3] whole on ONE GPU: 4096 voices, 44.1 kHz -> CubicResampler -> 5-band biquad EQ -> gain automation -> mix "
                 "(its 8-GPU form shards 512 voices per GPU); 2.5 s steps of one continuing render; 64 distinct noise buffers shared by the voices",
                 extra=serial_extra(lambda c: G.config4_eq(c, voices=4096, frames=128 * 94), 2, 128 * 94, 4096,
