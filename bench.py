@@ -784,24 +784,6 @@ def main():
             # the graphs / formulations the headline's algebra does not apply to, measured the same way
             vs, vw = args.variant_steps, 3
             variants = {}
-            variants["per_voice_spectra"] = run_variant(
-                "per_voice_spectra", torch, G, frames, vs, vw, lambda c: build_graph(c, voices_total, 0, args.taps, frames, G), 2,
-                {"coarse_premix": 0},
-                "the headline graph with option coarse_premix = 0: every voice's input transformed, the spectra of the voices summed "
-                "before ONE spectral multiply (round 2's default path)",
-                truth=(lambda: circular_truth(xsum, shared_ir(G, args.taps))) if xsum is not None else None)
-            pv = min(voices_total, 1024)
-            variants["private_ir"] = run_variant(
-                "private_ir", torch, G, frames, vs, vw, lambda c: build_graph(c, pv, 0, args.taps, frames, G, private=True), 2, {},
-                f"{pv} voices, each through its OWN {args.taps}-tap stereo impulse response: every voice's spectral multiply-accumulate is "
-                "evaluated (SURVEY.md 8(d) 'unique-IR-per-voice variant'; row a4)",
-                truth=(lambda: truths["private_ir"]) if truths else None)
-            variants["config5_1gpu"] = run_variant(
-                "config5_1gpu", torch, G, frames, vs, vw, lambda c: build_config5(c, 512, 0, 32768, frames, G), 16, {},
-                "BASELINE.json configs[4] whole on ONE GPU: 512 sources x 16-channel 32,768-tap private impulse responses -> 16-channel bus "
-                "(its 8-GPU form shards 64 sources per GPU)",
-                truth=(lambda: truths["config5_1gpu"]) if truths else None)
-            # ---- the latency-bound configurations (BASELINE.json configs[1], configs[3]) and the Kit scene (SURVEY.md 8f rank 4), VERDICT r3 item 3
             sf = int(2.5 * SR) // 128 * 128   # 2.5 s steps: these graphs play through (no looping), the buffers cover every step
             ss, sw = 6, 2
 
@@ -820,13 +802,8 @@ def main():
                             "host_ms_vs_device_ms": {"host_issue_ms_per_step": r["host_issue_ms_per_step"], "device_ms_per_step": r["device_ms_per_step"]},
                             "serial_bound": serial_bound(bound_frames, other, what)}
                 return extra
-            variants["config2_biquad"] = run_variant(
-                "config2_biquad", torch, G, frames, vs, vw, lambda c: build_config2(c, 256, frames, G), 1, {},
-                "BASELINE.json configs[1]: 256 mono voices -> BiQuadFilterNode (lowpass) -> Gain -> mono mix; latency bound, not bandwidth bound",
-                extra=serial_extra(lambda c: G.config2_biquad(c, voices=256, frames=SR + 256), 1, SR // 128 * 128, 256,
-                                   "the planner splits these well-conditioned low-passes along time (option biquad_time_split: pass A / scan / pass B "
-                                   "over G pieces, DESIGN.md section 4), which cuts the chain the bound is written for: frac > 1 says by how much",
-                                   frames))
+            # (config 4 first: 28,672 node records planned per step -- the host side of that variant is bound by cache misses, and it
+            # measured 7.2 instead of 3.9 ms per step when the records were allocated from the heap the earlier variants' contexts left behind)
             variants["config4_eq_1gpu"] = run_variant(
                 "config4_eq_1gpu", torch, G, sf, 14, sw, lambda c: build_config4(c, 4096, sf * (14 + sw), G), 2, {},   # (14 steps: with 6 the one chunk that drains the pipeline at the end was a seventh of the time)
                 "BASELINE.json configs[3] whole on ONE GPU: 4096 voices, 44.1 kHz -> CubicResampler -> 5-band biquad EQ -> gain automation -> mix "
@@ -835,6 +812,31 @@ def main():
                                    "the planner refuses to split this equaliser (its 100 Hz low shelf carries ~1e-4 of round-off noise in the reference's "
                                    "own arithmetic: any re-association leaves the 1e-5 contract, Context::biquadDeviation): one walk, five sections pipelined "
                                    "across lanes (biquad_pipe_kernel<5>)", sf))
+            variants["per_voice_spectra"] = run_variant(
+                "per_voice_spectra", torch, G, frames, vs, vw, lambda c: build_graph(c, voices_total, 0, args.taps, frames, G), 2,
+                {"coarse_premix": 0},
+                "the headline graph with option coarse_premix = 0: every voice's input transformed, the spectra of the voices summed "
+                "before ONE spectral multiply (round 2's default path)",
+                truth=(lambda: circular_truth(xsum, shared_ir(G, args.taps))) if xsum is not None else None)
+            pv = min(voices_total, 1024)
+            variants["private_ir"] = run_variant(
+                "private_ir", torch, G, frames, vs, vw, lambda c: build_graph(c, pv, 0, args.taps, frames, G, private=True), 2, {},
+                f"{pv} voices, each through its OWN {args.taps}-tap stereo impulse response: every voice's spectral multiply-accumulate is "
+                "evaluated (SURVEY.md 8(d) 'unique-IR-per-voice variant'; row a4)",
+                truth=(lambda: truths["private_ir"]) if truths else None)
+            variants["config5_1gpu"] = run_variant(
+                "config5_1gpu", torch, G, frames, vs, vw, lambda c: build_config5(c, 512, 0, 32768, frames, G), 16, {},
+                "BASELINE.json configs[4] whole on ONE GPU: 512 sources x 16-channel 32,768-tap private impulse responses -> 16-channel bus "
+                "(its 8-GPU form shards 64 sources per GPU)",
+                truth=(lambda: truths["config5_1gpu"]) if truths else None)
+            # ---- the latency-bound configurations (BASELINE.json configs[1], configs[3]) and the Kit scene (SURVEY.md 8f rank 4), VERDICT r3 item 3
+            variants["config2_biquad"] = run_variant(
+                "config2_biquad", torch, G, frames, vs, vw, lambda c: build_config2(c, 256, frames, G), 1, {},
+                "BASELINE.json configs[1]: 256 mono voices -> BiQuadFilterNode (lowpass) -> Gain -> mono mix; latency bound, not bandwidth bound",
+                extra=serial_extra(lambda c: G.config2_biquad(c, voices=256, frames=SR + 256), 1, SR // 128 * 128, 256,
+                                   "the planner splits these well-conditioned low-passes along time (option biquad_time_split: pass A / scan / pass B "
+                                   "over G pieces, DESIGN.md section 4), which cuts the chain the bound is written for: frac > 1 says by how much",
+                                   frames))
             variants["kit_scene"] = run_variant(
                 "kit_scene", torch, G, sf, ss, sw, lambda c: G.kit_scene(c, voices=256, frames=sf * (ss + sw) + 256, taps=65536), 2, {},
                 "SURVEY.md 8(f) rank 4: 256 panned voices -> two buses (one fading) -> master -> ReverbEffect shape (dry / down-mix -> "
