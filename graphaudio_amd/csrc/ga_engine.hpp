@@ -725,8 +725,9 @@ struct Context {
   // plan (the members read sample buffers, not slabs written earlier in the chunk) and the context owns its stream.
   // MEASURED (late round 4, headline graph): no gain -- 0.42 instead of 0.40 ms per step.  The next chunk's pre-mix is ~940 workgroups
   // that live as long as the launch and hold every CU; the forward transforms on the context's stream do not get on the machine until
-  // it ends (their stage reads 0.33 ms instead of 0.016), with stream2 at the lowest priority as well.  Off by default; kept as an
-  // option with its test (tests/test_gpu_async_host.py) because the route itself is sound.
+  // it ends (their stage reads 0.33 ms instead of 0.016), with stream2 at the lowest priority as well.  Off by default: an experiment,
+  // kept with the test that exercised it (tests/test_gpu_async_host.py); a sibling (the tables alone on stream2, any plan) failed
+  // test_steps_that_reuse_the_same_rows and was dropped undiagnosed -- do not switch this on without going through that first.
   bool premixStream = false;        // option "premix_stream"
   DevArena tablesB;                 // job tables of odd chunks in that mode
   hipEvent_t premixEv = nullptr;
