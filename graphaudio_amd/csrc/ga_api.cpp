@@ -378,7 +378,6 @@ int ga_set_option(ga_context* ctx, const char* key, double value) {
     else if (k == "coarse_tail_private") c.coarseTailPrivate = value != 0;
     else if (k == "sim_replay") c.simReplay = value != 0;
     else if (k == "twin_channels") c.twinChannels = value != 0;
-    else if (k == "premix_stream") c.premixStream = value != 0;
     else if (k == "cycle_delay_split") c.cycleDelaySplit = value != 0;
     else if (k == "resample_fast") c.resampleFast = value != 0;
     else if (k == "conv_reference_order") c.convRefOrder = (int)std::min(2.0, std::max(0.0, value));

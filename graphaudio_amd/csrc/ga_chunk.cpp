@@ -607,29 +607,10 @@ void Context::chunkExecute(ChunkRun& r) {
     GA_HIP(hipHostMalloc(&thost, thostBytes, hipHostMallocDefault));
   }
   ensure(tables, std::max(tablesHostBytes, tablesHostBBytes));
-  // the pre-mix on its own stream (Context::premixStream, decided while the convolver stage was planned): this chunk's tables go to the
-  // arena of its parity on stream2, behind the event of the chunk that used that arena last
-  const bool ps = premixStreamPlanned && stream2 && !ex.plan.launches.empty() && ex.plan.launches.front().kind == GA_STAGE_COARSE_SECTION;
-  premixStreamPlanned = false;
-  premixOnStream2Now = ps;
-  const int arena = (ps && slot) ? 1 : 0;
-  if (ps && arena) ensure(tablesB, std::max(tablesHostBytes, tablesHostBBytes));
-  DevArena& tdev = arena ? tablesB : tables;
-  hipStream_t sUp = ps ? stream2 : stream;
-  if (ps) {
-    if (!premixEv) GA_HIP(hipEventCreateWithFlags(&premixEv, hipEventDisableTiming));
-    if (arenaEv[arena]) GA_HIP(hipStreamWaitEvent(stream2, arenaEv[arena], 0));
-    if (allocSeq != allocSeqSeen) {   // something was allocated (and cleared on `stream`) since the last such chunk: behind it, this once
-      if (!planEv) GA_HIP(hipEventCreateWithFlags(&planEv, hipEventDisableTiming));
-      GA_HIP(hipEventRecord(planEv, stream));
-      GA_HIP(hipStreamWaitEvent(stream2, planEv, 0));
-    }
-  }
-  allocSeqSeen = allocSeq;
   std::memcpy(thost, ex.plan.host.data(), tbytes);
-  if (tableUploadKernel) launch_table_upload(sUp, tdev.p, thost, tbytes);   // (staging and arena sizes are multiples of 16)
-  else GA_HIP(hipMemcpyAsync(tdev.p, thost, tbytes, hipMemcpyHostToDevice, sUp));
-  uint8_t* base = (uint8_t*)tdev.p;
+  if (tableUploadKernel) launch_table_upload(stream, tables.p, thost, tbytes);   // (staging and arena sizes are multiples of 16)
+  else GA_HIP(hipMemcpyAsync(tables.p, thost, tbytes, hipMemcpyHostToDevice, stream));
+  uint8_t* base = (uint8_t*)tables.p;
 
   std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
   std::vector<int> evKind;
@@ -670,11 +651,6 @@ void Context::chunkExecute(ChunkRun& r) {
   }
   extraProf.clear();
   if (profile) GA_HIP(hipEventRecord(evEnd, stream));
-  {   // whoever writes this chunk's table arena next waits for this
-    if (!arenaEv[arena]) GA_HIP(hipEventCreateWithFlags(&arenaEv[arena], hipEventDisableTiming));
-    GA_HIP(hipEventRecord(arenaEv[arena], stream));
-  }
-  premixOnStream2Now = false;
   GA_HIP(hipGetLastError());
   r.tmLaunch = nowMs();
   if (profileNow) pendingProf.push_back(ProfBatch{evBegin, evEnd, std::move(evs), std::move(evKind), std::move(evBytes)});

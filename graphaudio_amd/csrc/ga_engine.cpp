@@ -18,7 +18,6 @@ void* Context::dalloc(size_t bytes) {
   if (bytes == 0) bytes = 256;
   GA_HIP(hipMalloc(&p, bytes));
   devBytes += (int64_t)bytes;
-  allocSeq++;
   return p;
 }
 float* Context::dallocSkewed(size_t bytes, void** base, size_t* total) {
@@ -175,7 +174,6 @@ void Context::ensure(DevArena& a, size_t bytes) {
   if (a.bytes >= bytes) return;
   if (a.p) {
     GA_HIP(hipStreamSynchronize(stream));
-    if (stream2) GA_HIP(hipStreamSynchronize(stream2));
     dfree(a.p, a.bytes);
     a.p = nullptr;
     a.bytes = 0;
@@ -265,12 +263,6 @@ Context::~Context() {
   if (coarseX.p) (void)hipFree(coarseX.p);
   if (coarseY.p) (void)hipFree(coarseY.p);
   if (coarseM.p) (void)hipFree(coarseM.p);
-  if (coarseM2.p) (void)hipFree(coarseM2.p);
-  if (tablesB.p) (void)hipFree(tablesB.p);
-  if (premixEv) (void)hipEventDestroy(premixEv);
-  if (planEv) (void)hipEventDestroy(planEv);
-  for (auto& e : arenaEv)
-    if (e) (void)hipEventDestroy(e);
   if (deferStage) (void)hipFree(deferStage);
   for (auto& r : retired) (void)hipFree(r.first);
   for (auto& kv : resamplers)
@@ -1057,11 +1049,7 @@ void Context::streamFlushToProcessed(NodeS& s) {
 // ---- formulation D (ga_coarse.hip) ----
 void Context::ensureOverlapStream() {
   if (stream2) return;
-  // (lowest priority: what runs here is the long streaming launch -- the pre-mix -- and the short dependent launches on the context's
-  // stream have to get compute units while it is in flight, not after it)
-  int prLo = 0, prHi = 0;
-  GA_HIP(hipDeviceGetStreamPriorityRange(&prLo, &prHi));
-  GA_HIP(hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, prLo));
+  GA_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
   for (auto& e : dGroupEv) GA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   GA_HIP(hipEventCreateWithFlags(&dJoinEv, hipEventDisableTiming));
 }

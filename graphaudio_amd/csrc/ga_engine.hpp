@@ -716,25 +716,6 @@ struct Context {
   std::vector<std::vector<NodeSeg>> segNodePool;
   std::vector<std::vector<Views>> viewsPool;
   DevArena coarseM;                 // mixed input signals of pre-mixed groups
-  DevArena coarseM2;                // ... of odd chunks when the pre-mix runs on its own stream (option "premix_stream")
-  // The pre-mix of chunk k + 1 has nothing to wait for in chunk k's transforms (its inputs are the voices' sample buffers), but on ONE
-  // stream it queues up behind them: forward, reduction, inverse and the gaps between five launches are 0.07 of the headline step's
-  // 0.40 ms.  With `premix_stream` the job tables and the pre-mix of a chunk go to `stream2`; the context's stream waits for the
-  // pre-mix's event and runs the rest.  Tables and mixed signals alternate between two arenas; stream2 waits for the event of the
-  // chunk that last used the arena it is about to write (arenaEv).  Only while nothing precedes the convolver stage in the chunk's
-  // plan (the members read sample buffers, not slabs written earlier in the chunk) and the context owns its stream.
-  // MEASURED (late round 4, headline graph): no gain -- 0.42 instead of 0.40 ms per step.  The next chunk's pre-mix is ~940 workgroups
-  // that live as long as the launch and hold every CU; the forward transforms on the context's stream do not get on the machine until
-  // it ends (their stage reads 0.33 ms instead of 0.016), with stream2 at the lowest priority as well.  Off by default: an experiment,
-  // kept with the test that exercised it (tests/test_gpu_async_host.py); a sibling (the tables alone on stream2, any plan) failed
-  // test_steps_that_reuse_the_same_rows and was dropped undiagnosed -- do not switch this on without going through that first.
-  bool premixStream = false;        // option "premix_stream"
-  DevArena tablesB;                 // job tables of odd chunks in that mode
-  hipEvent_t premixEv = nullptr;
-  hipEvent_t arenaEv[2] = {nullptr, nullptr};   // recorded on `stream` at the end of the chunk that used tables / tablesB
-  bool premixOnStream2Now = false;  // (this chunk: read by the convolver stage's launch closure)
-  uint64_t allocSeq = 0, allocSeqSeen = 0;   // device allocations so far: a fresh arena is cleared by a memset on `stream` while the chunk is
-  hipEvent_t planEv = nullptr;               // planned -- stream2 must not write it first (one serialised chunk per allocation burst)
   DevArena coarseX, coarseY;        // spectra frames of a convolver stage (shared by the stages of a chunk, which run in order)
   float2* coarseTw = nullptr;       // combine-pass twiddles [2][2049]: W_8192^k, W_16384^k
   const float2* coarseTwab();
@@ -824,7 +805,6 @@ struct Context {
   // freed at the next point where the stream is known to be idle (synchronize, destruction) -- hipFree would wait for the device
   std::vector<std::pair<void*, size_t>> retired;
   void freeRetired();
-  bool premixStreamPlanned = false;   // the chunk being planned put its pre-mix on stream2 (CoarseStage::enqueue -> chunkExecute)
   float* deferStage = nullptr;
   size_t deferStageBytes = 0;
   bool hostDefer = true;

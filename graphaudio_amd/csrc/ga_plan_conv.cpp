@@ -445,10 +445,8 @@ void CoarseStage::buildRows() {
     int xFrame[32], xIndex[32];
     for (int ch = 0; ch < g.nxr; ch++) {
       const size_t bytes = (size_t)(hl + frames) * sizeof(float);
-      // (odd chunks mix into the second arena while the pre-mix may run beside the previous chunk's transforms: Context::premixStream)
-      const DevArena& mArena = (c.premixStream && (c.chunkSeq & 1)) ? c.coarseM2 : c.coarseM;
-      if (pmUsed + bytes > mArena.bytes) fail(GA_ERR_INVALID_OPERATION, "internal: the pre-mix arena is too small for the plan");
-      float* mixed = (float*)((char*)mArena.p + pmUsed);
+      if (pmUsed + bytes > c.coarseM.bytes) fail(GA_ERR_INVALID_OPERATION, "internal: the pre-mix arena is too small for the plan");
+      float* mixed = (float*)((char*)c.coarseM.p + pmUsed);
       pmUsed += (bytes + 255) & ~(size_t)255;
       auto job = [&](float* out, const std::vector<PremixTerm>& tv, int64_t len, int64_t carryFrom) {
         PremixJob j{out, (int)pmTerms.size(), 0, len, carryFrom, 1, 0};
@@ -490,12 +488,7 @@ void CoarseStage::buildRows() {
   }
   // the previous chunk's bus on its way to the caller's page-locked rows (Context::pendingHandOver): one-term jobs at the head of
   // this launch -- their workgroups write over PCIe while the others stream the members' samples from HBM
-  ex.flushLevel();   // (materialised inputs: their launches come before the stage's)
-  // the pre-mix on its own stream (Context::premixStream): nothing of this chunk has been launched before the stage, the context owns
-  // its stream and renders are pipelined.  The previous chunk's bus then rides in the forward launch (the context's stream, behind the
-  // inverse transforms that wrote it), not in the pre-mix launch.
-  c.premixStreamPlanned = c.premixStream && c.ownStream && c.asyncMode && !pmJobs.empty() && ex.plan.launches.empty() && !c.comm;
-  if (!pmJobs.empty() && !c.pendingHandOver.empty() && !c.premixStreamPlanned) {
+  if (!pmJobs.empty() && !c.pendingHandOver.empty()) {
     std::vector<PremixJob> head;
     for (const Context::HandOver& h : c.pendingHandOver) {
       head.push_back(PremixJob{h.dst_dev, (int)pmTerms.size(), 1, h.n, h.n, 1 | 4, 0});
@@ -511,6 +504,7 @@ void CoarseStage::buildRows() {
     c.pendingHandOver.clear();
     c.stats.deferred_handovers++;
   }
+  ex.flushLevel();   // (materialised inputs)
 }
 
 void CoarseStage::buildJobs() {
@@ -708,8 +702,6 @@ void CoarseStage::enqueue() {
     fwds.push_back(f);
   }
   if (G > 1) c.ensureOverlapStream();
-  if (G > 1) c.premixStreamPlanned = false;   // (stream2 carries the overlapped multiply-accumulate stage there)
-  if (c.premixStreamPlanned) c.ensureOverlapStream();
   Context* cp = &c;
   ex.plan.add(GA_STAGE_COARSE_SECTION, [=](uint8_t* base) {
     // one piece of the section: a launch with its own profile events (the two stages overlap on two streams)
@@ -731,14 +723,8 @@ void CoarseStage::enqueue() {
       cp->stats.stage_flops[kind] += flops;
     };
     hipStream_t s2 = G > 1 ? cp->stream2 : st;
-    if (npm > 0) {
-      hipStream_t sp = cp->premixOnStream2Now ? cp->stream2 : st;   // (Context::premixStream: the tables were uploaded on that stream too)
-      timed(sp, LK_CPREMIX, pmBytes, pmFlops, [&] { return launch_coarse_premix(sp, (const PremixJob*)(base + pjo), npm, (const PremixTerm*)(base + pto), pmMaxN); });
-      if (cp->premixOnStream2Now) {   // everything else of the chunk follows on the context's stream
-        GA_HIP(hipEventRecord(cp->premixEv, sp));
-        GA_HIP(hipStreamWaitEvent(st, cp->premixEv, 0));
-      }
-    }
+    if (npm > 0)
+      timed(st, LK_CPREMIX, pmBytes, pmFlops, [&] { return launch_coarse_premix(st, (const PremixJob*)(base + pjo), npm, (const PremixTerm*)(base + pto), pmMaxN); });
     for (int g = 0; g < G; g++) {
       const FwdLaunch& f = fwds[g];
       if (f.nx > 0)
@@ -903,7 +889,6 @@ void Context::chunkConvScratch(ChunkRun& r) {
         size_t pm = 0;
         for (auto& kv : pmDepth) pm = std::max(pm, kv.second);
         if (pm) ensure(coarseM, pm);
-        if (pm && premixStream) ensure(coarseM2, pm);
       }
     }
     bRowX = bRowY = 0;

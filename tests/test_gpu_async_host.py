@@ -136,39 +136,6 @@ def test_caller_supplied_stream_rows_are_complete_after_a_stream_wait():
     ctx2.Dispose()
 
 
-@pytest.mark.parametrize("same_rows", [False, True])
-def test_premix_on_its_own_stream_equals_the_single_stream_render(same_rows):
-    """Option premix_stream (off by default -- measured: no gain): in pipelined renders the job tables and the pre-mix of a chunk go to a second stream, so that
-    they run beside the previous chunk's transforms; tables and mixed signals alternate between two arenas.  Bit for bit what one
-    stream produces -- many short steps in flight, the bus rows reused or not, a graph edit in between (the stage then has launches in
-    front of it for a chunk: back to one stream, and forth)."""
-    frames, steps = 128 * 120, 12
-    build = lambda c: G.config3_convolver(c, voices=24, taps=20000, frames=frames * steps, shared=True)
-    one, s1 = _steps(build, frames, steps, async_=True, pinned=True, same_rows=same_rows, coarse_min_blocks=1, premix_stream=0)
-    two, s2 = _steps(build, frames, steps, async_=True, pinned=True, same_rows=same_rows, coarse_min_blocks=1, premix_stream=1)
-    blocking, _ = _steps(build, frames, steps, async_=False, pinned=False, coarse_min_blocks=1)
-    assert s1["coarse_premixed_signals"] > 0 and s2["coarse_premixed_signals"] == s1["coarse_premixed_signals"]
-    for k in range(steps):
-        assert G.rms(one[k]) > 1e-4
-        assert np.array_equal(one[k], two[k]), k
-        assert np.array_equal(blocking[k], two[k]), k
-    # one blocking call of many chunks: pipelined inside the call
-    for opt in (0, 1):
-        ctx = OfflineAudioContext(SR)
-        ctx.SetOption("coarse_min_blocks", 1)
-        ctx.SetOption("max_chunk_blocks", 100)
-        ctx.SetOption("premix_stream", opt)
-        ch = build(ctx)
-        out = np.zeros((ch, frames * 4), np.float32)
-        ctx.Render(out, frames * 4)
-        ctx.Dispose()
-        if opt == 0:
-            ref = out
-        else:
-            assert np.array_equal(ref, out)
-            assert np.array_equal(np.concatenate(blocking[:4], axis=1), out) or G.rms(np.concatenate(blocking[:4], axis=1) - out) < 1e-6
-
-
 def test_the_resampler_table_doubles_without_stopping_the_pipeline():
     """The per-rate table of sample positions (resample_fast_kernel) holds 4096 blocks at first and doubles when a voice plays past it:
     the copy into the larger table is a plan entry, the old table is freed later (Context::retired) -- no wait, same samples."""
