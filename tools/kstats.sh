@@ -2,7 +2,7 @@
 # per-kernel times of the default bench under rocprofv3 (run on the GPU box from the repo root): tools/kstats.sh TAG
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 TAG=${1:-ks}
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o st -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}.err
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o st -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}.err
 cp $(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1) gpurun_out/${TAG}_kernel_stats.csv
 python3 - gpurun_out/${TAG}_kernel_stats.csv <<'PY'
 import csv, sys
